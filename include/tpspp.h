@@ -1,0 +1,101 @@
+/*
+ * tpspp.h -- C ABI of libtpspp_hip.so: the TPS++ rectification hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  The reference has no native code and no FFI:
+ * its "operator API" for this path is a handful of PyTorch calls inside two nn.Modules.  Each entry
+ * point below replaces the call sites cited next to it (paths relative to the reference tree,
+ * mmocr/models/textrecog/...); tps_pp_amd/ binds them with ctypes and INTEGRATION.md shows the
+ * few lines a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to densely packed row-major fp32 (int32 for indices); tensors
+ *     are NCHW like the reference's.  No allocation, no ownership transfer, no host synchronisation:
+ *     work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
+ *     the call returns immediately.  Re-entrant per stream.
+ *   - return value: 0 on success, a negative TPSPP_E* code otherwise; tpspp_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread.
+ *   - arithmetic contract (what makes the result equal the reference's, not merely close):
+ *       T-solve and grid:  zero-initialised, k-ascending fp32 FMA chains -- bit-identical to the
+ *                          reference's torch.bmm on the CPU;
+ *       sampler:           ATen bilinear / border / align_corners=True with the CPU kernel's weight
+ *                          form and FMA order -- bit-identical to F.grid_sample on the CPU.
+ */
+#ifndef TPSPP_H_
+#define TPSPP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPSPP_ABI_VERSION 1
+
+#define TPSPP_OK        0
+#define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define TPSPP_ENODEV  (-19)  /* no HIP device / wrong architecture */
+#define TPSPP_EIO      (-5)  /* the HIP runtime reported a launch error */
+
+typedef void* tpspp_stream_t; /* hipStream_t */
+
+/* ABI version of the loaded library (== TPSPP_ABI_VERSION it was built with). */
+int tpspp_abi_version(void);
+
+/* Message for the last non-zero return on this thread ("" if none). */
+const char* tpspp_last_error(void);
+
+/*
+ * T[b] = inv_delta_c (F+3 x F+3) @ [ctrl[b] (F x 2); 0 (3 x 2)]          -> T (N, F+3, 2)
+ * replaces: torch.bmm(batch_inv_delta_C, batch_C_prime_with_zeros)
+ *           preprocessor/tps_preprocessor.py:273-280, backbones/tps_pp/tps_pp.py:484,489-494
+ */
+int tpspp_solve_T(const float* inv_delta_c, const float* ctrl, int N, int F, float* T,
+                  tpspp_stream_t stream);
+
+/*
+ * grid[b,p,:] = [1, P.x, P.y, m_0..m_{F-1}] @ T[b]                         -> grid (N, n, 2)
+ *   p_xy == NULL: p_hat is (n, F+3), leading dimension p_hat_ld, rows [1, P.x, P.y, rbf_0..]
+ *                 (GridGenerator.P_hat, tps_preprocessor.py:255-268)
+ *   p_xy != NULL: p_hat is (n, F) rbf only (Attention_Enhanced_TPS.P_hat) and p_xy is (n, 2)
+ *   score (N, n, F) or NULL: m_k = rbf_k * (score_k * 0.5 + 1)   (tps_pp.py:474, thela = 0.5)
+ * replaces: torch.bmm(batch_P_hat, batch_T)   tps_preprocessor.py:281, tps_pp.py:467-479,495
+ */
+int tpspp_build_grid(const float* p_hat, int p_hat_ld, const float* p_xy, const float* score,
+                     const float* T, int N, int n, int F, float* grid, tpspp_stream_t stream);
+
+/*
+ * out = grid_sample(in, grid, mode='bilinear', padding_mode='border', align_corners=True)
+ *   in (N,C,H,W), grid (N,Ho,Wo,2) -> out (N,C,Ho,Wo); idx_or_null (N,Ho*Wo,2) int32 receives the
+ *   north-west corner (ix_nw, iy_nw) of every output pixel.
+ * replaces: F.grid_sample   tps_preprocessor.py:79-83, tps_pp.py:606-615
+ */
+int tpspp_grid_sample(const float* in, const float* grid, int N, int C, int H, int W, int Ho,
+                      int Wo, float* out, int32_t* idx_or_null, tpspp_stream_t stream);
+
+/*
+ * The fused hot path: T-solve -> grid -> bilinear warp of in0 (and in1 when non-NULL) in ONE kernel;
+ * T lives in LDS and the grid in registers, neither touches HBM unless grid_or_null is given.
+ *   in0 (N,C0,H0,W0) -> out0 (N,C0,Ho,Wo);  in1 (N,C1,H1,W1) -> out1 (N,C1,Ho,Wo)  [optional]
+ *   ctrl (N,F,2); score (N,Ho*Wo,F) or NULL; inv_delta_c (F+3,F+3); p_hat / p_hat_ld / p_xy as in
+ *   tpspp_build_grid; grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
+ * replaces: GridGenerator.build_P_prime + F.grid_sample   tps_preprocessor.py:71-83
+ *           Attention_Enhanced_TPS.build_P_prime + 2x F.grid_sample   tps_pp.py:597-615
+ */
+int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
+                   const float* in1, int C1, int H1, int W1,
+                   const float* ctrl, const float* score,
+                   const float* inv_delta_c, const float* p_hat, int p_hat_ld, const float* p_xy,
+                   int N, int F, int Ho, int Wo,
+                   float* out0, float* out1, float* grid_or_null, int32_t* idx_or_null,
+                   tpspp_stream_t stream);
+
+/*
+ * Launch-shape override for tpspp_warp_fwd (tuning / benchmarking only; results do not depend on
+ * it): images per workgroup and threads per workgroup; 0 = built-in heuristic.
+ */
+int tpspp_warp_set_tuning(int images_per_group, int threads_per_group);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPSPP_H_ */

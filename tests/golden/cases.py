@@ -1,0 +1,120 @@
+"""Input definitions of the golden cases.
+
+Inputs are never stored: they are regenerated, bit for bit, from `tps_pp_amd.synth` (a counter
+hash, no RNG streams).  `make_golden.py` (build container, has /root/reference) feeds them to the
+reference and stores only the reference's OUTPUTS in the .npz files next to this module; the tests
+regenerate the same inputs and compare oracle / HIP results with the stored outputs.
+Nothing here touches /root/reference.
+"""
+import os
+
+import numpy as np
+
+from tps_pp_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(name):
+    return np.load(os.path.join(HERE, name + ".npz"))
+
+
+# ---- G2: classic grid + sampler, F=20, 32x100 -> 32x100, N=8 -----------------------------------
+CL_F, CL_HW, CL_C, CL_N = 20, (32, 100), 3, 8
+# per-image perturbation of the control points: 0 = the module's initial lattice, large values
+# push much of the grid outside [-1,1] and exercise the border clamp.
+CL_PERTURB = np.array([0.0, 0.01, 0.05, 0.1, 0.3, 1.0, 2.0, 0.05], dtype=np.float32)
+
+
+def classic_initial_ctrl(F=CL_F):
+    """(F,2) fp32: bias of localization_fc2 -- values only, restated in oracle/tps_oracle.py too."""
+    half = F // 2
+    x = np.linspace(-1.0, 1.0, half)
+    top = np.stack([x, np.linspace(0.0, -1.0, num=half)], axis=1)
+    bot = np.stack([x, np.linspace(1.0, 0.0, num=half)], axis=1)
+    return np.concatenate([top, bot], axis=0).astype(np.float32)
+
+
+def classic_identity_ctrl(F=CL_F):
+    """(F,2) fp32: the fiducial lattice C itself (top edge y=-1, bottom edge y=+1): C' = C makes
+    the TPS the identity map."""
+    half = F // 2
+    x = np.linspace(-1.0, 1.0, half)
+    return np.concatenate([np.stack([x, -np.ones(half)], axis=1),
+                           np.stack([x, np.ones(half)], axis=1)], axis=0).astype(np.float32)
+
+
+def g2_inputs():
+    ctrl = classic_initial_ctrl()[None] + \
+        CL_PERTURB[:, None, None] * synth.dyadic((CL_N, CL_F, 2), "g2.ctrl", 2)
+    # image 7: identity lattice + small noise (the bench workload's control points)
+    ctrl[7] = classic_identity_ctrl() + 0.05 * synth.dyadic((CL_F, 2), "g2.ctrl7", 2)
+    img = synth.dyadic((CL_N, CL_C) + CL_HW, "g2.img", 2)
+    img_smooth = synth.smooth_image((CL_N, CL_C) + CL_HW, "g2.img_smooth", 2)
+    return dict(ctrl=ctrl.astype(np.float32), img=img, img_smooth=img_smooth)
+
+
+# ---- G3: TPS_PP warp stage, F=32 (2x16), 16x64, N=2 --------------------------------------------
+PP_POINT, PP_HW, PP_C, PP_N = (2, 16), (16, 64), 64, 2
+PP_F = PP_POINT[0] * PP_POINT[1]
+PP_PERTURB = np.array([0.02, 0.2], dtype=np.float32)
+
+
+def tpspp_initial_ctrl(point_size=PP_POINT):
+    py, px = point_size
+    x = np.linspace(0.1, px - 0.1, num=int(px)) / px
+    y = np.linspace(0.1, py - 0.1, num=int(py)) / py
+    return np.stack(np.meshgrid(x, y), axis=2).reshape(-1, 2).astype(np.float32)
+
+
+def g3_inputs():
+    n = PP_HW[0] * PP_HW[1]
+    ctrl = tpspp_initial_ctrl()[None] + \
+        PP_PERTURB[:, None, None] * synth.dyadic((PP_N, PP_F, 2), "g3.ctrl", 3)
+    score = synth.dyadic((PP_N, n, PP_F), "g3.score", 3)
+    feat_grid = synth.smooth_image((PP_N, PP_C, 2 * PP_HW[0], 2 * PP_HW[1]), "g3.feat_grid", 3)
+    x = synth.dyadic((PP_N, PP_C) + PP_HW, "g3.x", 3)
+    return dict(ctrl=ctrl.astype(np.float32), score=score, feat_grid=feat_grid, x=x)
+
+
+# ---- G1: classic module (localization CNN + grid + sampler), config[0]: N=4, 3x32x100 ----------
+G1_N = 4
+
+
+def bn_rule(name, shape):
+    """synth.state_dict_like override: BatchNorm statistics / affine need sane positive values."""
+    if name.endswith("running_var"):
+        return (0.25, 1.0)            # in [0.75, 1.25)
+    if name.endswith("running_mean"):
+        return (0.1, 0.0)
+    if name.endswith("num_batches_tracked"):
+        return (0.0, 0.0)
+    return None
+
+
+def g1_inputs():
+    return dict(img=synth.smooth_image((G1_N, 3, 32, 100), "g1.img", 1))
+
+
+def g1_state_rule(name, shape):
+    r = bn_rule(name, shape)
+    if r is not None:
+        return r
+    if name.endswith("localization_fc2.weight"):
+        return (0.02, 0.0)            # keep C' near the initial lattice (reference inits it to 0)
+    if ".conv." in name and len(shape) == 1 and name.endswith(".weight"):
+        return (0.25, 1.0)            # BatchNorm weight (gamma)
+    return None
+
+
+# keys left at the module's own initial value (the fiducial lattice lives in this bias)
+G1_KEEP = ("LocalizationNetwork.localization_fc2.bias", "GridGenerator.inv_delta_C",
+           "GridGenerator.P_hat")
+
+
+def synth_state(module_state, seed, rule=None, keep=()):
+    """name -> np.ndarray for every float tensor of a state_dict except `keep` (and integer
+    buffers such as num_batches_tracked, which are left alone)."""
+    shapes = {k: tuple(v.shape) for k, v in module_state.items()
+              if k not in keep and not k.endswith("num_batches_tracked")}
+    return synth.state_dict_like(shapes, seed, rule)

@@ -1,0 +1,180 @@
+"""-m gpu parity tests of the warp hot path, through the C ABI (tps_pp_amd.ops -> libtpspp_hip.so).
+
+Bars (BASELINE.json north_star): sampling grid and corner indices BIT-EXACT, warped tensors within
+1e-4 of the reference -- in fact every comparison below is bit-for-bit, against
+  (a) the committed golden outputs of the reference itself (tests/golden/*.npz), and
+  (b) the CPU oracle on fresh seeded inputs, including ragged / edge shapes.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from tps_pp_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north-star tolerance for warped values (we assert 0 where noted)
+
+
+def dev(a, cuda):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_biteq(a, b, what):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.dtype == np.float32:
+        ne = bits(a) != bits(b)
+    else:
+        ne = a != b
+    assert not ne.any(), f"{what}: {int(ne.sum())} of {ne.size} elements differ, " \
+                         f"max abs {np.abs(a.astype(np.float64) - b.astype(np.float64)).max():.3e}"
+
+
+# ---------------------------------------------------------------- golden: classic (G2) -----------
+def test_classic_warp_matches_reference_golden(cuda):
+    K = cases.load("constants")
+    G = cases.load("classic_warp")
+    inp = cases.g2_inputs()
+    inv, P_hat = dev(K["classic_inv_delta_C"], cuda), dev(K["classic_P_hat"], cuda)
+    for key_in, key_out in (("img", "out"), ("img_smooth", "out_smooth")):
+        out, _, grid, idx = ops.warp(dev(inp[key_in], cuda), dev(inp["ctrl"], cuda), inv, P_hat,
+                                     cases.CL_HW, want_grid=True, want_idx=True)
+        assert_biteq(grid, G["grid"], "grid vs reference bmm")
+        assert np.abs(out.cpu().numpy() - G[key_out]).max() <= TOL
+        assert_biteq(out, G[key_out], f"warped {key_in} vs reference grid_sample")
+
+
+def test_unfused_pieces_match_reference_golden(cuda):
+    K = cases.load("constants")
+    G = cases.load("classic_warp")
+    inp = cases.g2_inputs()
+    T = ops.solve_T(dev(K["classic_inv_delta_C"], cuda), dev(inp["ctrl"], cuda))
+    grid = ops.build_grid(dev(K["classic_P_hat"], cuda), T)
+    assert_biteq(grid, G["grid"], "build_grid")
+    out, idx = ops.grid_sample(dev(inp["img"], cuda),
+                               grid.reshape(cases.CL_N, *cases.CL_HW, 2), return_idx=True)
+    assert_biteq(out, G["out"], "grid_sample")
+
+
+# ---------------------------------------------------------------- golden: TPS_PP warp (G3) -------
+def test_tpspp_warp_matches_reference_golden(cuda):
+    K = cases.load("constants")
+    G = cases.load("tpspp_warp")
+    inp = cases.g3_inputs()
+    P_xy = K["pp_P"].astype(np.float32)
+    out0, out1, grid, _ = ops.warp(dev(inp["feat_grid"], cuda), dev(inp["ctrl"], cuda),
+                                   dev(K["pp_hat_C"], cuda), dev(K["pp_P_hat"], cuda), cases.PP_HW,
+                                   P_xy=dev(P_xy, cuda), score=dev(inp["score"], cuda),
+                                   in1=dev(inp["x"], cuda), want_grid=True)
+    assert_biteq(grid, G["grid"], "TPS_PP grid vs reference")
+    assert_biteq(out0, G["output"], "TPS_PP output")
+    assert_biteq(out1, G["mp_img"], "TPS_PP mp_img")
+
+
+# ---------------------------------------------------------------- oracle on fresh inputs ---------
+@pytest.mark.parametrize("N,C,H,W,Ho,Wo,F,perturb", [
+    (1, 1, 32, 100, 32, 100, 20, 0.05),     # the reference's own test shape (test_ocr_preprocessor.py:19-29)
+    (5, 3, 32, 100, 32, 100, 20, 0.3),
+    (3, 3, 32, 128, 32, 128, 20, 0.1),      # nrtr_tps++.py's commented-out preprocessor geometry
+    (7, 2, 17, 33, 9, 21, 6, 0.5),          # ragged: generic-F kernel, odd sizes, tile tail
+    (2, 5, 8, 8, 40, 70, 10, 2.0),          # upsampling warp, mostly clamped to the border
+    (33, 3, 32, 100, 32, 100, 20, 0.05),    # > one image group
+    (2, 3, 2, 2, 4, 4, 4, 1.0),             # tiny planes
+    (2, 3, 1, 64, 8, 64, 8, 0.2),           # H == 1: y scale is 0
+])
+def test_classic_warp_vs_oracle(cuda, oracle, N, C, H, W, Ho, Wo, F, perturb):
+    Kc = oracle.classic_constants(F, (Ho, Wo))
+    ctrl = oracle.classic_initial_ctrl(F)[None] + perturb * synth.dyadic((N, F, 2), "t.ctrl", N)
+    img = synth.dyadic((N, C, H, W), "t.img", N + 1)
+    ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (Ho, Wo), want_grid=True,
+                      want_idx=True)
+    out, _, grid, idx = ops.warp(dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda),
+                                 dev(Kc["P_hat"], cuda), (Ho, Wo), want_grid=True, want_idx=True)
+    assert_biteq(grid, ref["grid"], "grid")
+    assert_biteq(idx, ref["idx"], "corner indices")
+    assert_biteq(out, ref["out0"], "warped")
+
+
+@pytest.mark.parametrize("N,point,hw,C0,C1,with_score", [
+    (3, (2, 16), (16, 64), 64, 64, True),
+    (2, (2, 16), (16, 64), 64, 64, False),
+    (4, (2, 8), (8, 32), 6, 3, True),       # generic-F path with score + second input
+    (1, (1, 5), (4, 10), 2, 1, True),
+])
+def test_tpspp_warp_vs_oracle(cuda, oracle, N, point, hw, C0, C1, with_score):
+    Kp = oracle.tpspp_constants(hw, point)
+    F = point[0] * point[1]
+    n = hw[0] * hw[1]
+    ctrl = oracle.tpspp_initial_ctrl(point)[None] + 0.1 * synth.dyadic((N, F, 2), "p.ctrl", N)
+    score = synth.dyadic((N, n, F), "p.score", N) if with_score else None
+    in0 = synth.dyadic((N, C0, 2 * hw[0], 2 * hw[1]), "p.in0", N)
+    in1 = synth.dyadic((N, C1) + tuple(hw), "p.in1", N)
+    ref = oracle.warp(in0, ctrl, Kp["hat_C"], Kp["P_hat"], hw, P_xy=Kp["P_xy"], score=score,
+                      in1=in1, want_grid=True, want_idx=True)
+    out0, out1, grid, idx = ops.warp(dev(in0, cuda), dev(ctrl, cuda), dev(Kp["hat_C"], cuda),
+                                     dev(Kp["P_hat"], cuda), hw, P_xy=dev(Kp["P_xy"], cuda),
+                                     score=dev(score, cuda), in1=dev(in1, cuda), want_grid=True,
+                                     want_idx=True)
+    assert_biteq(grid, ref["grid"], "grid")
+    assert_biteq(idx, ref["idx"], "corner indices")
+    assert_biteq(out0, ref["out0"], "out0")
+    assert_biteq(out1, ref["out1"], "out1")
+
+
+def test_launch_shape_does_not_change_results(cuda, oracle):
+    Kc = oracle.classic_constants(20, (32, 100))
+    N = 19
+    ctrl = oracle.classic_initial_ctrl(20)[None] + 0.2 * synth.dyadic((N, 20, 2), "l.ctrl")
+    img = synth.dyadic((N, 3, 32, 100), "l.img")
+    ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (32, 100))["out0"]
+    args = (dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), dev(Kc["P_hat"], cuda),
+            (32, 100))
+    try:
+        for G, tpb in [(1, 64), (2, 128), (3, 192), (8, 256), (16, 256), (32, 64)]:
+            ops.set_warp_tuning(G, tpb)
+            assert_biteq(ops.warp(*args)[0], ref, f"G={G} tpb={tpb}")
+    finally:
+        ops.set_warp_tuning(0, 0)
+
+
+def test_full_size_batch512_properties(cuda, oracle):
+    """BASELINE.json configs[1] at full size: batch 512, 3x32x100, F=20.
+    (i) identity control points => the warp is the identity map up to fp32 grid rounding;
+    (ii) sample of images checked bit-for-bit against the oracle;
+    (iii) linearity: warp(a*x + y) == a*warp(x) + warp(y) to rounding (same grid)."""
+    N = 512
+    Kc = oracle.classic_constants(20, (32, 100))
+    inv, P_hat = dev(Kc["inv_delta_C"], cuda), dev(Kc["P_hat"], cuda)
+    img = synth.smooth_image((N, 3, 32, 100), "f.img")
+    ident = np.broadcast_to(cases.classic_identity_ctrl(20), (N, 20, 2)).copy()
+    out, _, grid, _ = ops.warp(dev(img, cuda), dev(ident, cuda), inv, P_hat, (32, 100), want_grid=True)
+    P = Kc["P"].astype(np.float32)
+    assert np.abs(grid.cpu().numpy() - P[None]).max() < 2e-5
+    assert np.abs(out.cpu().numpy() - img).max() < 2e-3
+    ctrl = ident + 0.05 * synth.dyadic((N, 20, 2), "f.ctrl")
+    x, y = synth.dyadic((N, 3, 32, 100), "f.x"), synth.dyadic((N, 3, 32, 100), "f.y")
+    ox = ops.warp(dev(x, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100))[0].cpu().numpy()
+    oy = ops.warp(dev(y, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100))[0].cpu().numpy()
+    oz = ops.warp(dev(0.5 * x + y, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100))[0].cpu().numpy()
+    assert np.abs(oz - (0.5 * ox + oy)).max() < 1e-5
+    sel = np.array([0, 1, 63, 64, 255, 256, 300, 511])
+    ref = oracle.warp(x[sel], ctrl[sel], Kc["inv_delta_C"], Kc["P_hat"], (32, 100))["out0"]
+    assert_biteq(ox[sel], ref, "batch-512 sample vs oracle")
+
+
+def test_bad_arguments_fail_loudly(cuda):
+    from tps_pp_amd import _lib
+    with pytest.raises(_lib.TpsppError):
+        ops.warp(torch.zeros(1, 1, 4, 4), torch.zeros(1, 4, 2), torch.zeros(7, 7), torch.zeros(16, 7),
+                 (4, 4))          # CPU tensors: no fallback
+    z = lambda *s: torch.zeros(*s, device=cuda)
+    with pytest.raises(_lib.TpsppError):
+        ops.warp(z(1, 1, 4, 4), z(1, 70, 2), z(73, 73), z(16, 73), (4, 4))   # F + 3 > 64
+    with pytest.raises(ValueError):
+        ops.warp(z(1, 1, 4, 4), z(1, 4, 2), z(7, 7), z(15, 7), (4, 4))       # P_hat rows != n

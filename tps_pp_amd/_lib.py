@@ -1,0 +1,62 @@
+"""ctypes binding of libtpspp_hip.so (C ABI: include/tpspp.h).
+
+The product has no fallback: if the library is missing or fails to load, importing an op raises.
+PyTorch is used only for device memory and streams -- tensors cross this boundary as raw pointers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtpspp_hip.so")
+ABI_VERSION = 1
+
+_f = ctypes.c_void_p       # device pointers travel as integers
+_i = ctypes.c_int
+
+_SIGNATURES = {
+    "tpspp_abi_version": ([], _i),
+    "tpspp_last_error": ([], ctypes.c_char_p),
+    "tpspp_solve_T": ([_f, _f, _i, _i, _f, _f], _i),
+    "tpspp_build_grid": ([_f, _i, _f, _f, _f, _i, _i, _i, _f, _f], _i),
+    "tpspp_grid_sample": ([_f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f], _i),
+    "tpspp_warp_fwd": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i,
+                        _f, _f, _f, _f, _f], _i),
+    "tpspp_warp_set_tuning": ([_i, _i], _i),
+}
+
+_lib = None
+
+
+class TpsppError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names include/tpspp.h declares (kept in sync by tests/test_capi_symbols.py)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded library; raises if it is absent (build it: `python -m tps_pp_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TpsppError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m tps_pp_amd.build`). There is no CPU or PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError if the ABI lost a symbol
+            fn.argtypes = argtypes
+            fn.restype = restype
+        got = L.tpspp_abi_version()
+        if got != ABI_VERSION:
+            raise TpsppError(f"libtpspp_hip.so ABI {got} != binding ABI {ABI_VERSION}: rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().tpspp_last_error().decode("utf-8", "replace")
+        raise TpsppError(f"{what} failed ({rc}): {msg}")

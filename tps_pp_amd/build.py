@@ -1,0 +1,58 @@
+"""Builds libtpspp_hip.so (the C-ABI library of include/tpspp.h) with hipcc for gfx950.
+
+In-tree build: the .so lands next to this file so that it travels with a `gpurun` snapshot and is
+visible to the driver's "which native code was loaded" check.  hipcc cross-compiles without a GPU.
+
+    python -m tps_pp_amd.build [--force] [--verbose]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtpspp_hip.so")
+ARCH = "gfx950"
+
+# -ffp-contract=off: hipcc's default (fast) would fuse a*b+c on its own; the parity contract
+# (include/tpspp.h) allows exactly the fmaf() calls written in the sources and nothing else.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(ROOT, "include", "tpspp.h"), os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libtpspp_hip.so")
+    tmp = LIB + ".tmp"
+    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC] + sources() + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout)
+    if verbose and r.stdout.strip():
+        print(r.stdout)
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True))

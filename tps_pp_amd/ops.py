@@ -1,0 +1,139 @@
+"""Tensor-level wrappers of the C ABI (include/tpspp.h).
+
+Each function mirrors one PyTorch call site of the reference (cited in the docstring) and hands raw
+device pointers + the current HIP stream to libtpspp_hip.so.  Inputs must be fp32 CUDA(HIP) tensors;
+anything else raises -- there is no eager / CPU fallback on purpose.
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(name, t, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.TpsppError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor "
+                              "(no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def solve_T(inv_delta_C, ctrl):
+    """torch.bmm(inv_delta_C.repeat(N,1,1), cat(ctrl, zeros(N,3,2)))  -> (N, F+3, 2)
+    (tps_preprocessor.py:273-280, tps_pp.py:484-494)."""
+    inv_delta_C, ctrl = _chk("inv_delta_C", inv_delta_C, 2), _chk("ctrl", ctrl, 3)
+    N, F, two = ctrl.shape
+    if two != 2 or tuple(inv_delta_C.shape) != (F + 3, F + 3):
+        raise ValueError("solve_T: shape mismatch")
+    T = torch.empty((N, F + 3, 2), device=ctrl.device, dtype=torch.float32)
+    with torch.cuda.device(ctrl.device):
+        rc = _lib.lib().tpspp_solve_T(_ptr(inv_delta_C), _ptr(ctrl), N, F, _ptr(T), _stream(ctrl))
+    _lib.check(rc, "tpspp_solve_T")
+    return T
+
+
+def build_grid(P_hat, T, P_xy=None, score=None):
+    """torch.bmm(batch_P_hat, T) -> (N, n, 2); with P_xy/score the TPS_PP form
+    `cat[1, P, P_hat*(score*0.5+1)] @ T` (tps_preprocessor.py:281, tps_pp.py:467-479,495)."""
+    P_hat, T = _chk("P_hat", P_hat, 2), _chk("T", T, 3)
+    N, K, _ = T.shape
+    F, n = K - 3, P_hat.shape[0]
+    if P_xy is not None:
+        P_xy = _chk("P_xy", P_xy, 2)
+    if score is not None:
+        score = _chk("score", score, 3)
+        if tuple(score.shape) != (N, n, F):
+            raise ValueError("build_grid: score must be (N, n, F)")
+    if P_hat.shape[1] != (F if P_xy is not None else F + 3):
+        raise ValueError("build_grid: P_hat has the wrong number of columns")
+    grid = torch.empty((N, n, 2), device=T.device, dtype=torch.float32)
+    with torch.cuda.device(T.device):
+        rc = _lib.lib().tpspp_build_grid(_ptr(P_hat), P_hat.shape[1], _ptr(P_xy), _ptr(score),
+                                         _ptr(T), N, n, F, _ptr(grid), _stream(T))
+    _lib.check(rc, "tpspp_build_grid")
+    return grid
+
+
+def grid_sample(inp, grid, return_idx=False):
+    """F.grid_sample(inp, grid, mode='bilinear', padding_mode='border', align_corners=True)
+    (tps_preprocessor.py:79-83, tps_pp.py:606-615).  grid: (N, Ho, Wo, 2)."""
+    inp, grid = _chk("input", inp, 4), _chk("grid", grid, 4)
+    N, C, H, W = inp.shape
+    if grid.shape[0] != N or grid.shape[3] != 2:
+        raise ValueError("grid_sample: grid must be (N, Ho, Wo, 2)")
+    Ho, Wo = int(grid.shape[1]), int(grid.shape[2])
+    out = torch.empty((N, C, Ho, Wo), device=inp.device, dtype=torch.float32)
+    idx = torch.empty((N, Ho * Wo, 2), device=inp.device, dtype=torch.int32) if return_idx else None
+    with torch.cuda.device(inp.device):
+        rc = _lib.lib().tpspp_grid_sample(_ptr(inp), _ptr(grid), N, C, H, W, Ho, Wo, _ptr(out),
+                                          _ptr(idx), _stream(inp))
+    _lib.check(rc, "tpspp_grid_sample")
+    return (out, idx) if return_idx else out
+
+
+def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
+         want_grid=False, want_idx=False, out0=None, out1=None):
+    """Fused build_P_prime + grid_sample(s): one kernel, T in LDS, grid in registers.
+
+    Returns (out0, out1 | None, grid | None, idx | None).
+    classic:  in0 = image, P_hat = GridGenerator.P_hat (n, F+3)     (tps_preprocessor.py:71-83)
+    TPS_PP :  in0 = feat_grid, in1 = x, P_hat (n, F) + P_xy (n, 2) + score (N, n, F)
+                                                                     (tps_pp.py:597-615)
+    """
+    in0, ctrl = _chk("in0", in0, 4), _chk("ctrl", ctrl, 3)
+    inv_delta_C, P_hat = _chk("inv_delta_C", inv_delta_C, 2), _chk("P_hat", P_hat, 2)
+    N, C0, H0, W0 = in0.shape
+    F = int(ctrl.shape[1])
+    Ho, Wo = int(out_hw[0]), int(out_hw[1])
+    n = Ho * Wo
+    if ctrl.shape[0] != N or ctrl.shape[2] != 2:
+        raise ValueError("warp: ctrl must be (N, F, 2)")
+    if tuple(inv_delta_C.shape) != (F + 3, F + 3):
+        raise ValueError("warp: inv_delta_C must be (F+3, F+3)")
+    if P_xy is not None:
+        P_xy = _chk("P_xy", P_xy, 2)
+        if tuple(P_xy.shape) != (n, 2):
+            raise ValueError("warp: P_xy must be (n, 2)")
+    if tuple(P_hat.shape) != (n, F if P_xy is not None else F + 3):
+        raise ValueError(f"warp: P_hat has shape {tuple(P_hat.shape)}")
+    if score is not None:
+        score = _chk("score", score, 3)
+        if tuple(score.shape) != (N, n, F):
+            raise ValueError("warp: score must be (N, n, F)")
+    C1 = H1 = W1 = 0
+    if in1 is not None:
+        in1 = _chk("in1", in1, 4)
+        if in1.shape[0] != N:
+            raise ValueError("warp: in1 batch mismatch")
+        _, C1, H1, W1 = in1.shape
+    dev = in0.device
+    if out0 is None:
+        out0 = torch.empty((N, C0, Ho, Wo), device=dev, dtype=torch.float32)
+    if in1 is not None and out1 is None:
+        out1 = torch.empty((N, C1, Ho, Wo), device=dev, dtype=torch.float32)
+    grid = torch.empty((N, n, 2), device=dev, dtype=torch.float32) if want_grid else None
+    idx = torch.empty((N, n, 2), device=dev, dtype=torch.int32) if want_idx else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().tpspp_warp_fwd(_ptr(in0), C0, H0, W0, _ptr(in1), C1, H1, W1, _ptr(ctrl),
+                                       _ptr(score), _ptr(inv_delta_C), _ptr(P_hat), P_hat.shape[1],
+                                       _ptr(P_xy), N, F, Ho, Wo, _ptr(out0), _ptr(out1),
+                                       _ptr(grid), _ptr(idx), _stream(in0))
+    _lib.check(rc, "tpspp_warp_fwd")
+    return out0, out1, grid, idx
+
+
+def set_warp_tuning(images_per_group=0, threads_per_group=0):
+    _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group)),
+               "tpspp_warp_set_tuning")
