@@ -73,11 +73,33 @@ int tpspp_grid_sample(const float* in, const float* grid, int N, int C, int H, i
                       int Wo, float* out, int32_t* idx_or_null, tpspp_stream_t stream);
 
 /*
+ * p_hat_t[c, p] = p_hat[p, c]: the batch-shared RBF table transposed to (cols, n) so that a wavefront
+ * whose lanes own consecutive output pixels reads it fully coalesced.  One-off preparation (the
+ * table is a module buffer); cols = F+3 (classic layout) or F (TPS_PP layout).
+ */
+int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, int cols, float* p_hat_t,
+                          tpspp_stream_t stream);
+
+/*
+ * Does the HOST copy of a classic-layout table (n = Ho*Wo rows of [1, P.x, P.y, rbf_0..rbf_{F-1}])
+ * have the exact (bitwise) 4-fold mirror symmetry of the reference's constants?  Returns 1 / 0.
+ * When 1, pass TPSPP_TABLE_MIRROR4 to tpspp_warp_fwd: one table row then serves four output pixels.
+ * (GridGenerator's table always has it: fiducials on the top/bottom edges at mirrored abscissae,
+ * tps_preprocessor.py:197-211, pixel centres mirrored about the image centre, :242-253.)
+ */
+int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, int Wo, int F);
+
+#define TPSPP_TABLE_MIRROR4 1   /* table_flags bit: symmetry verified by the caller */
+
+/*
  * The fused hot path: T-solve -> grid -> bilinear warp of in0 (and in1 when non-NULL) in ONE kernel;
  * T lives in LDS and the grid in registers, neither touches HBM unless grid_or_null is given.
  *   in0 (N,C0,H0,W0) -> out0 (N,C0,Ho,Wo);  in1 (N,C1,H1,W1) -> out1 (N,C1,Ho,Wo)  [optional]
  *   ctrl (N,F,2); score (N,Ho*Wo,F) or NULL; inv_delta_c (F+3,F+3); p_hat / p_hat_ld / p_xy as in
- *   tpspp_build_grid; grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
+ *   tpspp_build_grid; p_hat_t_or_null = tpspp_transpose_p_hat(p_hat) (same values, enables the
+ *   coalesced / LDS-staged fast kernels; NULL selects the generic kernel -- identical results);
+ *   table_flags: 0 or TPSPP_TABLE_MIRROR4 (only meaningful with p_hat_t, never changes results);
+ *   grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
  * replaces: GridGenerator.build_P_prime + F.grid_sample   tps_preprocessor.py:71-83
  *           Attention_Enhanced_TPS.build_P_prime + 2x F.grid_sample   tps_pp.py:597-615
  */
@@ -85,15 +107,25 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                    const float* in1, int C1, int H1, int W1,
                    const float* ctrl, const float* score,
                    const float* inv_delta_c, const float* p_hat, int p_hat_ld, const float* p_xy,
-                   int N, int F, int Ho, int Wo,
+                   const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
                    float* out0, float* out1, float* grid_or_null, int32_t* idx_or_null,
                    tpspp_stream_t stream);
 
 /*
  * Launch-shape override for tpspp_warp_fwd (tuning / benchmarking only; results do not depend on
- * it): images per workgroup and threads per workgroup; 0 = built-in heuristic.
+ * it): images per workgroup and threads per workgroup of the gather kernel (0 = heuristic), and
+ * kernel choice: 0 = automatic, 1 = force the gather kernel, 2 = require the LDS-staged kernel
+ * (TPSPP_EINVAL if the shape does not qualify), 3 = as 2 but ignore TPSPP_TABLE_MIRROR4; bands = workgroups per image pair in the LDS-staged
+ * kernel (0 = heuristic).
  */
-int tpspp_warp_set_tuning(int images_per_group, int threads_per_group);
+int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);
+
+/*
+ * Diagnostics: when device_buf is non-NULL the LDS-staged kernel writes 8 int64 shader-clock stamps
+ * per workgroup (start, T ready, grid expanded, images in LDS, stores retired, DMA issued, DMA
+ * landed, unused) into device_buf[workgroup * 8 + i].  NULL (default) disables it.
+ */
+int tpspp_warp_set_trace(long long* device_buf);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ def main():
     if not a.pp:
         K = constants.classic(20, (32, 100))
         inv, P_hat = torch.from_numpy(K["inv_delta_C"]).to(dev), torch.from_numpy(K["P_hat"]).to(dev)
+        P_hat_t = ops.transpose_p_hat(P_hat)
         hw, F = (32, 100), 20
         bytes_per_img = 3 * 32 * 100 * 4 * 2 + F * 2 * 4
         nbuf = 16
@@ -37,7 +38,8 @@ def main():
 
         def run(i):
             j = i % nbuf
-            ops.warp(ins[j], ctrls[j], inv, P_hat, hw, out0=outs[j])
+            ops.warp(ins[j], ctrls[j], inv, P_hat, hw, out0=outs[j], P_hat_t=P_hat_t,
+                     table_flags=ops.TABLE_MIRROR4)
     else:
         K = constants.tpspp((16, 64), (2, 16))
         inv, P_hat, P_xy = (torch.from_numpy(K[k]).to(dev) for k in ("hat_C", "P_hat", "P_xy"))
@@ -60,9 +62,11 @@ def main():
                      out0=o0[j], out1=o1[j])
 
     print(f"batch {N}  bytes/img {bytes_per_img}  per launch {bytes_per_img * N / 1e6:.1f} MB")
-    for G in (0, 1, 2, 4, 8, 16, 32):
-        for tpb in (64, 128, 256):
-            ops.set_warp_tuning(G, tpb)
+    configs = [(0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 3, 1), (0, 0, 3, 2)] if not a.pp else []
+    configs += [(G, tpb, 1, 0) for G in (0, 8) for tpb in (256,)]
+    for G, tpb, kern, bands in configs:
+        if True:
+            ops.set_warp_tuning(G, tpb, kern, bands)
             for i in range(20):
                 run(i)
             torch.cuda.synchronize()
@@ -73,9 +77,9 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.iters
-            print(f"G={G:2d} tpb={tpb:3d}: {us:8.2f} us/launch  {N / us:8.2f} Mimg/s  "
+            print(f"kernel={kern} bands={bands} G={G:2d} tpb={tpb:3d}: {us:8.2f} us/launch  {N / us:8.2f} Mimg/s  "
                   f"{bytes_per_img * N / us / 1e6:6.3f} TB/s  ({bytes_per_img * N / us / 1e6 / 8.0 * 100:.1f}% of 8 TB/s)")
-    ops.set_warp_tuning(0, 0)
+    ops.set_warp_tuning(0, 0, 0, 0)
 
 
 if __name__ == "__main__":

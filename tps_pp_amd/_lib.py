@@ -19,9 +19,12 @@ _SIGNATURES = {
     "tpspp_solve_T": ([_f, _f, _i, _i, _f, _f], _i),
     "tpspp_build_grid": ([_f, _i, _f, _f, _f, _i, _i, _i, _f, _f], _i),
     "tpspp_grid_sample": ([_f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f], _i),
-    "tpspp_warp_fwd": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _i, _i, _i, _i,
+    "tpspp_transpose_p_hat": ([_f, _i, _i, _i, _f, _f], _i),
+    "tpspp_table_mirror_symmetry": ([_f, _i, _i, _i, _i], _i),
+    "tpspp_warp_fwd": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i,
                         _f, _f, _f, _f, _f], _i),
-    "tpspp_warp_set_tuning": ([_i, _i], _i),
+    "tpspp_warp_set_tuning": ([_i, _i, _i, _i], _i),
+    "tpspp_warp_set_trace": ([_f], _i),
 }
 
 _lib = None

@@ -21,6 +21,9 @@
 // Compiled with -ffp-contract=off: the ONLY fused operations are the explicit fmaf() below.
 #include "tpspp_common.h"
 
+#include <cstring>
+#include <type_traits>
+
 namespace {
 
 constexpr int kWave = 64;
@@ -34,6 +37,7 @@ struct WarpParams {
     const float* inv_delta_c;
     const float* p_hat; int p_hat_ld;
     const float* p_xy;
+    const float* p_hat_t; // (cols, n) transposed copy of p_hat or nullptr
     int N, F, n;          // n = Ho*Wo
     float* out0; float* out1; float* grid; int32_t* idx;
     int G;                // images per workgroup
@@ -181,16 +185,23 @@ tps_warp_kernel(const WarpParams P)
     float r0 = 1.0f, r1, r2;
     {
         const float* ph = P.p_hat + (size_t)pc * P.p_hat_ld;
+        const float* pt = P.p_hat_t ? P.p_hat_t + pc : nullptr;   // column pc of (cols, n): coalesced
         if (PXY) {
             const float2 xy = reinterpret_cast<const float2*>(P.p_xy)[pc];
             r1 = xy.x; r2 = xy.y;
         } else {
-            r0 = ph[0]; r1 = ph[1]; r2 = ph[2];
+            if (pt) { r0 = pt[0]; r1 = pt[P.n]; r2 = pt[2 * (size_t)P.n]; pt += 3 * (size_t)P.n; }
+            else    { r0 = ph[0]; r1 = ph[1]; r2 = ph[2]; }
             ph += 3;
         }
         if (FCT > 0) {
+            if (pt) {
 #pragma unroll
-            for (int k = 0; k < FR; ++k) rbf[k] = ph[k];
+                for (int k = 0; k < FR; ++k) rbf[k] = pt[(size_t)k * P.n];
+            } else {
+#pragma unroll
+                for (int k = 0; k < FR; ++k) rbf[k] = ph[k];
+            }
         }
     }
 
@@ -335,7 +346,510 @@ grid_sample_kernel(const float* __restrict__ in, const float* __restrict__ grid,
     sample_planes(in + (size_t)b * C * H * W, out + (size_t)b * C * n + p, C, H * W, n, t);
 }
 
-int g_tune_G = 0, g_tune_tpb = 0;
+
+// ---- LDS-staged kernel: small single-input images (classic TPS-STN, 2*C*H*W*4 B <= ~150 KB) -------
+// One workgroup rectifies TWO images (adjacent in memory) with specialised wavefronts:
+//   * loader wavefronts (the last kLdsLoaders of the group) do nothing but stream the image pair
+//     HBM -> LDS with global_load_lds_dwordx4 (1 KB per wavefront instruction, no register round
+//     trip), all of it issued in the first few hundred cycles;
+//   * compute wavefronts solve T (wavefronts 0 and 1, one image each), expand the sampling grid of
+//     their pixels for BOTH images from the transposed P_hat (one coalesced 256-B row segment per
+//     instruction; each value feeds four FMA chains: x/y of image A and of image B) while the images
+//     are still in flight, then take the bilinear taps from LDS and store fully coalesced rows.
+// vmcnt retires in order per wavefront; keeping the long-latency image fetch in other wavefronts
+// than the P_hat reads is what lets the grid expansion overlap the HBM latency.
+// Every input byte crosses HBM -> CU exactly once.
+struct LdsParams {
+    const float* in; int C, H, W;
+    const float* ctrl; const float* inv_delta_c; const float* p_hat_t;
+    int N, n, Ho, Wo;
+    float* out; float* grid; int32_t* idx;
+    int compute_waves;  // wavefronts [0, compute_waves) own pixels, the rest load
+    int band_px;        // output pixels per band (a workgroup = one image pair x one band)
+    int bands;
+    long long* trace;   // optional: 8 shader-clock stamps per workgroup (tpspp_warp_set_trace)
+};
+
+__device__ __forceinline__ void stamp(long long* trace, int slot)
+{
+    if (trace && (threadIdx.x & (kWave - 1)) == 0) {
+        trace[(size_t)blockIdx.x * 8 + slot] = (long long)__builtin_amdgcn_s_memtime();
+        // slot 7: chip-wide 100 MHz wall clock at workgroup start (slot 0) -> dispatch skew
+        if (slot == 0) trace[(size_t)blockIdx.x * 8 + 7] = (long long)wall_clock64();
+    }
+}
+
+// compile-time loop: every index is a constant, so register arrays stay in registers
+template <int N, int I = 0, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+constexpr int kLdsMaxWaves = 16;
+constexpr int kLdsLoaders = 3;
+constexpr int kLdsFirstBurst = 8;   // DMA pieces per loader issued before the T barrier
+
+// Workgroup barrier that orders LDS traffic only: outstanding global loads and LDS-DMA keep flying
+// (a __syncthreads() would also drain vmcnt).
+__device__ __forceinline__ void lds_only_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+constexpr int kPrefetchK = 4;   // P_hat^T rows fetched before T is known (hides one L2 round trip)
+
+// HC/WC: input height/width known at compile time (0 = read them from the parameters)
+template <int F, int C, int PPT, int HC, int WC>
+__global__ void __launch_bounds__(kLdsMaxWaves * kWave, (PPT <= 2 ? 8 : 4))   // PPT <= 2: two groups per CU
+tps_warp_lds_kernel(const LdsParams P)
+{
+    constexpr int K = F + 3;
+    const int H = HC > 0 ? HC : P.H;
+    const int W = WC > 0 ? WC : P.W;
+    constexpr int PF = kPrefetchK < K ? kPrefetchK : K;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [ sT: K x float4 (TxA,TyA,TxB,TyB) | sInv: K*K (padded) | image pair, contiguous, + slack ]
+    float4* sT = reinterpret_cast<float4*>(smem);
+    float* sInv = smem + 4 * K;
+    float* sImg = sInv + ((K * K + 3) & ~3);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    // band-major block order: the bands of one pair are `npairs` blocks apart, i.e. on the same XCD
+    // whenever npairs % 8 == 0, so the second band's image fetch hits that XCD's L2
+    const int npairs = (P.N + 1) >> 1;
+    const int band = blockIdx.x / npairs;
+    const int pair = blockIdx.x - band * npairs;
+    const int b0 = pair * 2;
+    const bool hasB = (b0 + 1) < P.N;
+    const int HW = H * W;
+    const int img_elems = C * HW;                          // multiple of 4 (checked on the host)
+
+    if (wv == 0) stamp(P.trace, 0);
+    if (wv >= P.compute_waves) {
+        // ================= loader wavefronts =================
+        const int total_bytes = (hasB ? 2 : 1) * img_elems * 4;
+        const int pieces = (total_bytes + 1023) >> 10;
+        const char* src = reinterpret_cast<const char*>(P.in + (size_t)b0 * img_elems);
+        auto dma = [&](int piece) {
+            int off = piece * 1024 + lane * 16;
+            if (off >= total_bytes) off = 0;               // tail lanes re-read a valid address
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + off),
+                (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sImg) + piece * 1024),
+                16, 0, 0);
+        };
+        // a first burst that the memory queue accepts without stalling the issue, then the group's
+        // T barrier (so the compute wavefronts are not held up behind a full queue), then the rest
+        int piece = wv - P.compute_waves;
+        for (int i = 0; i < kLdsFirstBurst && piece < pieces; ++i, piece += kLdsLoaders) dma(piece);
+        lds_only_barrier();      // matches the T barrier of the compute wavefronts
+        for (; piece < pieces; piece += kLdsLoaders) dma(piece);
+        if (wv == P.compute_waves) stamp(P.trace, 5);            // DMA issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wv == P.compute_waves) stamp(P.trace, 6);            // DMA landed
+        __syncthreads();         // this wavefront's DMA has landed; release the group
+        return;
+    }
+
+    // ================= compute wavefronts =================
+    const int tpc = P.compute_waves * kWave;               // pixel stride between a thread's slots
+    const int band_lo = band * P.band_px;
+    const int band_hi = min(P.n, band_lo + P.band_px);
+
+    // ---- T-solve inputs: wavefront 0 -> image A, wavefront 1 -> image B; lane i owns row i ----
+    // inv_delta_C is read COALESCED (every workgroup of the launch wants these same 2 KB at the same
+    // moment: a row-per-lane read would put ~20x more requests on the few L2 lines that hold them)
+    // and turned into one row per lane through LDS.  Both wavefronts write identical values.
+    constexpr int KK = K * K;
+    constexpr int NINV = (KK + kWave - 1) / kWave;
+    float invv[NINV];
+    float cx = 0.0f, cy = 0.0f;                            // rows F..F+2 of [C';0] stay zero
+    if (wv < 2) {
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            invv[i] = P.inv_delta_c[e < KK ? e : KK - 1];
+        }
+        if (lane < F) {
+            const int b = (wv == 1 && hasB) ? b0 + 1 : b0;
+            const float2 c = reinterpret_cast<const float2*>(P.ctrl + (size_t)b * F * 2)[lane];
+            cx = c.x; cy = c.y;
+        }
+    }
+
+    // ---- this thread's pixels; first P_hat^T rows requested before T exists ----
+    // (pixel index kept as an unsigned BYTE offset: loads and stores then use the scalar-base +
+    //  32-bit-VGPR-offset addressing mode and need no 64-bit address arithmetic on the VALU)
+    unsigned poff[PPT];
+    bool live[PPT];
+    float pre[PF][PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = band_lo + tid + j * tpc;
+        live[j] = p < band_hi;
+        poff[j] = 4u * (unsigned)(live[j] ? p : band_hi - 1);
+    }
+    const char* pht = reinterpret_cast<const char*>(P.p_hat_t);
+    const size_t row_bytes = (size_t)P.n * 4;
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            pre[k][j] = *reinterpret_cast<const float*>(pht + k * row_bytes + poff[j]);
+
+    if (wv < 2) {
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            if (e < KK) sInv[e] = invv[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes visible to own reads
+        const float* hrow = sInv + (lane < K ? lane : K - 1) * K;   // stride K is odd: no conflicts
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float hv = hrow[q];
+            ax = fmaf(hv, readlane_f(cx, q), ax);
+            ay = fmaf(hv, readlane_f(cy, q), ay);
+        }
+        if (lane < K) {
+            float* dst = reinterpret_cast<float*>(sT + lane) + 2 * wv;
+            dst[0] = ax; dst[1] = ay;
+        }
+    }
+    lds_only_barrier();
+    if (wv == 0) stamp(P.trace, 1);                               // T ready
+
+    // ---- sampling grid for both images: k-ascending FMA chains, T broadcast from LDS ----
+    float gxA[PPT], gyA[PPT], gxB[PPT], gyB[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) gxA[j] = gyA[j] = gxB[j] = gyB[j] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const float4 t = sT[k];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            gxA[j] = fmaf(pre[k][j], t.x, gxA[j]);
+            gyA[j] = fmaf(pre[k][j], t.y, gyA[j]);
+            gxB[j] = fmaf(pre[k][j], t.z, gxB[j]);
+            gyB[j] = fmaf(pre[k][j], t.w, gyB[j]);
+        }
+    }
+    // unroll 8 keeps 8*PPT independent coalesced row reads in flight; a full unroll makes the
+    // scheduler hoist every load and spill
+#pragma unroll 8
+    for (int k = PF; k < K; ++k) {
+        const float4 t = sT[k];
+        const char* row = pht + k * row_bytes;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const float ph = *reinterpret_cast<const float*>(row + poff[j]);
+            gxA[j] = fmaf(ph, t.x, gxA[j]);
+            gyA[j] = fmaf(ph, t.y, gyA[j]);
+            gxB[j] = fmaf(ph, t.z, gxB[j]);
+            gyB[j] = fmaf(ph, t.w, gyB[j]);
+        }
+    }
+
+    // pin the finished grid here (the optimiser would otherwise sink the chains below the barrier)
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) asm volatile("" : "+v"(gxA[j]), "+v"(gyA[j]), "+v"(gxB[j]), "+v"(gyB[j]));
+
+    // ---- the image pair must have landed (loaders wait on their DMA before this barrier) ----
+    if (wv == 0) stamp(P.trace, 2);                               // grid expanded
+    __syncthreads();
+    if (wv == 0) stamp(P.trace, 3);                               // images in LDS
+
+    // ---- bilinear taps from LDS, coalesced stores ----
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const bool store = live[j] && (im == 0 || hasB);
+            const int b = b0 + im;
+            const float gx = im ? gxB[j] : gxA[j], gy = im ? gyB[j] : gyA[j];
+            const Taps t = make_taps(gx, gy, H, W);
+            if (P.grid && store)
+                *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid + (size_t)b * P.n * 2) +
+                                           2 * poff[j]) = make_float2(gx, gy);
+            if (P.idx && store)
+                *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx + (size_t)b * P.n * 2) +
+                                         2 * poff[j]) = make_int2(t.x0, t.y0);
+            const float* img = sImg + im * img_elems;
+            char* o = reinterpret_cast<char*>(P.out + (size_t)b * C * P.n);   // wave-uniform base
+            const bool inxy = t.inx && t.iny;
+            float res[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* pl = img + c * HW;
+                // the east neighbour is read unconditionally (the staged pair is followed by
+                // slack) and masked afterwards; o10 is already clamped to the last row
+                const float v00 = pl[t.o00];
+                float v01 = pl[t.o00 + 1];
+                float v10 = pl[t.o10];
+                float v11 = pl[t.o10 + 1];
+                v01 = t.inx ? v01 : 0.0f;
+                v10 = t.iny ? v10 : 0.0f;
+                v11 = inxy ? v11 : 0.0f;
+                float acc = v00 * t.nw;
+                acc = fmaf(v01, t.ne, acc);
+                acc = fmaf(v10, t.sw, acc);
+                acc = fmaf(v11, t.se, acc);
+                res[c] = acc;
+            }
+            if (store) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    *reinterpret_cast<float*>(o + c * row_bytes + poff[j]) = res[c];
+            }
+        }
+    }
+    if (wv == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(P.trace, 4);                                        // this wavefront's stores retired
+    }
+}
+
+// ---- LDS-staged kernel, mirror-symmetric table --------------------------------------------------
+// The reference's RBF table has an exact 4-fold mirror symmetry (the fiducials sit symmetrically on
+// the top/bottom edges, the pixel centres symmetrically in the rectified image):
+//     row(Ho-1-r, c)   = [1,  P.x, -P.y, rbf[(k + F/2) mod F]]
+//     row(r, Wo-1-c)   = [1, -P.x,  P.y, rbf[mirror of k inside its half]]
+// bit for bit in fp32 (the caller verifies that on the host before passing TPSPP_TABLE_MIRROR4).
+// A thread therefore loads ONE table row (F+3 coalesced reads, issued at kernel entry) and expands
+// the grid of its FOUR mirror pixels for BOTH images of the pair: 16 FMA chains per loaded value
+// instead of 4, i.e. a quarter of the table traffic through the vector memory pipeline, which is
+// what bounds the un-mirrored kernel at batch 512 (two images per CU against a 294 KB table).
+// Each chain is still the k-ascending fp32 FMA chain from zero of its own pixel.
+template <int F>
+__device__ __forceinline__ constexpr int perm_y(int k) { return (k + F / 2) % F; }
+template <int F>
+__device__ __forceinline__ constexpr int perm_x(int k) { return k < F / 2 ? F / 2 - 1 - k : F + F / 2 - 1 - k; }
+
+template <int F, int C, int HC, int WC>
+__global__ void __launch_bounds__(kLdsMaxWaves * kWave)
+tps_warp_lds_mirror_kernel(const LdsParams P)
+{
+    constexpr int K = F + 3;
+    const int H = HC > 0 ? HC : P.H;
+    const int W = WC > 0 ? WC : P.W;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* sT = reinterpret_cast<float4*>(smem);          // K x (TxA, TyA, TxB, TyB)
+    float* sInv = smem + 4 * K;                            // K*K (padded to 4)
+    float* sImg = sInv + ((K * K + 3) & ~3);               // image pair, contiguous, + slack
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int npairs = (P.N + 1) >> 1;
+    const int band = blockIdx.x / npairs;                  // band-major: see tps_warp_lds_kernel
+    const int pair = blockIdx.x - band * npairs;
+    const int b0 = pair * 2;
+    const bool hasB = (b0 + 1) < P.N;
+    const int HW = H * W;
+    const int img_elems = C * HW;
+
+    if (wv == 0) stamp(P.trace, 0);
+    if (wv >= P.compute_waves) {
+        // ================= loader wavefronts =================
+        const int total_bytes = (hasB ? 2 : 1) * img_elems * 4;
+        const int pieces = (total_bytes + 1023) >> 10;
+        const char* src = reinterpret_cast<const char*>(P.in + (size_t)b0 * img_elems);
+        auto dma = [&](int piece) {
+            int off = piece * 1024 + lane * 16;
+            if (off >= total_bytes) off = 0;               // tail lanes re-read a valid address
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + off),
+                (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sImg) + piece * 1024),
+                16, 0, 0);
+        };
+        int piece = wv - P.compute_waves;
+        for (int i = 0; i < kLdsFirstBurst && piece < pieces; ++i, piece += kLdsLoaders) dma(piece);
+        lds_only_barrier();      // matches the T barrier of the compute wavefronts
+        for (; piece < pieces; piece += kLdsLoaders) dma(piece);
+        if (wv == P.compute_waves) stamp(P.trace, 5);            // DMA issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wv == P.compute_waves) stamp(P.trace, 6);            // DMA landed
+        __syncthreads();
+        return;
+    }
+
+    // ================= compute wavefronts =================
+    // this thread's quadrant pixel (r, c), r < Ho/2, c < Wo/2, and its three mirror images
+    const int halfW = P.Wo >> 1;
+    const int nq = (P.Ho >> 1) * halfW;
+    const int q_hi = min(nq, (band + 1) * P.band_px);
+    const int qp_raw = band * P.band_px + tid;
+    const bool live = qp_raw < q_hi;
+    const int qp = live ? qp_raw : q_hi - 1;
+    const int r = qp / halfW, c = qp - r * halfW;
+    unsigned poff[4];                                      // byte offsets of the 4 pixels in a plane
+    poff[0] = 4u * (unsigned)(r * P.Wo + c);                           // (r, c)
+    poff[1] = 4u * (unsigned)(r * P.Wo + (P.Wo - 1 - c));              // x-mirror
+    poff[2] = 4u * (unsigned)((P.Ho - 1 - r) * P.Wo + c);              // y-mirror
+    poff[3] = 4u * (unsigned)((P.Ho - 1 - r) * P.Wo + (P.Wo - 1 - c)); // both
+
+    // ---- T-solve inputs: wavefront 0 -> image A, wavefront 1 -> image B; lane i owns row i ----
+    // inv_delta_C is read COALESCED (every workgroup of the launch wants these same 2 KB at the same
+    // moment: a row-per-lane read would put ~20x more requests on the few L2 lines that hold them)
+    // and turned into one row per lane through LDS.  Both wavefronts write identical values.
+    constexpr int KK = K * K;
+    constexpr int NINV = (KK + kWave - 1) / kWave;
+    float invv[NINV];
+    float cx = 0.0f, cy = 0.0f;                            
+    if (wv < 2) {
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            invv[i] = P.inv_delta_c[e < KK ? e : KK - 1];
+        }
+        if (lane < F) {
+            const int b = (wv == 1 && hasB) ? b0 + 1 : b0;
+            const float2 cc = reinterpret_cast<const float2*>(P.ctrl + (size_t)b * F * 2)[lane];
+            cx = cc.x; cy = cc.y;
+        }
+    }
+
+    // ---- the table row of (r, c): all K values requested now, consumed after the T barrier ----
+    float v[K];
+    {
+        const char* pht = reinterpret_cast<const char*>(P.p_hat_t);
+        const size_t row_bytes = (size_t)P.n * 4;
+#pragma unroll
+        for (int q = 0; q < K; ++q) v[q] = *reinterpret_cast<const float*>(pht + q * row_bytes + poff[0]);
+    }
+
+    if (wv < 2) {
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            if (e < KK) sInv[e] = invv[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes visible to own reads
+        const float* hrow = sInv + (lane < K ? lane : K - 1) * K;   // stride K is odd: no conflicts
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float hv = hrow[q];
+            ax = fmaf(hv, readlane_f(cx, q), ax);
+            ay = fmaf(hv, readlane_f(cy, q), ay);
+        }
+        if (lane < K) {
+            float* dst = reinterpret_cast<float*>(sT + lane) + 2 * wv;
+            dst[0] = ax; dst[1] = ay;
+        }
+    }
+    lds_only_barrier();
+    if (wv == 0) stamp(P.trace, 1);                               // T ready
+
+    // ---- 16 FMA chains: 4 mirror pixels x (image A, image B) x (x, y), each k-ascending ----
+    float gx[4][2], gy[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gx[m][0] = gx[m][1] = gy[m][0] = gy[m][1] = 0.0f;
+    static_for<K>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const float4 t = sT[q];
+        float val[4];
+        if constexpr (q == 0) {
+            val[0] = val[1] = val[2] = val[3] = v[0];
+        } else if constexpr (q == 1) {                     // P.x flips under the x-mirror
+            val[0] = v[1]; val[1] = -v[1]; val[2] = v[1]; val[3] = -v[1];
+        } else if constexpr (q == 2) {                     // P.y flips under the y-mirror
+            val[0] = v[2]; val[1] = v[2]; val[2] = -v[2]; val[3] = -v[2];
+        } else {
+            constexpr int k = q - 3;
+            val[0] = v[3 + k];
+            val[1] = v[3 + perm_x<F>(k)];
+            val[2] = v[3 + perm_y<F>(k)];
+            val[3] = v[3 + perm_x<F>(perm_y<F>(k))];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            gx[m][0] = fmaf(val[m], t.x, gx[m][0]);
+            gy[m][0] = fmaf(val[m], t.y, gy[m][0]);
+            gx[m][1] = fmaf(val[m], t.z, gx[m][1]);
+            gy[m][1] = fmaf(val[m], t.w, gy[m][1]);
+        }
+    });
+    // pin the finished grid HERE: without this the optimiser sinks the chains below the image
+    // barrier, next to their first use, and the grid expansion no longer overlaps the image fetch
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        asm volatile("" : "+v"(gx[m][0]), "+v"(gy[m][0]), "+v"(gx[m][1]), "+v"(gy[m][1]));
+    }
+
+    if (wv == 0) stamp(P.trace, 2);                               // grid expanded
+    __syncthreads();                                              // image pair is in LDS
+    if (wv == 0) stamp(P.trace, 3);
+
+    // ---- bilinear taps from LDS, coalesced stores ----
+    const size_t row_bytes = (size_t)P.n * 4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const bool store = live && (im == 0 || hasB);
+            const int b = b0 + im;
+            const Taps t = make_taps(gx[m][im], gy[m][im], H, W);
+            if (P.grid && store)
+                *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid + (size_t)b * P.n * 2) +
+                                           2 * poff[m]) = make_float2(gx[m][im], gy[m][im]);
+            if (P.idx && store)
+                *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx + (size_t)b * P.n * 2) +
+                                         2 * poff[m]) = make_int2(t.x0, t.y0);
+            const float* img = sImg + im * img_elems;
+            char* o = reinterpret_cast<char*>(P.out + (size_t)b * C * P.n);   // wave-uniform base
+            const bool inxy = t.inx && t.iny;
+            float res[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const float* pl = img + ch * HW;
+                const float v00 = pl[t.o00];
+                float v01 = pl[t.o00 + 1];                 // over-read masked below (slack after pair)
+                float v10 = pl[t.o10];
+                float v11 = pl[t.o10 + 1];
+                v01 = t.inx ? v01 : 0.0f;
+                v10 = t.iny ? v10 : 0.0f;
+                v11 = inxy ? v11 : 0.0f;
+                float acc = v00 * t.nw;
+                acc = fmaf(v01, t.ne, acc);
+                acc = fmaf(v10, t.sw, acc);
+                acc = fmaf(v11, t.se, acc);
+                res[ch] = acc;
+            }
+            if (store) {
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch)
+                    *reinterpret_cast<float*>(o + ch * row_bytes + poff[m]) = res[ch];
+            }
+        }
+    }
+    if (wv == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(P.trace, 4);
+    }
+}
+
+
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float* __restrict__ src, int ld, int n, int cols, float* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // index into dst (cols, n)
+    if (i >= n * cols) return;
+    const int c = i / n, p = i - c * n;
+    dst[i] = src[(size_t)p * ld + c];
+}
+
+int g_tune_G = 0, g_tune_tpb = 0, g_tune_kernel = 0, g_tune_bands = 0, g_tune_mirror = 0;
+long long* g_trace = nullptr;
 
 template <int FCT>
 void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStream_t st)
@@ -349,14 +863,52 @@ void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStre
 
 }  // namespace
 
-TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group)
+TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice,
+                                       int bands)
 {
+    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 3, "kernel_choice must be 0..3");
+    TPSPP_REQUIRE(bands >= 0 && bands <= 8, "bands must be in [0, 8]");
+    g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
+    g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
+    g_tune_bands = bands;
     TPSPP_REQUIRE(images_per_group >= 0 && images_per_group <= 64, "images_per_group out of range");
     TPSPP_REQUIRE(threads_per_group == 0 || (threads_per_group % 64 == 0 && threads_per_group >= 64 &&
                                              threads_per_group <= 256),
                   "threads_per_group must be 0 or a multiple of 64 in [64, 256]");
     g_tune_G = images_per_group;
     g_tune_tpb = threads_per_group;
+    return TPSPP_OK;
+}
+
+TPSPP_EXPORT int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, int Wo, int F)
+{
+    // HOST memory, classic (n, F+3) layout.  Bitwise check of the relations the mirror kernel uses.
+    if (!p_hat_host || Ho <= 0 || Wo <= 0 || F <= 0 || (F & 1) || (Ho & 1) || (Wo & 1) || p_hat_ld < F + 3)
+        return 0;
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto px = [&](int k) { return k < F / 2 ? F / 2 - 1 - k : F + F / 2 - 1 - k; };
+    auto py = [&](int k) { return (k + F / 2) % F; };
+    for (int r = 0; r < Ho / 2; ++r)
+        for (int c = 0; c < Wo / 2; ++c) {
+            const float* a = p_hat_host + (size_t)(r * Wo + c) * p_hat_ld;
+            const float* bx = p_hat_host + (size_t)(r * Wo + (Wo - 1 - c)) * p_hat_ld;
+            const float* by = p_hat_host + (size_t)((Ho - 1 - r) * Wo + c) * p_hat_ld;
+            const float* bxy = p_hat_host + (size_t)((Ho - 1 - r) * Wo + (Wo - 1 - c)) * p_hat_ld;
+            if (bits(bx[0]) != bits(a[0]) || bits(by[0]) != bits(a[0]) || bits(bxy[0]) != bits(a[0])) return 0;
+            if (bits(bx[1]) != bits(-a[1]) || bits(by[1]) != bits(a[1]) || bits(bxy[1]) != bits(-a[1])) return 0;
+            if (bits(bx[2]) != bits(a[2]) || bits(by[2]) != bits(-a[2]) || bits(bxy[2]) != bits(-a[2])) return 0;
+            for (int k = 0; k < F; ++k) {
+                if (bits(bx[3 + k]) != bits(a[3 + px(k)])) return 0;
+                if (bits(by[3 + k]) != bits(a[3 + py(k)])) return 0;
+                if (bits(bxy[3 + k]) != bits(a[3 + px(py(k))])) return 0;
+            }
+        }
+    return 1;
+}
+
+TPSPP_EXPORT int tpspp_warp_set_trace(long long* device_buf)
+{
+    g_trace = device_buf;
     return TPSPP_OK;
 }
 
@@ -400,11 +952,85 @@ TPSPP_EXPORT int tpspp_grid_sample(const float* in, const float* grid, int N, in
     return tpspp::check_launch("tpspp_grid_sample");
 }
 
+TPSPP_EXPORT int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, int cols,
+                                       float* p_hat_t, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(p_hat && p_hat_t, "tpspp_transpose_p_hat: null pointer");
+    TPSPP_REQUIRE(n > 0 && cols > 0 && p_hat_ld >= cols, "tpspp_transpose_p_hat: bad sizes");
+    TPSPP_REQUIRE((long)n * cols < (1L << 31), "tpspp_transpose_p_hat: table too large");
+    const int total = n * cols;
+    hipLaunchKernelGGL(transpose_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       tpspp::as_stream(stream), p_hat, p_hat_ld, n, cols, p_hat_t);
+    return tpspp::check_launch("tpspp_transpose_p_hat");
+}
+
+namespace {
+
+template <int F, int C, int HC, int WC>
+bool launch_lds_geo(const LdsParams& P, int ppt, int threads, size_t lds, hipStream_t st)
+{
+    const dim3 grid((unsigned)(((P.N + 1) / 2) * P.bands)), block(threads);
+    // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 1, HC, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 2, HC, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 3, HC, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 4, HC, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    switch (ppt) {
+    case 1: hipLaunchKernelGGL((tps_warp_lds_kernel<F, C, 1, HC, WC>), grid, block, lds, st, P); return true;
+    case 2: hipLaunchKernelGGL((tps_warp_lds_kernel<F, C, 2, HC, WC>), grid, block, lds, st, P); return true;
+    case 3: hipLaunchKernelGGL((tps_warp_lds_kernel<F, C, 3, HC, WC>), grid, block, lds, st, P); return true;
+    case 4: hipLaunchKernelGGL((tps_warp_lds_kernel<F, C, 4, HC, WC>), grid, block, lds, st, P); return true;
+    default: return false;
+    }
+}
+
+template <int F, int C, int HC, int WC>
+void launch_lds_mirror_geo(const LdsParams& P, int threads, size_t lds, hipStream_t st)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_mirror_kernel<F, C, HC, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)(((P.N + 1) / 2) * P.bands)), block(threads);
+    hipLaunchKernelGGL((tps_warp_lds_mirror_kernel<F, C, HC, WC>), grid, block, lds, st, P);
+}
+
+template <int F, int C>
+void launch_lds_mirror(const LdsParams& P, int threads, size_t lds, hipStream_t st)
+{
+    if (P.H == 32 && P.W == 100) launch_lds_mirror_geo<F, C, 32, 100>(P, threads, lds, st);
+    else launch_lds_mirror_geo<F, C, 0, 0>(P, threads, lds, st);
+}
+
+template <int F, int C>
+bool launch_lds(const LdsParams& P, int ppt, int threads, size_t lds, hipStream_t st)
+{
+    // the reference's own geometry (tps_preprocessor.py:39-43, crnn_tps.py:7-12) gets constants
+    if (P.H == 32 && P.W == 100) return launch_lds_geo<F, C, 32, 100>(P, ppt, threads, lds, st);
+    return launch_lds_geo<F, C, 0, 0>(P, ppt, threads, lds, st);
+}
+
+
+}  // namespace
+
 TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                                 const float* in1, int C1, int H1, int W1,
                                 const float* ctrl, const float* score,
                                 const float* inv_delta_c, const float* p_hat, int p_hat_ld,
-                                const float* p_xy, int N, int F, int Ho, int Wo,
+                                const float* p_xy, const float* p_hat_t, int table_flags,
+                                int N, int F, int Ho, int Wo,
                                 float* out0, float* out1, float* grid_or_null, int32_t* idx_or_null,
                                 tpspp_stream_t stream)
 {
@@ -415,12 +1041,63 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
     TPSPP_REQUIRE((in1 == nullptr) == (out1 == nullptr), "tpspp_warp_fwd: in1/out1 must come together");
     if (in1) TPSPP_REQUIRE(C1 > 0 && H1 > 0 && W1 > 0, "tpspp_warp_fwd: bad in1 sizes");
     if (N == 0) return TPSPP_OK;
+    hipStream_t st = tpspp::as_stream(stream);
+
+    // ---- LDS-staged kernel: single small input, classic layout, transposed table available ----
+    {
+        const int img_elems = C0 * H0 * W0;
+        const int K = F + 3;
+        const int n = Ho * Wo;
+        const int npairs = (N + 1) / 2;
+        // split the output pixels of a pair over `bands` workgroups while the pairs alone would
+        // leave CUs with fewer than two resident groups (the batch-512 case: 256 pairs, 256 CUs)
+        int bands = g_tune_bands > 0 ? g_tune_bands : (npairs < 512 ? 2 : 1);
+        if (n < bands * 2 * kWave) bands = 1;
+        const int band_px = (((n + bands - 1) / bands) + kWave - 1) / kWave * kWave;
+        const int max_cw = kLdsMaxWaves - kLdsLoaders;
+        const int ppt = (band_px + max_cw * kWave - 1) / (max_cw * kWave);
+        const int cw = ppt > 0 ? (band_px + ppt * kWave - 1) / (ppt * kWave) : 0;   // compute wavefronts
+        const int pieces = (2 * img_elems * 4 + 1023) / 1024;                      // 1-KB DMA pieces
+        // LDS: T | whole pieces of the image pair + the 1-float over-read of the east tap
+        const size_t lds = (size_t)(4 * K + ((K * K + 3) & ~3)) * sizeof(float) + (size_t)pieces * 1024 + 16;
+        const bool shape_ok = p_hat_t && !in1 && !score && !p_xy && F == 20 && (C0 == 1 || C0 == 3) &&
+                              (img_elems % 4 == 0) && lds <= 160 * 1024 && ppt >= 1 && ppt <= 4 &&
+                              cw >= 2 && (reinterpret_cast<uintptr_t>(in0) % 16 == 0);
+        if (g_tune_kernel == 2 && !shape_ok)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape does not qualify for the LDS kernel");
+        if (shape_ok && g_tune_kernel != 1) {
+            LdsParams L;
+            L.in = in0; L.C = C0; L.H = H0; L.W = W0;
+            L.ctrl = ctrl; L.inv_delta_c = inv_delta_c; L.p_hat_t = p_hat_t;
+            L.N = N; L.n = n; L.Ho = Ho; L.Wo = Wo;
+            L.out = out0; L.grid = grid_or_null; L.idx = idx_or_null;
+            L.compute_waves = cw; L.band_px = band_px; L.bands = bands; L.trace = g_trace;
+            // mirror-symmetric table (verified by the caller): one thread per quadrant pixel
+            if ((table_flags & TPSPP_TABLE_MIRROR4) && Ho % 2 == 0 && Wo % 2 == 0 && g_tune_mirror != 2) {
+                const int nq = (Ho / 2) * (Wo / 2);
+                int mb = g_tune_bands > 0 ? g_tune_bands : 1;
+                if (nq < mb * 2 * kWave) mb = 1;
+                int qpb = (((nq + mb - 1) / mb) + kWave - 1) / kWave * kWave;     // quadrant px per band
+                while (qpb > max_cw * kWave) { ++mb; qpb = (((nq + mb - 1) / mb) + kWave - 1) / kWave * kWave; }
+                const int mcw = qpb / kWave < 2 ? 2 : qpb / kWave;
+                L.compute_waves = mcw; L.band_px = qpb; L.bands = mb;
+                const int threads = (mcw + kLdsLoaders) * kWave;
+                if (C0 == 1) launch_lds_mirror<20, 1>(L, threads, lds, st);
+                else         launch_lds_mirror<20, 3>(L, threads, lds, st);
+                return tpspp::check_launch("tpspp_warp_fwd(lds-mirror)");
+            }
+            const int threads = (cw + kLdsLoaders) * kWave;
+            const bool ok = (C0 == 1) ? launch_lds<20, 1>(L, ppt, threads, lds, st)
+                                      : launch_lds<20, 3>(L, ppt, threads, lds, st);
+            if (ok) return tpspp::check_launch("tpspp_warp_fwd(lds)");
+        }
+    }
 
     WarpParams P;
     P.in0 = in0; P.C0 = C0; P.H0 = H0; P.W0 = W0;
     P.in1 = in1; P.C1 = in1 ? C1 : 0; P.H1 = in1 ? H1 : 1; P.W1 = in1 ? W1 : 1;
     P.ctrl = ctrl; P.score = score; P.inv_delta_c = inv_delta_c;
-    P.p_hat = p_hat; P.p_hat_ld = p_hat_ld; P.p_xy = p_xy;
+    P.p_hat = p_hat; P.p_hat_ld = p_hat_ld; P.p_xy = p_xy; P.p_hat_t = p_hat_t;
     P.N = N; P.F = F; P.n = Ho * Wo;
     P.out0 = out0; P.out1 = out1; P.grid = grid_or_null; P.idx = idx_or_null;
 
@@ -439,7 +1116,6 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
     const int K = F + 3;
     const size_t lds = (size_t)(((K * K + 3) & ~3) + 2 * G * K) * sizeof(float);
     const dim3 grid((unsigned)(P.tiles * P.chunks)), block(tpb);
-    hipStream_t st = tpspp::as_stream(stream);
     if (F == 20)      launch_warp<20>(P, grid, block, lds, st);
     else if (F == 32) launch_warp<32>(P, grid, block, lds, st);
     else              launch_warp<0>(P, grid, block, lds, st);

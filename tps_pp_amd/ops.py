@@ -83,8 +83,34 @@ def grid_sample(inp, grid, return_idx=False):
     return (out, idx) if return_idx else out
 
 
+def transpose_p_hat(P_hat):
+    """(n, cols) -> (cols, n) device copy for the coalesced kernels (one-off, per module buffer)."""
+    P_hat = _chk("P_hat", P_hat, 2)
+    n, cols = P_hat.shape
+    out = torch.empty((cols, n), device=P_hat.device, dtype=torch.float32)
+    with torch.cuda.device(P_hat.device):
+        rc = _lib.lib().tpspp_transpose_p_hat(_ptr(P_hat), cols, n, cols, _ptr(out), _stream(P_hat))
+    _lib.check(rc, "tpspp_transpose_p_hat")
+    return out
+
+
+TABLE_MIRROR4 = 1
+
+
+def table_mirror_symmetry(P_hat_host, out_hw, F):
+    """1 if the HOST tensor/array `P_hat_host` (n, F+3) has the exact 4-fold mirror symmetry of the
+    reference's GridGenerator table (then `table_flags=TABLE_MIRROR4` may be passed to warp)."""
+    import numpy as np
+    a = np.ascontiguousarray(P_hat_host.detach().cpu().numpy() if isinstance(P_hat_host, torch.Tensor)
+                             else P_hat_host, dtype=np.float32)
+    if a.ndim != 2 or a.shape[0] != out_hw[0] * out_hw[1]:
+        return 0
+    return int(_lib.lib().tpspp_table_mirror_symmetry(a.ctypes.data, a.shape[1], int(out_hw[0]),
+                                                      int(out_hw[1]), int(F)))
+
+
 def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
-         want_grid=False, want_idx=False, out0=None, out1=None):
+         want_grid=False, want_idx=False, out0=None, out1=None, P_hat_t=None, table_flags=0):
     """Fused build_P_prime + grid_sample(s): one kernel, T in LDS, grid in registers.
 
     Returns (out0, out1 | None, grid | None, idx | None).
@@ -112,6 +138,10 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
         score = _chk("score", score, 3)
         if tuple(score.shape) != (N, n, F):
             raise ValueError("warp: score must be (N, n, F)")
+    if P_hat_t is not None:
+        P_hat_t = _chk("P_hat_t", P_hat_t, 2)
+        if tuple(P_hat_t.shape) != (P_hat.shape[1], n):
+            raise ValueError("warp: P_hat_t must be P_hat transposed")
     C1 = H1 = W1 = 0
     if in1 is not None:
         in1 = _chk("in1", in1, 4)
@@ -128,12 +158,16 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
     with torch.cuda.device(dev):
         rc = _lib.lib().tpspp_warp_fwd(_ptr(in0), C0, H0, W0, _ptr(in1), C1, H1, W1, _ptr(ctrl),
                                        _ptr(score), _ptr(inv_delta_C), _ptr(P_hat), P_hat.shape[1],
-                                       _ptr(P_xy), N, F, Ho, Wo, _ptr(out0), _ptr(out1),
+                                       _ptr(P_xy), _ptr(P_hat_t), int(table_flags), N, F, Ho, Wo,
+                                       _ptr(out0), _ptr(out1),
                                        _ptr(grid), _ptr(idx), _stream(in0))
     _lib.check(rc, "tpspp_warp_fwd")
     return out0, out1, grid, idx
 
 
-def set_warp_tuning(images_per_group=0, threads_per_group=0):
-    _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group)),
+def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
+    """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel (error if not applicable);
+    bands: workgroups per image pair in the LDS-staged kernel (0 = heuristic)."""
+    _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group),
+                                                int(kernel_choice), int(bands)),
                "tpspp_warp_set_tuning")
