@@ -118,3 +118,52 @@ def synth_state(module_state, seed, rule=None, keep=()):
     shapes = {k: tuple(v.shape) for k, v in module_state.items()
               if k not in keep and not k.endswith("num_batches_tracked")}
     return synth.state_dict_like(shapes, seed, rule)
+
+
+# ---- G4 / G5: full TPS_PP module, v2 wiring (reference default) and v1 wiring, N=2 --------------
+G4_N = 2
+TPSPP_KEEP = ("TPE.localization_fc2.bias", "atten_tps.hat_C", "atten_tps.P_hat")
+
+
+def tpspp_state_rule(name, shape):
+    if name.endswith("localization_fc2.weight"):
+        return (0.02, 0.0)            # keep C' near the initial lattice (reference inits it to 0)
+    if ".norm1.weight" in name or ".norm2.weight" in name:
+        return (0.25, 1.0)            # LayerNorm gamma ~ 1
+    if ".norm1.bias" in name or ".norm2.bias" in name:
+        return (0.1, 0.0)
+    return None
+
+
+def g4_inputs(variant="ResNet45v2"):
+    """x = stage-2 input (N,64,16,64); outs = [stage-0 input, stage-1 input] at the variant's
+    geometry (resnet_v2_large.py:183-191).  Post-ReLU features: non-negative."""
+    tag = "g4" if variant == "ResNet45v2" else "g5"
+    x = np.abs(synth.smooth_image((G4_N, 64, 16, 64), tag + ".x", 4))
+    o0 = np.abs(synth.smooth_image((G4_N, 32, 32, 128), tag + ".o0", 4))
+    o1_hw = (32, 128) if variant == "ResNet45v2" else (16, 64)
+    o1 = np.abs(synth.smooth_image((G4_N, 32) + o1_hw, tag + ".o1", 4))
+    return dict(x=x, outs=[o0, o1])
+
+
+def sub(a):
+    """Channel-subsampled view stored for the big intermediates (every 8th channel)."""
+    return np.ascontiguousarray(a[:, ::8])
+
+
+# ---- G7: backbone stem + layer1 + layer2 (eval-mode BN), N=2, 3x32x128 ---------------------------
+G7_N = 2
+G7_STRIDES = [1, 2, 2, 1, 2]      # the geometry TPS_PP's default wiring needs (SURVEY.md fact 0.4)
+
+
+def backbone_state_rule(name, shape):
+    r = bn_rule(name, shape)
+    if r is not None:
+        return r
+    if (".bn" in name or name.startswith("bn") or ".downsample.1." in name) and name.endswith(".weight"):
+        return (0.25, 1.0)            # BatchNorm gamma
+    return None
+
+
+def g7_inputs():
+    return dict(img=synth.smooth_image((G7_N, 3, 32, 128), "g7.img", 7))

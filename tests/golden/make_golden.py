@@ -121,7 +121,121 @@ def case_g1(R):
     save("classic_module", ctrl=ctrl.numpy(), grid=grid.numpy(), out=out.numpy())
 
 
-CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1)
+def _tpspp_case(R, variant, fname):
+    mod = R["tps_pp"]
+    m = quiet(mod.TPS_PP)
+    if variant == "ResNet45":
+        # the reference hard-codes type='ResNet45v2' (tps_pp.py:522); its other branch is reached
+        # by patching the instance exactly as SURVEY.md section 0 fact 4 describes
+        m.type = "ResNet45"
+        m.down0 = sys.modules["mmcv.cnn"].ConvModule(32, m.img_channel, kernel_size=3, stride=2, padding=1)
+        for n in ("down0_1", "down1_1", "down_feat", "up_sample"):
+            delattr(m, n)
+    m.eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    inp = cases.g4_inputs(variant)
+    x, outs = t(inp["x"]), [t(o) for o in inp["outs"]]
+    # named intermediates through forward hooks on the reference's own sub-modules
+    inter = {}
+
+    def hook(name):
+        def f(_m, _i, o):
+            inter[name] = (o[0] if isinstance(o, tuple) else o).detach().clone()
+        return f
+    hs = []
+    for i in range(4):
+        hs.append(m.MSFA.conv.k_encoder[i].register_forward_hook(hook(f"enc{i}")))
+        hs.append(m.MSFA.conv.k_decoder[i].register_forward_hook(hook(f"dec{i}_conv")))
+    hs.append(m.MSFA.conv.atten.register_forward_hook(hook("cbam")))
+    hs.append(m.TPE.atten[0].register_forward_hook(hook("dgab")))
+    hs.append(m.MSFA.register_forward_hook(lambda _m, i, o: inter.__setitem__("feat_cat", i[0].detach().clone())))
+    grids = {}
+    orig = m.atten_tps.build_P_prime
+
+    def spy(c, s_, d):
+        g = orig(c, s_, d)
+        grids["ctrl"], grids["grid"] = c.detach().clone(), g.detach().clone()
+        return g
+    m.atten_tps.build_P_prime = spy
+    res = m(x, outs)
+    for h in hs:
+        h.remove()
+    # oracle pin: the functional restatement reproduces the reference bit for bit on this machine
+    from oracle import tpspp_oracle as TO
+    o = TO.tpspp_forward({k: v for k, v in m.state_dict().items()}, inp["x"], inp["outs"], variant)
+    assert biteq(o["ctrl"], grids["ctrl"].numpy()), "regressor oracle != reference (ctrl)"
+    assert biteq(o["pc_score"], res["pc_score"].numpy()), "regressor oracle != reference (score)"
+    assert biteq(o["grid"], grids["grid"].numpy())
+    assert biteq(o["output"], res["output"].numpy()) and biteq(o["mp_img"], res["mp_img"].numpy())
+    arrs = dict(ctrl=grids["ctrl"].numpy(), pc_score=res["pc_score"].numpy(), grid=grids["grid"].numpy(),
+                output=res["output"].numpy(), mp_img=res["mp_img"].numpy())
+    if variant == "ResNet45v2":
+        arrs.update(feat_cat_sub=cases.sub(inter["feat_cat"].numpy()), cbam=inter["cbam"].numpy(),
+                    dgab_sub=cases.sub(inter["dgab"].numpy()))
+        for i in range(4):
+            arrs[f"enc{i}_sub"] = cases.sub(inter[f"enc{i}"].numpy())
+            arrs[f"dec{i}_conv_sub"] = cases.sub(inter[f"dec{i}_conv"].numpy())
+    save(fname, **arrs)
+    return m
+
+
+def case_g4(R):
+    m = _tpspp_case(R, "ResNet45v2", "tpspp_module_v2")
+    # the state_dict layout itself is part of the drop-in contract
+    import json
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump({"TPS_PP": {k: list(v.shape) for k, v in m.state_dict().items()},
+                   "TPSPreprocessor(20,(32,100),(32,100),3)": {
+                       k: list(v.shape) for k, v in R["tps_preprocessor"].TPSPreprocessor(
+                           20, (32, 100), (32, 100), 3).state_dict().items()}}, f, indent=1)
+    print("  wrote state_dict_keys.json")
+
+
+def case_g5(R):
+    _tpspp_case(R, "ResNet45", "tpspp_module_v1")
+
+
+def case_g7(R):
+    m = R["resnet_v2_large"].ResNetABI_v2_large(strides=cases.G7_STRIDES)
+    m.eval()
+    full = m.state_dict()
+    keep = {k: v for k, v in full.items() if k.startswith(("conv1.", "bn1.", "layer1.", "layer2."))}
+    sd = cases.synth_state(keep, 7, cases.backbone_state_rule)
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    img = cases.g7_inputs()["img"]
+    got = {}
+
+    class Spy(torch.nn.Module):
+        def forward(self, x, outs, **kw):
+            got["x"], got["outs"] = x.detach().clone(), [o.detach().clone() for o in outs]
+            return {"output": x}
+    m(t(img), Spy())
+    from oracle import tpspp_oracle as TO
+    ox, oouts = TO.backbone_stem({k: v for k, v in m.state_dict().items()}, img)
+    assert biteq(ox.numpy(), got["x"].numpy()), "backbone oracle != reference"
+    assert all(biteq(a.numpy(), b.numpy()) for a, b in zip(oouts, got["outs"]))
+    save("backbone_stem", x=got["x"].numpy(), outs0_sub=np.ascontiguousarray(got["outs"][0].numpy()[:, ::4]),
+         outs1_sub=np.ascontiguousarray(got["outs"][1].numpy()[:, ::4]))
+
+
+def case_g1_pin(R):
+    """(no file) the classic-module oracle reproduces the reference on G1."""
+    m = R["tps_preprocessor"].TPSPreprocessor(num_fiducial=cases.CL_F, img_size=cases.CL_HW,
+                                              rectified_img_size=cases.CL_HW, num_img_channel=3)
+    m.eval()
+    sd = cases.synth_state(m.state_dict(), 1, cases.g1_state_rule, cases.G1_KEEP)
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    from oracle import tpspp_oracle as TO
+    img = cases.g1_inputs()["img"]
+    o = TO.classic_forward({k: v for k, v in m.state_dict().items()}, img)
+    assert biteq(o["ctrl"], m.LocalizationNetwork(t(img)).numpy())
+    assert biteq(o["out"], m(t(img)).numpy())
+    print("  classic-module oracle == reference (bitwise)")
+
+
+CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1, g1_pin=case_g1_pin,
+             g4=case_g4, g5=case_g5, g7=case_g7)
 
 
 def main(argv):

@@ -1,0 +1,85 @@
+"""-m gpu: the module-level drop-ins on a real MI355X against the reference's golden outputs.
+
+Two bars per module:
+  * the transformation stage (hand-written HIP), fed the reference's own control points / score:
+    BIT-EXACT against the reference's grid and warped tensors;
+  * the whole forward (regressor still on PyTorch-ROCm library kernels, whose summation order is
+    not the CPU's): warped tensors within the north-star tolerance 1e-4 on image-like inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from tps_pp_amd import TPS_PP, TPSPreprocessor, build_backbone
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_biteq(a, b, what):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    ne = bits(a) != bits(b)
+    assert a.shape == b.shape and not ne.any(), \
+        f"{what}: {int(ne.sum())} of {ne.size} differ, max abs {np.abs(a - b).max():.3e}"
+
+
+def test_classic_module_against_reference(cuda):
+    G = cases.load("classic_module")
+    m = TPSPreprocessor(num_fiducial=cases.CL_F, img_size=cases.CL_HW,
+                        rectified_img_size=cases.CL_HW, num_img_channel=3).eval()
+    sd = cases.synth_state(m.state_dict(), 1, cases.g1_state_rule, cases.G1_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    img = dev(cases.g1_inputs()["img"], cuda)
+    with torch.no_grad():
+        out, grid, idx = m.rectify(img, dev(G["ctrl"], cuda), want_grid=True, want_idx=True)
+        assert_biteq(grid, G["grid"], "grid from the reference's control points")
+        assert_biteq(out, G["out"], "rectified image from the reference's control points")
+        full = m(img)
+        ctrl = m.LocalizationNetwork(img)
+    assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 1e-5
+    assert np.abs(full.cpu().numpy() - G["out"]).max() <= TOL
+    # the reference's own test (test_ocr_preprocessor.py:19-29): shape of a 1x1x32x100 forward
+    p1 = TPSPreprocessor(20, (32, 100), (32, 100), 1).eval().to(cuda)
+    with torch.no_grad():
+        assert p1(torch.randn(1, 1, 32, 100, device=cuda)).shape == torch.Size([1, 1, 32, 100])
+
+
+@pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"),
+                                           ("ResNet45", "tpspp_module_v1")])
+def test_tpspp_module_against_reference(cuda, variant, fname):
+    G = cases.load(fname)
+    m = build_backbone(dict(type="TPS_PP", variant=variant)).eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    inp = cases.g4_inputs(variant)
+    x, outs = dev(inp["x"], cuda), [dev(o, cuda) for o in inp["outs"]]
+    with torch.no_grad():
+        ctrl, score, feat_grid = m.regress(x, outs)
+        # transformation stage from the reference's control points and score
+        out0, out1, grid = m.rectify(feat_grid.contiguous(), x, dev(G["ctrl"], cuda),
+                                     dev(G["pc_score"], cuda), want_grid=True)
+        res = m(x, outs)
+    assert_biteq(grid, G["grid"], "grid")
+    assert_biteq(out1, G["mp_img"], "mp_img (samples the raw input)")
+    if variant == "ResNet45":
+        assert_biteq(out0, G["output"], "output (feat_grid is the raw input in this wiring)")
+    else:
+        assert np.abs(out0.cpu().numpy() - G["output"]).max() <= TOL
+    assert set(res) == {"output", "logits", "mp_img", "pc_score"} and res["logits"] is None
+    assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 2e-5
+    assert np.abs(score.cpu().numpy() - G["pc_score"]).max() < 1e-4
+    # whole forward, regressor on the GPU: image-like inputs, north-star tolerance
+    assert np.abs(res["mp_img"].cpu().numpy() - G["mp_img"]).max() <= 5 * TOL
+    assert np.abs(res["output"].cpu().numpy() - G["output"]).max() <= 5 * TOL
+    assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])

@@ -1,0 +1,132 @@
+"""CPU tests of the host-side mirror of the reference's module API (no GPU compute)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import tps_pp_amd
+from tps_pp_amd import (BACKBONES, PREPROCESSOR, TPS_PP, TPSPreprocessor, _lib, build_backbone,
+                        build_preprocessor, constants)
+
+KEYS = json.load(open(os.path.join(cases.HERE, "state_dict_keys.json")))
+
+
+def test_constructor_assertions_like_the_reference():
+    """tests/test_models/test_ocr_preprocessor.py:9-17 of the reference."""
+    with pytest.raises(AssertionError):
+        TPSPreprocessor(num_fiducial=-1)
+    with pytest.raises(AssertionError):
+        TPSPreprocessor(img_size=32)
+    with pytest.raises(AssertionError):
+        TPSPreprocessor(rectified_img_size=100)
+    with pytest.raises(AssertionError):
+        TPSPreprocessor(num_img_channel="bgr")
+    with pytest.raises(AssertionError):
+        TPS_PP(img_size=[16, 64])
+    with pytest.raises(AssertionError):
+        TPS_PP(rectified_img_size=64)
+
+
+def test_registries_build_from_the_reference_configs():
+    # configs/textrecog/nrtr/nrtr_tps++.py:38 and configs/_base_/recog_models/crnn_tps.py:7-12
+    m = build_backbone(dict(type="TPS_PP"))
+    assert isinstance(m, TPS_PP) and m.num_fiducial == 32 and m.rectified_img_size == (16, 64)
+    p = build_preprocessor(dict(type="TPSPreprocessor", num_fiducial=20, img_size=(32, 100),
+                                rectified_img_size=(32, 100), num_img_channel=1))
+    assert isinstance(p, TPSPreprocessor)
+    assert "TPS_PPv2" in PREPROCESSOR and "TPS_PP" in BACKBONES
+    with pytest.raises(KeyError):
+        build_backbone(dict(type="NoSuchThing"))
+    with pytest.raises(KeyError):
+        build_backbone(dict(num_fiducial=3))
+
+
+def test_state_dict_layout_matches_the_reference():
+    m = TPS_PP()
+    sd = m.state_dict()
+    assert list(sd) == list(KEYS["TPS_PP"])
+    assert all(list(sd[k].shape) == KEYS["TPS_PP"][k] for k in sd)
+    p = TPSPreprocessor(20, (32, 100), (32, 100), 3)
+    ref = KEYS["TPSPreprocessor(20,(32,100),(32,100),3)"]
+    sdp = p.state_dict()
+    assert list(sdp) == list(ref) and all(list(sdp[k].shape) == ref[k] for k in sdp)
+    # a state_dict in the reference's layout loads strictly
+    m.load_state_dict({k: torch.zeros(v) for k, v in KEYS["TPS_PP"].items()}, strict=True)
+
+
+def test_buffers_and_initial_control_points_match_the_reference():
+    K = cases.load("constants")
+    m = TPS_PP()
+    assert np.array_equal(m.atten_tps.hat_C.numpy(), K["pp_hat_C"])
+    assert np.array_equal(m.atten_tps.P_hat.numpy(), K["pp_P_hat"])
+    assert np.array_equal(m.atten_tps.P, K["pp_P"]) and np.array_equal(m.atten_tps.C, K["pp_C"])
+    assert torch.count_nonzero(m.TPE.localization_fc2.weight) == 0
+    assert np.array_equal(m.TPE.localization_fc2.bias.detach().numpy().reshape(-1, 2),
+                          cases.tpspp_initial_ctrl())
+    p = TPSPreprocessor(20, (32, 100), (32, 100), 1)
+    assert np.array_equal(p.GridGenerator.inv_delta_C.numpy(), K["classic_inv_delta_C"])
+    assert np.array_equal(p.GridGenerator.P_hat.numpy(), K["classic_P_hat"])
+    assert np.array_equal(p.LocalizationNetwork.localization_fc2.bias.detach().numpy().reshape(-1, 2),
+                          cases.classic_initial_ctrl())
+
+
+def test_regressor_matches_oracle_on_cpu():
+    """The regressor is still library PyTorch: on the CPU it must agree with the oracle exactly."""
+    from oracle import tpspp_oracle as TO
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    inp = cases.g4_inputs()
+    with torch.no_grad():
+        cp, sc, fg = m.regress(torch.from_numpy(inp["x"]), [torch.from_numpy(o) for o in inp["outs"]])
+        ocp, osc, ofg, _ = TO.tpspp_regress(dict(m.state_dict()), inp["x"], inp["outs"])
+    assert torch.equal(cp, ocp) and torch.equal(sc, osc) and torch.equal(fg, ofg)
+    G = cases.load("tpspp_module_v2")
+    np.testing.assert_allclose(cp.numpy(), G["ctrl"], atol=2e-5, rtol=0)
+
+
+def test_no_cpu_fallback_and_forward_only():
+    p = TPSPreprocessor(20, (32, 100), (32, 100), 3)
+    with pytest.raises(NotImplementedError):
+        p(torch.zeros(1, 3, 32, 100))                     # grad mode on, parameters require grad
+    with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
+        p(torch.zeros(1, 3, 32, 100))
+    m = TPS_PP()
+    with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
+        m(torch.zeros(1, 64, 16, 64), [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 32, 128)])
+
+
+def test_variant_geometry_is_checked_with_a_useful_message():
+    m = TPS_PP()
+    with torch.no_grad(), pytest.raises(ValueError, match="variant='ResNet45'"):
+        m(torch.zeros(1, 64, 16, 64), [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 16, 64)])
+    v1 = TPS_PP(variant="ResNet45")
+    assert "down0_1.conv.weight" not in v1.state_dict()
+    assert tuple(v1.down0.conv.weight.shape) == (64, 32, 3, 3)
+
+
+def test_register_into_a_mmocr_like_builder(monkeypatch):
+    import sys
+    import types
+    from tps_pp_amd.registry import Registry, register_into_mmocr
+    fake = types.ModuleType("mmocr.models.builder")
+    fake.BACKBONES, fake.PREPROCESSOR = Registry("models"), Registry("preprocessor")
+    pk, pm = types.ModuleType("mmocr"), types.ModuleType("mmocr.models")
+    pk.models, pm.builder = pm, fake
+    monkeypatch.setitem(sys.modules, "mmocr", pk)
+    monkeypatch.setitem(sys.modules, "mmocr.models", pm)
+    monkeypatch.setitem(sys.modules, "mmocr.models.builder", fake)
+    assert register_into_mmocr() is True
+    assert fake.BACKBONES.get("TPS_PP") is TPS_PP
+    assert fake.PREPROCESSOR.get("TPSPreprocessor") is TPSPreprocessor
+
+
+def test_constants_builders_reproduce_reference_tables():
+    K = cases.load("constants")
+    c = constants.classic(20, (32, 100))
+    np.testing.assert_allclose(c["inv_delta_C"], K["classic_inv_delta_C"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c["P_hat"], K["classic_P_hat"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(constants.classic_identity_ctrl(20), cases.classic_identity_ctrl(20))

@@ -1,0 +1,189 @@
+"""CPU tests: the oracle against the reference's own outputs (tests/golden/*.npz).
+
+The grid generator and sampler are C with explicit fmaf(): bit-exact on any host.  The regressor /
+backbone oracles are PyTorch-CPU convolutions whose blocking may differ between CPU models, so they
+are held to a tight tolerance here (they were bit-exact in the container that generated the
+fixtures: make_golden.py asserts it)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import tpspp_oracle as TO
+
+CONV_TOL = 2e-5
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def biteq(a, b):
+    return a.shape == b.shape and np.array_equal(bits(a), bits(b))
+
+
+def tsd(sd):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def test_constants_match_reference(oracle):
+    K = cases.load("constants")
+    c = oracle.classic_constants(cases.CL_F, cases.CL_HW)
+    p = oracle.tpspp_constants(cases.PP_HW, cases.PP_POINT)
+    assert np.array_equal(c["C"], K["classic_C"]) and np.array_equal(c["P"], K["classic_P"])
+    assert np.array_equal(p["C"], K["pp_C"]) and np.array_equal(p["P"], K["pp_P"])
+    # np.linalg.inv / np.log may differ in the last ulp between LAPACK / libm builds
+    np.testing.assert_allclose(c["inv_delta_C"], K["classic_inv_delta_C"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c["P_hat"], K["classic_P_hat"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(p["hat_C"], K["pp_hat_C"], rtol=1e-5, atol=2e-4)   # entries up to 223
+    np.testing.assert_allclose(p["P_hat"], K["pp_P_hat"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(oracle.classic_initial_ctrl(20), cases.classic_initial_ctrl(20))
+    assert np.array_equal(oracle.tpspp_initial_ctrl((2, 16)), cases.tpspp_initial_ctrl((2, 16)))
+
+
+def test_classic_grid_and_sampler_bit_exact(oracle):
+    K, G, inp = cases.load("constants"), cases.load("classic_warp"), cases.g2_inputs()
+    T = oracle.solve_T(K["classic_inv_delta_C"], inp["ctrl"])
+    grid = oracle.build_grid(K["classic_P_hat"], T)
+    assert biteq(grid, G["grid"])
+    out, idx = oracle.grid_sample(inp["img"], grid, cases.CL_HW, return_idx=True)
+    assert biteq(out, G["out"])
+    assert biteq(oracle.grid_sample(inp["img_smooth"], grid, cases.CL_HW), G["out_smooth"])
+    # indices are consistent with the grid: floor of the clamped un-normalised coordinate
+    H, W = cases.CL_HW
+    ix = np.clip(((grid[..., 0] + np.float32(1)) * np.float32(0.5)) * np.float32(W - 1), 0, W - 1)
+    assert np.array_equal(idx[..., 0], np.floor(ix).astype(np.int32))
+    # the other two weight forms stay within float rounding of the reference
+    for wf in (0, 1):
+        assert np.abs(oracle.grid_sample(inp["img"], grid, cases.CL_HW, wf) - G["out"]).max() < 5e-7
+    # fused entry == pieces
+    r = oracle.warp(inp["img"], inp["ctrl"], K["classic_inv_delta_C"], K["classic_P_hat"],
+                    cases.CL_HW, want_grid=True, want_idx=True)
+    assert biteq(r["grid"], G["grid"]) and biteq(r["out0"], G["out"]) and np.array_equal(r["idx"], idx)
+    # the border clamp was exercised by the large perturbations
+    assert (np.abs(G["grid"]) > 1.0).mean() > 0.02
+
+
+def test_tpspp_warp_stage_bit_exact(oracle):
+    K, G, inp = cases.load("constants"), cases.load("tpspp_warp"), cases.g3_inputs()
+    r = oracle.warp(inp["feat_grid"], inp["ctrl"], K["pp_hat_C"], K["pp_P_hat"], cases.PP_HW,
+                    P_xy=K["pp_P"].astype(np.float32), score=inp["score"], in1=inp["x"],
+                    want_grid=True)
+    assert biteq(r["grid"], G["grid"])
+    assert biteq(r["out0"], G["output"]) and biteq(r["out1"], G["mp_img"])
+
+
+def _classic_sd():
+    import json, os
+    keys = json.load(open(os.path.join(cases.HERE, "state_dict_keys.json")))
+    shapes = keys["TPSPreprocessor(20,(32,100),(32,100),3)"]
+    sd = cases.synth_state({k: np.empty(v) for k, v in shapes.items()}, 1, cases.g1_state_rule,
+                           cases.G1_KEEP)
+    K = cases.load("constants")
+    sd["LocalizationNetwork.localization_fc2.bias"] = cases.classic_initial_ctrl(20).reshape(-1)
+    sd["GridGenerator.inv_delta_C"] = K["classic_inv_delta_C"]
+    sd["GridGenerator.P_hat"] = K["classic_P_hat"]
+    return sd
+
+
+def test_classic_module_oracle(oracle):
+    G = cases.load("classic_module")
+    sd = _classic_sd()
+    o = TO.classic_forward(tsd(sd), cases.g1_inputs()["img"])
+    np.testing.assert_allclose(o["ctrl"], G["ctrl"], atol=CONV_TOL, rtol=0)
+    # the transformation stage from the reference's own control points: bit-exact
+    r = oracle.warp(cases.g1_inputs()["img"], G["ctrl"], sd["GridGenerator.inv_delta_C"],
+                    sd["GridGenerator.P_hat"], cases.CL_HW, want_grid=True)
+    assert biteq(r["grid"], G["grid"]) and biteq(r["out0"], G["out"])
+
+
+def _tpspp_sd(variant):
+    import json, os
+    shapes = json.load(open(os.path.join(cases.HERE, "state_dict_keys.json")))["TPS_PP"]
+    if variant == "ResNet45":
+        shapes = {k: v for k, v in shapes.items()
+                  if not k.startswith(("down0_1.", "down1_1.", "down_feat."))}
+        shapes["down0.conv.weight"] = [64, 32, 3, 3]
+    sd = cases.synth_state({k: np.empty(v) for k, v in shapes.items()}, 4, cases.tpspp_state_rule,
+                           cases.TPSPP_KEEP)
+    K = cases.load("constants")
+    sd["TPE.localization_fc2.bias"] = cases.tpspp_initial_ctrl().reshape(-1)
+    sd["atten_tps.hat_C"], sd["atten_tps.P_hat"] = K["pp_hat_C"], K["pp_P_hat"]
+    return sd
+
+
+@pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"),
+                                           ("ResNet45", "tpspp_module_v1")])
+def test_tpspp_module_oracle(oracle, variant, fname):
+    G = cases.load(fname)
+    sd = _tpspp_sd(variant)
+    inp = cases.g4_inputs(variant)
+    with torch.no_grad():
+        ctrl, score, feat_grid, inter = TO.tpspp_regress(tsd(sd), inp["x"], inp["outs"], variant)
+    np.testing.assert_allclose(ctrl.numpy(), G["ctrl"], atol=CONV_TOL, rtol=0)
+    np.testing.assert_allclose(score.numpy(), G["pc_score"], atol=CONV_TOL, rtol=0)
+    if variant == "ResNet45v2":
+        np.testing.assert_allclose(cases.sub(inter["feat_cat"].numpy()), G["feat_cat_sub"], atol=CONV_TOL)
+        np.testing.assert_allclose(inter["cbam"].numpy(), G["cbam"], atol=CONV_TOL)
+        np.testing.assert_allclose(cases.sub(inter["dgab"].numpy()), G["dgab_sub"], atol=1e-4)
+        for i in range(4):
+            np.testing.assert_allclose(cases.sub(inter[f"enc{i}"].numpy()), G[f"enc{i}_sub"], atol=CONV_TOL)
+    # transformation stage from the reference's control points and score
+    K = cases.load("constants")
+    P_xy = K["pp_P"].astype(np.float32)
+    r = oracle.warp(feat_grid.numpy(), G["ctrl"], sd["atten_tps.hat_C"], sd["atten_tps.P_hat"],
+                    cases.PP_HW, P_xy=P_xy, score=G["pc_score"], in1=inp["x"], want_grid=True)
+    assert biteq(r["grid"], G["grid"])
+    assert biteq(r["out1"], G["mp_img"])                 # samples the raw input: exact on any host
+    if variant == "ResNet45":
+        assert biteq(r["out0"], G["output"])             # feat_grid is the raw input here
+    else:
+        assert np.abs(r["out0"] - G["output"]).max() <= 1e-4
+
+
+def test_backbone_stem_oracle():
+    G = cases.load("backbone_stem")
+    import json  # shapes come from the golden arrays + the architecture (resnet_v2_large.py:77-135)
+    shapes = {"conv1.weight": (32, 3, 3, 3), "conv1.bias": (32,)}
+    for p in ("bn1",):
+        shapes.update({f"{p}.weight": (32,), f"{p}.bias": (32,), f"{p}.running_mean": (32,),
+                       f"{p}.running_var": (32,)})
+
+    def block(prefix, cin, cout, down):
+        shapes[f"{prefix}.conv1.weight"] = (cout, cin, 1, 1)
+        shapes[f"{prefix}.conv2.weight"] = (cout, cout, 3, 3)
+        for b in ("bn1", "bn2"):
+            for s_ in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"{prefix}.{b}.{s_}"] = (cout,)
+        if down:
+            shapes[f"{prefix}.downsample.0.weight"] = (cout, cin, 1, 1)
+            for s_ in ("weight", "bias", "running_mean", "running_var"):
+                shapes[f"{prefix}.downsample.1.{s_}"] = (cout,)
+    # layer1: 3 blocks 32->32 stride 1 (no downsample); layer2: 4 blocks 32->64 stride 2
+    for b in range(3):
+        block(f"layer1.{b}", 32, 32, False)
+    for b in range(4):
+        block(f"layer2.{b}", 32 if b == 0 else 64, 64, b == 0)
+    sd = cases.synth_state({k: np.empty(v) for k, v in shapes.items()}, 7, cases.backbone_state_rule)
+    x, outs = TO.backbone_stem(tsd(sd), cases.g7_inputs()["img"])
+    np.testing.assert_allclose(x.numpy(), G["x"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs[0].numpy()[:, ::4], G["outs0_sub"], atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs[1].numpy()[:, ::4], G["outs1_sub"], atol=1e-4, rtol=1e-5)
+
+
+def test_oracle_edge_cases(oracle):
+    """Shapes the reference's own test uses (test_ocr_preprocessor.py:19-29: 1x1x32x100) and
+    degenerate ones: every grid point outside [-1,1] must give a border pixel, exactly."""
+    Kc = oracle.classic_constants(20, (32, 100))
+    img = np.arange(32 * 100, dtype=np.float32).reshape(1, 1, 32, 100)
+    far = np.full((1, 20, 2), 50.0, np.float32)          # all control points far to the south-east
+    r = oracle.warp(img, far, Kc["inv_delta_C"], Kc["P_hat"], (32, 100), want_idx=True)
+    assert r["out0"].shape == (1, 1, 32, 100)
+    assert np.all(r["out0"] == img[0, 0, 31, 99])
+    assert np.all(r["idx"][..., 0] == 99) and np.all(r["idx"][..., 1] == 31)
+    nan = np.full((1, 20, 2), np.nan, np.float32)        # NaN coordinates clamp to pixel (0, 0)
+    r = oracle.warp(img, nan, Kc["inv_delta_C"], Kc["P_hat"], (32, 100), want_idx=True)
+    assert np.all(r["idx"] == 0)
+    empty = oracle.warp(np.zeros((0, 3, 32, 100), np.float32), np.zeros((0, 20, 2), np.float32),
+                        Kc["inv_delta_C"], Kc["P_hat"], (32, 100))
+    assert empty["out0"].shape == (0, 3, 32, 100)

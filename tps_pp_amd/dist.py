@@ -1,0 +1,64 @@
+"""Batch sharding across the GPUs of one node (one process per GPU) and the one collective the
+inference path has: the all-gather of per-image recognition outputs.
+
+Reference: data-parallel only: `MMDistributedDataParallel` for training
+(`mmocr/apis/train.py:59-67`) and `multi_gpu_test`'s result gather for evaluation
+(`tools/test.py:202-207`).  Every image is independent (no BatchNorm in TPS_PP; backbone BN in eval
+mode), so rank r simply owns the contiguous slice [lo, hi) of the batch; the rectification path
+itself needs NO collective.  `all_gather_rows` is what carries the decoder logits
+(N_local, 40, 93) fp32 to every rank: RCCL ("nccl" backend on ROCm) over xGMI for GPU tensors, gloo
+for the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items: int, rank: int, world_size: int):
+    """Contiguous, balanced slice [lo, hi) of `n_items` owned by `rank` (first `n % world` ranks get
+    one extra item)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank/world_size {rank}/{world_size}")
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(t: torch.Tensor, rank: int, world_size: int):
+    lo, hi = shard_bounds(t.shape[0], rank, world_size)
+    return t[lo:hi]
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None):
+    """Gather the per-rank row blocks produced by `shard_batch` back into the (n_total, ...) tensor,
+    on every rank.  Ragged shards are padded to the largest shard for the collective (one
+    `all_gather_into_tensor`: a single large message per link instead of world_size small ones) and
+    trimmed afterwards."""
+    if not dist.is_available() or not dist.is_initialized():
+        if local.shape[0] != n_total:
+            raise RuntimeError("all_gather_rows: no process group and local != total")
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(n_total, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank}: local has {local.shape[0]} rows, shard is {hi - lo}")
+    cap = (n_total + world - 1) // world
+    tail = tuple(local.shape[1:])
+    send = local.contiguous()
+    if send.shape[0] != cap:
+        pad = torch.zeros((cap - send.shape[0],) + tail, dtype=local.dtype, device=local.device)
+        send = torch.cat([send, pad], dim=0)
+    recv = torch.empty((world * cap,) + tail, dtype=local.dtype, device=local.device)
+    try:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    except (RuntimeError, NotImplementedError):          # gloo builds without the fused form
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send, group=group)
+        recv = torch.cat(parts, dim=0)
+    if n_total == world * cap:
+        return recv
+    pieces = []
+    for r in range(world):
+        rlo, rhi = shard_bounds(n_total, r, world)
+        pieces.append(recv[r * cap: r * cap + (rhi - rlo)])
+    return torch.cat(pieces, dim=0)

@@ -1,0 +1,389 @@
+"""TPS++ (attention-enhanced TPS) rectifier behind the reference's BACKBONES API.
+
+Mirror of `mmocr/models/textrecog/backbones/tps_pp/tps_pp.py` + `DGAB.py` (reference): registry
+name `TPS_PP` (`tps_pp.py:499-500`; also `TPS_PPv2` in PREPROCESSOR, the name
+`preprocessor/__init__.py:6` expects), constructor signature and assertions (`:505-516`), call
+contract `forward(batch_img, outs) -> dict(output, logits=None, mp_img, pc_score)` (`:564-625`) and
+the 60-entry `state_dict` (58 parameters + buffers `atten_tps.hat_C`, `atten_tps.P_hat`), so
+released checkpoints load unchanged.
+
+Division of labour in this round:
+  * the transformation stage -- `Attention_Enhanced_TPS.build_P_prime` + both `F.grid_sample` calls
+    (`:597-615`) -- is ONE hand-written HIP kernel (T in LDS, grid in registers, arithmetic identical
+    to the reference's CPU run);
+  * the control-point regressor (MSFA / TPE / DGAB, `:84-325`) still runs on PyTorch-ROCm library
+    kernels; its MFMA replacement is the next row of the build plan.
+No CPU fallback: CPU tensors raise.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import constants, ops
+from .registry import BACKBONES, PREPROCESSOR
+
+
+class ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule as the reference uses it: `conv` (Conv2d, bias because there is no norm
+    layer) followed by `activate` (ReLU, in place on the conv's own output)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride,
+                              padding=padding, bias=True)
+        self.activate = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.activate(self.conv(x))
+
+
+class ChannelAttentionModule(nn.Module):
+    """`tps_pp.py:27-50` (ratio > 0 branch; the only one instantiated)."""
+
+    def __init__(self, channel, ratio=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.max_pool = nn.AdaptiveMaxPool2d(1)
+        self.shared_MLP = nn.Sequential(
+            nn.Conv2d(channel, channel // ratio, 1, bias=False), nn.ReLU(),
+            nn.Conv2d(channel // ratio, channel, 1, bias=False))
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.sigmoid(self.shared_MLP(self.avg_pool(x)) + self.shared_MLP(self.max_pool(x)))
+
+
+class SpatialAttentionModule(nn.Module):
+    """`tps_pp.py:53-65`."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv2d = nn.Conv2d(2, 1, kernel_size=3, stride=1, padding=1)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        avgout = torch.mean(x, dim=1, keepdim=True)
+        maxout, _ = torch.max(x, dim=1, keepdim=True)
+        return self.sigmoid(self.conv2d(torch.cat([avgout, maxout], dim=1)))
+
+
+class CBAM(nn.Module):
+    """`tps_pp.py:68-82`."""
+
+    def __init__(self, channel, ratio=16):
+        super().__init__()
+        self.ratio = ratio
+        self.channel_attention = ChannelAttentionModule(channel, ratio)
+        self.spatial_attention = SpatialAttentionModule()
+
+    def forward(self, x):
+        out = self.channel_attention(x) * x
+        return self.spatial_attention(out) * out
+
+
+class Encoder_Decoder_Feature_Extractor(nn.Module):
+    """U-Net of `tps_pp.py:84-169`: 4 strided 3x3 encoders, CBAM bottleneck, 4 nearest-upsample +
+    3x3 decoders with skip additions."""
+
+    def __init__(self, in_channels=512, num_channels=64, attn_mode="nearest", stride=2,
+                 ratio=(1, 1, 1), u_channel=2):
+        super().__init__()
+        self.stride = stride
+        nc = num_channels
+        self.k_encoder = nn.Sequential(
+            ConvModule(in_channels * u_channel, nc * ratio[0], 3, stride=1, padding=1),
+            ConvModule(nc * ratio[0], nc * ratio[1], 3, stride=2, padding=1),
+            ConvModule(nc * ratio[1], nc * ratio[2], 3, stride=stride, padding=1),
+            ConvModule(nc, nc, 3, stride=(2, 1), padding=1))
+        self.atten = CBAM(nc * ratio[2])
+
+        def dec(cin, cout, scale):
+            return nn.Sequential(nn.Upsample(scale_factor=scale, mode=attn_mode),
+                                 ConvModule(cin, cout, 3, stride=1, padding=1))
+        self.k_decoder = nn.Sequential(
+            dec(nc, nc, (2, 1)),
+            dec(nc * ratio[2], nc * ratio[1], stride),
+            dec(nc * ratio[1], nc * ratio[0], 2),
+            dec(nc * ratio[0], in_channels, 1))
+
+    def forward(self, k):
+        features = []
+        for layer in self.k_encoder:
+            k = layer(k)
+            features.append(k)
+        point = features[-1]
+        k = self.atten(point)
+        n = len(self.k_decoder)
+        for i in range(n - 1):
+            k = self.k_decoder[i](k)
+            k = k + features[n - 2 - i]
+        k = self.k_decoder[-1](k)
+        return {"decoded_feature": k, "encoded_feature": point}
+
+
+class Multi_Scale_Fearue_Aggregation(nn.Module):
+    """`tps_pp.py:172-229` (class name spelt as in the reference: it is a state_dict-visible name
+    only through its attribute `MSFA`, but configs/tools may import it)."""
+
+    def __init__(self, num_img_channel, point_size, p_stride, num_map=2):
+        super().__init__()
+        self.num_img_channel = num_img_channel
+        self.point_x = point_size[1]
+        self.point_y = point_size[0]
+        self.tf_ratio = 4
+        self.conv = Encoder_Decoder_Feature_Extractor(in_channels=num_img_channel, num_channels=64,
+                                                      stride=p_stride, u_channel=num_map)
+        self.num_fiducial = self.point_y * self.point_x
+
+    def forward(self, batch_img):
+        logits = self.conv(batch_img)
+        return {"de_feat": logits["decoded_feature"], "en_feat": logits["encoded_feature"]}
+
+
+class Mlp(nn.Module):
+    """`DGAB.py:7-23` (dropout p = 0 is the identity and is omitted)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class DGAB_Block(nn.Module):
+    """Dynamic gated attention of `DGAB.py:25-55`.  `proj` is an nn.Linear applied to a (b,c,h,w)
+    tensor, i.e. along W -- valid only because W == dim (kept as is)."""
+
+    def __init__(self, dim, point=8, qkv_bias=False, height=1, width=63):
+        super().__init__()
+        self.mlp_h = nn.Sequential(nn.Linear(height + point, height + 1, bias=qkv_bias))
+        self.mlp_w = nn.Sequential(nn.Linear(width + point, width + 1, bias=qkv_bias))
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, y):
+        y = y.transpose(1, 2)                                   # b t c -> b c t
+        w = self.mlp_w(torch.cat([x.mean(2), y], 2))
+        v_w = w[:, :, :-1].softmax(dim=-1).unsqueeze(2)
+        h = self.mlp_h(torch.cat([x.mean(3), y], 2))
+        v_h = h[:, :, :-1].softmax(dim=-1).unsqueeze(3)
+        x = v_h * x * h[:, :, -1].unsqueeze(-1).unsqueeze(-1) + \
+            v_w * x * w[:, :, -1].unsqueeze(-1).unsqueeze(-1)
+        return self.proj(x)
+
+
+class DGAB(nn.Module):
+    """`DGAB.py:58-77`: LayerNorm over (H, W), gated attention, MLP along W; drop_path = identity."""
+
+    def __init__(self, dim, mlp_ratio=4.0, width=128, high=32, point=16, qkv_bias=False,
+                 skip_lam=1.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm([high, width])
+        self.attn = DGAB_Block(dim, point=point, width=width, height=high, qkv_bias=qkv_bias)
+        self.drop_path = nn.Identity()
+        self.norm2 = nn.LayerNorm([high, width])
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.skip_lam = skip_lam
+
+    def forward(self, x, y):
+        x = x + self.drop_path(self.attn(self.norm1(x), y)) / self.skip_lam
+        x = x + self.drop_path(self.mlp(self.norm2(x))) / self.skip_lam
+        return x
+
+
+class Transformation_Parameter_Estimation(nn.Module):
+    """`tps_pp.py:231-325`: DGAB, control-point FCs, attention score."""
+
+    def __init__(self, img_channel, point_channel, num_img_channel, point_size, img_size):
+        super().__init__()
+        self.num_img_channel = num_img_channel
+        self.point_x = point_size[1]
+        self.point_y = point_size[0]
+        self.tf_layers = 1
+        self.scale = num_img_channel ** -0.5
+        self.without_as = False
+        self.num_fiducial = self.point_y * self.point_x
+        self.p_linear = nn.Sequential(nn.Linear(point_channel, 32), nn.Linear(32, 64 * 2))
+        self.feat_linear = nn.Sequential(nn.Linear(img_channel, 32), nn.Linear(32, 64 * 2))
+        self.atten = nn.ModuleList([
+            DGAB(dim=num_img_channel, point=self.num_fiducial, width=img_size[1], high=img_size[0])
+            for _ in range(self.tf_layers)])
+        self.localization_fc1 = nn.Sequential(nn.Linear(num_img_channel, 256), nn.ReLU(True),
+                                              nn.Linear(256, 2), nn.ReLU(True))
+        self.localization_fc2 = nn.Linear(2 * self.num_fiducial, self.num_fiducial * 2)
+        # fc2 starts as "weight 0, bias = initial lattice" (tps_pp.py:277-285)
+        self.localization_fc2.weight.data.fill_(0)
+        self.localization_fc2.bias.data = torch.from_numpy(
+            constants.tpspp_initial_ctrl(point_size)).float().view(-1)
+
+    def atten_score(self, a, b):
+        attn = torch.einsum("bmc,bnc->bmn", a, b)
+        attn = attn.mul(self.scale)
+        return torch.tanh(attn)
+
+    def get_score(self, point, feat):
+        feat = feat.flatten(2).transpose(1, 2)                  # b c h w -> b (h w) c
+        pc_score = self.atten_score(self.feat_linear(feat), self.p_linear(point))
+        if self.without_as:
+            pc_score = torch.zeros_like(pc_score)
+        return pc_score
+
+    def forward(self, en_feat, de_feat):
+        batch_size = en_feat.size(0)
+        en_feat = en_feat.flatten(2).transpose(1, 2)            # b c h w -> b (h w) c
+        for atten_layer in self.atten:
+            de_feat = atten_layer(de_feat, en_feat)
+        control_point = self.localization_fc2(
+            self.localization_fc1(en_feat).view(batch_size, -1)).view(batch_size,
+                                                                      self.num_fiducial, 2)
+        return control_point, self.get_score(en_feat, de_feat)
+
+
+class Attention_Enhanced_TPS(nn.Module):
+    """Constants and grid expansion of `tps_pp.py:328-496`.  `hat_C` IS the inverse of delta_C (the
+    reference's buffer name is kept); the per-image `build_inv_delta_C` (:408-435) is dead code there
+    and is not reproduced."""
+
+    def __init__(self, rectified_img_size, point_size):
+        super().__init__()
+        self.eps = constants.EPS
+        self.thela = 0.5
+        self.point_size = point_size
+        self.point_y, self.point_x = point_size[0], point_size[1]
+        self.num_fiducial = self.point_y * self.point_x
+        self.rectified_img_height = rectified_img_size[0]
+        self.rectified_img_width = rectified_img_size[1]
+        k = constants.tpspp(rectified_img_size, point_size)
+        self.C, self.P = k["C"], k["P"]
+        self.register_buffer("hat_C", torch.from_numpy(k["hat_C"]))
+        self.register_buffer("P_hat", torch.from_numpy(k["P_hat"]))
+        self._P_xy_host = k["P_xy"]
+        self._prep = None
+
+    def device_constants(self, device):
+        """(P_xy, P_hat_t) on `device`; P is not a registered buffer in the reference (it does a
+        per-call `torch.tensor(self.P).float().to(device)`, tps_pp.py:472): cached here instead."""
+        p = self.P_hat
+        key = (p.data_ptr(), p._version, str(device))
+        if self._prep is None or self._prep[0] != key:
+            self._prep = (key, torch.from_numpy(self._P_xy_host).to(device), ops.transpose_p_hat(p))
+        return self._prep[1], self._prep[2]
+
+    def build_P_prime(self, batch_C_prime, pc_score, device="cuda"):
+        """(N,F,2), (N,n,F) -> (N,n,2) sampling grid (`tps_pp.py:481-496`), HIP kernels."""
+        P_xy, _ = self.device_constants(batch_C_prime.device)
+        T = ops.solve_T(self.hat_C, batch_C_prime)
+        return ops.build_grid(self.P_hat, T, P_xy=P_xy, score=pc_score)
+
+
+@BACKBONES.register_module()
+class TPS_PP(nn.Module):
+    """TPS++ rectifier (`tps_pp.py:499-625`).
+
+    Args (as the reference): img_size, rectified_img_size (tuples), num_img_channel, point_size,
+        p_stride, visual_point, init_cfg.
+    Extra: variant -- 'ResNet45v2' (default; the wiring the reference hard-codes at :522: both
+        `outs` at 2x the resolution of `batch_img`) or 'ResNet45' (the reference's other branch,
+        :549-552,574-579: `outs[0]` at 2x, `outs[1]` at 1x -- the geometry the shipped config's
+        backbone strides [2,1,2,1,2] actually produce).
+    """
+
+    def __init__(self, img_size=(16, 64), rectified_img_size=(16, 64), num_img_channel=64,
+                 point_size=(2, 16), p_stride=2, visual_point=False, init_cfg=None,
+                 variant="ResNet45v2"):
+        super().__init__()
+        assert isinstance(img_size, tuple)
+        assert isinstance(rectified_img_size, tuple)
+        assert variant in ("ResNet45v2", "ResNet45")
+        self.init_cfg = init_cfg
+        self.heads = 16
+        self.type = variant
+        self.visual_point = visual_point
+        self.num_fiducial = point_size[0] * point_size[1]
+        self.img_size = img_size
+        self.point_size = point_size
+        self.rectified_img_size = rectified_img_size
+        self.num_img_channel = num_img_channel
+        self.point_channel = num_img_channel
+        self.img_channel = num_img_channel
+        ic = self.img_channel
+        self.MSFA = Multi_Scale_Fearue_Aggregation(num_img_channel, point_size, p_stride, num_map=3)
+        # (the reference passes point_channel / img_channel swapped, :240 vs :534; both are 64)
+        self.TPE = Transformation_Parameter_Estimation(self.point_channel, self.img_channel,
+                                                       num_img_channel, point_size, img_size)
+        if variant == "ResNet45v2":
+            self.down0 = ConvModule(32, ic, 1)
+            self.down1 = ConvModule(32, ic, 1)
+            self.down2 = ConvModule(64, ic, 1)
+            self.down0_1 = ConvModule(ic, ic, 3, stride=2, padding=1)
+            self.down1_1 = ConvModule(ic, ic, 3, stride=2, padding=1)
+            self.up_sample = nn.Upsample(scale_factor=2, mode="nearest")
+            self.down_feat = ConvModule(3 * ic, ic, 1)
+        else:
+            self.down0 = ConvModule(32, ic, 3, stride=2, padding=1)
+            self.down1 = ConvModule(32, ic, 1)
+            self.down2 = ConvModule(64, ic, 1)
+        self.atten_tps = Attention_Enhanced_TPS(rectified_img_size, point_size)
+
+    def init_weights(self):
+        pass
+
+    def grid(self, a1, a2, a3):
+        return self.down_feat(torch.cat((a1, a2, self.up_sample(a3)), dim=1))
+
+    def regress(self, batch_img, outs):
+        """Control points, attention score and the feature map to rectify (`tps_pp.py:572-594`)."""
+        h, w = batch_img.shape[-2:]
+        if self.type == "ResNet45v2":
+            if tuple(outs[1].shape[-2:]) != (2 * h, 2 * w) or tuple(outs[0].shape[-2:]) != (2 * h, 2 * w):
+                raise ValueError(
+                    f"TPS_PP(variant='ResNet45v2') needs outs[0], outs[1] at {(2 * h, 2 * w)}, got "
+                    f"{tuple(outs[0].shape[-2:])}, {tuple(outs[1].shape[-2:])}: backbone strides "
+                    "[2,1,2,1,2] (configs/textrecog/nrtr/nrtr_tps++.py) produce the 'ResNet45' "
+                    "geometry -- build with variant='ResNet45' (the reference itself fails here)")
+            feat0 = self.down0(outs[0])
+            feat1 = self.down1(outs[1])
+            feat2 = self.down2(batch_img)
+            feat_cat = torch.cat((self.down0_1(feat0), self.down1_1(feat1), feat2), dim=1)
+            feat_grid = self.grid(feat0, feat1, feat2)
+        else:
+            feat0 = self.down0(outs[0])
+            feat1 = self.down1(outs[1])
+            feat2 = self.down2(batch_img)
+            feat_cat = torch.cat((feat0, feat1, feat2), dim=1)
+            feat_grid = batch_img
+        logits = self.MSFA(feat_cat)
+        control_point, atten_score = self.TPE(logits["en_feat"], logits["de_feat"])
+        return control_point, atten_score, feat_grid
+
+    def rectify(self, feat_grid, batch_img, control_point, atten_score, want_grid=False):
+        """The transformation stage alone (`tps_pp.py:597-615`): one fused HIP kernel."""
+        at = self.atten_tps
+        P_xy, P_hat_t = at.device_constants(batch_img.device)
+        out0, out1, grid, _ = ops.warp(feat_grid, control_point, at.hat_C, at.P_hat,
+                                       self.rectified_img_size, P_xy=P_xy, score=atten_score,
+                                       in1=batch_img, want_grid=want_grid, P_hat_t=P_hat_t)
+        return (out0, out1, grid) if want_grid else (out0, out1)
+
+    def forward(self, batch_img, outs, **kwargs):
+        """batch_img (N,64,16,64), outs = [stage-0 input, stage-1 input] ->
+        dict(output, logits=None, mp_img, pc_score)."""
+        if torch.is_grad_enabled() and (batch_img.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "TPS_PP (HIP path) is forward-only: run under torch.no_grad() (backward for the "
+                "warp op is on the roadmap, SURVEY.md section 8f F2)")
+        control_point, atten_score, feat_grid = self.regress(batch_img, outs)
+        output, mp_img = self.rectify(feat_grid.float().contiguous(), batch_img.float().contiguous(),
+                                      control_point.float(), atten_score.float().contiguous())
+        return {"output": output, "logits": None, "mp_img": mp_img, "pc_score": atten_score}
+
+
+# `preprocessor/__init__.py:6` of the reference imports a (never released) `TPS_PPv2` into the
+# PREPROCESSOR registry; the name is provided so configs referring to it resolve.
+PREPROCESSOR.register_module(name="TPS_PPv2", module=TPS_PP)

@@ -1,0 +1,146 @@
+"""Classic RARE TPS-STN rectifier behind the reference's PREPROCESSOR API.
+
+Mirror of `mmocr/models/textrecog/preprocessor/tps_preprocessor.py` (reference): same registry name,
+constructor signature and assertion behaviour (`:37-49`), same sub-module / buffer names, hence the same
+`state_dict` keys (`LocalizationNetwork.conv.{0,1,4,5,8,9,12,13}.*`, `LocalizationNetwork.
+localization_fc1.0.*`, `LocalizationNetwork.localization_fc2.*`, `GridGenerator.inv_delta_C`,
+`GridGenerator.P_hat`), same `forward(batch_img) -> Tensor`.
+
+What differs is underneath: `GridGenerator.build_P_prime` + `F.grid_sample` (`:71-83`) run as ONE
+hand-written HIP kernel (`tps_pp_amd/csrc/tpspp_warp.hip` through the C ABI of `include/tpspp.h`).
+There is no PyTorch / CPU fallback for that path: CPU tensors raise.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import constants, ops
+from .registry import PREPROCESSOR
+
+
+class BasePreprocessor(nn.Module):
+    """`preprocessor/base_preprocessor.py:8-13`: identity preprocessor with an `init_cfg` slot."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+    def init_weights(self):
+        pass
+
+    def forward(self, x, **kwargs):
+        return x
+
+
+class LocalizationNetwork(nn.Module):
+    """Predicts the fiducial points C' (N, F, 2) from the image (`tps_preprocessor.py:88-156`)."""
+
+    def __init__(self, num_fiducial, num_img_channel):
+        super().__init__()
+        self.num_fiducial = num_fiducial
+        self.num_img_channel = num_img_channel
+        self.conv = nn.Sequential(
+            nn.Conv2d(num_img_channel, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64), nn.ReLU(True),
+            nn.MaxPool2d(2, 2),
+            nn.Conv2d(64, 128, 3, 1, 1, bias=False), nn.BatchNorm2d(128), nn.ReLU(True),
+            nn.MaxPool2d(2, 2),
+            nn.Conv2d(128, 256, 3, 1, 1, bias=False), nn.BatchNorm2d(256), nn.ReLU(True),
+            nn.MaxPool2d(2, 2),
+            nn.Conv2d(256, 512, 3, 1, 1, bias=False), nn.BatchNorm2d(512), nn.ReLU(True),
+            nn.AdaptiveAvgPool2d(1))
+        self.localization_fc1 = nn.Sequential(nn.Linear(512, 256), nn.ReLU(True))
+        self.localization_fc2 = nn.Linear(256, num_fiducial * 2)
+        # fc2 starts as "weight 0, bias = initial fiducials" (tps_preprocessor.py:130-140)
+        self.localization_fc2.weight.data.fill_(0)
+        self.localization_fc2.bias.data = torch.from_numpy(
+            constants.classic_initial_ctrl(num_fiducial)).float().view(-1)
+
+    def forward(self, batch_img):
+        n = batch_img.size(0)
+        feat = self.conv(batch_img).view(n, -1)
+        return self.localization_fc2(self.localization_fc1(feat)).view(n, self.num_fiducial, 2)
+
+
+class GridGenerator(nn.Module):
+    """Holds inv_delta_C / P_hat and expands the sampling grid (`tps_preprocessor.py:159-282`)."""
+
+    def __init__(self, num_fiducial, rectified_img_size):
+        super().__init__()
+        self.eps = constants.EPS
+        self.rectified_img_height = rectified_img_size[0]
+        self.rectified_img_width = rectified_img_size[1]
+        self.num_fiducial = num_fiducial
+        k = constants.classic(num_fiducial, rectified_img_size)
+        self.C, self.P = k["C"], k["P"]
+        self.register_buffer("inv_delta_C", torch.from_numpy(k["inv_delta_C"]))
+        self.register_buffer("P_hat", torch.from_numpy(k["P_hat"]))
+        self._prep = None        # (key, P_hat_t, table_flags): device-side view of P_hat for the kernels
+
+    def prepared_table(self):
+        """(P_hat_t, table_flags) for the current P_hat buffer: the transposed copy the coalesced
+        kernels read, and whether the table has the reference's mirror symmetry (checked bitwise,
+        once per buffer version; a checkpoint that loads a different table simply gets 0)."""
+        p = self.P_hat
+        key = (p.data_ptr(), p._version, str(p.device))
+        if self._prep is None or self._prep[0] != key:
+            flags = 0
+            if ops.table_mirror_symmetry(p, (self.rectified_img_height, self.rectified_img_width),
+                                         self.num_fiducial):
+                flags |= ops.TABLE_MIRROR4
+            self._prep = (key, ops.transpose_p_hat(p), flags)
+        return self._prep[1], self._prep[2]
+
+    def build_P_prime(self, batch_C_prime, device="cuda"):
+        """(N, F, 2) -> (N, n, 2): `bmm(P_hat, bmm(inv_delta_C, [C'; 0]))` as two HIP kernels with the
+        reference's summation order (`tps_preprocessor.py:270-282`)."""
+        T = ops.solve_T(self.inv_delta_C, batch_C_prime)
+        return ops.build_grid(self.P_hat, T)
+
+
+@PREPROCESSOR.register_module()
+class TPSPreprocessor(BasePreprocessor):
+    """Rectification network of RARE (TPS-based STN), `tps_preprocessor.py:24-85`.
+
+    Args:
+        num_fiducial (int): number of fiducial points.
+        img_size (tuple(int, int)): (H, W) of the input image.
+        rectified_img_size (tuple(int, int)): (H_r, W_r) of the rectified image.
+        num_img_channel (int): input channels.
+        init_cfg (dict or list[dict], optional): kept for config compatibility.
+    """
+
+    def __init__(self, num_fiducial=20, img_size=(32, 100), rectified_img_size=(32, 100),
+                 num_img_channel=1, init_cfg=None):
+        super().__init__(init_cfg=init_cfg)
+        assert isinstance(num_fiducial, int)
+        assert num_fiducial > 0
+        assert isinstance(img_size, tuple)
+        assert isinstance(rectified_img_size, tuple)
+        assert isinstance(num_img_channel, int)
+        self.num_fiducial = num_fiducial
+        self.img_size = img_size
+        self.rectified_img_size = rectified_img_size
+        self.num_img_channel = num_img_channel
+        self.LocalizationNetwork = LocalizationNetwork(num_fiducial, num_img_channel)
+        self.GridGenerator = GridGenerator(num_fiducial, rectified_img_size)
+
+    def rectify(self, batch_img, batch_C_prime, want_grid=False, want_idx=False):
+        """The hot path alone: control points -> rectified image (fused HIP kernel)."""
+        gg = self.GridGenerator
+        P_hat_t, flags = gg.prepared_table()
+        out, _, grid, idx = ops.warp(batch_img, batch_C_prime, gg.inv_delta_C, gg.P_hat,
+                                     self.rectified_img_size, want_grid=want_grid,
+                                     want_idx=want_idx, P_hat_t=P_hat_t, table_flags=flags)
+        if want_grid or want_idx:
+            return out, grid, idx
+        return out
+
+    def forward(self, batch_img):
+        """(N, C, H, W) -> (N, C, H_r, W_r)."""
+        if torch.is_grad_enabled() and (batch_img.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "TPSPreprocessor (HIP path) is forward-only: run under torch.no_grad() / eval "
+                "inference (backward for the warp op is on the roadmap, SURVEY.md section 8f F2)")
+        batch_C_prime = self.LocalizationNetwork(batch_img)
+        return self.rectify(batch_img.float(), batch_C_prime.float())
