@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- rectified images/sec of the TPS hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one step = one launch of the fused TPS grid-gen + bilinear
+grid_sample HIP kernel on a batch of 512 synthetic 3x32x100 fp32 images, 20 fiducials, control
+points = fiducial lattice + 0.05 * noise.  Inputs are resident in HBM before the timed region; the
+steps rotate over enough distinct input/output buffers (> 256 MB) that the Infinity Cache cannot
+hold the working set.  Weak scaling: every rank rectifies its own 512-image batches, there is no
+data-path collective (images are independent).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- algorithmic HBM bytes per launch / average launch duration (HIP events on the
+                  launch stream over the timed region) against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, OpenMP over images) timed on
+                  this box's host cores on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from tps_pp_amd import TPSPreprocessor, constants, ops, synth  # noqa: E402
+
+BATCH, C, H, W, F = 512, 3, 32, 100, 20
+# SURVEY.md section 8d / DESIGN.md section 5: image in + control points + image out, per image
+BYTES_PER_IMG = C * H * W * 4 + F * 2 * 4 + C * H * W * 4          # 76,960
+HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md
+CACHE_BYTES = 256 << 20
+
+
+def load_traffic():
+    """HBM bytes per launch from the PMC passes, if a summary was committed (profiles/)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(p)).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(img, ctrl, inv, p_hat, budget_s=12.0):
+    """The CPU oracle on the host cores, same workload, bounded sample."""
+    from oracle import tps_oracle as O
+    O.build()
+    threads = O.max_threads()
+    O.warp(img, ctrl, inv, p_hat, (H, W))                           # warm-up (page faults, OpenMP)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.warp(img, ctrl, inv, p_hat, (H, W))
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s or reps >= 2000:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": reps * BATCH / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} batches of {BATCH} images (3x32x100, F=20) in {dt:.1f} s, "
+                      f"oracle/tps_oracle.c with {threads} OpenMP threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- the module boundary a recognizer would hold (constants, prepared table) ----
+    mod = TPSPreprocessor(num_fiducial=F, img_size=(H, W), rectified_img_size=(H, W),
+                          num_img_channel=C).eval().to(dev)
+    gg = mod.GridGenerator
+    p_hat_t, flags = gg.prepared_table()
+
+    # ---- synthetic inputs, resident in HBM; buffer 0 is the exactly reproducible one ----
+    per_set = 2 * BATCH * C * H * W * 4
+    nbuf = max(2, (2 * CACHE_BYTES + per_set - 1) // per_set)       # >= 2x the Infinity Cache
+    ident = constants.classic_identity_ctrl(F)
+    img0 = synth.dyadic((BATCH, C, H, W), f"bench.img.r{rank}")
+    ctrl0 = (ident[None] + 0.05 * synth.dyadic((BATCH, F, 2), f"bench.ctrl.r{rank}")).astype(np.float32)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = [torch.from_numpy(img0).to(dev)]
+    ctrls = [torch.from_numpy(ctrl0).to(dev)]
+    ident_d = torch.from_numpy(ident).to(dev)
+    for _ in range(1, nbuf):
+        imgs.append(torch.rand((BATCH, C, H, W), generator=g, device=dev) * 2 - 1)
+        ctrls.append(ident_d[None] + 0.05 * (torch.rand((BATCH, F, 2), generator=g, device=dev) * 2 - 1))
+    outs = [torch.empty((BATCH, C, H, W), device=dev) for _ in range(nbuf)]
+
+    def step(i):
+        j = i % nbuf
+        ops.warp(imgs[j], ctrls[j], gg.inv_delta_C, gg.P_hat, (H, W), out0=outs[j],
+                 P_hat_t=p_hat_t, table_flags=flags)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()                                                    # on the launch stream
+    for i in range(a.steps):
+        step(a.warmup + i)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    ev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        tt = torch.tensor([dt, ev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, ev_ms = float(tt[0]), float(tt[1])
+
+    # ---- parity spot-check of what was just measured (not timed) ----
+    max_err = None
+    if rank == 0:
+        from oracle import tps_oracle as O
+        O.build()
+        step(0)
+        torch.cuda.synchronize(dev)
+        sel = [0, 1, 255, 511]
+        ref = O.warp(img0[sel], ctrl0[sel], gg.inv_delta_C.cpu().numpy(), gg.P_hat.cpu().numpy(), (H, W))
+        max_err = float(np.abs(outs[0][sel].cpu().numpy() - ref["out0"]).max())
+
+    if rank == 0:
+        launch_us = ev_ms * 1e3 / a.steps
+        achieved = BYTES_PER_IMG * BATCH / (launch_us * 1e-6) / 1e9
+        rec = {
+            "metric": "rectified images/sec (3x32x100)",
+            "value": world * BATCH * a.steps / dt,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt * 1e3 / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: fused TPS grid-gen + bilinear "
+                                   "grid_sample HIP kernel, batch 512 per GPU, 3x32x100 fp32, "
+                                   "20 fiducials, inputs resident in HBM",
+                       "batch_per_gpu": BATCH, "rotating_buffer_sets": int(nbuf),
+                       "working_set_MB": round(nbuf * per_set / 1e6, 1)},
+            "max_abs_err_vs_oracle": max_err,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                         "kernel": "tps_warp_lds_mirror_kernel<20,3,32,100>",
+                         "launch_us": launch_us,
+                         "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(img0, ctrl0, gg.inv_delta_C.cpu().numpy(),
+                                               gg.P_hat.cpu().numpy())
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof/* (scripts/collect_profiles.sh) into the committed summaries under profiles/:
+
+  profiles/rNN_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py`
+  profiles/rNN_pmc_summary.md           HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes,
+                                        with the calibration against the plain-copy kernel
+  profiles/pmc_traffic.json             what bench.py reports as roofline.traffic
+
+Counter handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected
+in separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reads exactly 1/2 of a wide coalesced
+read stream -- the factor is re-measured here on a copy of known size rather than assumed.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof")
+DST = os.path.join(ROOT, "profiles")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KERNEL = "tps_warp_lds_mirror_kernel"
+COPY_BYTES = 512 * 3 * 32 * 100 * 4          # scripts/ubench/copy_bench.hip: bytes read = bytes written
+ALGO_BYTES = 512 * 76960
+
+
+def mean_counter(path, kernel_substr, counter):
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"),
+                os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
+    stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_stats.csv")))}
+    krow = next(v for k, v in stats.items() if KERNEL in k)
+    bench_line = [l for l in open(os.path.join(SRC, "bench_trace.log")) if l.startswith("{")][-1]
+    bench = json.loads(bench_line)
+
+    f_copy, _ = mean_counter(os.path.join(SRC, "cal_FETCH_SIZE", "copy_counter_collection.csv"), "copy_k(", "FETCH_SIZE")
+    w_copy, _ = mean_counter(os.path.join(SRC, "cal_WRITE_SIZE", "copy_counter_collection.csv"), "copy_k(", "WRITE_SIZE")
+    f_corr = COPY_BYTES / (f_copy * 1024.0)
+    w_corr = COPY_BYTES / (w_copy * 1024.0)
+    f_k, nf = mean_counter(os.path.join(SRC, "pmc_FETCH_SIZE", "bench_counter_collection.csv"), KERNEL, "FETCH_SIZE")
+    w_k, nw = mean_counter(os.path.join(SRC, "pmc_WRITE_SIZE", "bench_counter_collection.csv"), KERNEL, "WRITE_SIZE")
+    rd = f_k * 1024.0 * f_corr
+    wr = w_k * 1024.0 * w_corr
+    traffic = rd + wr
+    js = {"round": TAG, "kernel": krow["Name"], "hbm_bytes_per_launch": traffic,
+          "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+          "algorithmic_bytes_per_launch": ALGO_BYTES, "traffic_over_algorithmic": traffic / ALGO_BYTES,
+          "FETCH_SIZE_KiB_raw": f_k, "WRITE_SIZE_KiB_raw": w_k,
+          "fetch_correction_measured_on_copy": f_corr, "write_correction_measured_on_copy": w_corr,
+          "dispatches_averaged": [nf, nw]}
+    json.dump(js, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+    with open(os.path.join(DST, f"{TAG}_pmc_summary.md"), "w") as f:
+        f.write(f"""# {TAG}: rocprofv3 summary for `python3 bench.py` (MI355X, 1 GPU)
+
+Command lines: `scripts/collect_profiles.sh` (run through gpurun).  Raw CSVs: `gpurun_out/prof/` (scratch).
+
+## Kernel trace (`rocprofv3 --kernel-trace --stats`, file `{TAG}_bench_kernel_stats.csv`)
+
+| kernel | calls | average ns | min ns | max ns |
+|---|---|---|---|---|
+| `{krow['Name'][:90]}` | {krow['Calls']} | {float(krow['AverageNs']):.0f} | {krow['MinNs']} | {krow['MaxNs']} |
+
+bench.py's own HIP-event figure in the same (profiled) run: launch_us = {bench['roofline']['launch_us']:.2f}
+(rocprofv3 serialises dispatches, so profiled runs are slower than the un-profiled bench line).
+
+## HBM traffic (`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, separate passes)
+
+Calibration on `copy_k` (scripts/ubench/copy_bench.hip, {COPY_BYTES} B read and {COPY_BYTES} B written per launch):
+FETCH_SIZE reads {f_copy:.1f} KiB -> correction x{f_corr:.4f} (the gfx950 "1/2 of a wide coalesced stream" factor),
+WRITE_SIZE reads {w_copy:.1f} KiB -> correction x{w_corr:.4f}.
+
+| per launch of the warp kernel | raw counter (KiB) | corrected bytes |
+|---|---|---|
+| read  (FETCH_SIZE, {nf} dispatches) | {f_k:.1f} | {rd:,.0f} |
+| write (WRITE_SIZE, {nw} dispatches) | {w_k:.1f} | {wr:,.0f} |
+| total | | {traffic:,.0f} |
+
+Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / algorithmic = {traffic / ALGO_BYTES:.3f}
+(the excess is the batch-shared table and inv_delta_C, which the algorithmic figure excludes).
+""")
+    print(json.dumps(js, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 """Exactly reproducible synthetic tensors (inputs and weights).
 
-Every value is ``k / 2**23 - 1`` with ``k`` the top 24 bits ... of a counter-based 64-bit
+Every value is ``k / 2**23 - 1`` with ``k`` the top 24 bits of a counter-based 64-bit
 integer hash of (seed, tensor name, flat index), i.e. a dyadic rational in [-1, 1) that is exactly
 representable in fp32.  No dependence on the numpy / torch RNG streams, so the GPU box, this
 container and the golden-vector generator (tests/golden/make_golden.py) all see bit-identical data
