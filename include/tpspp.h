@@ -115,7 +115,8 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  * Launch-shape override for tpspp_warp_fwd (tuning / benchmarking only; results do not depend on
  * it): images per workgroup and threads per workgroup of the gather kernel (0 = heuristic), and
  * kernel choice: 0 = automatic, 1 = force the gather kernel, 2 = require the LDS-staged kernel
- * (TPSPP_EINVAL if the shape does not qualify), 3 = as 2 but ignore TPSPP_TABLE_MIRROR4; bands = workgroups per image pair in the LDS-staged
+ * (TPSPP_EINVAL if the shape does not qualify), 3 = as 2 but ignore TPSPP_TABLE_MIRROR4,
+ * 4 = require the plane-streaming kernel; bands = workgroups per image pair in the LDS-staged
  * kernel (0 = heuristic).
  */
 int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);

@@ -43,6 +43,7 @@ def main():
     else:
         K = constants.tpspp((16, 64), (2, 16))
         inv, P_hat, P_xy = (torch.from_numpy(K[k]).to(dev) for k in ("hat_C", "P_hat", "P_xy"))
+        P_hat_t = ops.transpose_p_hat(P_hat)
         hw, F = (16, 64), 32
         bytes_per_img = 1966336
         nbuf = 2
@@ -59,11 +60,11 @@ def main():
         def run(i):
             j = i % nbuf
             ops.warp(ins0[j], ctrls[j], inv, P_hat, hw, P_xy=P_xy, score=scores[j], in1=ins1[j],
-                     out0=o0[j], out1=o1[j])
+                     out0=o0[j], out1=o1[j], P_hat_t=P_hat_t)
 
     print(f"batch {N}  bytes/img {bytes_per_img}  per launch {bytes_per_img * N / 1e6:.1f} MB")
-    configs = [(0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 3, 1), (0, 0, 3, 2)] if not a.pp else []
-    configs += [(G, tpb, 1, 0) for G in (0, 8) for tpb in (256,)]
+    configs = [(0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 3, 1), (0, 0, 3, 2)] if not a.pp else [(0, 0, 4, 0)]
+    configs += [(G, tpb, 1, 0) for G in ((0, 8) if not a.pp else (1, 4)) for tpb in (256,)]
     for G, tpb, kern, bands in configs:
         if True:
             ops.set_warp_tuning(G, tpb, kern, bands)

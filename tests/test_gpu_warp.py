@@ -78,13 +78,19 @@ def test_tpspp_warp_matches_reference_golden(cuda):
     G = cases.load("tpspp_warp")
     inp = cases.g3_inputs()
     P_xy = K["pp_P"].astype(np.float32)
-    out0, out1, grid, _ = ops.warp(dev(inp["feat_grid"], cuda), dev(inp["ctrl"], cuda),
-                                   dev(K["pp_hat_C"], cuda), dev(K["pp_P_hat"], cuda), cases.PP_HW,
-                                   P_xy=dev(P_xy, cuda), score=dev(inp["score"], cuda),
-                                   in1=dev(inp["x"], cuda), want_grid=True)
-    assert_biteq(grid, G["grid"], "TPS_PP grid vs reference")
-    assert_biteq(out0, G["output"], "TPS_PP output")
-    assert_biteq(out1, G["mp_img"], "TPS_PP mp_img")
+    P_hat = dev(K["pp_P_hat"], cuda)
+    try:
+        for kernel, P_hat_t in ((1, None), (4, None), (4, ops.transpose_p_hat(P_hat))):
+            ops.set_warp_tuning(0, 0, kernel, 0)      # 1 = gather kernel, 4 = plane-streaming kernel
+            out0, out1, grid, _ = ops.warp(dev(inp["feat_grid"], cuda), dev(inp["ctrl"], cuda),
+                                           dev(K["pp_hat_C"], cuda), P_hat, cases.PP_HW,
+                                           P_xy=dev(P_xy, cuda), score=dev(inp["score"], cuda),
+                                           in1=dev(inp["x"], cuda), want_grid=True, P_hat_t=P_hat_t)
+            assert_biteq(grid, G["grid"], f"TPS_PP grid vs reference (kernel {kernel})")
+            assert_biteq(out0, G["output"], f"TPS_PP output (kernel {kernel})")
+            assert_biteq(out1, G["mp_img"], f"TPS_PP mp_img (kernel {kernel})")
+    finally:
+        ops.set_warp_tuning(0, 0, 0, 0)
 
 
 # ---------------------------------------------------------------- oracle on fresh inputs ---------
@@ -98,7 +104,7 @@ def test_tpspp_warp_matches_reference_golden(cuda):
     (2, 3, 2, 2, 4, 4, 4, 1.0),             # tiny planes
     (2, 3, 1, 64, 8, 64, 8, 0.2),           # H == 1: y scale is 0
     (9, 1, 32, 100, 32, 100, 20, 0.2),      # odd batch, 1 channel: LDS kernel with a lone last image
-    (4, 3, 48, 160, 48, 160, 20, 0.1),      # pair = 180 KB: too big for LDS -> gather kernel
+    (4, 3, 48, 160, 48, 160, 20, 0.1),      # pair = 180 KB: too big for the pair kernel
     (6, 3, 16, 64, 16, 64, 20, 0.3),        # small planes: LDS kernel with 2 pixel slots
     (3, 3, 32, 100, 31, 99, 20, 0.2),       # odd output size: table is not mirror-symmetric
 ])
@@ -127,6 +133,10 @@ def test_classic_warp_vs_oracle(cuda, oracle, N, C, H, W, Ho, Wo, F, perturb):
     (2, (2, 16), (16, 64), 64, 64, False),
     (4, (2, 8), (8, 32), 6, 3, True),       # generic-F path with score + second input
     (1, (2, 3), (4, 10), 2, 1, True),
+    (5, (2, 16), (16, 64), 7, 3, True),     # unequal channel counts: one input runs out of planes
+    (2, (2, 16), (16, 64), 1, 5, True),
+    (3, (2, 10), (10, 50), 4, 4, True),     # F = 20 in the TPS_PP layout, planes not KB-multiples
+    (2, (2, 16), (8, 64), 3, 2, False),     # one pixel per thread
 ])
 def test_tpspp_warp_vs_oracle(cuda, oracle, N, point, hw, C0, C1, with_score):
     Kp = oracle.tpspp_constants(hw, point)
@@ -138,14 +148,22 @@ def test_tpspp_warp_vs_oracle(cuda, oracle, N, point, hw, C0, C1, with_score):
     in1 = synth.dyadic((N, C1) + tuple(hw), "p.in1", N)
     ref = oracle.warp(in0, ctrl, Kp["hat_C"], Kp["P_hat"], hw, P_xy=Kp["P_xy"], score=score,
                       in1=in1, want_grid=True, want_idx=True)
-    out0, out1, grid, idx = ops.warp(dev(in0, cuda), dev(ctrl, cuda), dev(Kp["hat_C"], cuda),
-                                     dev(Kp["P_hat"], cuda), hw, P_xy=dev(Kp["P_xy"], cuda),
-                                     score=dev(score, cuda), in1=dev(in1, cuda), want_grid=True,
-                                     want_idx=True)
-    assert_biteq(grid, ref["grid"], "grid")
-    assert_biteq(idx, ref["idx"], "corner indices")
-    assert_biteq(out0, ref["out0"], "out0")
-    assert_biteq(out1, ref["out1"], "out1")
+    P_hat = dev(Kp["P_hat"], cuda)
+    try:
+        # gather kernel / automatic choice (plane-streaming kernel where the shape qualifies),
+        # with and without the transposed table
+        for kernel, P_hat_t in ((1, None), (0, None), (0, ops.transpose_p_hat(P_hat))):
+            ops.set_warp_tuning(0, 0, kernel, 0)
+            out0, out1, grid, idx = ops.warp(dev(in0, cuda), dev(ctrl, cuda), dev(Kp["hat_C"], cuda),
+                                             P_hat, hw, P_xy=dev(Kp["P_xy"], cuda),
+                                             score=dev(score, cuda), in1=dev(in1, cuda),
+                                             want_grid=True, want_idx=True, P_hat_t=P_hat_t)
+            assert_biteq(grid, ref["grid"], f"grid (kernel {kernel})")
+            assert_biteq(idx, ref["idx"], f"corner indices (kernel {kernel})")
+            assert_biteq(out0, ref["out0"], f"out0 (kernel {kernel})")
+            assert_biteq(out1, ref["out1"], f"out1 (kernel {kernel})")
+    finally:
+        ops.set_warp_tuning(0, 0, 0, 0)
 
 
 def test_launch_shape_does_not_change_results(cuda, oracle):

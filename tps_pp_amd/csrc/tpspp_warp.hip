@@ -20,14 +20,14 @@
 //
 // Compiled with -ffp-contract=off: the ONLY fused operations are the explicit fmaf() below.
 #include "tpspp_common.h"
+#include "tpspp_warp_dev.h"
+#include "tpspp_warp_stream.h"
 
 #include <cstring>
-#include <type_traits>
 
 namespace {
 
-constexpr int kWave = 64;
-constexpr int kMaxK = 64;  // F + 3 <= 64: one lane per row of T in the wave-level solve
+using namespace tpspp_dev;
 
 struct WarpParams {
     const float* in0; int C0, H0, W0;
@@ -45,108 +45,6 @@ struct WarpParams {
     int xcd_map;          // 1: chunks % 8 == 0 -> all tiles of a chunk share an XCD (its L2)
 };
 
-struct Taps {
-    int o00, o01, o10, o11;   // offsets inside one H x W plane (clamped: always readable)
-    float nw, ne, sw, se;
-    bool inx, iny;            // is the east column / south row inside the plane
-    int x0, y0;
-};
-
-// ATen bilinear, padding_mode='border', align_corners=True; weight form and rounding of the CPU
-// vector kernel (oracle/tps_oracle.c, weight_form 2).
-__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W)
-{
-    Taps t;
-    float ix = ((gx + 1.0f) * 0.5f) * (float)(W - 1);
-    float iy = ((gy + 1.0f) * 0.5f) * (float)(H - 1);
-    const float limx = (float)(W - 1), limy = (float)(H - 1);
-    ix = (ix > 0.0f) ? ix : 0.0f;   // NaN -> 0
-    iy = (iy > 0.0f) ? iy : 0.0f;
-    ix = (ix < limx) ? ix : limx;
-    iy = (iy < limy) ? iy : limy;
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const float w = ix - fx, e = 1.0f - w, nn = iy - fy, s = 1.0f - nn;
-    t.nw = s * e; t.ne = s * w; t.sw = nn * e; t.se = nn * w;
-    t.inx = (x0 + 1) < W;
-    t.iny = (y0 + 1) < H;
-    const int x1 = t.inx ? x0 + 1 : x0;
-    const int y1 = t.iny ? y0 + 1 : y0;
-    t.o00 = y0 * W + x0; t.o01 = y0 * W + x1;
-    t.o10 = y1 * W + x0; t.o11 = y1 * W + x1;
-    t.x0 = x0; t.y0 = y0;
-    return t;
-}
-
-__device__ __forceinline__ float bilerp(const float* __restrict__ pl, const Taps& t)
-{
-    float v00 = pl[t.o00];
-    float v01 = pl[t.o01];
-    float v10 = pl[t.o10];
-    float v11 = pl[t.o11];
-    v01 = t.inx ? v01 : 0.0f;
-    v10 = t.iny ? v10 : 0.0f;
-    v11 = (t.inx && t.iny) ? v11 : 0.0f;
-    float acc = v00 * t.nw;
-    acc = fmaf(v01, t.ne, acc);
-    acc = fmaf(v10, t.sw, acc);
-    acc = fmaf(v11, t.se, acc);
-    return acc;
-}
-
-__device__ __forceinline__ void sample_planes(const float* __restrict__ in, float* __restrict__ out,
-                                              int C, int HW, int n, const Taps& t)
-{
-    int c = 0;
-    for (; c + 4 <= C; c += 4) {
-        const float r0 = bilerp(in + (size_t)(c + 0) * HW, t);
-        const float r1 = bilerp(in + (size_t)(c + 1) * HW, t);
-        const float r2 = bilerp(in + (size_t)(c + 2) * HW, t);
-        const float r3 = bilerp(in + (size_t)(c + 3) * HW, t);
-        out[(size_t)(c + 0) * n] = r0;
-        out[(size_t)(c + 1) * n] = r1;
-        out[(size_t)(c + 2) * n] = r2;
-        out[(size_t)(c + 3) * n] = r3;
-    }
-    if (c + 3 == C) {   // the 3-channel image case: keep all 12 taps in flight
-        const float r0 = bilerp(in + (size_t)(c + 0) * HW, t);
-        const float r1 = bilerp(in + (size_t)(c + 1) * HW, t);
-        const float r2 = bilerp(in + (size_t)(c + 2) * HW, t);
-        out[(size_t)(c + 0) * n] = r0;
-        out[(size_t)(c + 1) * n] = r1;
-        out[(size_t)(c + 2) * n] = r2;
-        return;
-    }
-    for (; c < C; ++c) out[(size_t)c * n] = bilerp(in + (size_t)c * HW, t);
-}
-
-__device__ __forceinline__ float readlane_f(float v, int lane)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// One wavefront: T[i] = sum_q inv[i][q] * Cz[q], q ascending, FMA chain from 0.  Lane i owns row i.
-// `inv` may be LDS or global.  Returns (Tx, Ty) of row `lane` (garbage for lane >= K).
-__device__ __forceinline__ float2 wave_solve_T(const float* inv, const float* __restrict__ ctrl_b,
-                                               int F, int K, int lane)
-{
-    float cx = 0.0f, cy = 0.0f;             // rows F..F+2 of [C';0] are the appended zeros
-    if (lane < F) {
-        const float2 c = reinterpret_cast<const float2*>(ctrl_b)[lane];
-        cx = c.x; cy = c.y;
-    }
-    const int row = lane < K ? lane : K - 1;
-    const float* h = inv + row * K;
-    float ax = 0.0f, ay = 0.0f;
-    for (int q = 0; q < K; ++q) {
-        const float hv = h[q];
-        const float bx = readlane_f(cx, q);
-        const float by = readlane_f(cy, q);
-        ax = fmaf(hv, bx, ax);
-        ay = fmaf(hv, by, ay);
-    }
-    return make_float2(ax, ay);
-}
 
 // FCT > 0: F known at compile time, the pixel's P_hat row lives in registers across the image group.
 // FCT == 0: any F (F + 3 <= 64); the row is re-read (L1/L2) for every image.
@@ -370,37 +268,12 @@ struct LdsParams {
     long long* trace;   // optional: 8 shader-clock stamps per workgroup (tpspp_warp_set_trace)
 };
 
-__device__ __forceinline__ void stamp(long long* trace, int slot)
-{
-    if (trace && (threadIdx.x & (kWave - 1)) == 0) {
-        trace[(size_t)blockIdx.x * 8 + slot] = (long long)__builtin_amdgcn_s_memtime();
-        // slot 7: chip-wide 100 MHz wall clock at workgroup start (slot 0) -> dispatch skew
-        if (slot == 0) trace[(size_t)blockIdx.x * 8 + 7] = (long long)wall_clock64();
-    }
-}
 
-// compile-time loop: every index is a constant, so register arrays stay in registers
-template <int N, int I = 0, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<N, I + 1>(f);
-    }
-}
 
 constexpr int kLdsMaxWaves = 16;
 constexpr int kLdsLoaders = 3;
 constexpr int kLdsFirstBurst = 8;   // DMA pieces per loader issued before the T barrier
 
-// Workgroup barrier that orders LDS traffic only: outstanding global loads and LDS-DMA keep flying
-// (a __syncthreads() would also drain vmcnt).
-__device__ __forceinline__ void lds_only_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 constexpr int kPrefetchK = 4;   // P_hat^T rows fetched before T is known (hides one L2 round trip)
 
@@ -866,7 +739,7 @@ void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStre
 TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice,
                                        int bands)
 {
-    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 3, "kernel_choice must be 0..3");
+    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 4, "kernel_choice must be 0..4");
     TPSPP_REQUIRE(bands >= 0 && bands <= 8, "bands must be in [0, 8]");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
@@ -1065,7 +938,7 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                               cw >= 2 && (reinterpret_cast<uintptr_t>(in0) % 16 == 0);
         if (g_tune_kernel == 2 && !shape_ok)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape does not qualify for the LDS kernel");
-        if (shape_ok && g_tune_kernel != 1) {
+        if (shape_ok && g_tune_kernel != 1 && g_tune_kernel != 4) {
             LdsParams L;
             L.in = in0; L.C = C0; L.H = H0; L.W = W0;
             L.ctrl = ctrl; L.inv_delta_c = inv_delta_c; L.p_hat_t = p_hat_t;
@@ -1091,6 +964,21 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                                       : launch_lds<20, 3>(L, ppt, threads, lds, st);
             if (ok) return tpspp::check_launch("tpspp_warp_fwd(lds)");
         }
+    }
+
+    // ---- plane-streaming kernel: channel planes through an LDS ring (TPS_PP geometry) ----
+    {
+        tpspp::StreamArgs A;
+        A.in0 = in0; A.C0 = C0; A.H0 = H0; A.W0 = W0;
+        A.in1 = in1; A.C1 = C1; A.H1 = H1; A.W1 = W1;
+        A.ctrl = ctrl; A.score = score; A.inv_delta_c = inv_delta_c;
+        A.p_hat = p_hat; A.p_hat_ld = p_hat_ld; A.p_xy = p_xy; A.p_hat_t = p_hat_t;
+        A.N = N; A.F = F; A.Ho = Ho; A.Wo = Wo;
+        A.out0 = out0; A.out1 = out1; A.grid = grid_or_null; A.idx = idx_or_null;
+        const bool ok = tpspp::stream_kernel_applicable(A);
+        if (g_tune_kernel == 4 && !ok)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape does not qualify for the streaming kernel");
+        if (ok && g_tune_kernel != 1) return tpspp::launch_stream_kernel(A, g_trace, st);
     }
 
     WarpParams P;
