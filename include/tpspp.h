@@ -89,7 +89,10 @@ int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, int cols, flo
  */
 int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, int Wo, int F);
 
-#define TPSPP_TABLE_MIRROR4 1   /* table_flags bit: symmetry verified by the caller */
+#define TPSPP_TABLE_MIRROR4 1      /* table_flags bit: symmetry verified by the caller */
+#define TPSPP_SCORE_TRANSPOSED 2   /* table_flags bit: `score` is laid out (N, F, n) instead of the
+                                      reference's (N, n, F): lanes that own consecutive pixels then read
+                                      it coalesced.  Same values, same results. */
 
 /*
  * The fused hot path: T-solve -> grid -> bilinear warp of in0 (and in1 when non-NULL) in ONE kernel;
@@ -98,7 +101,8 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
  *   ctrl (N,F,2); score (N,Ho*Wo,F) or NULL; inv_delta_c (F+3,F+3); p_hat / p_hat_ld / p_xy as in
  *   tpspp_build_grid; p_hat_t_or_null = tpspp_transpose_p_hat(p_hat) (same values, enables the
  *   coalesced / LDS-staged fast kernels; NULL selects the generic kernel -- identical results);
- *   table_flags: 0 or TPSPP_TABLE_MIRROR4 (only meaningful with p_hat_t, never changes results);
+ *   table_flags: OR of TPSPP_TABLE_MIRROR4 (only meaningful with p_hat_t) and
+ *   TPSPP_SCORE_TRANSPOSED; neither changes results;
  *   grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
  * replaces: GridGenerator.build_P_prime + F.grid_sample   tps_preprocessor.py:71-83
  *           Attention_Enhanced_TPS.build_P_prime + 2x F.grid_sample   tps_pp.py:597-615

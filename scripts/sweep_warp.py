@@ -51,7 +51,9 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(0)
         ins0 = [torch.rand((N, 64, 32, 128), generator=g).to(dev) for i in range(nbuf)]
         ins1 = [torch.rand((N, 64, 16, 64), generator=g).to(dev) for i in range(nbuf)]
-        scores = [(torch.rand((N, 1024, 32), generator=g) * 2 - 1).to(dev) for i in range(nbuf)]
+        scores = [(torch.rand((N, 32, 1024), generator=g) * 2 - 1).to(dev).transpose(1, 2) for i in range(nbuf)]
+        if os.environ.get('SCORE_REF_LAYOUT'):
+            scores = [s_.contiguous() for s_ in scores]
         ctrls = [torch.from_numpy(init[None] + 0.02 * synth.dyadic((N, 32, 2), f"s.c{i}")).to(dev)
                  for i in range(nbuf)]
         o0 = [torch.empty((N, 64, 16, 64), device=dev) for i in range(nbuf)]

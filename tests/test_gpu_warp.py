@@ -152,11 +152,17 @@ def test_tpspp_warp_vs_oracle(cuda, oracle, N, point, hw, C0, C1, with_score):
     try:
         # gather kernel / automatic choice (plane-streaming kernel where the shape qualifies),
         # with and without the transposed table
-        for kernel, P_hat_t in ((1, None), (0, None), (0, ops.transpose_p_hat(P_hat))):
+        # ... and with the score in the reference's (N, n, F) layout or as the transposed view of an
+        # (N, F, n) buffer (what TPS_PP produces)
+        sc_ref = dev(score, cuda)
+        sc_t = None if score is None else dev(np.ascontiguousarray(score.transpose(0, 2, 1)), cuda).transpose(1, 2)
+        for kernel, P_hat_t, sc in ((1, None, sc_ref), (0, None, sc_ref), (1, None, sc_t),
+                                    (0, ops.transpose_p_hat(P_hat), sc_ref),
+                                    (0, ops.transpose_p_hat(P_hat), sc_t)):
             ops.set_warp_tuning(0, 0, kernel, 0)
             out0, out1, grid, idx = ops.warp(dev(in0, cuda), dev(ctrl, cuda), dev(Kp["hat_C"], cuda),
                                              P_hat, hw, P_xy=dev(Kp["P_xy"], cuda),
-                                             score=dev(score, cuda), in1=dev(in1, cuda),
+                                             score=sc, in1=dev(in1, cuda),
                                              want_grid=True, want_idx=True, P_hat_t=P_hat_t)
             assert_biteq(grid, ref["grid"], f"grid (kernel {kernel})")
             assert_biteq(idx, ref["idx"], f"corner indices (kernel {kernel})")

@@ -33,7 +33,7 @@ struct WarpParams {
     const float* in0; int C0, H0, W0;
     const float* in1; int C1, H1, W1;
     const float* ctrl;
-    const float* score;
+    const float* score; int score_t;   // score_t: 1 = (N, F, n) layout
     const float* inv_delta_c;
     const float* p_hat; int p_hat_ld;
     const float* p_xy;
@@ -129,9 +129,15 @@ tps_warp_kernel(const WarpParams P)
             ax = fmaf(r1, t1.x, ax); ay = fmaf(r1, t1.y, ay);
             ax = fmaf(r2, t2.x, ax); ay = fmaf(r2, t2.y, ay);
         }
-        const float* srow = SCORE ? P.score + ((size_t)b * P.n + p) * F : nullptr;
+        // score element (b, p, k) sits at sbase[k * sk]: sk = 1 in the reference's (N, n, F) layout
+        const float* srow = nullptr;
+        size_t sk = 1;
+        if (SCORE) {
+            if (P.score_t) { srow = P.score + (size_t)b * F * P.n + p; sk = (size_t)P.n; }
+            else           { srow = P.score + ((size_t)b * P.n + p) * F; }
+        }
         if (FCT > 0) {
-            if (SCORE && (FCT % 4 == 0)) {
+            if (SCORE && (FCT % 4 == 0) && !P.score_t) {
 #pragma unroll
                 for (int k4 = 0; k4 < FR / 4; ++k4) {
                     const float4 s4 = reinterpret_cast<const float4*>(srow)[k4];
@@ -151,7 +157,7 @@ tps_warp_kernel(const WarpParams P)
                 for (int k = 0; k < FR; ++k) {
                     float m = rbf[k];
                     if (SCORE) {
-                        float gq = srow[k] * 0.5f;
+                        float gq = srow[k * sk] * 0.5f;
                         gq = gq + 1.0f;
                         m = m * gq;
                     }
@@ -164,7 +170,7 @@ tps_warp_kernel(const WarpParams P)
             for (int k = 0; k < F; ++k) {
                 float m = ph[k];
                 if (SCORE) {
-                    float gq = srow[k] * 0.5f;
+                    float gq = srow[k * sk] * 0.5f;
                     gq = gq + 1.0f;
                     m = m * gq;
                 }
@@ -972,6 +978,7 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
         A.in0 = in0; A.C0 = C0; A.H0 = H0; A.W0 = W0;
         A.in1 = in1; A.C1 = C1; A.H1 = H1; A.W1 = W1;
         A.ctrl = ctrl; A.score = score; A.inv_delta_c = inv_delta_c;
+        A.score_t = (score && (table_flags & TPSPP_SCORE_TRANSPOSED)) ? 1 : 0;
         A.p_hat = p_hat; A.p_hat_ld = p_hat_ld; A.p_xy = p_xy; A.p_hat_t = p_hat_t;
         A.N = N; A.F = F; A.Ho = Ho; A.Wo = Wo;
         A.out0 = out0; A.out1 = out1; A.grid = grid_or_null; A.idx = idx_or_null;
@@ -985,6 +992,7 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
     P.in0 = in0; P.C0 = C0; P.H0 = H0; P.W0 = W0;
     P.in1 = in1; P.C1 = in1 ? C1 : 0; P.H1 = in1 ? H1 : 1; P.W1 = in1 ? W1 : 1;
     P.ctrl = ctrl; P.score = score; P.inv_delta_c = inv_delta_c;
+    P.score_t = (score && (table_flags & TPSPP_SCORE_TRANSPOSED)) ? 1 : 0;
     P.p_hat = p_hat; P.p_hat_ld = p_hat_ld; P.p_xy = p_xy; P.p_hat_t = p_hat_t;
     P.N = N; P.F = F; P.n = Ho * Wo;
     P.out0 = out0; P.out1 = out1; P.grid = grid_or_null; P.idx = idx_or_null;

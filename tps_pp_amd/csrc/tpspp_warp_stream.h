@@ -12,6 +12,7 @@ struct StreamArgs {
     const float* ctrl; const float* score; const float* inv_delta_c;
     const float* p_hat; int p_hat_ld; const float* p_xy; const float* p_hat_t;
     int N, F, Ho, Wo;
+    int score_t;               // 1: score is (N, F, n)
     float* out0; float* out1; float* grid; int32_t* idx;
 };
 

@@ -28,8 +28,9 @@ using namespace tpspp_dev;
 namespace {
 
 constexpr int kComputeWaves = 8;
-constexpr int kLoaders = 2;
+constexpr int kLoaders = 4;
 constexpr int kRing = 3;
+constexpr int kCPS = 2;                                     // channels of each input per stage
 constexpr int kThreads = (kComputeWaves + kLoaders) * kWave;
 constexpr int kCT = kComputeWaves * kWave;                 // pixel stride between a thread's slots
 
@@ -39,6 +40,7 @@ struct StreamParams {
     const float* ctrl; const float* score; const float* inv_delta_c;
     const float* p_hat; int p_hat_ld; const float* p_xy; const float* p_hat_t;
     int N, n;
+    int score_t;               // 1: score is (N, F, n)
     float* out0; float* out1; float* grid; int32_t* idx;
     int pieces0, pieces1;      // 1-KB DMA pieces per plane of in0 / in1 (in1: 0 when absent)
     int per_loader;            // pieces every loader issues per stage (stage padded to a multiple)
@@ -112,7 +114,7 @@ tps_warp_stream_kernel(const StreamParams P)
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int b = blockIdx.x;
     const int HW0 = P.H0 * P.W0, HW1 = P.H1 * P.W1;
-    const int stages = max(P.C0, P.C1);                    // one channel of each input per stage
+    const int stages = (max(P.C0, P.C1) + kCPS - 1) / kCPS;   // kCPS channels of each input per stage
 
     if (wv == 0) stamp(P.trace, 0);
     if (wv >= kComputeWaves) {
@@ -122,17 +124,21 @@ tps_warp_stream_kernel(const StreamParams P)
         const char* base1 = reinterpret_cast<const char*>(P.in1);
         const long long end0 = (long long)P.N * P.C0 * HW0 * 4;
         const long long end1 = (long long)P.N * P.C1 * HW1 * 4;
-        const int total = P.pieces0 + P.pieces1;
+        const int per_ch = P.pieces0 + P.pieces1;           // slot layout: [in0 c | in1 c] x kCPS
+        const int total = per_ch * kCPS;
         auto issue_stage = [&](int s) {
             char* slot = ring + (s % kRing) * P.slot_bytes;
             for (int i = 0; i < P.per_loader; ++i) {
                 int piece = ld + i * kLoaders;
                 if (piece >= total) piece = total - 1;      // padding: repeat the last piece
-                const bool second = piece >= P.pieces0;
-                const int pp = second ? piece - P.pieces0 : piece;
+                const int sub = piece / per_ch;             // which channel of the stage
+                const int q = piece - sub * per_ch;
+                const bool second = q >= P.pieces0;
+                const int pp = second ? q - P.pieces0 : q;
                 const int C = second ? P.C1 : P.C0;
                 const int HW = second ? HW1 : HW0;
-                const int c = s < C ? s : C - 1;           // an exhausted input re-reads its last plane
+                const int ch = s * kCPS + sub;
+                const int c = ch < C ? ch : C - 1;         // an exhausted input re-reads its last plane
                 long long off = ((long long)b * C + c) * HW * 4 + (long long)pp * 1024 + lane * 16;
                 const long long end = second ? end1 : end0;
                 if (off + 16 > end) off = end - 16;        // tail of the tensor: stay inside it
@@ -142,14 +148,15 @@ tps_warp_stream_kernel(const StreamParams P)
                     (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
             }
         };
-        issue_stage(0);
-        if (stages > 1) issue_stage(1);
+        // run kRing-1 stages ahead of the consumers
+        for (int s = 0; s < kRing - 1 && s < stages; ++s) issue_stage(s);
         lds_only_barrier();                                 // T barrier of the compute wavefronts
         for (int s = 0; s < stages; ++s) {
-            // stage s must have landed; stage s+1 (issued earlier) may stay in flight
-            wait_vmcnt(s + 1 < stages ? P.per_loader : 0);
+            // stage s must have landed; the stages issued after it may stay in flight
+            const int ahead = min(stages - 1 - s, kRing - 2);
+            wait_vmcnt(ahead * P.per_loader);
             lds_only_barrier();                             // A(s): slot s%R ready, slot (s-1)%R drained
-            if (s + 2 < stages) issue_stage(s + 2);
+            if (s + kRing - 1 < stages) issue_stage(s + kRing - 1);
         }
         return;
     }
@@ -238,7 +245,18 @@ tps_warp_stream_kernel(const StreamParams P)
             ax = fmaf(r2[j], t2.x, ax); ay = fmaf(r2[j], t2.y, ay);
         }
         const float* srow = SCORE ? P.score + ((size_t)b * P.n + pix[j]) * F : nullptr;
-        if (SCORE && (F % 4 == 0)) {
+        if (SCORE && P.score_t) {
+            // (N, F, n) layout: one coalesced 256-B row segment per k across the wavefront
+            const float* scol = P.score + (size_t)b * F * P.n + pix[j];
+#pragma unroll
+            for (int k = 0; k < F; ++k) {
+                float gq = scol[(size_t)k * P.n] * 0.5f;
+                gq = gq + 1.0f;
+                const float m = rbf[j][k] * gq;
+                const float2 tk = sT[3 + k];
+                ax = fmaf(m, tk.x, ax); ay = fmaf(m, tk.y, ay);
+            }
+        } else if (SCORE && (F % 4 == 0)) {
 #pragma unroll
             for (int k4 = 0; k4 < F / 4; ++k4) {
                 const float4 s4 = reinterpret_cast<const float4*>(srow)[k4];
@@ -269,6 +287,10 @@ tps_warp_stream_kernel(const StreamParams P)
         gx[j] = ax; gy[j] = ay;
     }
 
+    // pin the finished grid here (keeps the optimiser from sinking the chains into the stream loop)
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) asm volatile("" : "+v"(gx[j]), "+v"(gy[j]));
+
     // ---- taps of both inputs, once per image ----
     TapRegs t0[PPT], t1[PPT];
 #pragma unroll
@@ -288,23 +310,28 @@ tps_warp_stream_kernel(const StreamParams P)
     char* o0 = reinterpret_cast<char*>(P.out0 + (size_t)b * P.C0 * P.n);
     char* o1 = reinterpret_cast<char*>(P.out1 ? P.out1 + (size_t)b * P.C1 * P.n : nullptr);
     const size_t row_bytes = (size_t)P.n * 4;
+    const int ch_bytes = (P.pieces0 + P.pieces1) * 1024;
     for (int s = 0; s < stages; ++s) {
         lds_only_barrier();                                       // A(s)
         const char* slot = ring + (s % kRing) * P.slot_bytes;
-        const float* pl0 = reinterpret_cast<const float*>(slot);
-        const float* pl1 = reinterpret_cast<const float*>(slot + off1);
-        if (s < P.C0) {
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const float r = lds_bilerp(pl0, t0[j]);
-                if (live[j]) *reinterpret_cast<float*>(o0 + s * row_bytes + 4u * (unsigned)pix[j]) = r;
+        for (int sub = 0; sub < kCPS; ++sub) {
+            const int ch = s * kCPS + sub;
+            const float* pl0 = reinterpret_cast<const float*>(slot + sub * ch_bytes);
+            const float* pl1 = reinterpret_cast<const float*>(slot + sub * ch_bytes + off1);
+            if (ch < P.C0) {
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) {
+                    const float r = lds_bilerp(pl0, t0[j]);
+                    if (live[j]) *reinterpret_cast<float*>(o0 + ch * row_bytes + 4u * (unsigned)pix[j]) = r;
+                }
             }
-        }
-        if (P.in1 && s < P.C1) {
+            if (P.in1 && ch < P.C1) {
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const float r = lds_bilerp(pl1, t1[j]);
-                if (live[j]) *reinterpret_cast<float*>(o1 + s * row_bytes + 4u * (unsigned)pix[j]) = r;
+                for (int j = 0; j < PPT; ++j) {
+                    const float r = lds_bilerp(pl1, t1[j]);
+                    if (live[j]) *reinterpret_cast<float*>(o1 + ch * row_bytes + 4u * (unsigned)pix[j]) = r;
+                }
             }
         }
     }
@@ -361,8 +388,8 @@ bool stream_kernel_applicable(const StreamArgs& a)
     if (a.in1 && (long long)a.N * a.C1 * a.H1 * a.W1 * 4 < 1024) return false;
     const int p0 = (a.H0 * a.W0 * 4 + 1023) / 1024;
     const int p1 = a.in1 ? (a.H1 * a.W1 * 4 + 1023) / 1024 : 0;
-    const int per_loader = (p0 + p1 + kLoaders - 1) / kLoaders;
-    if (per_loader > 32) return false;                                          // counted vmcnt range
+    const int per_loader = ((p0 + p1) * kCPS + kLoaders - 1) / kLoaders;
+    if (per_loader * (kRing - 2) > 32) return false;                            // counted vmcnt range
     const int K = a.F + 3;
     const size_t slot = (size_t)per_loader * kLoaders * 1024 + 16;
     const size_t lds = (size_t)(((2 * K + 3) & ~3) + ((K * K + 3) & ~3)) * 4 + kRing * slot;
@@ -376,11 +403,11 @@ int launch_stream_kernel(const StreamArgs& a, long long* trace, hipStream_t st)
     P.in1 = a.in1; P.C1 = a.in1 ? a.C1 : 0; P.H1 = a.in1 ? a.H1 : 1; P.W1 = a.in1 ? a.W1 : 1;
     P.ctrl = a.ctrl; P.score = a.score; P.inv_delta_c = a.inv_delta_c;
     P.p_hat = a.p_hat; P.p_hat_ld = a.p_hat_ld; P.p_xy = a.p_xy; P.p_hat_t = a.p_hat_t;
-    P.N = a.N; P.n = a.Ho * a.Wo;
+    P.N = a.N; P.n = a.Ho * a.Wo; P.score_t = a.score_t;
     P.out0 = a.out0; P.out1 = a.out1; P.grid = a.grid; P.idx = a.idx;
     P.pieces0 = (a.H0 * a.W0 * 4 + 1023) / 1024;
     P.pieces1 = a.in1 ? (a.H1 * a.W1 * 4 + 1023) / 1024 : 0;
-    P.per_loader = (P.pieces0 + P.pieces1 + kLoaders - 1) / kLoaders;
+    P.per_loader = ((P.pieces0 + P.pieces1) * kCPS + kLoaders - 1) / kLoaders;
     P.slot_bytes = P.per_loader * kLoaders * 1024 + 16;
     P.trace = trace;
     const int K = a.F + 3;

@@ -95,6 +95,7 @@ def transpose_p_hat(P_hat):
 
 
 TABLE_MIRROR4 = 1
+SCORE_TRANSPOSED = 2
 
 
 def table_mirror_symmetry(P_hat_host, out_hw, F):
@@ -135,9 +136,15 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
     if tuple(P_hat.shape) != (n, F if P_xy is not None else F + 3):
         raise ValueError(f"warp: P_hat has shape {tuple(P_hat.shape)}")
     if score is not None:
-        score = _chk("score", score, 3)
-        if tuple(score.shape) != (N, n, F):
+        # (N, n, F) as the reference produces it, or a transposed VIEW of an (N, F, n) buffer: the
+        # latter is what lets lanes that own consecutive pixels read the score coalesced
+        if not isinstance(score, torch.Tensor) or score.dim() != 3 or tuple(score.shape) != (N, n, F):
             raise ValueError("warp: score must be (N, n, F)")
+        if score.stride() == (F * n, 1, n) and n > 1 and F > 1:
+            table_flags = int(table_flags) | SCORE_TRANSPOSED
+            score = _chk("score", score.transpose(1, 2), 3)      # the underlying (N, F, n) buffer
+        else:
+            score = _chk("score", score, 3)
     if P_hat_t is not None:
         P_hat_t = _chk("P_hat_t", P_hat_t, 2)
         if tuple(P_hat_t.shape) != (P_hat.shape[1], n):

@@ -222,9 +222,12 @@ class Transformation_Parameter_Estimation(nn.Module):
             constants.tpspp_initial_ctrl(point_size)).float().view(-1)
 
     def atten_score(self, a, b):
-        attn = torch.einsum("bmc,bnc->bmn", a, b)
+        # same dot products as the reference's einsum('bmc,bnc->bmn'), but the result buffer is laid
+        # out (N, F, n) and returned as its (N, n, F) transposed VIEW: same shape and values for
+        # every consumer, and the warp kernel reads it coalesced (ops.warp detects the stride)
+        attn = torch.einsum("bnc,bmc->bnm", b, a)
         attn = attn.mul(self.scale)
-        return torch.tanh(attn)
+        return torch.tanh(attn).transpose(1, 2)
 
     def get_score(self, point, feat):
         feat = feat.flatten(2).transpose(1, 2)                  # b c h w -> b (h w) c
