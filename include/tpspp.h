@@ -116,6 +116,27 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                    tpspp_stream_t stream);
 
 /*
+ * out = act(conv2d(cat_c(up(src_0), up(src_1), up(src_2)), W) + bias [+ residual]) [+ residual]
+ * fp32, NCHW, 1x1 or 3x3 kernel with "same" padding ((K-1)/2), stride (sh, sw), on the fp32 matrix
+ * cores (exact fp32 products, fp32 accumulation).
+ *   src_ptrs[i]   (N, C_i, H_i, W_i); src_dims + 5*i = {C_i, H_i, W_i, uh_i, uw_i}: source i is
+ *                 nearest-upsampled by (uh_i, uw_i) on the fly; all sources share the logical size;
+ *                 with nsrc > 1 every C_i must be a multiple of 32 (1x1) / 8 (3x3)
+ *   weight_t      (Cin*KH*KW, Cout) = the PyTorch weight (Cout, Cin, KH, KW) flattened and
+ *                 transposed once by the caller (BatchNorm, if any, folded in)
+ *   bias          (Cout) or NULL;  residual (N, Cout, Ho, Wo) or NULL
+ *   res_mode      0 none, 1 act(conv + bias) + residual, 2 act(conv + bias + residual)
+ * replaces: mmcv ConvModule / nn.Conv2d (+ nn.Upsample, torch.cat, skip additions)
+ *           backbones/tps_pp/tps_pp.py:126-131,149-154,156-169,538-552,560-562;
+ *           preprocessor/tps_preprocessor.py:101-128; backbones/resnet_v2_large.py:131-135;
+ *           layers/conv_layer.py:12-33
+ */
+int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
+                     const float* weight_t, const float* bias, const float* residual,
+                     int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
+                     float* out, int Ho, int Wo, tpspp_stream_t stream);
+
+/*
  * Launch-shape override for tpspp_warp_fwd (tuning / benchmarking only; results do not depend on
  * it): images per workgroup and threads per workgroup of the gather kernel (0 = heuristic), and
  * kernel choice: 0 = automatic, 1 = force the gather kernel, 2 = require the LDS-staged kernel

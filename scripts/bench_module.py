@@ -1,0 +1,46 @@
+"""Whole-module throughput on the GPU box: TPS_PP.forward (regressor + fused warp) and the split."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tps_pp_amd import TPS_PP, TPSPreprocessor  # noqa: E402
+
+dev = torch.device("cuda:0")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+m = TPS_PP().eval().to(dev)
+x = torch.rand(N, 64, 16, 64, device=dev)
+o0 = torch.rand(N, 32, 32, 128, device=dev)
+o1 = torch.rand(N, 32, 32, 128, device=dev)
+with torch.no_grad():
+    t_full = timeit(lambda: m(x, [o0, o1]))
+    t_reg = timeit(lambda: m.regress(x, [o0, o1]))
+    cp, sc, fg = m.regress(x, [o0, o1])
+    fg = fg.contiguous()
+    t_warp = timeit(lambda: m.rectify(fg, x, cp, sc))
+print(f"TPS_PP batch {N}: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | regressor {t_reg:.2f} ms "
+      f"({0.82 * N / t_reg:.1f} TFLOP/s) | warp {t_warp * 1e3:.0f} us")
+p = TPSPreprocessor(20, (32, 100), (32, 100), 3).eval().to(dev)
+img = torch.rand(N, 3, 32, 100, device=dev)
+with torch.no_grad():
+    t_full = timeit(lambda: p(img))
+    t_loc = timeit(lambda: p.LocalizationNetwork(img))
+print(f"TPSPreprocessor batch {N}: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | localisation net {t_loc:.2f} ms")

@@ -1,0 +1,75 @@
+"""-m gpu: the fp32 MFMA convolution against PyTorch's CPU conv (the oracle's arithmetic) on the
+shapes the TPS++ feature extractor, the localisation network and the backbone stem use."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tps_pp_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def ref_conv(srcs, w, b, k, stride, relu, res, res_mode):
+    xs = []
+    for e in srcs:
+        x, uh, uw = (e, 1, 1) if isinstance(e, torch.Tensor) else e
+        xs.append(F.interpolate(x, scale_factor=(uh, uw), mode="nearest") if (uh, uw) != (1, 1) else x)
+    y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=(k - 1) // 2)
+    if res_mode == 2:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    if res_mode == 1:
+        y = y + res
+    return y
+
+
+CASES = [
+    # name, sources [(C,H,W,uh,uw)], Cout, k, stride, relu, res_mode, N
+    ("down0 1x1 32->64 @32x128", [(32, 32, 128, 1, 1)], 64, 1, (1, 1), True, 0, 3),
+    ("down0_1 3x3 s2 64->64", [(64, 32, 128, 1, 1)], 64, 3, (2, 2), True, 0, 2),
+    ("down_feat 1x1 cat(64,64,up 64)->64", [(64, 32, 128, 1, 1), (64, 32, 128, 1, 1), (64, 16, 64, 2, 2)], 64, 1, (1, 1), True, 0, 2),
+    ("k_encoder.0 3x3 192->64 @16x64", [(64, 16, 64, 1, 1), (64, 16, 64, 1, 1), (64, 16, 64, 1, 1)], 64, 3, (1, 1), True, 0, 2),
+    ("k_encoder.3 3x3 s(2,1) @4x16", [(64, 4, 16, 1, 1)], 64, 3, (2, 1), True, 0, 3),
+    ("k_decoder.0 up(2,1)+3x3 + skip", [(64, 2, 16, 2, 1)], 64, 3, (1, 1), True, 1, 3),
+    ("k_decoder.2 up2+3x3 + skip @16x64", [(64, 8, 32, 2, 2)], 64, 3, (1, 1), True, 1, 2),
+    ("stem 3x3 3->32 @32x128 (folded BN)", [(3, 32, 128, 1, 1)], 32, 3, (1, 1), True, 0, 2),
+    ("BasicBlock conv2 3x3 s2 + downsample residual", [(64, 32, 128, 1, 1)], 64, 3, (2, 2), True, 2, 2),
+    ("localisation conv 3x3 3->64 @32x100 no bias", [(3, 32, 100, 1, 1)], 64, 3, (1, 1), False, 0, 2),
+    ("wide 1x1 64->256 odd pixels", [(64, 7, 9, 1, 1)], 256, 1, (1, 1), False, 0, 2),
+    ("Cout not multiple of 64", [(16, 9, 13, 1, 1)], 40, 3, (1, 1), True, 0, 1),
+]
+
+
+@pytest.mark.parametrize("name,srcs,cout,k,stride,relu,res_mode,N", CASES, ids=[c[0] for c in CASES])
+def test_conv_matches_cpu_reference(cuda, name, srcs, cout, k, stride, relu, res_mode, N):
+    xs = [(t(synth.dyadic((N, c, h, w), f"{name}.x{i}", 1)), uh, uw) for i, (c, h, w, uh, uw) in enumerate(srcs)]
+    cin = sum(s_[0] for s_ in srcs)
+    w = t(synth.dyadic((cout, cin, k, k), name + ".w", 1, 1.0 / np.sqrt(cin * k * k)))
+    b = None if "no bias" in name else t(synth.dyadic((cout,), name + ".b", 1, 0.1))
+    y0 = ref_conv(xs, w, b, k, stride, relu, None, 0)
+    res = t(synth.dyadic(tuple(y0.shape), name + ".r", 1)) if res_mode else None
+    ref = ref_conv(xs, w, b, k, stride, relu, res, res_mode)
+    wt, bb = ops.prep_conv_weight(w.to(cuda), conv_bias=None if b is None else b.to(cuda))
+    got = ops.conv2d([(x.to(cuda), uh, uw) for x, uh, uw in xs], wt, bb, k, stride, relu,
+                     None if res is None else res.to(cuda), res_mode)
+    assert got.shape == ref.shape
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 2e-5, f"{name}: max abs err {err:.3e}"
+
+
+def test_folded_batchnorm(cuda):
+    N, cin, cout = 2, 32, 64
+    x = t(synth.dyadic((N, cin, 16, 64), "bn.x"))
+    w = t(synth.dyadic((cout, cin, 3, 3), "bn.w", 0, 1.0 / np.sqrt(cin * 9)))
+    gamma = t(synth.dyadic((cout,), "bn.g", 0, 0.25, 1.0)); beta = t(synth.dyadic((cout,), "bn.b", 0, 0.1))
+    mean = t(synth.dyadic((cout,), "bn.m", 0, 0.1)); var = t(synth.dyadic((cout,), "bn.v", 0, 0.25, 1.0))
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, None, padding=1), mean, var, gamma, beta, False, 0.1, 1e-5))
+    wt, bb = ops.prep_conv_weight(w.to(cuda), bn=tuple(v.to(cuda) for v in (gamma, beta, mean, var)))
+    got = ops.conv2d([x.to(cuda)], wt, bb, 3, 1, True)
+    assert (got.cpu() - ref).abs().max().item() <= 3e-5

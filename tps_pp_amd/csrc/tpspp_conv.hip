@@ -1,0 +1,198 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+// every product rounded once, k-ordered accumulation) for the TPS++ feature extractor and the
+// recognizer's conv stem: 1x1 and 3x3 kernels, strides 1/2/(2,1), "same" padding, up to three
+// channel-concatenated sources each with its own integer nearest-neighbour upsampling (so
+// `cat(a1, a2, Upsample(a3))` and `Upsample -> conv` never materialise), fused bias + ReLU and an
+// optional residual added before or after the activation.
+//
+// GEMM view:  D[cout][pixel] = W[cout][k] * X[k][pixel],  k = (ci*KH + ky)*KW + kx.
+// The weights are the MFMA A operand and the im2col matrix the B operand, so that in the C/D layout
+// (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) the 32 lanes of a half-wavefront hold 32
+// CONSECUTIVE PIXELS of one output channel: stores are 128-B coalesced rows of the NCHW output.
+//
+// Workgroup = 256 threads = 4 wavefronts = 128 output pixels x 64 output channels; wavefront w owns
+// pixels [32w, 32w+32) and both 32-channel halves (two 32x32 accumulators, the X fragment is shared).
+// K is consumed in chunks of KC input channels (KC*KH*KW values of k): the weight slab (k-major,
+// pre-transposed once on the host) and the im2col slab are staged in LDS k-major, so a fragment read
+// is 32 consecutive floats per half-wavefront (conflict-free).  LDS per workgroup <= 55 KB: two
+// workgroups per CU overlap one's staging (VALU address arithmetic + gathers through L1/L2, 9x
+// reuse of every input element for a 3x3 kernel) with the other's MFMA phase.
+//
+// Replaces (reference, mmocr/models/textrecog/): mmcv ConvModule / nn.Conv2d call sites
+// backbones/tps_pp/tps_pp.py:126-131,149-154,538-552,560-562; preprocessor/tps_preprocessor.py:101-128;
+// backbones/resnet_v2_large.py:131-135 and layers/conv_layer.py:12-33 (BatchNorm folded on the host).
+// Bound: MFMA (fp32 matrix rate = 157 TFLOP/s peak).
+#include "tpspp_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int BM = 128;       // output pixels per workgroup
+constexpr int BN = 64;        // output channels per workgroup
+constexpr int kThreads = 256;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvSrc {
+    const float* p;
+    int C, H, W;              // stored size
+    int uh, uw;               // nearest upsampling factors: logical size (H*uh, W*uw)
+};
+
+struct ConvParams {
+    ConvSrc src[3];
+    int nsrc;
+    const float* wt;          // (K, Cout), k-major; K = Cin*KH*KW
+    const float* bias;        // (Cout) or null
+    const float* res;         // (N, Cout, Ho, Wo) or null
+    float* out;               // (N, Cout, Ho, Wo)
+    int N, Cin, Cout, Hi, Wi, Ho, Wo, sh, sw, ph, pw;
+    int relu;                 // 1: ReLU
+    int res_mode;             // 1: out = act(conv + bias) + res; 2: out = act(conv + bias + res)
+};
+
+template <int KH, int KW, int KC>
+__global__ void __launch_bounds__(kThreads, 2)
+conv_igemm_f32_kernel(const ConvParams P)
+{
+    constexpr int TAPS = KH * KW;
+    constexpr int KCK = KC * TAPS;                 // k values per chunk (even)
+    static_assert(KCK % 2 == 0, "chunk must hold an even number of k");
+    __shared__ float sX[KCK][BM];                  // im2col slab,  k-major
+    __shared__ float sW[KCK][BN];                  // weight slab,  k-major
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = tid / kWave;
+    const int n = blockIdx.z;
+    const int co_base = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM;
+    const int HoWo = P.Ho * P.Wo;
+
+    // this thread's pixel for the staging pass (fixed: BM = 128, 256 threads -> two k rows per pass)
+    const int sm = tid & (BM - 1);
+    const int skk0 = tid >> 7;                     // 0 or 1
+    const int spix = m0 + sm;
+    const bool spix_ok = spix < HoWo;
+    const int soy = spix_ok ? spix / P.Wo : 0;
+    const int sox = spix_ok ? spix - soy * P.Wo : 0;
+    const int iy0 = soy * P.sh - P.ph, ix0 = sox * P.sw - P.pw;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+
+    const int half = lane >> 5, l31 = lane & 31;
+    int cbase = 0;                                 // first channel of the current source
+    int s = 0;
+    ConvSrc cur = P.src[0];
+    for (int c0 = 0; c0 < P.Cin; c0 += KC) {
+        while (c0 >= cbase + cur.C) { cbase += cur.C; ++s; cur = P.src[s]; }
+        const float* sp = cur.p + ((size_t)n * cur.C + (c0 - cbase)) * cur.H * cur.W;
+        const int plane = cur.H * cur.W;
+        // ---- stage the im2col slab: sX[kk][m] = in[c0 + kk/TAPS][iy][ix] (0 outside) ----
+#pragma unroll
+        for (int kk = skk0; kk < KCK; kk += 2) {
+            const int ci = kk / TAPS, t = kk - ci * TAPS;
+            const int ky = t / KW, kx = t - ky * KW;
+            const int iy = iy0 + ky, ix = ix0 + kx;
+            float v = 0.0f;
+            if (spix_ok && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (c0 + ci) < P.Cin)
+                v = sp[(size_t)ci * plane + (iy / cur.uh) * cur.W + (ix / cur.uw)];
+            sX[kk][sm] = v;
+        }
+        // ---- stage the weight slab: sW[kk][co] = wt[(c0*TAPS + kk)][co_base + co] ----
+        {
+            const float* wp = P.wt + (size_t)c0 * TAPS * P.Cout + co_base;
+            const int kmax = min(KCK, (P.Cin - c0) * TAPS);
+            for (int e = tid; e < KCK * BN; e += kThreads) {
+                const int kk = e / BN, co = e - kk * BN;
+                sW[kk][co] = (kk < kmax && co_base + co < P.Cout) ? wp[(size_t)kk * P.Cout + co] : 0.0f;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: 2 k per instruction; lanes 0-31 take k, lanes 32-63 take k+1 ----
+#pragma unroll 4
+        for (int k2 = 0; k2 < KCK; k2 += 2) {
+            const float b = sX[k2 + half][wv * 32 + l31];
+            const float a0 = sW[k2 + half][l31];
+            const float a1 = sW[k2 + half][32 + l31];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual, ReLU; half-wavefronts store 128-B rows ----
+    const int pix = m0 + wv * 32 + l31;
+    if (pix < HoWo) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < P.Cout) {
+                    float v = h2 ? acc1[r] : acc0[r];
+                    if (P.bias) v = v + P.bias[co];
+                    const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
+                    if (P.res_mode == 2) v = v + P.res[o];
+                    if (P.relu) v = v > 0.0f ? v : 0.0f;
+                    if (P.res_mode == 1) v = v + P.res[o];
+                    P.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KH, int KW, int KC>
+void launch_conv(const ConvParams& P, hipStream_t st)
+{
+    const dim3 grid((unsigned)((P.Ho * P.Wo + BM - 1) / BM), (unsigned)((P.Cout + BN - 1) / BN), (unsigned)P.N);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<KH, KW, KC>), grid, dim3(kThreads), 0, st, P);
+}
+
+}  // namespace
+
+TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
+                                  const float* weight_t, const float* bias, const float* residual,
+                                  int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
+                                  float* out, int Ho, int Wo, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(src_ptrs && src_dims && weight_t && out, "tpspp_conv2d_fwd: null pointer");
+    TPSPP_REQUIRE(nsrc >= 1 && nsrc <= 3, "tpspp_conv2d_fwd: 1..3 sources");
+    TPSPP_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3), "tpspp_conv2d_fwd: kernel must be 1x1 or 3x3");
+    TPSPP_REQUIRE(N >= 0 && Cout > 0 && sh >= 1 && sw >= 1 && Ho > 0 && Wo > 0, "tpspp_conv2d_fwd: bad sizes");
+    TPSPP_REQUIRE(res_mode >= 0 && res_mode <= 2 && (res_mode == 0) == (residual == nullptr),
+                  "tpspp_conv2d_fwd: residual / res_mode mismatch");
+    TPSPP_REQUIRE(N <= 65535 && (Cout + BN - 1) / BN <= 65535, "tpspp_conv2d_fwd: grid too large");
+    ConvParams P;
+    P.nsrc = nsrc;
+    int cin = 0, Hi = -1, Wi = -1;
+    const int KC = (KH == 1) ? 32 : 8;
+    for (int i = 0; i < nsrc; ++i) {
+        const int* d = src_dims + 5 * i;                      // C, H, W, uh, uw
+        TPSPP_REQUIRE(src_ptrs[i] && d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] >= 1 && d[4] >= 1,
+                      "tpspp_conv2d_fwd: bad source %d", i);
+        TPSPP_REQUIRE(nsrc == 1 || d[0] % KC == 0,
+                      "tpspp_conv2d_fwd: concatenated sources need channel counts that are multiples of %d", KC);
+        P.src[i].p = src_ptrs[i];
+        P.src[i].C = d[0]; P.src[i].H = d[1]; P.src[i].W = d[2]; P.src[i].uh = d[3]; P.src[i].uw = d[4];
+        const int lh = d[1] * d[3], lw = d[2] * d[4];
+        TPSPP_REQUIRE(Hi < 0 || (Hi == lh && Wi == lw), "tpspp_conv2d_fwd: sources disagree on the logical size");
+        Hi = lh; Wi = lw;
+        cin += d[0];
+    }
+    for (int i = nsrc; i < 3; ++i) P.src[i] = P.src[nsrc - 1];
+    P.Cin = cin; P.Cout = Cout; P.N = N; P.Hi = Hi; P.Wi = Wi; P.Ho = Ho; P.Wo = Wo;
+    P.sh = sh; P.sw = sw; P.ph = (KH - 1) / 2; P.pw = (KW - 1) / 2;
+    TPSPP_REQUIRE(Ho == (Hi + 2 * P.ph - KH) / sh + 1 && Wo == (Wi + 2 * P.pw - KW) / sw + 1,
+                  "tpspp_conv2d_fwd: output size does not match input size / stride ('same' padding)");
+    P.wt = weight_t; P.bias = bias; P.res = residual; P.out = out;
+    P.relu = relu ? 1 : 0; P.res_mode = res_mode;
+    if (N == 0) return TPSPP_OK;
+    hipStream_t st = tpspp::as_stream(stream);
+    if (KH == 1) launch_conv<1, 1, 32>(P, st);
+    else         launch_conv<3, 3, 8>(P, st);
+    return tpspp::check_launch("tpspp_conv2d_fwd");
+}

@@ -172,6 +172,65 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
     return out0, out1, grid, idx
 
 
+def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5):
+    """PyTorch conv weight (Cout, Cin, KH, KW) -> (weight_t (Cin*KH*KW, Cout), bias (Cout) | None) for
+    `conv2d`.  `bn` = (gamma, beta, running_mean, running_var): eval-mode BatchNorm folded in
+    (y = gamma * (conv(x) + b - mean) / sqrt(var + eps) + beta)."""
+    w = weight.detach().float()
+    b = None if conv_bias is None else conv_bias.detach().float()
+    if bn is not None:
+        gamma, beta, mean, var = (t.detach().float() for t in bn)
+        scale = gamma / torch.sqrt(var + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = beta - mean * scale if b is None else beta + (b - mean) * scale
+    cout = w.shape[0]
+    return w.reshape(cout, -1).t().contiguous(), (None if b is None else b.contiguous())
+
+
+def conv2d(srcs, weight_t, bias, kernel, stride=(1, 1), relu=True, residual=None, res_mode=0, out=None):
+    """Fused conv on the fp32 matrix cores (`tpspp_conv2d_fwd`).
+
+    srcs: list of 1..3 entries `tensor` or `(tensor, uh, uw)`: channel-concatenated, each nearest-
+    upsampled by (uh, uw) on the fly.  weight_t/bias from `prep_conv_weight`.  kernel: 1 or 3
+    ("same" padding).  residual/res_mode: 1 = act(conv)+res, 2 = act(conv+res)."""
+    import ctypes
+    ts, dims = [], []
+    for e in srcs:
+        t, uh, uw = (e, 1, 1) if isinstance(e, torch.Tensor) else e
+        t = _chk("conv source", t, 4)
+        ts.append(t)
+        dims += [t.shape[1], t.shape[2], t.shape[3], int(uh), int(uw)]
+    N = ts[0].shape[0]
+    Hi, Wi = ts[0].shape[2] * dims[3], ts[0].shape[3] * dims[4]
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    pad = (kernel - 1) // 2
+    Ho = (Hi + 2 * pad - kernel) // sh + 1
+    Wo = (Wi + 2 * pad - kernel) // sw + 1
+    weight_t = _chk("weight_t", weight_t, 2)
+    Cout = weight_t.shape[1]
+    if weight_t.shape[0] != sum(t.shape[1] for t in ts) * kernel * kernel:
+        raise ValueError("conv2d: weight_t rows != Cin*KH*KW")
+    if bias is not None:
+        bias = _chk("bias", bias, 1)
+    if residual is not None:
+        residual = _chk("residual", residual, 4)
+        if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2):
+            raise ValueError("conv2d: residual shape / res_mode")
+    elif res_mode != 0:
+        raise ValueError("conv2d: res_mode without residual")
+    if out is None:
+        out = torch.empty((N, Cout, Ho, Wo), device=ts[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    dim_arr = (ctypes.c_int * len(dims))(*dims)
+    with torch.cuda.device(ts[0].device):
+        rc = _lib.lib().tpspp_conv2d_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
+                                         len(ts), _ptr(weight_t), _ptr(bias), _ptr(residual), int(res_mode),
+                                         int(bool(relu)), N, Cout, kernel, kernel, sh, sw, _ptr(out), Ho, Wo,
+                                         _stream(ts[0]))
+    _lib.check(rc, "tpspp_conv2d_fwd")
+    return out
+
+
 def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
     """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel (error if not applicable);
     bands: workgroups per image pair in the LDS-staged kernel (0 = heuristic)."""
