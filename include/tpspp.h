@@ -123,7 +123,11 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *                 nearest-upsampled by (uh_i, uw_i) on the fly; all sources share the logical size;
  *                 with nsrc > 1 every C_i must be a multiple of 32 (1x1) / 8 (3x3)
  *   weight_t      (Cin*KH*KW, Cout) = the PyTorch weight (Cout, Cin, KH, KW) flattened and
- *                 transposed once by the caller (BatchNorm, if any, folded in)
+ *                 transposed once by the caller (BatchNorm, if any, folded in): generic kernel
+ *   weight_tiled  the same values arranged (chunk, tap, channel-in-chunk, cout) with
+ *                 KC = tpspp_conv_chunk_channels(K) channels per chunk, zero-padded to whole
+ *                 chunks: [ceil(Cin/KC)][KH*KW][KC][Cout]; enables the tiled kernel (either pointer
+ *                 may be NULL; results agree to fp32 rounding, the summation order differs)
  *   bias          (Cout) or NULL;  residual (N, Cout, Ho, Wo) or NULL
  *   res_mode      0 none, 1 act(conv + bias) + residual, 2 act(conv + bias + residual)
  * replaces: mmcv ConvModule / nn.Conv2d (+ nn.Upsample, torch.cat, skip additions)
@@ -132,9 +136,16 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *           layers/conv_layer.py:12-33
  */
 int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
-                     const float* weight_t, const float* bias, const float* residual,
+                     const float* weight_t, const float* weight_tiled, const float* bias,
+                     const float* residual,
                      int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
                      float* out, int Ho, int Wo, tpspp_stream_t stream);
+
+/* Channels per K-chunk of the tiled conv kernel for a 1x1 / 3x3 kernel (layout of weight_tiled). */
+int tpspp_conv_chunk_channels(int kernel_size);
+
+/* Tuning / testing: non-zero forces the generic conv kernel even when weight_tiled is given. */
+int tpspp_conv_set_tuning(int force_generic);
 
 /*
  * Launch-shape override for tpspp_warp_fwd (tuning / benchmarking only; results do not depend on

@@ -55,12 +55,19 @@ def test_conv_matches_cpu_reference(cuda, name, srcs, cout, k, stride, relu, res
     y0 = ref_conv(xs, w, b, k, stride, relu, None, 0)
     res = t(synth.dyadic(tuple(y0.shape), name + ".r", 1)) if res_mode else None
     ref = ref_conv(xs, w, b, k, stride, relu, res, res_mode)
-    wt, bb = ops.prep_conv_weight(w.to(cuda), conv_bias=None if b is None else b.to(cuda))
-    got = ops.conv2d([(x.to(cuda), uh, uw) for x, uh, uw in xs], wt, bb, k, stride, relu,
-                     None if res is None else res.to(cuda), res_mode)
-    assert got.shape == ref.shape
-    err = (got.cpu() - ref).abs().max().item()
-    assert err <= 2e-5, f"{name}: max abs err {err:.3e}"
+    cw = ops.prep_conv_weight(w.to(cuda), conv_bias=None if b is None else b.to(cuda),
+                              src_channels=[s_[0] for s_ in srcs])
+    from tps_pp_amd import _lib
+    try:
+        for force_generic in (0, 1):          # tiled kernel (where a tile fits) and generic kernel
+            _lib.lib().tpspp_conv_set_tuning(force_generic)
+            got = ops.conv2d([(x.to(cuda), uh, uw) for x, uh, uw in xs], cw, stride, relu,
+                             None if res is None else res.to(cuda), res_mode)
+            assert got.shape == ref.shape
+            err = (got.cpu() - ref).abs().max().item()
+            assert err <= 2e-5, f"{name} (generic={force_generic}): max abs err {err:.3e}"
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
 
 
 def test_folded_batchnorm(cuda):
@@ -70,6 +77,6 @@ def test_folded_batchnorm(cuda):
     gamma = t(synth.dyadic((cout,), "bn.g", 0, 0.25, 1.0)); beta = t(synth.dyadic((cout,), "bn.b", 0, 0.1))
     mean = t(synth.dyadic((cout,), "bn.m", 0, 0.1)); var = t(synth.dyadic((cout,), "bn.v", 0, 0.25, 1.0))
     ref = F.relu(F.batch_norm(F.conv2d(x, w, None, padding=1), mean, var, gamma, beta, False, 0.1, 1e-5))
-    wt, bb = ops.prep_conv_weight(w.to(cuda), bn=tuple(v.to(cuda) for v in (gamma, beta, mean, var)))
-    got = ops.conv2d([x.to(cuda)], wt, bb, 3, 1, True)
+    cw = ops.prep_conv_weight(w.to(cuda), bn=tuple(v.to(cuda) for v in (gamma, beta, mean, var)))
+    got = ops.conv2d([x.to(cuda)], cw, 1, True)
     assert (got.cpu() - ref).abs().max().item() <= 3e-5

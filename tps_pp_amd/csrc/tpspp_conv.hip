@@ -145,6 +145,187 @@ conv_igemm_f32_kernel(const ConvParams P)
     }
 }
 
+// ---- tiled kernel: the input PATCH of a rectangular output tile is staged once per channel chunk ---
+// (coalesced row copies, every input element fetched once instead of KH*KW times) and the im2col
+// matrix is never materialised: with k ordered (tap, channel) inside a chunk, the B fragment of lane
+// (pixel (ty,tx), half h) for tap (ky,kx), channel pair c2 is
+//     patch[2*c2 + h][ty*SH + ky][tx*SW + kx]  =  lane_base + compile-time offset,
+// i.e. one ds_read_b32 with an immediate and no address arithmetic in the MFMA loop.  The next
+// chunk's patch and weight slab are prefetched into registers while the current chunk is multiplied.
+// Requires weights pre-arranged as (chunk, tap, channel-in-chunk, cout) -- tpspp_conv_arrange_weight.
+template <int KH, int SH, int SW, int TH, int TW, int KC>
+struct TileCfg {
+    static constexpr int KW = KH;
+    static constexpr int TAPS = KH * KW;
+    static constexpr int PH = (TH - 1) * SH + KH;      // patch rows
+    static constexpr int PW = (TW - 1) * SW + KW;      // patch cols
+    static constexpr int PS = PH * PW;                 // floats per channel of the patch
+    static constexpr int KCK = KC * TAPS;
+    static constexpr int PATCH = KC * PS;
+    static constexpr int NP = (PATCH + kThreads - 1) / kThreads;          // patch floats per thread
+    static constexpr int NW4 = (KCK * BN / 4 + kThreads - 1) / kThreads;  // weight float4 per thread
+};
+
+template <int KH, int SH, int SW, int TH, int TW, int KC>
+__global__ void __launch_bounds__(kThreads, 2)
+conv_tiled_f32_kernel(const ConvParams P)
+{
+    using Cfg = TileCfg<KH, SH, SW, TH, TW, KC>;
+    constexpr int KW = Cfg::KW, TAPS = Cfg::TAPS, PH = Cfg::PH, PW = Cfg::PW, PS = Cfg::PS;
+    constexpr int KCK = Cfg::KCK, PATCH = Cfg::PATCH, NP = Cfg::NP, NW4 = Cfg::NW4;
+    static_assert(TH * TW == BM, "tile must hold 128 pixels");
+    static_assert(KC % 2 == 0, "channel pairs");
+    __shared__ __attribute__((aligned(16))) float sP[PATCH];
+    __shared__ __attribute__((aligned(16))) float sW[KCK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = tid / kWave;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ctiles = (P.Cout + BN - 1) / BN;
+    const int n = blockIdx.z / ctiles;
+    const int co_base = (blockIdx.z - n * ctiles) * BN;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int iy_base = oy0 * SH - P.ph, ix_base = ox0 * SW - P.pw;
+    const int HoWo = P.Ho * P.Wo;
+
+    // this lane's pixel inside the tile and its B-fragment base address in the patch
+    const int tp = wv * 32 + l31;
+    const int ty = tp / TW, tx = tp - ty * TW;
+    const int lane_base = half * PS + ty * SH * PW + tx * SW;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+
+    float rp[NP];
+    float4 rw[NW4];
+    int cbase = 0, s = 0;
+    ConvSrc cur = P.src[0];
+    const int nchunks = (P.Cin + KC - 1) / KC;
+
+    auto prefetch = [&](int chunk) {
+        const int c0 = chunk * KC;
+        while (c0 >= cbase + cur.C) { cbase += cur.C; ++s; cur = P.src[s]; }
+        const float* sp = cur.p + ((size_t)n * cur.C + (c0 - cbase)) * cur.H * cur.W;
+        const int plane = cur.H * cur.W;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = tid + i * kThreads;
+            float v = 0.0f;
+            if (e < PATCH) {
+                const int ci = e / PS, r = e - ci * PS;
+                const int py = r / PW, px = r - py * PW;
+                const int iy = iy_base + py, ix = ix_base + px;
+                if (iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (c0 + ci) < P.Cin)
+                    v = sp[(size_t)ci * plane + (iy / cur.uh) * cur.W + (ix / cur.uw)];
+            }
+            rp[i] = v;
+        }
+        // weights: (chunk, tap, ci, cout) -> this chunk's slab is KCK rows of Cout floats
+        const float* wp = P.wt + (size_t)chunk * KCK * P.Cout + co_base;
+#pragma unroll
+        for (int i = 0; i < NW4; ++i) {
+            const int e = tid + i * kThreads;                     // float4 index inside the slab
+            const int kk = e / (BN / 4), c4 = e - kk * (BN / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < KCK && co_base + 4 * c4 + 3 < P.Cout)
+                v = *reinterpret_cast<const float4*>(wp + (size_t)kk * P.Cout + 4 * c4);
+            rw[i] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = tid + i * kThreads;
+            if (e < PATCH) sP[e] = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NW4; ++i) {
+            const int e = tid + i * kThreads;
+            if (e < KCK * BN / 4) reinterpret_cast<float4*>(sW)[e] = rw[i];
+        }
+    };
+
+    prefetch(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        commit();
+        __syncthreads();
+        if (chunk + 1 < nchunks) prefetch(chunk + 1);     // in flight during the MFMA phase
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+            for (int c2 = 0; c2 < KC / 2; ++c2) {
+                const float b = sP[lane_base + 2 * c2 * PS + ky * PW + kx];
+                const float a0 = sW[(tap * KC + 2 * c2 + half) * BN + l31];
+                const float a1 = sW[(tap * KC + 2 * c2 + half) * BN + 32 + l31];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < P.Ho && ox < P.Wo) {
+        const int pix = oy * P.Wo + ox;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < P.Cout) {
+                    float v = h2 ? acc1[r] : acc0[r];
+                    if (P.bias) v = v + P.bias[co];
+                    const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
+                    if (P.res_mode == 2) v = v + P.res[o];
+                    if (P.relu) v = v > 0.0f ? v : 0.0f;
+                    if (P.res_mode == 1) v = v + P.res[o];
+                    P.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KH, int SH, int SW, int TH, int TW, int KC>
+void launch_tiled(const ConvParams& P, hipStream_t st)
+{
+    const int ctiles = (P.Cout + BN - 1) / BN;
+    const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH), (unsigned)(P.N * ctiles));
+    hipLaunchKernelGGL((conv_tiled_f32_kernel<KH, SH, SW, TH, TW, KC>), grid, dim3(kThreads), 0, st, P);
+}
+
+// picks a tile for the output width; returns false when no tiled instantiation fits
+bool launch_tiled_any(const ConvParams& P, int KH, hipStream_t st)
+{
+    if ((P.Cout % 4) != 0) return false;                          // float4 weight rows
+    if ((long)P.N * ((P.Cout + BN - 1) / BN) > 65535) return false;
+#define TPSPP_TILE(KHv, SHv, SWv, THv, TWv, KCv) { launch_tiled<KHv, SHv, SWv, THv, TWv, KCv>(P, st); return true; }
+    if (KH == 1) {
+        if (P.sh != 1 || P.sw != 1) return false;
+        if (P.Wo >= 128) TPSPP_TILE(1, 1, 1, 1, 128, 32)
+        if (P.Wo >= 64) TPSPP_TILE(1, 1, 1, 2, 64, 32)
+        if (P.Wo >= 32) TPSPP_TILE(1, 1, 1, 4, 32, 32)
+        TPSPP_TILE(1, 1, 1, 8, 16, 32)
+    }
+    if (P.sh == 1 && P.sw == 1) {
+        if (P.Wo >= 64) TPSPP_TILE(3, 1, 1, 2, 64, 8)
+        if (P.Wo >= 32) TPSPP_TILE(3, 1, 1, 4, 32, 8)
+        TPSPP_TILE(3, 1, 1, 8, 16, 8)
+    }
+    if (P.sh == 2 && P.sw == 2) {
+        if (P.Wo >= 64) TPSPP_TILE(3, 2, 2, 2, 64, 8)
+        if (P.Wo >= 32) TPSPP_TILE(3, 2, 2, 4, 32, 8)
+        TPSPP_TILE(3, 2, 2, 8, 16, 8)
+    }
+    if (P.sh == 2 && P.sw == 1) TPSPP_TILE(3, 2, 1, 8, 16, 8)
+#undef TPSPP_TILE
+    return false;
+}
+
 template <int KH, int KW, int KC>
 void launch_conv(const ConvParams& P, hipStream_t st)
 {
@@ -152,14 +333,28 @@ void launch_conv(const ConvParams& P, hipStream_t st)
     hipLaunchKernelGGL((conv_igemm_f32_kernel<KH, KW, KC>), grid, dim3(kThreads), 0, st, P);
 }
 
+int g_conv_force_generic = 0;
+
 }  // namespace
 
+TPSPP_EXPORT int tpspp_conv_set_tuning(int force_generic)
+{
+    g_conv_force_generic = force_generic ? 1 : 0;
+    return TPSPP_OK;
+}
+
+TPSPP_EXPORT int tpspp_conv_chunk_channels(int kernel_size)
+{
+    return kernel_size == 1 ? 32 : 8;
+}
+
 TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
-                                  const float* weight_t, const float* bias, const float* residual,
+                                  const float* weight_t, const float* weight_tiled, const float* bias,
+                                  const float* residual,
                                   int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
                                   float* out, int Ho, int Wo, tpspp_stream_t stream)
 {
-    TPSPP_REQUIRE(src_ptrs && src_dims && weight_t && out, "tpspp_conv2d_fwd: null pointer");
+    TPSPP_REQUIRE(src_ptrs && src_dims && (weight_t || weight_tiled) && out, "tpspp_conv2d_fwd: null pointer");
     TPSPP_REQUIRE(nsrc >= 1 && nsrc <= 3, "tpspp_conv2d_fwd: 1..3 sources");
     TPSPP_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3), "tpspp_conv2d_fwd: kernel must be 1x1 or 3x3");
     TPSPP_REQUIRE(N >= 0 && Cout > 0 && sh >= 1 && sw >= 1 && Ho > 0 && Wo > 0, "tpspp_conv2d_fwd: bad sizes");
@@ -192,6 +387,12 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
     P.relu = relu ? 1 : 0; P.res_mode = res_mode;
     if (N == 0) return TPSPP_OK;
     hipStream_t st = tpspp::as_stream(stream);
+    if (weight_tiled && g_conv_force_generic == 0) {
+        ConvParams Q = P;
+        Q.wt = weight_tiled;
+        if (launch_tiled_any(Q, KH, st)) return tpspp::check_launch("tpspp_conv2d_fwd(tiled)");
+    }
+    TPSPP_REQUIRE(weight_t, "tpspp_conv2d_fwd: shape needs the generic kernel but weight_t is NULL");
     if (KH == 1) launch_conv<1, 1, 32>(P, st);
     else         launch_conv<3, 3, 8>(P, st);
     return tpspp::check_launch("tpspp_conv2d_fwd");

@@ -172,10 +172,18 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
     return out0, out1, grid, idx
 
 
-def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5):
-    """PyTorch conv weight (Cout, Cin, KH, KW) -> (weight_t (Cin*KH*KW, Cout), bias (Cout) | None) for
-    `conv2d`.  `bn` = (gamma, beta, running_mean, running_var): eval-mode BatchNorm folded in
-    (y = gamma * (conv(x) + b - mean) / sqrt(var + eps) + beta)."""
+class ConvWeight:
+    """Device-side weights of one fused convolution, prepared once: `wt` (K, Cout) for the generic
+    kernel, `tiled` [chunk][tap][channel-in-chunk][Cout] for the tiled kernel, `bias` (Cout) | None."""
+
+    def __init__(self, wt, tiled, bias, kernel):
+        self.wt, self.tiled, self.bias, self.kernel = wt, tiled, bias, kernel
+
+
+def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5, src_channels=None):
+    """PyTorch conv weight (Cout, Cin, KH, KW) [+ eval-mode BatchNorm (gamma, beta, mean, var), folded:
+    y = gamma * (conv(x) + b - mean) / sqrt(var + eps) + beta] -> ConvWeight.
+    `src_channels`: channel counts of the concatenated sources (chunks never straddle a source)."""
     w = weight.detach().float()
     b = None if conv_bias is None else conv_bias.detach().float()
     if bn is not None:
@@ -183,17 +191,27 @@ def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5):
         scale = gamma / torch.sqrt(var + eps)
         w = w * scale.view(-1, 1, 1, 1)
         b = beta - mean * scale if b is None else beta + (b - mean) * scale
-    cout = w.shape[0]
-    return w.reshape(cout, -1).t().contiguous(), (None if b is None else b.contiguous())
+    cout, cin, kh, kw = w.shape
+    wt = w.reshape(cout, -1).t().contiguous()
+    kc = 32 if kh == 1 else 8
+    tiled = None
+    if src_channels is None or len(src_channels) == 1 or all(c % kc == 0 for c in src_channels):
+        nch = (cin + kc - 1) // kc
+        wp = torch.zeros((cout, nch * kc, kh, kw), device=w.device, dtype=torch.float32)
+        wp[:, :cin] = w
+        # (cout, chunk, ci, ky, kx) -> (chunk, ky, kx, ci, cout)
+        tiled = wp.view(cout, nch, kc, kh, kw).permute(1, 3, 4, 2, 0).contiguous()
+    return ConvWeight(wt, tiled, None if b is None else b.contiguous(), kh)
 
 
-def conv2d(srcs, weight_t, bias, kernel, stride=(1, 1), relu=True, residual=None, res_mode=0, out=None):
+def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=None):
     """Fused conv on the fp32 matrix cores (`tpspp_conv2d_fwd`).
 
     srcs: list of 1..3 entries `tensor` or `(tensor, uh, uw)`: channel-concatenated, each nearest-
-    upsampled by (uh, uw) on the fly.  weight_t/bias from `prep_conv_weight`.  kernel: 1 or 3
-    ("same" padding).  residual/res_mode: 1 = act(conv)+res, 2 = act(conv+res)."""
+    upsampled by (uh, uw) on the fly.  cw: ConvWeight from `prep_conv_weight` ("same" padding).
+    residual/res_mode: 1 = act(conv)+res, 2 = act(conv+res)."""
     import ctypes
+    weight_t, bias, kernel = cw.wt, cw.bias, cw.kernel
     ts, dims = [], []
     for e in srcs:
         t, uh, uw = (e, 1, 1) if isinstance(e, torch.Tensor) else e
@@ -224,7 +242,8 @@ def conv2d(srcs, weight_t, bias, kernel, stride=(1, 1), relu=True, residual=None
     dim_arr = (ctypes.c_int * len(dims))(*dims)
     with torch.cuda.device(ts[0].device):
         rc = _lib.lib().tpspp_conv2d_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
-                                         len(ts), _ptr(weight_t), _ptr(bias), _ptr(residual), int(res_mode),
+                                         len(ts), _ptr(weight_t), _ptr(cw.tiled), _ptr(bias), _ptr(residual),
+                                         int(res_mode),
                                          int(bool(relu)), N, Cout, kernel, kernel, sh, sw, _ptr(out), Ho, Wo,
                                          _stream(ts[0]))
     _lib.check(rc, "tpspp_conv2d_fwd")
