@@ -141,6 +141,14 @@ int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc
                      int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
                      float* out, int Ho, int Wo, tpspp_stream_t stream);
 
+/*
+ * out (N, C, H/2, W/2) = MaxPool2d(kernel 2, stride 2)(in);  out (N, C) = AdaptiveAvgPool2d(1)(in)
+ * replaces: preprocessor/tps_preprocessor.py:110,114,118,126 (LocalizationNetwork.conv)
+ */
+int tpspp_maxpool2x2_fwd(const float* in, int N, int C, int H, int W, float* out, tpspp_stream_t stream);
+int tpspp_global_avgpool_fwd(const float* in, int N, int C, int H, int W, float* out,
+                             tpspp_stream_t stream);
+
 /* Channels per K-chunk of the tiled conv kernel for a 1x1 / 3x3 kernel (layout of weight_tiled). */
 int tpspp_conv_chunk_channels(int kernel_size);
 

@@ -250,6 +250,39 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
     return out
 
 
+def maxpool2x2(x):
+    """nn.MaxPool2d(2, 2) (tps_preprocessor.py:110,114,118)."""
+    x = _chk("input", x, 4)
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H // 2, W // 2), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_maxpool2x2_fwd(_ptr(x), N, C, H, W, _ptr(out), _stream(x))
+    _lib.check(rc, "tpspp_maxpool2x2_fwd")
+    return out
+
+
+def global_avgpool(x):
+    """nn.AdaptiveAvgPool2d(1) -> (N, C) (tps_preprocessor.py:126)."""
+    x = _chk("input", x, 4)
+    N, C, H, W = x.shape
+    out = torch.empty((N, C), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_global_avgpool_fwd(_ptr(x), N, C, H, W, _ptr(out), _stream(x))
+    _lib.check(rc, "tpspp_global_avgpool_fwd")
+    return out
+
+
+def linear(x, cw, relu=False):
+    """y = act(x @ W^T + b) for x (N, Cin) on the conv kernel: the batch plays the role of the pixels
+    of a 1x1 convolution over a (1, Cin, 1, N) image.  cw = prep_conv_weight(W.view(Cout, Cin, 1, 1), conv_bias=b).
+    Returns (N, Cout)."""
+    x = _chk("input", x, 2)
+    n, cin = x.shape
+    xt = x.t().contiguous().view(1, cin, 1, n)
+    y = conv2d([xt], cw, 1, relu)                      # (1, Cout, 1, N)
+    return y.view(-1, n).t().contiguous()
+
+
 def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
     """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel (error if not applicable);
     bands: workgroups per image pair in the LDS-staged kernel (0 = heuristic)."""

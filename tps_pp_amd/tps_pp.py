@@ -336,11 +336,48 @@ class TPS_PP(nn.Module):
     def init_weights(self):
         pass
 
+    # ---- hand-written conv path (fp32 MFMA kernels, tps_pp_amd/csrc/tpspp_conv.hip) -------------
+    def _conv_weights(self):
+        """ConvWeight per conv layer, rebuilt when a parameter changes (version counters)."""
+        convs = {"down0": self.down0, "down1": self.down1, "down2": self.down2}
+        if self.type == "ResNet45v2":
+            convs.update(down0_1=self.down0_1, down1_1=self.down1_1, down_feat=self.down_feat)
+        for i in range(4):
+            convs[f"enc{i}"] = self.MSFA.conv.k_encoder[i]
+            convs[f"dec{i}"] = self.MSFA.conv.k_decoder[i][1]
+        key = tuple((n, m.conv.weight._version, m.conv.bias._version, m.conv.weight.data_ptr())
+                    for n, m in convs.items())
+        cache = getattr(self, "_cw_cache", None)
+        if cache is None or cache[0] != key:
+            srcs = {"down_feat": [64, 64, 64], "enc0": [64, 64, 64]}
+            cw = {n: ops.prep_conv_weight(m.conv.weight, conv_bias=m.conv.bias, src_channels=srcs.get(n))
+                  for n, m in convs.items()}
+            self._cw_cache = cache = (key, cw)
+        return cache[1]
+
+    def _msfa_hip(self, feat_srcs, cw):
+        """Encoder_Decoder_Feature_Extractor.forward (`tps_pp.py:156-169`) on the fused conv kernel:
+        the concat feeding k_encoder.0, every nn.Upsample and every skip addition are folded into
+        the convolutions that consume / produce them."""
+        p = self.MSFA.conv.stride
+        e0 = ops.conv2d(feat_srcs, cw["enc0"], 1)
+        e1 = ops.conv2d([e0], cw["enc1"], 2)
+        e2 = ops.conv2d([e1], cw["enc2"], p)
+        e3 = ops.conv2d([e2], cw["enc3"], (2, 1))
+        k = self.MSFA.conv.atten(e3)
+        k = ops.conv2d([(k.contiguous(), 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1)
+        k = ops.conv2d([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
+        k = ops.conv2d([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
+        k = ops.conv2d([k], cw["dec3"], 1)
+        return e3, k
+
     def grid(self, a1, a2, a3):
         return self.down_feat(torch.cat((a1, a2, self.up_sample(a3)), dim=1))
 
     def regress(self, batch_img, outs):
-        """Control points, attention score and the feature map to rectify (`tps_pp.py:572-594`)."""
+        """Control points, attention score and the feature map to rectify (`tps_pp.py:572-594`).
+        GPU tensors take the hand-written conv kernels; CPU tensors (host-side tests of the mirror
+        against the oracle) take the plain PyTorch composition of the same layers."""
         h, w = batch_img.shape[-2:]
         if self.type == "ResNet45v2":
             if tuple(outs[1].shape[-2:]) != (2 * h, 2 * w) or tuple(outs[0].shape[-2:]) != (2 * h, 2 * w):
@@ -349,6 +386,9 @@ class TPS_PP(nn.Module):
                     f"{tuple(outs[0].shape[-2:])}, {tuple(outs[1].shape[-2:])}: backbone strides "
                     "[2,1,2,1,2] (configs/textrecog/nrtr/nrtr_tps++.py) produce the 'ResNet45' "
                     "geometry -- build with variant='ResNet45' (the reference itself fails here)")
+        if batch_img.is_cuda:
+            return self._regress_hip(batch_img, outs)
+        if self.type == "ResNet45v2":
             feat0 = self.down0(outs[0])
             feat1 = self.down1(outs[1])
             feat2 = self.down2(batch_img)
@@ -362,6 +402,27 @@ class TPS_PP(nn.Module):
             feat_grid = batch_img
         logits = self.MSFA(feat_cat)
         control_point, atten_score = self.TPE(logits["en_feat"], logits["de_feat"])
+        return control_point, atten_score, feat_grid
+
+    def _regress_hip(self, batch_img, outs):
+        cw = self._conv_weights()
+        x = batch_img.float().contiguous()
+        o0, o1 = outs[0].float().contiguous(), outs[1].float().contiguous()
+        if self.type == "ResNet45v2":
+            feat0 = ops.conv2d([o0], cw["down0"], 1)
+            feat1 = ops.conv2d([o1], cw["down1"], 1)
+            feat2 = ops.conv2d([x], cw["down2"], 1)
+            d0 = ops.conv2d([feat0], cw["down0_1"], 2)
+            d1 = ops.conv2d([feat1], cw["down1_1"], 2)
+            # grid(): cat(feat0, feat1, Upsample(feat2)) -> 1x1 conv, nothing materialised
+            feat_grid = ops.conv2d([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1)
+            cat_srcs = [d0, d1, feat2]
+        else:
+            cat_srcs = [ops.conv2d([o0], cw["down0"], 2), ops.conv2d([o1], cw["down1"], 1),
+                        ops.conv2d([x], cw["down2"], 1)]
+            feat_grid = x
+        en_feat, de_feat = self._msfa_hip(cat_srcs, cw)
+        control_point, atten_score = self.TPE(en_feat, de_feat)
         return control_point, atten_score, feat_grid
 
     def rectify(self, feat_grid, batch_img, control_point, atten_score, want_grid=False):

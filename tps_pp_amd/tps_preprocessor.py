@@ -7,8 +7,10 @@ localization_fc1.0.*`, `LocalizationNetwork.localization_fc2.*`, `GridGenerator.
 `GridGenerator.P_hat`), same `forward(batch_img) -> Tensor`.
 
 What differs is underneath: `GridGenerator.build_P_prime` + `F.grid_sample` (`:71-83`) run as ONE
-hand-written HIP kernel (`tps_pp_amd/csrc/tpspp_warp.hip` through the C ABI of `include/tpspp.h`).
-There is no PyTorch / CPU fallback for that path: CPU tensors raise.
+hand-written HIP kernel (`tps_pp_amd/csrc/tpspp_warp.hip` through the C ABI of `include/tpspp.h`), and
+the localisation network's convolutions (BatchNorm folded), pooling and FCs run on the hand-written
+fp32 MFMA conv / pooling kernels when the module is in eval mode on a GPU.
+There is no PyTorch / CPU fallback for the rectification path: CPU tensors raise.
 """
 import numpy as np
 import torch
@@ -55,8 +57,36 @@ class LocalizationNetwork(nn.Module):
         self.localization_fc2.bias.data = torch.from_numpy(
             constants.classic_initial_ctrl(num_fiducial)).float().view(-1)
 
+    def _hip_weights(self):
+        """ConvWeights (eval-mode BatchNorm folded into the convolutions) per layer, rebuilt when a
+        parameter or running statistic changes."""
+        mods = [self.conv[i] for i in (0, 1, 4, 5, 8, 9, 12, 13)] + [self.localization_fc1[0], self.localization_fc2]
+        key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        cache = getattr(self, "_cw_cache", None)
+        if cache is None or cache[0] != key:
+            cw = []
+            for ci, bi in ((0, 1), (4, 5), (8, 9), (12, 13)):
+                bn = self.conv[bi]
+                cw.append(ops.prep_conv_weight(self.conv[ci].weight, bn=(bn.weight, bn.bias, bn.running_mean,
+                                                                       bn.running_var), eps=bn.eps))
+            fc1, fc2 = self.localization_fc1[0], self.localization_fc2
+            cw.append(ops.prep_conv_weight(fc1.weight.view(fc1.out_features, fc1.in_features, 1, 1), conv_bias=fc1.bias))
+            cw.append(ops.prep_conv_weight(fc2.weight.view(fc2.out_features, fc2.in_features, 1, 1), conv_bias=fc2.bias))
+            self._cw_cache = cache = (key, cw)
+        return cache[1]
+
     def forward(self, batch_img):
         n = batch_img.size(0)
+        if batch_img.is_cuda and not self.training:
+            # hand-written path: fp32 MFMA convolutions with BatchNorm folded in, HIP pooling kernels,
+            # the two FCs as 1x1 convolutions over the batch
+            cw = self._hip_weights()
+            x = batch_img.float().contiguous()
+            for i in range(3):
+                x = ops.maxpool2x2(ops.conv2d([x], cw[i], 1, True))
+            x = ops.global_avgpool(ops.conv2d([x], cw[3], 1, True))
+            x = ops.linear(x, cw[4], relu=True)
+            return ops.linear(x, cw[5], relu=False).view(n, self.num_fiducial, 2)
         feat = self.conv(batch_img).view(n, -1)
         return self.localization_fc2(self.localization_fc1(feat)).view(n, self.num_fiducial, 2)
 
