@@ -83,3 +83,32 @@ def test_tpspp_module_against_reference(cuda, variant, fname):
     assert np.abs(res["mp_img"].cpu().numpy() - G["mp_img"]).max() <= 5 * TOL
     assert np.abs(res["output"].cpu().numpy() - G["output"]).max() <= 5 * TOL
     assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])
+
+
+def test_backbone_stem_and_tps_call_site(cuda):
+    """Stem + layer1 + layer2 of ResNetABI_v2_large on the MFMA conv kernels (BatchNorm folded) against
+    the reference's outputs, and the `tpsnet(x, outs)` call contract (resnet_v2_large.py:183-191)."""
+    from tps_pp_amd import ResNetABI_v2_large
+    G = cases.load("backbone_stem")
+    m = ResNetABI_v2_large(strides=cases.G7_STRIDES).eval()
+    keep = {k: v for k, v in m.state_dict().items() if k.startswith(("conv1.", "bn1.", "layer1.", "layer2."))}
+    sd = cases.synth_state(keep, 7, cases.backbone_state_rule)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    got = {}
+
+    class Spy(torch.nn.Module):
+        def forward(self, x, outs, **kw):
+            got["x"], got["outs"] = x, list(outs)
+            return {"output": x}
+    with torch.no_grad():
+        res = m(dev(cases.g7_inputs()["img"], cuda), Spy())
+    assert set(res) == {"output", "img_ref"} and res["output"].shape == torch.Size([cases.G7_N, 512, 4, 16])
+    assert np.abs(got["x"].cpu().numpy() - G["x"]).max() <= 2e-4
+    assert np.abs(got["outs"][0].cpu().numpy()[:, ::4] - G["outs0_sub"]).max() <= 2e-4
+    assert np.abs(got["outs"][1].cpu().numpy()[:, ::4] - G["outs1_sub"]).max() <= 2e-4
+    # end to end with the real rectifier in the loop
+    tps = build_backbone(dict(type="TPS_PP")).eval().to(cuda)
+    with torch.no_grad():
+        res = m(dev(cases.g7_inputs()["img"], cuda), tps)
+    assert res["img_ref"].shape == torch.Size([cases.G7_N, 64, 16, 64]) and torch.isfinite(res["output"]).all()

@@ -130,3 +130,28 @@ def test_constants_builders_reproduce_reference_tables():
     np.testing.assert_allclose(c["inv_delta_C"], K["classic_inv_delta_C"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(c["P_hat"], K["classic_P_hat"], rtol=1e-6, atol=1e-7)
     assert np.array_equal(constants.classic_identity_ctrl(20), cases.classic_identity_ctrl(20))
+
+
+def test_backbone_mirror_matches_oracle_on_cpu():
+    """ResNetABI_v2_large mirror (PyTorch path, CPU) == the functional oracle == the reference's
+    golden outputs for stem + layer1 + layer2."""
+    from oracle import tpspp_oracle as TO
+    from tps_pp_amd import ResNetABI_v2_large
+    m = ResNetABI_v2_large(strides=cases.G7_STRIDES).eval()
+    keep = {k: v for k, v in m.state_dict().items() if k.startswith(("conv1.", "bn1.", "layer1.", "layer2."))}
+    sd = cases.synth_state(keep, 7, cases.backbone_state_rule)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    got = {}
+
+    class Spy(torch.nn.Module):
+        def forward(self, x, outs, **kw):
+            got["x"], got["outs"] = x, list(outs)
+            return {"output": x}
+    img = cases.g7_inputs()["img"]
+    with torch.no_grad():
+        m(torch.from_numpy(img), Spy())
+    ox, oouts = TO.backbone_stem(dict(m.state_dict()), img)
+    assert torch.equal(got["x"], ox) and all(torch.equal(a, b) for a, b in zip(got["outs"], oouts))
+    G = cases.load("backbone_stem")
+    np.testing.assert_allclose(got["x"].numpy(), G["x"], atol=1e-4, rtol=1e-5)
+    assert len(m.state_dict()) == 295          # same number of entries as the reference's backbone

@@ -9,7 +9,8 @@ from .registry import (BACKBONES, PREPROCESSOR, build_backbone, build_preprocess
                        register_into_mmocr)
 from .tps_preprocessor import TPSPreprocessor, LocalizationNetwork, GridGenerator  # noqa: F401
 from .tps_pp import TPS_PP, Attention_Enhanced_TPS  # noqa: F401
+from .resnet_v2_large import ResNetABI_v2_large, BasicBlock  # noqa: F401
 
 __all__ = ["BACKBONES", "PREPROCESSOR", "build_backbone", "build_preprocessor",
            "register_into_mmocr", "TPSPreprocessor", "LocalizationNetwork", "GridGenerator",
-           "TPS_PP", "Attention_Enhanced_TPS"]
+           "TPS_PP", "Attention_Enhanced_TPS", "ResNetABI_v2_large", "BasicBlock"]

@@ -1,0 +1,146 @@
+"""The recognizer backbone that calls TPS++: `ResNetABI_v2_large` behind the reference's API.
+
+Mirror of `mmocr/models/textrecog/backbones/resnet_v2_large.py:25-196` + `layers/conv_layer.py:12-33`
+(BasicBlock with `use_conv1x1=True`: conv1 = 1x1, conv2 = 3x3 with the block's stride, 1x1 + BN
+downsample when the stride or the width changes): same constructor arguments, same `state_dict`
+keys (`conv1.*`, `bn1.*`, `layer{1..5}.{i}.{conv1,bn1,conv2,bn2,downsample.0,downsample.1}.*`), same
+call contract `forward(x, tpsnet=None, test=False, **kw) -> dict(output, img_ref)` with the TPS
+network invoked before stage index 2 on `(x, outs)` (`:183-191`).
+
+In eval mode on a GPU every convolution runs on the hand-written fp32 MFMA kernel with its BatchNorm
+folded in and the residual add + ReLU fused into the second convolution's epilogue.  Training mode /
+CPU tensors use the plain PyTorch composition (BatchNorm statistics need it).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import BACKBONES
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, use_conv1x1=False):
+        super().__init__()
+        if use_conv1x1:
+            self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=1, bias=False)
+            self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        else:   # mmcv.cnn.resnet.BasicBlock: 3x3 (stride) then 3x3
+            self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+            self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+        self.use_conv1x1 = use_conv1x1
+
+    def forward(self, x):
+        if x.is_cuda and not self.training:
+            return self._forward_hip(x)
+        residual = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        return self.relu(out + residual)
+
+    def _weights(self):
+        mods = [self.conv1, self.bn1, self.conv2, self.bn2] + \
+            ([self.downsample[0], self.downsample[1]] if self.downsample is not None else [])
+        key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        cache = getattr(self, "_cw_cache", None)
+        if cache is None or cache[0] != key:
+            def fold(conv, bn):
+                return ops.prep_conv_weight(conv.weight, bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                                            eps=bn.eps)
+            cw = [fold(self.conv1, self.bn1), fold(self.conv2, self.bn2),
+                  fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None]
+            self._cw_cache = cache = (key, cw)
+        return cache[1]
+
+    def _forward_hip(self, x):
+        c1, c2, cd = self._weights()
+        x = x.float().contiguous()
+        s1 = self.conv1.stride
+        out = ops.conv2d([x], c1, s1, True)
+        residual = x if cd is None else ops.conv2d([x], cd, self.downsample[0].stride, False)
+        # relu(bn2(conv2(out)) + residual): residual add and ReLU live in the conv epilogue
+        return ops.conv2d([out], c2, self.conv2.stride, True, residual=residual, res_mode=2)
+
+
+@BACKBONES.register_module()
+class ResNetABI_v2_large(nn.Module):
+    """`resnet_v2_large.py:25-196`."""
+
+    def __init__(self, in_channels=3, stem_channels=32, base_channels=32, arch_settings=[3, 4, 6, 6, 3],
+                 strides=[2, 1, 2, 1, 1], p_strides=[2, 1, 2, 1, 1], out_indices=None,
+                 last_stage_pool=False, init_cfg=None):
+        super().__init__()
+        assert isinstance(in_channels, int)
+        assert isinstance(stem_channels, int)
+        assert isinstance(arch_settings, list) and all(isinstance(a, int) for a in arch_settings)
+        assert isinstance(strides, list) and all(isinstance(a, int) for a in strides)
+        assert len(arch_settings) == len(strides)
+        assert out_indices is None or isinstance(out_indices, (list, tuple))
+        assert isinstance(last_stage_pool, bool)
+        self.init_cfg = init_cfg
+        self.out_indices = out_indices
+        self.last_stage_pool = last_stage_pool
+        self.block = BasicBlock
+        self.inplanes = stem_channels
+        self.conv1 = nn.Conv2d(in_channels, stem_channels, kernel_size=3, stride=1, padding=1)
+        self.bn1 = nn.BatchNorm2d(stem_channels)
+        self.relu1 = nn.ReLU()
+        self.res_layers = []
+        planes = base_channels
+        for i, num_blocks in enumerate(arch_settings):
+            layer = self._make_layer(self.inplanes, planes, num_blocks, strides[i])
+            self.inplanes = planes * BasicBlock.expansion
+            planes *= 2
+            name = f"layer{i + 1}"
+            self.add_module(name, layer)
+            self.res_layers.append(name)
+
+    def init_weights(self):
+        pass
+
+    @staticmethod
+    def _make_layer(inplanes, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or inplanes != planes:
+            downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False),
+                                       nn.BatchNorm2d(planes))
+        layers = [BasicBlock(inplanes, planes, stride=stride, downsample=downsample, use_conv1x1=True)]
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(planes, planes, use_conv1x1=True))
+        return nn.Sequential(*layers)
+
+    def _stem(self, x):
+        if x.is_cuda and not self.training:
+            mods = [self.conv1, self.bn1]
+            key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+            cache = getattr(self, "_cw_cache", None)
+            if cache is None or cache[0] != key:
+                bn = self.bn1
+                cw = ops.prep_conv_weight(self.conv1.weight, conv_bias=self.conv1.bias, eps=bn.eps,
+                                          bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
+                self._cw_cache = cache = (key, cw)
+            return ops.conv2d([x.float().contiguous()], cache[1], 1, True)
+        return self.relu1(self.bn1(self.conv1(x)))
+
+    def forward(self, x, tpsnet=None, test=False, **kwargs):
+        """(N, 3, H, W) -> dict(output, img_ref); `tpsnet(x, outs, **kwargs)` runs before stage 2 and
+        its 'output' replaces x (`resnet_v2_large.py:183-191`)."""
+        x = self._stem(x)
+        outs = []
+        outputs = None
+        for i, name in enumerate(self.res_layers):
+            if i == 2 and tpsnet is not None:
+                outputs = tpsnet(x, outs, **kwargs)
+                if outputs.get("output", None) is not None:
+                    x = outputs["output"]
+            outs.append(x)
+            x = getattr(self, name)(x)
+        return {"output": x, "img_ref": outputs.get("output", None) if outputs is not None else None}
