@@ -142,6 +142,24 @@ int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc
                      float* out, int Ho, int Wo, tpspp_stream_t stream);
 
 /*
+ * DGAB block of the TPS++ regressor on a (N, C, 16, 64) feature map x with the point features
+ * y (N, C, 32) [= en_feat (N, C, 2, 16) viewed per channel]:
+ *     xn = LayerNorm_(16,64)(x);  A = gated attention(xn, y);  x1 = x + proj(A);
+ *     out = x1 + fc2(gelu(fc1(LayerNorm_(16,64)(x1))))          (proj / fc1 / fc2 act along W)
+ *   ln*_w/b (16,64); mlp_w_t (96,65) and mlp_h_t (48,17) = the bias-free Linear weights transposed;
+ *   proj_slab [64][64], fc1_slab [4][64][64], fc2_slab [4][64][64]: Linear weights permuted into the
+ *   MFMA k-slot order (slot 2*ks+half holds input feature 32*(ks>>4)+(ks&3)+8*((ks&15)>>2)+4*half);
+ *   fc1 split into 4 blocks of 64 hidden units; biases in natural order; scratch (N,C,16,64).
+ * replaces: backbones/tps_pp/DGAB.py:25-77 as called at backbones/tps_pp/tps_pp.py:318-319
+ */
+int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const float* ln1_b,
+                   const float* mlp_w_t, const float* mlp_h_t, const float* proj_slab,
+                   const float* proj_b, const float* ln2_w, const float* ln2_b,
+                   const float* fc1_slab, const float* fc1_b, const float* fc2_slab,
+                   const float* fc2_b, float* scratch, float* out, int N, int C,
+                   tpspp_stream_t stream);
+
+/*
  * out (N, C, H/2, W/2) = MaxPool2d(kernel 2, stride 2)(in);  out (N, C) = AdaptiveAvgPool2d(1)(in)
  * replaces: preprocessor/tps_preprocessor.py:110,114,118,126 (LocalizationNetwork.conv)
  */

@@ -32,6 +32,9 @@ with torch.no_grad():
     enf = en.flatten(2).transpose(1, 2)
     print("CBAM            %.3f ms" % timeit(lambda: m.MSFA.conv.atten(en)))
     print("DGAB            %.3f ms" % timeit(lambda: T.atten[0](de, enf)))
+    from tps_pp_amd import ops
+    dw = ops.DgabWeights(T.atten[0])
+    print("DGAB (HIP)      %.3f ms" % timeit(lambda: ops.dgab(de, en.view(N, 64, 32), dw)))
     d = T.atten[0]
     print("  norm1         %.3f ms" % timeit(lambda: d.norm1(de)))
     xn = d.norm1(de)

@@ -1,0 +1,31 @@
+"""-m gpu: the fused DGAB kernels against the oracle's functional restatement of DGAB.py."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import tpspp_oracle as TO
+from tps_pp_amd import TPS_PP, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dgab_matches_oracle(cuda):
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N = 3
+    from tps_pp_amd import synth
+    x = torch.from_numpy(synth.dyadic((N, 64, 16, 64), "dgab.x"))
+    en = torch.from_numpy(synth.dyadic((N, 64, 2, 16), "dgab.en"))
+    with torch.no_grad():
+        ref = TO.dgab(dict(m.state_dict()), "TPE.atten.0", x, en.flatten(2).transpose(1, 2))
+    m.to(cuda)
+    dw = ops.DgabWeights(m.TPE.atten[0])
+    got = ops.dgab(x.to(cuda), en.to(cuda).view(N, 64, 32), dw)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 1e-4, f"max abs err {err:.3e}"
+    # and against the module's own PyTorch composition on the GPU
+    with torch.no_grad():
+        ref2 = m.TPE.atten[0](x.to(cuda), en.to(cuda).flatten(2).transpose(1, 2))
+    assert (got - ref2).abs().max().item() <= 1e-4

@@ -1,0 +1,309 @@
+// DGAB (dynamic gated-attention block) of the TPS++ regressor for gfx950, two kernels:
+//
+//   dgab_gate_kernel   (VALU, HBM-bound)  one wavefront per (image, channel) plane of 16x64:
+//       LayerNorm over the plane -> xn;  w = mlp_w([mean_H(xn), y]),  h = mlp_h([mean_W(xn), y]);
+//       v_w = softmax(w[:-1]), v_h = softmax(h[:-1]);  A = v_h*xn*h[-1] + v_w*xn*w[-1]
+//   dgab_chain_kernel  (fp32 MFMA)        persistent workgroups, 128 rows (8 planes) per tile:
+//       x1 = x + proj(A);  out = x1 + fc2(gelu(fc1(LayerNorm(x1))))
+//       with proj / fc1 / fc2 = nn.Linear along the LAST axis (W = 64 = dim, DGAB.py:36,52,71,76).
+//
+// The chain kernel never moves activations through LDS: a lane owns one tensor row (64 values split
+// between the two half-wavefront lanes that share the row) in exactly the register pattern in which
+// v_mfma_f32_32x32x2_f32 delivers its result -- lane (row, half), accumulator h2, register r holds
+// feature f = 32*h2 + (r&3) + 8*(r>>2) + 4*half -- and the next GEMM consumes those registers
+// directly as its B fragments, with the weight slabs pre-permuted on the host so that k-slot
+// (h2*16 + r, half) multiplies feature f.  LDS holds only the weights (Wp, W1, W2: 144 KB, loaded
+// once per persistent workgroup).  Bound: MFMA (38.6 GFLOP per 512 images at the fp32 matrix rate).
+//
+// Reference: mmocr/models/textrecog/backbones/tps_pp/DGAB.py:25-77 (DGAB_Block.forward, Mlp.forward,
+// DGAB.forward), called from tps_pp.py:318-319.
+#include "tpspp_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int H = 16, W = 64, PT = 32, HID = 256;       // plane, points, MLP hidden width
+constexpr float kEps = 1e-5f;                            // nn.LayerNorm default
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gate kernel: lane = column, 16 registers = the rows of that column
+struct GateParams {
+    const float* x;        // (N, C, 16, 64)
+    const float* y;        // (N, C, 32): en_feat viewed per channel (the reference's y^T)
+    const float* g1; const float* b1;       // LayerNorm affine (16, 64)
+    const float* mw_t;     // (96, 65): mlp_w weight transposed  [input][output]
+    const float* mh_t;     // (48, 17): mlp_h weight transposed
+    float* a;              // (N, C, 16, 64)
+    int planes;
+};
+
+__global__ void __launch_bounds__(256)
+dgab_gate_kernel(const GateParams P)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pl = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (pl >= P.planes) return;
+    const float* xp = P.x + (size_t)pl * H * W;
+    float v[H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) v[r] = xp[r * W + lane];
+    const float yv = lane < PT ? P.y[(size_t)pl * PT + lane] : 0.0f;
+
+    // LayerNorm over the 16x64 plane (two-pass)
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < H; ++r) s += v[r];
+    const float mean = wave_sum(s) * (1.0f / (H * W));
+    float q = 0.0f;
+#pragma unroll
+    for (int r = 0; r < H; ++r) { const float d = v[r] - mean; q += d * d; }
+    const float var = wave_sum(q) * (1.0f / (H * W));
+    const float rstd = 1.0f / sqrtf(var + kEps);
+    float colsum = 0.0f;
+    float rowmean[H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+        v[r] = (v[r] - mean) * rstd * P.g1[r * W + lane] + P.b1[r * W + lane];
+        colsum += v[r];
+        rowmean[r] = wave_sum(v[r]) * (1.0f / W);      // x.mean(3): over the columns
+    }
+    const float colmean = colsum * (1.0f / H);          // x.mean(2): over the rows
+
+    // w = mlp_w(cat[colmean (64), y (32)]) -> 65 outputs: lane o < 64 owns w[o]; w[64] by every lane
+    float wo = 0.0f, wlast = 0.0f;
+    for (int i = 0; i < W; ++i) {
+        const float in = readlane_f(colmean, i);
+        wo = fmaf(P.mw_t[i * (W + 1) + lane], in, wo);
+        wlast = fmaf(P.mw_t[i * (W + 1) + W], in, wlast);
+    }
+    for (int t = 0; t < PT; ++t) {
+        const float in = readlane_f(yv, t);
+        wo = fmaf(P.mw_t[(W + t) * (W + 1) + lane], in, wo);
+        wlast = fmaf(P.mw_t[(W + t) * (W + 1) + W], in, wlast);
+    }
+    // h = mlp_h(cat[rowmean (16), y (32)]) -> 17 outputs: lane o < 17 owns h[o]
+    float ho = 0.0f;
+    {
+        const int o = lane < H + 1 ? lane : H;
+#pragma unroll
+        for (int r = 0; r < H; ++r) ho = fmaf(P.mh_t[r * (H + 1) + o], rowmean[r], ho);
+        for (int t = 0; t < PT; ++t) ho = fmaf(P.mh_t[(H + t) * (H + 1) + o], readlane_f(yv, t), ho);
+    }
+    // softmaxes over w[0:64] (all lanes) and h[0:16] (lanes 0..15)
+    const float wmax = wave_max(wo);
+    const float we = expf(wo - wmax);
+    const float vw = we / wave_sum(we);
+    const float hin = lane < H ? ho : -INFINITY;
+    const float hmax = wave_max(hin);
+    const float he = lane < H ? expf(ho - hmax) : 0.0f;
+    const float vh = he / wave_sum(he);
+    const float hlast = readlane_f(ho, H);
+
+    // A = (v_h * xn) * h_last + (v_w * xn) * w_last      (op order of DGAB.py:50)
+    float* ap = P.a + (size_t)pl * H * W;
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+        const float vhr = readlane_f(vh, r);
+        float t1 = vhr * v[r];
+        t1 = t1 * hlast;
+        float t2 = vw * v[r];
+        t2 = t2 * wlast;
+        ap[r * W + lane] = t1 + t2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// chain kernel
+struct ChainParams {
+    const float* x;        // (rows, 64) residual input (the DGAB input)
+    const float* a;        // (rows, 64) gated attention output (input of proj)
+    const float* wp_s;     // [64 k-slots][64 out]           proj,  permuted slab
+    const float* w1_s;     // [4 blocks][64 k-slots][64 out]  fc1 (out = hidden unit inside block)
+    const float* w2_s;     // [4 blocks][64 k-slots][64 out]  fc2 (k-slot = hidden unit inside block)
+    const float* bp; const float* b1; const float* b2;       // (64), (256), (64)
+    const float* g2; const float* be2;                       // LayerNorm-2 affine (16, 64)
+    float* out;            // (rows, 64)
+    int tiles;             // rows / 128
+};
+
+// feature owned by (k-slot index ks = h2*16 + r, half) in the MFMA C/D layout
+__device__ __forceinline__ constexpr int feat(int ks, int half)
+{
+    return 32 * (ks >> 4) + (ks & 3) + 8 * ((ks & 15) >> 2) + 4 * half;
+}
+
+// D[i][row] += sum over the 32 k-slot pairs: A = slab[(2*ks + half)*64 + i], B = in[ks]
+__device__ __forceinline__ void gemm64(const float* __restrict__ slab, const float (&in)[32], int half, int l31,
+                                       f32x16& acc0, f32x16& acc1)
+{
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        const float a0 = slab[(2 * ks + half) * 64 + l31];
+        const float a1 = slab[(2 * ks + half) * 64 + 32 + l31];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, in[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, in[ks], acc1, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float plane_sum(float v)
+{
+    // the 32 lanes that hold one 16-row plane: row bits 0..3 of the lane index and the half bit (5)
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+dgab_chain_kernel(const ChainParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sWp = smem;                       // 64*64
+    float* sW1 = sWp + 64 * 64;              // 4*64*64
+    float* sW2 = sW1 + 4 * 64 * 64;          // 4*64*64
+    float* sB = sW2 + 4 * 64 * 64;           // bp (64) | b1 (256) | b2 (64)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64 * 64 / 4; i += 256) reinterpret_cast<float4*>(sWp)[i] = reinterpret_cast<const float4*>(P.wp_s)[i];
+    for (int i = tid; i < 4 * 64 * 64 / 4; i += 256) {
+        reinterpret_cast<float4*>(sW1)[i] = reinterpret_cast<const float4*>(P.w1_s)[i];
+        reinterpret_cast<float4*>(sW2)[i] = reinterpret_cast<const float4*>(P.w2_s)[i];
+    }
+    for (int i = tid; i < 64; i += 256) { sB[i] = P.bp[i]; sB[64 + HID + i] = P.b2[i]; }
+    for (int i = tid; i < HID; i += 256) sB[64 + i] = P.b1[i];
+    __syncthreads();
+
+    const int lane = tid & (kWave - 1);
+    const int wv = tid / kWave;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int prow = l31 & (H - 1);          // row inside its 16-row plane (LayerNorm affine index)
+
+    for (int tile = blockIdx.x; tile < P.tiles; tile += gridDim.x) {
+        const size_t row = (size_t)tile * 128 + wv * 32 + l31;
+        const float* ar = P.a + row * W;
+        const float* xr = P.x + row * W;
+        // ---- this lane's 32 features of its row: float4 groups at f = 32*h2 + 8*q + 4*half ----
+        float in[32], xres[32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {        // g = h2*4 + q  <->  k-slots 4g .. 4g+3
+            const int f = 32 * (g >> 2) + 8 * (g & 3) + 4 * half;
+            const float4 va = *reinterpret_cast<const float4*>(ar + f);
+            const float4 vx = *reinterpret_cast<const float4*>(xr + f);
+            in[4 * g + 0] = va.x; in[4 * g + 1] = va.y; in[4 * g + 2] = va.z; in[4 * g + 3] = va.w;
+            xres[4 * g + 0] = vx.x; xres[4 * g + 1] = vx.y; xres[4 * g + 2] = vx.z; xres[4 * g + 3] = vx.w;
+        }
+        // ---- x1 = x + proj(A) ----
+        f32x16 c0, c1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = 0.0f; c1[i] = 0.0f; }
+        gemm64(sWp, in, half, l31, c0, c1);
+        float x1[32];
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const float p = (ks < 16 ? c0[ks & 15] : c1[ks & 15]) + sB[feat(ks, half)];
+            x1[ks] = xres[ks] + p;
+        }
+        // ---- LayerNorm over each 16x64 plane (32 lanes x 32 registers), two-pass ----
+        float s = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) s += x1[ks];
+        const float mean = plane_sum(s) * (1.0f / (H * W));
+        float q = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) { const float d = x1[ks] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(plane_sum(q) * (1.0f / (H * W)) + kEps);
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const int f = feat(ks, half);
+            in[ks] = (x1[ks] - mean) * rstd * P.g2[prow * W + f] + P.be2[prow * W + f];
+        }
+        // ---- out = x1 + fc2(gelu(fc1(xn))): hidden units in 4 blocks of 64, never leaving registers ----
+        f32x16 o0, o1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] = 0.0f; o1[i] = 0.0f; }
+#pragma unroll 1
+        for (int hb = 0; hb < 4; ++hb) {
+            f32x16 h0, h1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { h0[i] = 0.0f; h1[i] = 0.0f; }
+            gemm64(sW1 + hb * 64 * 64, in, half, l31, h0, h1);
+            float hid[32];
+#pragma unroll
+            for (int ks = 0; ks < 32; ++ks) {
+                const float z = (ks < 16 ? h0[ks & 15] : h1[ks & 15]) + sB[64 + hb * 64 + feat(ks, half)];
+                hid[ks] = 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));     // exact GELU
+            }
+            gemm64(sW2 + hb * 64 * 64, hid, half, l31, o0, o1);
+        }
+        float* orow = P.out + row * W;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int f = 32 * (g >> 2) + 8 * (g & 3) + 4 * half;
+            float4 v;
+            float* pv = &v.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ks = 4 * g + e;
+                pv[e] = x1[ks] + ((ks < 16 ? o0[ks & 15] : o1[ks & 15]) + sB[64 + HID + feat(ks, half)]);
+            }
+            *reinterpret_cast<float4*>(orow + f) = v;
+        }
+    }
+}
+
+}  // namespace
+
+TPSPP_EXPORT int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const float* ln1_b,
+                                const float* mlp_w_t, const float* mlp_h_t, const float* proj_slab,
+                                const float* proj_b, const float* ln2_w, const float* ln2_b,
+                                const float* fc1_slab, const float* fc1_b, const float* fc2_slab,
+                                const float* fc2_b, float* scratch, float* out, int N, int C,
+                                tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(x && y && ln1_w && ln1_b && mlp_w_t && mlp_h_t && proj_slab && proj_b && ln2_w && ln2_b &&
+                  fc1_slab && fc1_b && fc2_slab && fc2_b && scratch && out, "tpspp_dgab_fwd: null pointer");
+    TPSPP_REQUIRE(N >= 0 && C > 0 && (C % 8) == 0, "tpspp_dgab_fwd: channels must be a multiple of 8");
+    if (N == 0) return TPSPP_OK;
+    hipStream_t st = tpspp::as_stream(stream);
+    const int planes = N * C;
+    GateParams G;
+    G.x = x; G.y = y; G.g1 = ln1_w; G.b1 = ln1_b; G.mw_t = mlp_w_t; G.mh_t = mlp_h_t; G.a = scratch;
+    G.planes = planes;
+    hipLaunchKernelGGL(dgab_gate_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
+    int rc = tpspp::check_launch("tpspp_dgab_fwd(gate)");
+    if (rc) return rc;
+    ChainParams Q;
+    Q.x = x; Q.a = scratch; Q.wp_s = proj_slab; Q.w1_s = fc1_slab; Q.w2_s = fc2_slab;
+    Q.bp = proj_b; Q.b1 = fc1_b; Q.b2 = fc2_b; Q.g2 = ln2_w; Q.be2 = ln2_b; Q.out = out;
+    Q.tiles = planes / 8;                                           // 8 planes = 128 rows per tile
+    const size_t lds = (size_t)(64 * 64 + 2 * 4 * 64 * 64 + 64 + HID + 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    const int grid = Q.tiles < 256 ? Q.tiles : 256;                 // persistent: one workgroup per CU
+    hipLaunchKernelGGL(dgab_chain_kernel, dim3((unsigned)grid), dim3(256), lds, st, Q);
+    return tpspp::check_launch("tpspp_dgab_fwd(chain)");
+}

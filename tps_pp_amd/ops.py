@@ -250,6 +250,51 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
     return out
 
 
+def _mfma_feature_perm(device):
+    """slot 2*ks + half -> input feature held by (accumulator register ks, half-wavefront `half`) in the
+    C/D layout of v_mfma_f32_32x32x2_f32 (see tpspp_dgab.hip)."""
+    perm = []
+    for ks in range(32):
+        for half in range(2):
+            perm.append(32 * (ks >> 4) + (ks & 3) + 8 * ((ks & 15) >> 2) + 4 * half)
+    return torch.tensor(perm, device=device, dtype=torch.long)
+
+
+class DgabWeights:
+    def __init__(self, blk):
+        """blk: the DGAB module (norm1, attn.{mlp_h,mlp_w,proj}, norm2, mlp.{fc1,fc2})."""
+        f = lambda t: t.detach().float().contiguous()
+        dev = blk.norm1.weight.device
+        perm = _mfma_feature_perm(dev)
+        self.ln1_w, self.ln1_b = f(blk.norm1.weight), f(blk.norm1.bias)
+        self.ln2_w, self.ln2_b = f(blk.norm2.weight), f(blk.norm2.bias)
+        self.mw_t = f(blk.attn.mlp_w[0].weight.t())              # (96, 65)
+        self.mh_t = f(blk.attn.mlp_h[0].weight.t())              # (48, 17)
+        self.proj_slab = f(blk.attn.proj.weight[:, perm].t())    # [slot][out]
+        self.proj_b = f(blk.attn.proj.bias)
+        w1, w2 = blk.mlp.fc1.weight.detach().float(), blk.mlp.fc2.weight.detach().float()
+        self.fc1_slab = torch.stack([w1[hb * 64:(hb + 1) * 64][:, perm].t() for hb in range(4)]).contiguous()
+        self.fc2_slab = torch.stack([w2[:, hb * 64 + perm].t() for hb in range(4)]).contiguous()
+        self.fc1_b, self.fc2_b = f(blk.mlp.fc1.bias), f(blk.mlp.fc2.bias)
+
+
+def dgab(x, y, dw):
+    """DGAB.forward (DGAB.py:74-77) fused: x (N, C, 16, 64), y (N, C, 32) -> (N, C, 16, 64)."""
+    x, y = _chk("x", x, 4), _chk("y", y, 3)
+    N, C, H, W = x.shape
+    if (H, W) != (16, 64) or tuple(y.shape) != (N, C, 32):
+        raise ValueError("dgab: needs x (N, C, 16, 64) and y (N, C, 32)")
+    out = torch.empty_like(x)
+    scratch = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_dgab_fwd(_ptr(x), _ptr(y), _ptr(dw.ln1_w), _ptr(dw.ln1_b), _ptr(dw.mw_t),
+                                       _ptr(dw.mh_t), _ptr(dw.proj_slab), _ptr(dw.proj_b), _ptr(dw.ln2_w),
+                                       _ptr(dw.ln2_b), _ptr(dw.fc1_slab), _ptr(dw.fc1_b), _ptr(dw.fc2_slab),
+                                       _ptr(dw.fc2_b), _ptr(scratch), _ptr(out), N, C, _stream(x))
+    _lib.check(rc, "tpspp_dgab_fwd")
+    return out
+
+
 def maxpool2x2(x):
     """nn.MaxPool2d(2, 2) (tps_preprocessor.py:110,114,118)."""
     x = _chk("input", x, 4)

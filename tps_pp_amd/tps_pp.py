@@ -422,8 +422,24 @@ class TPS_PP(nn.Module):
                         ops.conv2d([x], cw["down2"], 1)]
             feat_grid = x
         en_feat, de_feat = self._msfa_hip(cat_srcs, cw)
-        control_point, atten_score = self.TPE(en_feat, de_feat)
+        control_point, atten_score = self._tpe_hip(en_feat, de_feat)
         return control_point, atten_score, feat_grid
+
+    def _tpe_hip(self, en_feat, de_feat):
+        """Transformation_Parameter_Estimation.forward (`tps_pp.py:315-325`) with the DGAB block on the
+        fused kernels (tpspp_dgab.hip); the two small FC stacks and the score GEMM still use library
+        kernels."""
+        T = self.TPE
+        blk = T.atten[0]
+        key = tuple((t.data_ptr(), t._version) for t in blk.parameters())
+        cache = getattr(self, "_dgab_cache", None)
+        if cache is None or cache[0] != key:
+            self._dgab_cache = cache = (key, ops.DgabWeights(blk))
+        n = en_feat.size(0)
+        de = ops.dgab(de_feat, en_feat.reshape(n, en_feat.size(1), -1), cache[1])
+        en = en_feat.flatten(2).transpose(1, 2)
+        control_point = T.localization_fc2(T.localization_fc1(en).view(n, -1)).view(n, T.num_fiducial, 2)
+        return control_point, T.get_score(en, de)
 
     def rectify(self, feat_grid, batch_img, control_point, atten_score, want_grid=False):
         """The transformation stage alone (`tps_pp.py:597-615`): one fused HIP kernel."""
