@@ -160,6 +160,19 @@ int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const flo
                    tpspp_stream_t stream);
 
 /*
+ * Attention score: score_t[b, pt, px] = tanh(scale * sum_j f[b, j, px] * p[b, pt, j]) with
+ *   f = W2 (W1 de_feat[b, :, px] + b1) + b2   (feat_linear: Linear 64->32, Linear 32->128, no activation)
+ *   de_feat (N, 64, n); w1_slab [64][32] = W1 transposed; w2_slab [32 k-slots][128] = W2 columns in
+ *   the MFMA order (slot 2*ks+half <- input feature (ks&3) + 8*(ks>>2) + 4*half), transposed;
+ *   p (N, 32, 128) = p_linear(point features); score_t (N, 32, n) -- the (N, F, n) layout that
+ *   tpspp_warp_fwd takes with TPSPP_SCORE_TRANSPOSED.
+ * replaces: backbones/tps_pp/tps_pp.py:293-312 (get_score / atten_score)
+ */
+int tpspp_score_fwd(const float* de_feat, const float* w1_slab, const float* b1, const float* w2_slab,
+                    const float* b2, const float* p, float scale, float* score_t, int N, int n,
+                    tpspp_stream_t stream);
+
+/*
  * out (N, C, H/2, W/2) = MaxPool2d(kernel 2, stride 2)(in);  out (N, C) = AdaptiveAvgPool2d(1)(in)
  * replaces: preprocessor/tps_preprocessor.py:110,114,118,126 (LocalizationNetwork.conv)
  */

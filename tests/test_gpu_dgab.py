@@ -29,3 +29,20 @@ def test_dgab_matches_oracle(cuda):
     with torch.no_grad():
         ref2 = m.TPE.atten[0](x.to(cuda), en.to(cuda).flatten(2).transpose(1, 2))
     assert (got - ref2).abs().max().item() <= 1e-4
+
+
+def test_score_matches_oracle(cuda):
+    from tps_pp_amd import synth
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N = 3
+    de = torch.from_numpy(synth.dyadic((N, 64, 16, 64), "sc.de"))
+    en = torch.from_numpy(synth.dyadic((N, 32, 64), "sc.en"))
+    with torch.no_grad():
+        ref = m.TPE.get_score(en, de)                      # PyTorch composition on the CPU
+        p1 = m.TPE.p_linear(en)
+    m.to(cuda)
+    got = ops.score(de.to(cuda), p1.to(cuda).contiguous(), ops.ScoreWeights(m.TPE.feat_linear), m.TPE.scale)
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref).abs().max().item() <= 2e-5

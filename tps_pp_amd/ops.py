@@ -295,6 +295,35 @@ def dgab(x, y, dw):
     return out
 
 
+class ScoreWeights:
+    def __init__(self, feat_linear):
+        """feat_linear: nn.Sequential(Linear(64, 32), Linear(32, 128)) (tps_pp.py:257-260)."""
+        l1, l2 = feat_linear[0], feat_linear[1]
+        dev = l1.weight.device
+        perm16 = torch.tensor([(ks & 3) + 8 * (ks >> 2) + 4 * half for ks in range(16) for half in range(2)],
+                              device=dev, dtype=torch.long)
+        self.w1_slab = l1.weight.detach().float().t().contiguous()              # [64][32]
+        self.w2_slab = l2.weight.detach().float()[:, perm16].t().contiguous()   # [32 slots][128]
+        self.b1 = l1.bias.detach().float().contiguous()
+        self.b2 = l2.bias.detach().float().contiguous()
+
+
+def score(de_feat, p, sw, scale):
+    """get_score (tps_pp.py:303-312) fused: de_feat (N, 64, H, W), p (N, 32, 128) -> (N, H*W, 32) as
+    the transposed VIEW of an (N, 32, H*W) buffer."""
+    de_feat, p = _chk("de_feat", de_feat, 4), _chk("p", p, 3)
+    N, C, H, W = de_feat.shape
+    if C != 64 or tuple(p.shape) != (N, 32, 128):
+        raise ValueError("score: needs de_feat (N, 64, H, W) and p (N, 32, 128)")
+    n = H * W
+    out = torch.empty((N, 32, n), device=de_feat.device, dtype=torch.float32)
+    with torch.cuda.device(de_feat.device):
+        rc = _lib.lib().tpspp_score_fwd(_ptr(de_feat), _ptr(sw.w1_slab), _ptr(sw.b1), _ptr(sw.w2_slab),
+                                        _ptr(sw.b2), _ptr(p), float(scale), _ptr(out), N, n, _stream(de_feat))
+    _lib.check(rc, "tpspp_score_fwd")
+    return out.transpose(1, 2)
+
+
 def maxpool2x2(x):
     """nn.MaxPool2d(2, 2) (tps_preprocessor.py:110,114,118)."""
     x = _chk("input", x, 4)

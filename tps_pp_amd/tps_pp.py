@@ -433,13 +433,18 @@ class TPS_PP(nn.Module):
         blk = T.atten[0]
         key = tuple((t.data_ptr(), t._version) for t in blk.parameters())
         cache = getattr(self, "_dgab_cache", None)
+        key = key + tuple((t.data_ptr(), t._version) for t in T.feat_linear.parameters())
         if cache is None or cache[0] != key:
-            self._dgab_cache = cache = (key, ops.DgabWeights(blk))
+            self._dgab_cache = cache = (key, ops.DgabWeights(blk), ops.ScoreWeights(T.feat_linear))
         n = en_feat.size(0)
         de = ops.dgab(de_feat, en_feat.reshape(n, en_feat.size(1), -1), cache[1])
         en = en_feat.flatten(2).transpose(1, 2)
         control_point = T.localization_fc2(T.localization_fc1(en).view(n, -1)).view(n, T.num_fiducial, 2)
-        return control_point, T.get_score(en, de)
+        if T.without_as:
+            return control_point, torch.zeros((n, de.shape[2] * de.shape[3], T.num_fiducial), device=de.device)
+        # point side of the score: 32 points per image through two tiny Linears (library kernels)
+        p1 = T.p_linear(en).contiguous()
+        return control_point, ops.score(de, p1, cache[2], T.scale)
 
     def rectify(self, feat_grid, batch_img, control_point, atten_score, want_grid=False):
         """The transformation stage alone (`tps_pp.py:597-615`): one fused HIP kernel."""
@@ -459,8 +464,9 @@ class TPS_PP(nn.Module):
                 "TPS_PP (HIP path) is forward-only: run under torch.no_grad() (backward for the "
                 "warp op is on the roadmap, SURVEY.md section 8f F2)")
         control_point, atten_score, feat_grid = self.regress(batch_img, outs)
-        output, mp_img = self.rectify(feat_grid.float().contiguous(), batch_img.float().contiguous(),
-                                      control_point.float(), atten_score.float().contiguous())
+        # (the score stays the transposed view of its (N, F, n) buffer: ops.warp reads it in place)
+        output, mp_img = self.rectify(feat_grid.float(), batch_img.float(), control_point.float(),
+                                      atten_score.float())
         return {"output": output, "logits": None, "mp_img": mp_img, "pc_score": atten_score}
 
 
