@@ -173,6 +173,27 @@ int tpspp_score_fwd(const float* de_feat, const float* w1_slab, const float* b1,
                     tpspp_stream_t stream);
 
 /*
+ * CBAM(64, ratio 16) on the (N, 64, 2, 16) bottleneck map: mlp0_w (4,64), mlp2_w (64,4) = the
+ * bias-free shared 1x1 MLP; sp_w (1,2,3,3), sp_b (1) = the spatial-attention conv.
+ * replaces: backbones/tps_pp/tps_pp.py:27-82 as called at :163
+ */
+int tpspp_cbam_fwd(const float* x, const float* mlp0_w, const float* mlp2_w, const float* sp_w,
+                   const float* sp_b, float* out, int N, tpspp_stream_t stream);
+
+/*
+ * Per-point stages on en_feat (N, 64, 2, 16) [point t = flattened (2,16) index]:
+ *   ctrl (N,32,2) = fc2( relu(fc1b( relu(fc1a(en[:, t])) )) flattened )     fc1a (256,64) fc1b (2,256) fc2 (64,64)
+ *   p    (N,32,128) = pl1( pl0(en[:, t]) )                                   pl0 (32,64)   pl1 (128,32)
+ * weights / biases in nn.Linear layout.
+ * replaces: backbones/tps_pp/tps_pp.py:321-323 (localization_fc1/fc2) and :305 (p_linear)
+ */
+int tpspp_tpe_points_fwd(const float* en_feat, const float* fc1a_w, const float* fc1a_b,
+                         const float* fc1b_w, const float* fc1b_b, const float* fc2_w,
+                         const float* fc2_b, const float* pl0_w, const float* pl0_b,
+                         const float* pl1_w, const float* pl1_b, float* ctrl, float* p, int N,
+                         tpspp_stream_t stream);
+
+/*
  * out (N, C, H/2, W/2) = MaxPool2d(kernel 2, stride 2)(in);  out (N, C) = AdaptiveAvgPool2d(1)(in)
  * replaces: preprocessor/tps_preprocessor.py:110,114,118,126 (LocalizationNetwork.conv)
  */

@@ -46,3 +46,23 @@ def test_score_matches_oracle(cuda):
     got = ops.score(de.to(cuda), p1.to(cuda).contiguous(), ops.ScoreWeights(m.TPE.feat_linear), m.TPE.scale)
     assert got.shape == ref.shape
     assert (got.cpu() - ref).abs().max().item() <= 2e-5
+
+
+def test_cbam_and_point_stages_match_pytorch_cpu(cuda):
+    from tps_pp_amd import synth
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N = 5
+    e3 = torch.from_numpy(np.abs(synth.dyadic((N, 64, 2, 16), "pt.e3")))
+    with torch.no_grad():
+        ref_cbam = m.MSFA.conv.atten(e3)
+        en = e3.flatten(2).transpose(1, 2)
+        ref_ctrl = m.TPE.localization_fc2(m.TPE.localization_fc1(en).view(N, -1)).view(N, 32, 2)
+        ref_p = m.TPE.p_linear(en)
+    m.to(cuda)
+    got_cbam = ops.cbam(e3.to(cuda), m.MSFA.conv.atten)
+    ctrl, p = ops.tpe_points(e3.to(cuda), m.TPE)
+    assert (got_cbam.cpu() - ref_cbam).abs().max().item() <= 1e-6
+    assert (ctrl.cpu() - ref_ctrl).abs().max().item() <= 2e-6
+    assert (p.cpu() - ref_p).abs().max().item() <= 1e-5

@@ -324,6 +324,43 @@ def score(de_feat, p, sw, scale):
     return out.transpose(1, 2)
 
 
+def cbam(x, atten):
+    """CBAM.forward (tps_pp.py:77-82) on the (N, 64, 2, 16) bottleneck map, one fused kernel."""
+    x = _chk("x", x, 4)
+    if tuple(x.shape[1:]) != (64, 2, 16):
+        raise ValueError("cbam: needs (N, 64, 2, 16)")
+    f = lambda t: t.detach().float().contiguous()
+    ca, sa = atten.channel_attention, atten.spatial_attention
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_cbam_fwd(_ptr(x), _ptr(f(ca.shared_MLP[0].weight.view(4, 64))),
+                                       _ptr(f(ca.shared_MLP[2].weight.view(64, 4))), _ptr(f(sa.conv2d.weight)),
+                                       _ptr(f(sa.conv2d.bias)), _ptr(out), x.shape[0], _stream(x))
+    _lib.check(rc, "tpspp_cbam_fwd")
+    return out
+
+
+def tpe_points(en_feat, tpe):
+    """localization_fc1/fc2 and p_linear of Transformation_Parameter_Estimation (tps_pp.py:305,321-323)
+    on en_feat (N, 64, 2, 16): returns (ctrl (N, 32, 2), p (N, 32, 128))."""
+    en_feat = _chk("en_feat", en_feat, 4)
+    if tuple(en_feat.shape[1:]) != (64, 2, 16):
+        raise ValueError("tpe_points: needs (N, 64, 2, 16)")
+    N = en_feat.shape[0]
+    f = lambda t: t.detach().float().contiguous()
+    l1a, l1b, l2 = tpe.localization_fc1[0], tpe.localization_fc1[2], tpe.localization_fc2
+    p0, p1 = tpe.p_linear[0], tpe.p_linear[1]
+    ctrl = torch.empty((N, 32, 2), device=en_feat.device, dtype=torch.float32)
+    p = torch.empty((N, 32, 128), device=en_feat.device, dtype=torch.float32)
+    ws = [f(t) for t in (l1a.weight, l1a.bias, l1b.weight, l1b.bias, l2.weight, l2.bias, p0.weight, p0.bias,
+                         p1.weight, p1.bias)]
+    with torch.cuda.device(en_feat.device):
+        rc = _lib.lib().tpspp_tpe_points_fwd(_ptr(en_feat), *[_ptr(w) for w in ws], _ptr(ctrl), _ptr(p), N,
+                                             _stream(en_feat))
+    _lib.check(rc, "tpspp_tpe_points_fwd")
+    return ctrl, p
+
+
 def maxpool2x2(x):
     """nn.MaxPool2d(2, 2) (tps_preprocessor.py:110,114,118)."""
     x = _chk("input", x, 4)

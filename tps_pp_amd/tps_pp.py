@@ -364,8 +364,8 @@ class TPS_PP(nn.Module):
         e1 = ops.conv2d([e0], cw["enc1"], 2)
         e2 = ops.conv2d([e1], cw["enc2"], p)
         e3 = ops.conv2d([e2], cw["enc3"], (2, 1))
-        k = self.MSFA.conv.atten(e3)
-        k = ops.conv2d([(k.contiguous(), 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1)
+        k = ops.cbam(e3, self.MSFA.conv.atten)
+        k = ops.conv2d([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1)
         k = ops.conv2d([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
         k = ops.conv2d([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
         k = ops.conv2d([k], cw["dec3"], 1)
@@ -427,8 +427,8 @@ class TPS_PP(nn.Module):
 
     def _tpe_hip(self, en_feat, de_feat):
         """Transformation_Parameter_Estimation.forward (`tps_pp.py:315-325`) with the DGAB block on the
-        fused kernels (tpspp_dgab.hip); the two small FC stacks and the score GEMM still use library
-        kernels."""
+        fused kernels (tpspp_dgab.hip), the per-point FC stacks on tpspp_points.hip and the score on
+        tpspp_score.hip: no library kernel is left on the GPU path of the regressor."""
         T = self.TPE
         blk = T.atten[0]
         key = tuple((t.data_ptr(), t._version) for t in blk.parameters())
@@ -438,12 +438,9 @@ class TPS_PP(nn.Module):
             self._dgab_cache = cache = (key, ops.DgabWeights(blk), ops.ScoreWeights(T.feat_linear))
         n = en_feat.size(0)
         de = ops.dgab(de_feat, en_feat.reshape(n, en_feat.size(1), -1), cache[1])
-        en = en_feat.flatten(2).transpose(1, 2)
-        control_point = T.localization_fc2(T.localization_fc1(en).view(n, -1)).view(n, T.num_fiducial, 2)
+        control_point, p1 = ops.tpe_points(en_feat, T)
         if T.without_as:
             return control_point, torch.zeros((n, de.shape[2] * de.shape[3], T.num_fiducial), device=de.device)
-        # point side of the score: 32 points per image through two tiny Linears (library kernels)
-        p1 = T.p_linear(en).contiguous()
         return control_point, ops.score(de, p1, cache[2], T.scale)
 
     def rectify(self, feat_grid, batch_img, control_point, atten_score, want_grid=False):
