@@ -68,12 +68,53 @@ def cpu_baseline(img, ctrl, inv, p_hat, budget_s=12.0):
                       f"oracle/tps_oracle.c with {threads} OpenMP threads"}
 
 
+def extra_measurements(dev):
+    """Not the headline metric: the other two figures BASELINE.md section 5 asks for, measured with the
+    same protocol (inputs resident, HIP events, warm caches) on rank 0 at N = 1.
+      * warp stage at the TPS_PP geometry (batch 512, fp32): HBM roofline fraction;
+      * whole TPS++ module forward (regressor + warp, batch 512, fp32): images/s against the
+        north-star's >= 50k."""
+    from tps_pp_amd import TPS_PP
+
+    def timeit(fn, iters, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / iters
+
+    n = 512
+    m = TPS_PP().eval().to(dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand((n, 64, 16, 64), generator=g, device=dev)
+    o0 = torch.rand((n, 32, 32, 128), generator=g, device=dev)
+    o1 = torch.rand((n, 32, 32, 128), generator=g, device=dev)
+    with torch.no_grad():
+        t_full = timeit(lambda: m(x, [o0, o1]), 10, 4)
+        cp, sc, fg = m.regress(x, [o0, o1])
+        t_warp = timeit(lambda: m.rectify(fg, x, cp, sc), 20, 3)
+    bytes_img = 1966336                                  # SURVEY.md section 8d, G-PP warp stage fp32
+    bw = bytes_img * n / (t_warp * 1e-3) / 1e9
+    return {"tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
+                                           "gflop_per_image": 0.82},
+            "tpspp_warp_stage_batch512_fp32": {"us_per_batch": t_warp * 1e3, "achieved_GBps": bw,
+                                               "frac_of_hbm_peak": bw / HBM_PEAK_GBS,
+                                               "algorithmic_bytes_per_image": bytes_img,
+                                               "kernel": "tps_warp_stream_kernel<32,true,true,2>"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,6 +220,8 @@ def main():
                          "launch_us": launch_us,
                          "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH},
         }
+        if world == 1 and not a.no_extras:
+            rec["extra"] = extra_measurements(dev)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(img0, ctrl0, gg.inv_delta_C.cpu().numpy(),
                                                gg.P_hat.cpu().numpy())

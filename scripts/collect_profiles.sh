@@ -11,11 +11,11 @@ rm -rf $OUT; mkdir -p $OUT
 STEPS=${STEPS:-400}
 # 1. kernel trace + stats of the bench command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
-    python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+    python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline --no-extras > $OUT/bench_trace.log 2>&1
 # 2. PMC passes (own runs, nothing but --pmc)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- \
-      python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_pmc_$c.log 2>&1
+      python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_pmc_$c.log 2>&1
   rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -o copy -- \
       ./scripts/ubench/copy_bench > $OUT/copy_pmc_$c.log 2>&1
 done
