@@ -160,6 +160,20 @@ int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const flo
                    tpspp_stream_t stream);
 
 /*
+ * The pointwise front of TPS_PP (ResNet45v2 wiring) fused: feat0 = relu(W0 outs0 + b0),
+ * feat1 = relu(W1 outs1 + b1) at (H, W); feat2 = relu(W2 x + b2) at (H/2, W/2);
+ * feat_grid = relu(Wg cat(feat0, feat1, Upsample2(feat2)) + bg).
+ *   outs0/outs1 (N,32,H,W), x (N,64,H/2,W/2); w0/w1_slab [32][64], w2_slab [64][64] = the 1x1 weights
+ *   transposed; wg_slab [3][64 k-slots (MFMA order, see tpspp_dgab_fwd)][64]; outputs (N,64,...).
+ * replaces: backbones/tps_pp/tps_pp.py:560-562,581-585 (down0, down1, down2, up_sample + cat + down_feat)
+ */
+int tpspp_front_fwd(const float* outs0, const float* outs1, const float* x,
+                    const float* w0_slab, const float* b0, const float* w1_slab, const float* b1,
+                    const float* w2_slab, const float* b2, const float* wg_slab, const float* bg,
+                    float* feat0, float* feat1, float* feat2, float* feat_grid,
+                    int N, int H, int W, tpspp_stream_t stream);
+
+/*
  * Attention score: score_t[b, pt, px] = tanh(scale * sum_j f[b, j, px] * p[b, pt, j]) with
  *   f = W2 (W1 de_feat[b, :, px] + b1) + b2   (feat_linear: Linear 64->32, Linear 32->128, no activation)
  *   de_feat (N, 64, n); w1_slab [64][32] = W1 transposed; w2_slab [32 k-slots][128] = W2 columns in

@@ -66,3 +66,22 @@ def test_cbam_and_point_stages_match_pytorch_cpu(cuda):
     assert (got_cbam.cpu() - ref_cbam).abs().max().item() <= 1e-6
     assert (ctrl.cpu() - ref_ctrl).abs().max().item() <= 2e-6
     assert (p.cpu() - ref_p).abs().max().item() <= 1e-5
+
+
+def test_front_matches_pytorch_cpu(cuda):
+    from tps_pp_amd import synth
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N = 2
+    o0 = torch.from_numpy(np.abs(synth.dyadic((N, 32, 32, 128), "fr.o0")))
+    o1 = torch.from_numpy(np.abs(synth.dyadic((N, 32, 32, 128), "fr.o1")))
+    x = torch.from_numpy(np.abs(synth.dyadic((N, 64, 16, 64), "fr.x")))
+    with torch.no_grad():
+        r0, r1, r2 = m.down0(o0), m.down1(o1), m.down2(x)
+        rg = m.grid(r0, r1, r2)
+    m.to(cuda)
+    f0, f1, f2, fg = ops.front(o0.to(cuda), o1.to(cuda), x.to(cuda), ops.FrontWeights(m))
+    for got, ref, nm in ((f0, r0, "feat0"), (f1, r1, "feat1"), (f2, r2, "feat2"), (fg, rg, "feat_grid")):
+        assert got.shape == ref.shape
+        assert (got.cpu() - ref).abs().max().item() <= 2e-5, nm

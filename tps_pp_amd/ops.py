@@ -324,6 +324,40 @@ def score(de_feat, p, sw, scale):
     return out.transpose(1, 2)
 
 
+class FrontWeights:
+    def __init__(self, m):
+        """m: TPS_PP (ResNet45v2 wiring): down0, down1, down2, down_feat ConvModules."""
+        f = lambda t: t.detach().float().contiguous()
+        perm = _mfma_feature_perm(m.down0.conv.weight.device)
+        self.w0 = f(m.down0.conv.weight.view(64, 32).t())
+        self.w1 = f(m.down1.conv.weight.view(64, 32).t())
+        self.w2 = f(m.down2.conv.weight.view(64, 64).t())
+        wg = m.down_feat.conv.weight.detach().float().view(64, 192)
+        self.wg = torch.stack([wg[:, blk * 64 + perm].t() for blk in range(3)]).contiguous()
+        self.b0, self.b1, self.b2, self.bg = (f(c.conv.bias) for c in (m.down0, m.down1, m.down2, m.down_feat))
+
+
+def front(o0, o1, x, fw):
+    """down0/down1/down2 + grid() of TPS_PP.forward (tps_pp.py:560-562,581-585) in one kernel.
+    Returns (feat0, feat1, feat2, feat_grid)."""
+    o0, o1, x = _chk("outs[0]", o0, 4), _chk("outs[1]", o1, 4), _chk("x", x, 4)
+    N, c0, H, W = o0.shape
+    if c0 != 32 or tuple(o1.shape) != (N, 32, H, W) or tuple(x.shape) != (N, 64, H // 2, W // 2):
+        raise ValueError("front: needs outs (N,32,H,W) x2 and x (N,64,H/2,W/2)")
+    dev = o0.device
+    feat0 = torch.empty((N, 64, H, W), device=dev, dtype=torch.float32)
+    feat1 = torch.empty_like(feat0)
+    feat_grid = torch.empty_like(feat0)
+    feat2 = torch.empty((N, 64, H // 2, W // 2), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().tpspp_front_fwd(_ptr(o0), _ptr(o1), _ptr(x), _ptr(fw.w0), _ptr(fw.b0), _ptr(fw.w1),
+                                        _ptr(fw.b1), _ptr(fw.w2), _ptr(fw.b2), _ptr(fw.wg), _ptr(fw.bg),
+                                        _ptr(feat0), _ptr(feat1), _ptr(feat2), _ptr(feat_grid), N, H, W,
+                                        _stream(o0))
+    _lib.check(rc, "tpspp_front_fwd")
+    return feat0, feat1, feat2, feat_grid
+
+
 def cbam(x, atten):
     """CBAM.forward (tps_pp.py:77-82) on the (N, 64, 2, 16) bottleneck map, one fused kernel."""
     x = _chk("x", x, 4)

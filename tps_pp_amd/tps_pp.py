@@ -409,13 +409,16 @@ class TPS_PP(nn.Module):
         x = batch_img.float().contiguous()
         o0, o1 = outs[0].float().contiguous(), outs[1].float().contiguous()
         if self.type == "ResNet45v2":
-            feat0 = ops.conv2d([o0], cw["down0"], 1)
-            feat1 = ops.conv2d([o1], cw["down1"], 1)
-            feat2 = ops.conv2d([x], cw["down2"], 1)
+            # down0 / down1 / down2 and grid() (cat + Upsample + down_feat) are pointwise: one fused,
+            # register-chained MFMA kernel (tpspp_front.hip)
+            fkey = tuple((t.data_ptr(), t._version) for mdl in (self.down0, self.down1, self.down2, self.down_feat)
+                         for t in mdl.parameters())
+            fc = getattr(self, "_front_cache", None)
+            if fc is None or fc[0] != fkey:
+                self._front_cache = fc = (fkey, ops.FrontWeights(self))
+            feat0, feat1, feat2, feat_grid = ops.front(o0, o1, x, fc[1])
             d0 = ops.conv2d([feat0], cw["down0_1"], 2)
             d1 = ops.conv2d([feat1], cw["down1_1"], 2)
-            # grid(): cat(feat0, feat1, Upsample(feat2)) -> 1x1 conv, nothing materialised
-            feat_grid = ops.conv2d([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1)
             cat_srcs = [d0, d1, feat2]
         else:
             cat_srcs = [ops.conv2d([o0], cw["down0"], 2), ops.conv2d([o1], cw["down1"], 1),
