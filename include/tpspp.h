@@ -117,6 +117,7 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
 
 /*
  * out = act(conv2d(cat_c(up(src_0), up(src_1), up(src_2)), W) + bias [+ residual]) [+ residual]
+ *       [* post_scale + post_shift]
  * fp32, NCHW, 1x1 or 3x3 kernel with "same" padding ((K-1)/2), stride (sh, sw), on the fp32 matrix
  * cores (exact fp32 products, fp32 accumulation).
  *   src_ptrs[i]   (N, C_i, H_i, W_i); src_dims + 5*i = {C_i, H_i, W_i, uh_i, uw_i}: source i is
@@ -130,14 +131,16 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *                 may be NULL; results agree to fp32 rounding, the summation order differs)
  *   bias          (Cout) or NULL;  residual (N, Cout, Ho, Wo) or NULL
  *   res_mode      0 none, 1 act(conv + bias) + residual, 2 act(conv + bias + residual)
+ *   post_scale/post_shift (Cout) or NULL: per-channel affine applied last (an eval-mode BatchNorm that
+ *                 FOLLOWS the activation: backbones/nrtr_modality_transformer.py:42-48)
  * replaces: mmcv ConvModule / nn.Conv2d (+ nn.Upsample, torch.cat, skip additions)
  *           backbones/tps_pp/tps_pp.py:126-131,149-154,156-169,538-552,560-562;
  *           preprocessor/tps_preprocessor.py:101-128; backbones/resnet_v2_large.py:131-135;
- *           layers/conv_layer.py:12-33
+ *           layers/conv_layer.py:12-33; backbones/nrtr_modality_transformer.py:19-48
  */
 int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
                      const float* weight_t, const float* weight_tiled, const float* bias,
-                     const float* residual,
+                     const float* residual, const float* post_scale, const float* post_shift,
                      int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
                      float* out, int Ho, int Wo, tpspp_stream_t stream);
 

@@ -167,3 +167,20 @@ def backbone_state_rule(name, shape):
 
 def g7_inputs():
     return dict(img=synth.smooth_image((G7_N, 3, 32, 128), "g7.img", 7))
+
+
+# ---- G8: NRTRModalityTransform (upstream NRTR conv stem), N=2, 3x32x100 -----------------------------
+G8_N = 2
+
+
+def nrtr_state_rule(name, shape):
+    r = bn_rule(name, shape)
+    if r is not None:
+        return r
+    if name.startswith("bn_") and name.endswith(".weight"):
+        return (0.25, 1.0)
+    return None
+
+
+def g8_inputs():
+    return dict(img=synth.smooth_image((G8_N, 3, 32, 100), "g8.img", 8))

@@ -234,8 +234,17 @@ def case_g1_pin(R):
     print("  classic-module oracle == reference (bitwise)")
 
 
+def case_g8(R):
+    m = R["nrtr_modality_transformer"].NRTRModalityTransform()
+    m.eval()
+    sd = cases.synth_state(m.state_dict(), 8, cases.nrtr_state_rule)
+    m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    out = m(t(cases.g8_inputs()["img"]))
+    save("nrtr_stem", out=out.numpy())
+
+
 CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1, g1_pin=case_g1_pin,
-             g4=case_g4, g5=case_g5, g7=case_g7)
+             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8)
 
 
 def main(argv):

@@ -112,3 +112,18 @@ def test_backbone_stem_and_tps_call_site(cuda):
     with torch.no_grad():
         res = m(dev(cases.g7_inputs()["img"], cuda), tps)
     assert res["img_ref"].shape == torch.Size([cases.G7_N, 64, 16, 64]) and torch.isfinite(res["output"]).all()
+
+
+def test_nrtr_modality_transform_against_reference(cuda):
+    from tps_pp_amd import NRTRModalityTransform
+    G = cases.load("nrtr_stem")
+    m = NRTRModalityTransform().eval()
+    sd = cases.synth_state(m.state_dict(), 8, cases.nrtr_state_rule)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    img = cases.g8_inputs()["img"]
+    with torch.no_grad():
+        cpu = m(torch.from_numpy(img))                    # PyTorch composition on the CPU
+        got = m.to(cuda)(dev(img, cuda))
+    assert np.abs(cpu.numpy() - G["out"]).max() <= 1e-4
+    assert got.shape == torch.Size([cases.G8_N, 512, 1, 25])
+    assert np.abs(got.cpu().numpy() - G["out"]).max() <= 1e-4

@@ -155,3 +155,13 @@ def test_backbone_mirror_matches_oracle_on_cpu():
     G = cases.load("backbone_stem")
     np.testing.assert_allclose(got["x"].numpy(), G["x"], atol=1e-4, rtol=1e-5)
     assert len(m.state_dict()) == 295          # same number of entries as the reference's backbone
+
+
+def test_nrtr_stem_mirror_layout_and_registry():
+    from tps_pp_amd import NRTRModalityTransform
+    m = build_backbone(dict(type="NRTRModalityTransform"))
+    assert isinstance(m, NRTRModalityTransform)
+    keys = list(m.state_dict())
+    assert keys[:2] == ["conv_1.weight", "conv_1.bias"] and "bn_2.running_var" in keys and keys[-2:] == ["linear.weight", "linear.bias"]
+    with torch.no_grad():
+        assert m.eval()(torch.zeros(1, 3, 32, 100)).shape == torch.Size([1, 512, 1, 25])

@@ -10,7 +10,9 @@ from .registry import (BACKBONES, PREPROCESSOR, build_backbone, build_preprocess
 from .tps_preprocessor import TPSPreprocessor, LocalizationNetwork, GridGenerator  # noqa: F401
 from .tps_pp import TPS_PP, Attention_Enhanced_TPS  # noqa: F401
 from .resnet_v2_large import ResNetABI_v2_large, BasicBlock  # noqa: F401
+from .nrtr_modality_transformer import NRTRModalityTransform  # noqa: F401
 
 __all__ = ["BACKBONES", "PREPROCESSOR", "build_backbone", "build_preprocessor",
            "register_into_mmocr", "TPSPreprocessor", "LocalizationNetwork", "GridGenerator",
-           "TPS_PP", "Attention_Enhanced_TPS", "ResNetABI_v2_large", "BasicBlock"]
+           "TPS_PP", "Attention_Enhanced_TPS", "ResNetABI_v2_large", "BasicBlock",
+           "NRTRModalityTransform"]

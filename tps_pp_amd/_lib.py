@@ -23,7 +23,7 @@ _SIGNATURES = {
     "tpspp_table_mirror_symmetry": ([_f, _i, _i, _i, _i], _i),
     "tpspp_warp_fwd": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i,
                         _f, _f, _f, _f, _f], _i),
-    "tpspp_conv2d_fwd": ([_f, _f, _i, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f], _i),
+    "tpspp_conv2d_fwd": ([_f, _f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f], _i),
     "tpspp_dgab_fwd": ([_f] * 16 + [_i, _i, _f], _i),
     "tpspp_score_fwd": ([_f, _f, _f, _f, _f, _f, ctypes.c_float, _f, _i, _i, _f], _i),
     "tpspp_front_fwd": ([_f] * 15 + [_i, _i, _i, _f], _i),

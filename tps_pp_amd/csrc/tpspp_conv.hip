@@ -45,6 +45,8 @@ struct ConvParams {
     const float* wt;          // (K, Cout), k-major; K = Cin*KH*KW
     const float* bias;        // (Cout) or null
     const float* res;         // (N, Cout, Ho, Wo) or null
+    const float* post_scale;  // (Cout) or null: out = act(...) * post_scale + post_shift  (BatchNorm AFTER
+    const float* post_shift;  //                 the activation, nrtr_modality_transformer.py:42-48)
     float* out;               // (N, Cout, Ho, Wo)
     int N, Cin, Cout, Hi, Wi, Ho, Wo, sh, sw, ph, pw;
     int relu;                 // 1: ReLU
@@ -138,6 +140,7 @@ conv_igemm_f32_kernel(const ConvParams P)
                     if (P.res_mode == 2) v = v + P.res[o];
                     if (P.relu) v = v > 0.0f ? v : 0.0f;
                     if (P.res_mode == 1) v = v + P.res[o];
+                    if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
                     P.out[o] = v;
                 }
             }
@@ -283,6 +286,7 @@ conv_tiled_f32_kernel(const ConvParams P)
                     if (P.res_mode == 2) v = v + P.res[o];
                     if (P.relu) v = v > 0.0f ? v : 0.0f;
                     if (P.res_mode == 1) v = v + P.res[o];
+                    if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
                     P.out[o] = v;
                 }
             }
@@ -350,7 +354,7 @@ TPSPP_EXPORT int tpspp_conv_chunk_channels(int kernel_size)
 
 TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
                                   const float* weight_t, const float* weight_tiled, const float* bias,
-                                  const float* residual,
+                                  const float* residual, const float* post_scale, const float* post_shift,
                                   int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
                                   float* out, int Ho, int Wo, tpspp_stream_t stream)
 {
@@ -383,7 +387,9 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
     P.sh = sh; P.sw = sw; P.ph = (KH - 1) / 2; P.pw = (KW - 1) / 2;
     TPSPP_REQUIRE(Ho == (Hi + 2 * P.ph - KH) / sh + 1 && Wo == (Wi + 2 * P.pw - KW) / sw + 1,
                   "tpspp_conv2d_fwd: output size does not match input size / stride ('same' padding)");
+    TPSPP_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "tpspp_conv2d_fwd: post_scale/post_shift come together");
     P.wt = weight_t; P.bias = bias; P.res = residual; P.out = out;
+    P.post_scale = post_scale; P.post_shift = post_shift;
     P.relu = relu ? 1 : 0; P.res_mode = res_mode;
     if (N == 0) return TPSPP_OK;
     hipStream_t st = tpspp::as_stream(stream);

@@ -176,14 +176,16 @@ class ConvWeight:
     """Device-side weights of one fused convolution, prepared once: `wt` (K, Cout) for the generic
     kernel, `tiled` [chunk][tap][channel-in-chunk][Cout] for the tiled kernel, `bias` (Cout) | None."""
 
-    def __init__(self, wt, tiled, bias, kernel):
+    def __init__(self, wt, tiled, bias, kernel, post_scale=None, post_shift=None):
         self.wt, self.tiled, self.bias, self.kernel = wt, tiled, bias, kernel
+        self.post_scale, self.post_shift = post_scale, post_shift
 
 
-def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5, src_channels=None):
+def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5, src_channels=None, post_bn=None):
     """PyTorch conv weight (Cout, Cin, KH, KW) [+ eval-mode BatchNorm (gamma, beta, mean, var), folded:
     y = gamma * (conv(x) + b - mean) / sqrt(var + eps) + beta] -> ConvWeight.
-    `src_channels`: channel counts of the concatenated sources (chunks never straddle a source)."""
+    `src_channels`: channel counts of the concatenated sources (chunks never straddle a source).
+    `post_bn`: a BatchNorm that FOLLOWS the activation (applied as a per-channel affine in the epilogue)."""
     w = weight.detach().float()
     b = None if conv_bias is None else conv_bias.detach().float()
     if bn is not None:
@@ -201,7 +203,12 @@ def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5, src_channels=Non
         wp[:, :cin] = w
         # (cout, chunk, ci, ky, kx) -> (chunk, ky, kx, ci, cout)
         tiled = wp.view(cout, nch, kc, kh, kw).permute(1, 3, 4, 2, 0).contiguous()
-    return ConvWeight(wt, tiled, None if b is None else b.contiguous(), kh)
+    ps = pb = None
+    if post_bn is not None:
+        gamma, beta, mean, var = (t.detach().float() for t in post_bn)
+        ps = (gamma / torch.sqrt(var + eps)).contiguous()
+        pb = (beta - mean * ps).contiguous()
+    return ConvWeight(wt, tiled, None if b is None else b.contiguous(), kh, ps, pb)
 
 
 def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=None):
@@ -243,7 +250,7 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
     with torch.cuda.device(ts[0].device):
         rc = _lib.lib().tpspp_conv2d_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
                                          len(ts), _ptr(weight_t), _ptr(cw.tiled), _ptr(bias), _ptr(residual),
-                                         int(res_mode),
+                                         _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode),
                                          int(bool(relu)), N, Cout, kernel, kernel, sh, sw, _ptr(out), Ho, Wo,
                                          _stream(ts[0]))
     _lib.check(rc, "tpspp_conv2d_fwd")
