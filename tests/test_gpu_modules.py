@@ -122,7 +122,7 @@ def test_nrtr_modality_transform_against_reference(cuda):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     img = cases.g8_inputs()["img"]
     with torch.no_grad():
-        cpu = m(torch.from_numpy(img))                    # PyTorch composition on the CPU
+        cpu = m._forward_torch(torch.from_numpy(img))     # PyTorch composition on the CPU (test hook)
         got = m.to(cuda)(dev(img, cuda))
     assert np.abs(cpu.numpy() - G["out"]).max() <= 1e-4
     assert got.shape == torch.Size([cases.G8_N, 512, 1, 25])

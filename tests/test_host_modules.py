@@ -74,14 +74,15 @@ def test_buffers_and_initial_control_points_match_the_reference():
 
 
 def test_regressor_matches_oracle_on_cpu():
-    """The regressor is still library PyTorch: on the CPU it must agree with the oracle exactly."""
+    """Wiring / state_dict check of the mirror without a GPU: its layers composed with plain PyTorch
+    (the explicit test hook, never used by forward()) must agree with the oracle exactly."""
     from oracle import tpspp_oracle as TO
     m = TPS_PP().eval()
     sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     inp = cases.g4_inputs()
     with torch.no_grad():
-        cp, sc, fg = m.regress(torch.from_numpy(inp["x"]), [torch.from_numpy(o) for o in inp["outs"]])
+        cp, sc, fg = m._regress_torch(torch.from_numpy(inp["x"]), [torch.from_numpy(o) for o in inp["outs"]])
         ocp, osc, ofg, _ = TO.tpspp_regress(dict(m.state_dict()), inp["x"], inp["outs"])
     assert torch.equal(cp, ocp) and torch.equal(sc, osc) and torch.equal(fg, ofg)
     G = cases.load("tpspp_module_v2")
@@ -97,6 +98,9 @@ def test_no_cpu_fallback_and_forward_only():
     m = TPS_PP()
     with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
         m(torch.zeros(1, 64, 16, 64), [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 32, 128)])
+    from tps_pp_amd import ResNetABI_v2_large
+    with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
+        ResNetABI_v2_large().eval()(torch.zeros(1, 3, 32, 128))
 
 
 def test_variant_geometry_is_checked_with_a_useful_message():
@@ -149,7 +153,7 @@ def test_backbone_mirror_matches_oracle_on_cpu():
             return {"output": x}
     img = cases.g7_inputs()["img"]
     with torch.no_grad():
-        m(torch.from_numpy(img), Spy())
+        m._forward_torch(torch.from_numpy(img), Spy())
     ox, oouts = TO.backbone_stem(dict(m.state_dict()), img)
     assert torch.equal(got["x"], ox) and all(torch.equal(a, b) for a, b in zip(got["outs"], oouts))
     G = cases.load("backbone_stem")
@@ -164,4 +168,6 @@ def test_nrtr_stem_mirror_layout_and_registry():
     keys = list(m.state_dict())
     assert keys[:2] == ["conv_1.weight", "conv_1.bias"] and "bn_2.running_var" in keys and keys[-2:] == ["linear.weight", "linear.bias"]
     with torch.no_grad():
-        assert m.eval()(torch.zeros(1, 3, 32, 100)).shape == torch.Size([1, 512, 1, 25])
+        assert m.eval()._forward_torch(torch.zeros(1, 3, 32, 100)).shape == torch.Size([1, 512, 1, 25])
+    with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 32, 100))

@@ -2,8 +2,7 @@
 
 Mirror of `mmocr/models/textrecog/backbones/nrtr_modality_transformer.py:8-56`: conv3x3 s2 (3->32), ReLU,
 BatchNorm, conv3x3 s2 (32->64), ReLU, BatchNorm, then a Linear(512, 512) over the (h, c) axis of every
-image column.  Same `state_dict` keys (`conv_1`, `bn_1`, `conv_2`, `bn_2`, `linear`).  In eval mode on a
-GPU both convolutions run on the fp32 MFMA kernel with ReLU and the *following* BatchNorm fused into
+image column.  Same `state_dict` keys (`conv_1`, `bn_1`, `conv_2`, `bn_2`, `linear`).  Both convolutions run on the fp32 MFMA kernel with ReLU and the *following* BatchNorm fused into
 the epilogue (per-channel affine after the activation), and the Linear runs as a 1x1 convolution over
 the (image, column) positions.
 """
@@ -44,15 +43,18 @@ class NRTRModalityTransform(nn.Module):
         return cache[1]
 
     def forward(self, x):
-        if x.is_cuda and not self.training:
-            c1, c2, lin = self._weights()
-            x = ops.conv2d([x.float().contiguous()], c1, 2, True)
-            x = ops.conv2d([x], c2, 2, True)
-            n, c, h, w = x.size()
-            # (n, c, h, w) -> rows (n, w) x features (h, c): layout plumbing for the Linear
-            rows = x.permute(0, 3, 2, 1).contiguous().view(n * w, h * c)
-            y = ops.linear(rows, lin)                               # (n*w, 512)
-            return y.view(n, w, 512).permute(0, 2, 1).contiguous().view(n, -1, 1, w)
+        ops.require_gpu(x, "NRTRModalityTransform", self.training)
+        c1, c2, lin = self._weights()
+        x = ops.conv2d([x.float().contiguous()], c1, 2, True)
+        x = ops.conv2d([x], c2, 2, True)
+        n, c, h, w = x.size()
+        # (n, c, h, w) -> rows (n, w) x features (h, c): layout plumbing for the Linear
+        rows = x.permute(0, 3, 2, 1).contiguous().view(n * w, h * c)
+        y = ops.linear(rows, lin)                               # (n*w, 512)
+        return y.view(n, w, 512).permute(0, 2, 1).contiguous().view(n, -1, 1, w)
+
+    def _forward_torch(self, x):
+        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
         x = self.bn_1(self.relu_1(self.conv_1(x)))
         x = self.bn_2(self.relu_2(self.conv_2(x)))
         n, c, h, w = x.size()

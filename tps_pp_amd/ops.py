@@ -30,6 +30,16 @@ def _chk(name, t, ndim=None):
     return t.contiguous()
 
 
+def require_gpu(t, who, training=False):
+    """Module forwards call this first: the product has no CPU path and no library-kernel path."""
+    if not t.is_cuda:
+        raise _lib.TpsppError(f"{who}: tensor is on {t.device}; the HIP path needs a GPU tensor "
+                              "(no CPU fallback)")
+    if training:
+        raise NotImplementedError(f"{who} (HIP path) is forward-only: call .eval() and run under "
+                                  "torch.no_grad() (SURVEY.md section 8f, row F2)")
+
+
 def solve_T(inv_delta_C, ctrl):
     """torch.bmm(inv_delta_C.repeat(N,1,1), cat(ctrl, zeros(N,3,2)))  -> (N, F+3, 2)
     (tps_preprocessor.py:273-280, tps_pp.py:484-494)."""

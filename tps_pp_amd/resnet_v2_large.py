@@ -7,9 +7,9 @@ keys (`conv1.*`, `bn1.*`, `layer{1..5}.{i}.{conv1,bn1,conv2,bn2,downsample.0,dow
 call contract `forward(x, tpsnet=None, test=False, **kw) -> dict(output, img_ref)` with the TPS
 network invoked before stage index 2 on `(x, outs)` (`:183-191`).
 
-In eval mode on a GPU every convolution runs on the hand-written fp32 MFMA kernel with its BatchNorm
-folded in and the residual add + ReLU fused into the second convolution's epilogue.  Training mode /
-CPU tensors use the plain PyTorch composition (BatchNorm statistics need it).
+Every convolution runs on the hand-written fp32 MFMA kernel with its BatchNorm folded in and the
+residual add + ReLU fused into the second convolution's epilogue (eval mode, GPU tensors; anything
+else raises: there is no CPU or library-kernel path).
 """
 import torch
 import torch.nn as nn
@@ -37,8 +37,11 @@ class BasicBlock(nn.Module):
         self.use_conv1x1 = use_conv1x1
 
     def forward(self, x):
-        if x.is_cuda and not self.training:
-            return self._forward_hip(x)
+        ops.require_gpu(x, "BasicBlock", self.training)
+        return self._forward_hip(x)
+
+    def _forward_torch(self, x):
+        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
         residual = x
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -118,7 +121,7 @@ class ResNetABI_v2_large(nn.Module):
         return nn.Sequential(*layers)
 
     def _stem(self, x):
-        if x.is_cuda and not self.training:
+        if True:
             mods = [self.conv1, self.bn1]
             key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
             cache = getattr(self, "_cw_cache", None)
@@ -128,12 +131,15 @@ class ResNetABI_v2_large(nn.Module):
                                           bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
                 self._cw_cache = cache = (key, cw)
             return ops.conv2d([x.float().contiguous()], cache[1], 1, True)
-        return self.relu1(self.bn1(self.conv1(x)))
 
     def forward(self, x, tpsnet=None, test=False, **kwargs):
         """(N, 3, H, W) -> dict(output, img_ref); `tpsnet(x, outs, **kwargs)` runs before stage 2 and
         its 'output' replaces x (`resnet_v2_large.py:183-191`)."""
-        x = self._stem(x)
+        ops.require_gpu(x, "ResNetABI_v2_large", self.training)
+        return self._run(x, tpsnet, self._stem, lambda blk, t: blk(t), **kwargs)
+
+    def _run(self, x, tpsnet, stem, apply_block, **kwargs):
+        x = stem(x)
         outs = []
         outputs = None
         for i, name in enumerate(self.res_layers):
@@ -142,5 +148,11 @@ class ResNetABI_v2_large(nn.Module):
                 if outputs.get("output", None) is not None:
                     x = outputs["output"]
             outs.append(x)
-            x = getattr(self, name)(x)
+            for blk in getattr(self, name):
+                x = apply_block(blk, x)
         return {"output": x, "img_ref": outputs.get("output", None) if outputs is not None else None}
+
+    def _forward_torch(self, x, tpsnet=None, **kwargs):
+        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
+        return self._run(x, tpsnet, lambda t: self.relu1(self.bn1(self.conv1(t))),
+                         lambda blk, t: blk._forward_torch(t), **kwargs)

@@ -376,8 +376,7 @@ class TPS_PP(nn.Module):
 
     def regress(self, batch_img, outs):
         """Control points, attention score and the feature map to rectify (`tps_pp.py:572-594`).
-        GPU tensors take the hand-written conv kernels; CPU tensors (host-side tests of the mirror
-        against the oracle) take the plain PyTorch composition of the same layers."""
+        Hand-written kernels only; CPU tensors raise (no fallback)."""
         h, w = batch_img.shape[-2:]
         if self.type == "ResNet45v2":
             if tuple(outs[1].shape[-2:]) != (2 * h, 2 * w) or tuple(outs[0].shape[-2:]) != (2 * h, 2 * w):
@@ -386,8 +385,12 @@ class TPS_PP(nn.Module):
                     f"{tuple(outs[0].shape[-2:])}, {tuple(outs[1].shape[-2:])}: backbone strides "
                     "[2,1,2,1,2] (configs/textrecog/nrtr/nrtr_tps++.py) produce the 'ResNet45' "
                     "geometry -- build with variant='ResNet45' (the reference itself fails here)")
-        if batch_img.is_cuda:
-            return self._regress_hip(batch_img, outs)
+        ops.require_gpu(batch_img, "TPS_PP")
+        return self._regress_hip(batch_img, outs)
+
+    def _regress_torch(self, batch_img, outs):
+        """TEST HOOK, never called by forward(): the same layers composed with plain PyTorch ops, so that
+        host-side tests can check the mirror's wiring / state_dict against the oracle without a GPU."""
         if self.type == "ResNet45v2":
             feat0 = self.down0(outs[0])
             feat1 = self.down1(outs[1])

@@ -76,17 +76,21 @@ class LocalizationNetwork(nn.Module):
         return cache[1]
 
     def forward(self, batch_img):
+        """fp32 MFMA convolutions with BatchNorm folded in, HIP pooling kernels, the two FCs as 1x1
+        convolutions over the batch.  No CPU / library-kernel path."""
+        ops.require_gpu(batch_img, "LocalizationNetwork", self.training)
         n = batch_img.size(0)
-        if batch_img.is_cuda and not self.training:
-            # hand-written path: fp32 MFMA convolutions with BatchNorm folded in, HIP pooling kernels,
-            # the two FCs as 1x1 convolutions over the batch
-            cw = self._hip_weights()
-            x = batch_img.float().contiguous()
-            for i in range(3):
-                x = ops.maxpool2x2(ops.conv2d([x], cw[i], 1, True))
-            x = ops.global_avgpool(ops.conv2d([x], cw[3], 1, True))
-            x = ops.linear(x, cw[4], relu=True)
-            return ops.linear(x, cw[5], relu=False).view(n, self.num_fiducial, 2)
+        cw = self._hip_weights()
+        x = batch_img.float().contiguous()
+        for i in range(3):
+            x = ops.maxpool2x2(ops.conv2d([x], cw[i], 1, True))
+        x = ops.global_avgpool(ops.conv2d([x], cw[3], 1, True))
+        x = ops.linear(x, cw[4], relu=True)
+        return ops.linear(x, cw[5], relu=False).view(n, self.num_fiducial, 2)
+
+    def _forward_torch(self, batch_img):
+        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
+        n = batch_img.size(0)
         feat = self.conv(batch_img).view(n, -1)
         return self.localization_fc2(self.localization_fc1(feat)).view(n, self.num_fiducial, 2)
 
