@@ -30,6 +30,10 @@ constexpr int kWave = 64;
 constexpr int BM = 128;       // output pixels per workgroup
 constexpr int BN = 64;        // output channels per workgroup
 constexpr int kThreads = 256;
+#ifndef KC3
+#define KC3 4
+#endif
+constexpr int kKC3 = KC3;       // input channels per K-chunk of the 3x3 kernels (layout of weight_tiled)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -316,16 +320,16 @@ bool launch_tiled_any(const ConvParams& P, int KH, hipStream_t st)
         TPSPP_TILE(1, 1, 1, 8, 16, 32)
     }
     if (P.sh == 1 && P.sw == 1) {
-        if (P.Wo >= 64) TPSPP_TILE(3, 1, 1, 2, 64, 8)
-        if (P.Wo >= 32) TPSPP_TILE(3, 1, 1, 4, 32, 8)
-        TPSPP_TILE(3, 1, 1, 8, 16, 8)
+        if (P.Wo >= 64) TPSPP_TILE(3, 1, 1, 2, 64, kKC3)
+        if (P.Wo >= 32) TPSPP_TILE(3, 1, 1, 4, 32, kKC3)
+        TPSPP_TILE(3, 1, 1, 8, 16, kKC3)
     }
     if (P.sh == 2 && P.sw == 2) {
-        if (P.Wo >= 64) TPSPP_TILE(3, 2, 2, 2, 64, 8)
-        if (P.Wo >= 32) TPSPP_TILE(3, 2, 2, 4, 32, 8)
-        TPSPP_TILE(3, 2, 2, 8, 16, 8)
+        if (P.Wo >= 64) TPSPP_TILE(3, 2, 2, 2, 64, kKC3)
+        if (P.Wo >= 32) TPSPP_TILE(3, 2, 2, 4, 32, kKC3)
+        TPSPP_TILE(3, 2, 2, 8, 16, kKC3)
     }
-    if (P.sh == 2 && P.sw == 1) TPSPP_TILE(3, 2, 1, 8, 16, 8)
+    if (P.sh == 2 && P.sw == 1) TPSPP_TILE(3, 2, 1, 8, 16, kKC3)
 #undef TPSPP_TILE
     return false;
 }
@@ -349,7 +353,7 @@ TPSPP_EXPORT int tpspp_conv_set_tuning(int force_generic)
 
 TPSPP_EXPORT int tpspp_conv_chunk_channels(int kernel_size)
 {
-    return kernel_size == 1 ? 32 : 8;
+    return kernel_size == 1 ? 32 : kKC3;
 }
 
 TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_dims, int nsrc,
@@ -368,7 +372,7 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
     ConvParams P;
     P.nsrc = nsrc;
     int cin = 0, Hi = -1, Wi = -1;
-    const int KC = (KH == 1) ? 32 : 8;
+    const int KC = (KH == 1) ? 32 : kKC3;
     for (int i = 0; i < nsrc; ++i) {
         const int* d = src_dims + 5 * i;                      // C, H, W, uh, uw
         TPSPP_REQUIRE(src_ptrs[i] && d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] >= 1 && d[4] >= 1,

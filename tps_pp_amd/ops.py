@@ -205,7 +205,7 @@ def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5, src_channels=Non
         b = beta - mean * scale if b is None else beta + (b - mean) * scale
     cout, cin, kh, kw = w.shape
     wt = w.reshape(cout, -1).t().contiguous()
-    kc = 32 if kh == 1 else 8
+    kc = int(_lib.lib().tpspp_conv_chunk_channels(int(kh)))
     tiled = None
     if src_channels is None or len(src_channels) == 1 or all(c % kc == 0 for c in src_channels):
         nch = (cin + kc - 1) // kc
