@@ -513,7 +513,7 @@ __device__ __forceinline__ constexpr int perm_y(int k) { return (k + F / 2) % F;
 template <int F>
 __device__ __forceinline__ constexpr int perm_x(int k) { return k < F / 2 ? F / 2 - 1 - k : F + F / 2 - 1 - k; }
 
-template <int F, int C, int HC, int WC>
+template <int F, int C, int HC, int WC, bool AUX>
 __global__ void __launch_bounds__(kLdsMaxWaves * kWave)
 tps_warp_lds_mirror_kernel(const LdsParams P)
 {
@@ -670,44 +670,49 @@ tps_warp_lds_mirror_kernel(const LdsParams P)
     if (wv == 0) stamp(P.trace, 3);
 
     // ---- bilinear taps from LDS, coalesced stores ----
+    // Every store is  wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset: no 64-bit
+    // vector address arithmetic in this VALU-bound phase.
     const size_t row_bytes = (size_t)P.n * 4;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    if (live) {
 #pragma unroll
         for (int im = 0; im < 2; ++im) {
-            const bool store = live && (im == 0 || hasB);
+            if (im == 1 && !hasB) break;                   // wave-uniform
             const int b = b0 + im;
-            const Taps t = make_taps(gx[m][im], gy[m][im], H, W);
-            if (P.grid && store)
-                *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid + (size_t)b * P.n * 2) +
-                                           2 * poff[m]) = make_float2(gx[m][im], gy[m][im]);
-            if (P.idx && store)
-                *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx + (size_t)b * P.n * 2) +
-                                         2 * poff[m]) = make_int2(t.x0, t.y0);
             const float* img = sImg + im * img_elems;
-            char* o = reinterpret_cast<char*>(P.out + (size_t)b * C * P.n);   // wave-uniform base
-            const bool inxy = t.inx && t.iny;
-            float res[C];
+            typedef __attribute__((address_space(1))) char gchar;
+            typedef __attribute__((address_space(1))) float gfloat;
+            gchar* oc[C];                                  // per-plane bases, kept in SGPR pairs
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) {
-                const float* pl = img + ch * HW;
-                const float v00 = pl[t.o00];
-                float v01 = pl[t.o00 + 1];                 // over-read masked below (slack after pair)
-                float v10 = pl[t.o10];
-                float v11 = pl[t.o10 + 1];
-                v01 = t.inx ? v01 : 0.0f;
-                v10 = t.iny ? v10 : 0.0f;
-                v11 = inxy ? v11 : 0.0f;
-                float acc = v00 * t.nw;
-                acc = fmaf(v01, t.ne, acc);
-                acc = fmaf(v10, t.sw, acc);
-                acc = fmaf(v11, t.se, acc);
-                res[ch] = acc;
+                oc[ch] = (gchar*)(P.out) + ((size_t)b * C + ch) * row_bytes;
+                asm volatile("" : "+s"(oc[ch]));
             }
-            if (store) {
+            char* og = AUX ? reinterpret_cast<char*>(P.grid) + (size_t)b * 2 * row_bytes : nullptr;
+            char* oi = AUX ? reinterpret_cast<char*>(P.idx) + (size_t)b * 2 * row_bytes : nullptr;
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch)
-                    *reinterpret_cast<float*>(o + ch * row_bytes + poff[m]) = res[ch];
+            for (int m = 0; m < 4; ++m) {
+                const Taps t = make_taps(gx[m][im], gy[m][im], H, W);
+                if constexpr (AUX) {
+                    if (P.grid) *reinterpret_cast<float2*>(og + 2u * poff[m]) = make_float2(gx[m][im], gy[m][im]);
+                    if (P.idx) *reinterpret_cast<int2*>(oi + 2u * poff[m]) = make_int2(t.x0, t.y0);
+                }
+                const bool inxy = t.inx && t.iny;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const float* pl = img + ch * HW;
+                    const float v00 = pl[t.o00];
+                    float v01 = pl[t.o00 + 1];             // over-read masked below (slack after pair)
+                    float v10 = pl[t.o10];
+                    float v11 = pl[t.o10 + 1];
+                    v01 = t.inx ? v01 : 0.0f;
+                    v10 = t.iny ? v10 : 0.0f;
+                    v11 = inxy ? v11 : 0.0f;
+                    float acc = v00 * t.nw;
+                    acc = fmaf(v01, t.ne, acc);
+                    acc = fmaf(v10, t.sw, acc);
+                    acc = fmaf(v11, t.se, acc);
+                    *(gfloat*)(oc[ch] + poff[m]) = acc;
+                }
             }
         }
     }
@@ -872,18 +877,26 @@ bool launch_lds_geo(const LdsParams& P, int ppt, int threads, size_t lds, hipStr
     }
 }
 
-template <int F, int C, int HC, int WC>
-void launch_lds_mirror_geo(const LdsParams& P, int threads, size_t lds, hipStream_t st)
+template <int F, int C, int HC, int WC, bool AUX>
+void launch_lds_mirror_aux(const LdsParams& P, int threads, size_t lds, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_mirror_kernel<F, C, HC, WC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_mirror_kernel<F, C, HC, WC, AUX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         attr_done = true;
     }
     const dim3 grid((unsigned)(((P.N + 1) / 2) * P.bands)), block(threads);
-    hipLaunchKernelGGL((tps_warp_lds_mirror_kernel<F, C, HC, WC>), grid, block, lds, st, P);
+    hipLaunchKernelGGL((tps_warp_lds_mirror_kernel<F, C, HC, WC, AUX>), grid, block, lds, st, P);
+}
+
+template <int F, int C, int HC, int WC>
+void launch_lds_mirror_geo(const LdsParams& P, int threads, size_t lds, hipStream_t st)
+{
+    // the optional grid / tap-index outputs get their own instantiation: the common call wants neither
+    if (P.grid || P.idx) launch_lds_mirror_aux<F, C, HC, WC, true>(P, threads, lds, st);
+    else launch_lds_mirror_aux<F, C, HC, WC, false>(P, threads, lds, st);
 }
 
 template <int F, int C>

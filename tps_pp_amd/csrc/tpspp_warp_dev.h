@@ -39,8 +39,10 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W)
     t.iny = (y0 + 1) < H;
     const int x1 = t.inx ? x0 + 1 : x0;
     const int y1 = t.iny ? y0 + 1 : y0;
-    t.o00 = y0 * W + x0; t.o01 = y0 * W + x1;
-    t.o10 = y1 * W + x0; t.o11 = y1 * W + x1;
+    // 24-bit multiplies are full rate (rows and widths are far below 2^24)
+    const int r0 = __mul24(y0, W), r1 = __mul24(y1, W);
+    t.o00 = r0 + x0; t.o01 = r0 + x1;
+    t.o10 = r1 + x0; t.o11 = r1 + x1;
     t.x0 = x0; t.y0 = y0;
     return t;
 }
