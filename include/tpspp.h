@@ -23,6 +23,7 @@
 #ifndef TPSPP_H_
 #define TPSPP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -131,6 +132,8 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *                 may be NULL; results agree to fp32 rounding, the summation order differs)
  *   bias          (Cout) or NULL;  residual (N, Cout, Ho, Wo) or NULL
  *   res_mode      0 none, 1 act(conv + bias) + residual, 2 act(conv + bias + residual)
+ *   relu          activation code: 0 none, 1 ReLU, 2 GELU in its exact erf form (nn.GELU / mmcv.GELU,
+ *                 common/modules/transformer_module.py:116,121)
  *   post_scale/post_shift (Cout) or NULL: per-channel affine applied last (an eval-mode BatchNorm that
  *                 FOLLOWS the activation: backbones/nrtr_modality_transformer.py:42-48)
  * replaces: mmcv ConvModule / nn.Conv2d (+ nn.Upsample, torch.cat, skip additions)
@@ -240,6 +243,88 @@ int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kerne
  * landed, unused) into device_buf[workgroup * 8 + i].  NULL (default) disables it.
  */
 int tpspp_warp_set_trace(long long* device_buf);
+
+/* ===== Recogniser head after TPS++: NRTR encoder / decoder ==========
+ *
+ * Layout convention of the head: activations are CHANNEL-MAJOR matrices X[c][m] (row = feature,
+ * column = token; m = image * T + token), fp32, dense.  Linear weights are passed K-MAJOR: the
+ * PyTorch weight (out_features, in_features) transposed once by the caller to (in_features,
+ * out_features).  d_k = d_v = 64 (n_head = d_model / 64), dropout is the identity (inference).
+ */
+
+/* out (cols, rows) = in (rows, cols) transposed. */
+int tpspp_transpose2d(const float* in, int rows, int cols, float* out, tpspp_stream_t stream);
+
+/*
+ * y[c][m] = (x[c][m] - mean_m) / sqrt(var_m + eps) * gamma[c] + beta[c], statistics over the C rows of
+ * column m (biased variance): nn.LayerNorm(C) applied to every token of a channel-major (C, M) matrix.
+ * replaces: common/layers/transformer_layers.py:44,46,103-105; encoders/nrtr_encoder.py:49;
+ *           decoders/nrtr_decoder.py:77
+ */
+int tpspp_layernorm_cm_fwd(const float* x, const float* gamma, const float* beta, int C, int M, float eps,
+                           float* y, tpspp_stream_t stream);
+
+/*
+ * Multi-head self-attention of the encoder on already projected q/k/v:
+ *   qkv (3C, N*T) channel-major: rows [0,C) = q, [C,2C) = k, [2C,3C) = v; head h = rows [64h, 64h+64)
+ *   out (C, N*T):  softmax_j(q_i . k_j / 8  masked to j < valid_len[b]) . v_j   per image b and head
+ *   valid_len (N) device int32 or NULL (no mask); T <= 256.
+ * replaces: common/modules/transformer_module.py:24-33,82-93 (ScaledDotProductAttention inside
+ *           MultiHeadAttention) with the key mask of encoders/nrtr_encoder.py:51-65
+ */
+int tpspp_attn_enc_fwd(const float* qkv, int N, int C, int T, const int* valid_len, float* out,
+                       tpspp_stream_t stream);
+
+/* Scratch sizes (bytes) for the two calls below; 0 on bad arguments. */
+size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner);
+size_t tpspp_nrtr_decoder_workspace(int N, int C, int T, int d_inner, int n_layers, int max_seq_len,
+                                    int num_out);
+
+/*
+ * NRTREncoder.forward: feat (N, C, H, W) viewed as (N, C, T = H*W) -> LayerNorm(layer_stack(tokens)).
+ *   layer_ptrs   n_layers x 12 device pointers, per layer in this order (K-major weights, NULL = absent bias):
+ *                norm1.weight, norm1.bias, [linear_q|linear_k|linear_v].weight^T concatenated (C, 3C),
+ *                its bias (3C) | NULL, fc.weight^T (C, C), fc.bias | NULL, norm2.weight, norm2.bias,
+ *                mlp.w_1.weight^T (C, d_inner), mlp.w_1.bias, mlp.w_2.weight^T (d_inner, C), mlp.w_2.bias
+ *   ln_g, ln_b   the encoder's final layer_norm
+ *   valid_len    (N) int32 device or NULL: number of valid tokens per image = min(T, ceil(T * valid_ratio))
+ *   out_cm       (C, N*T) channel-major result or NULL;  out_ntc (N, T, C) (the reference's return) or NULL
+ * Layer order ('norm','self_attn','norm','ffn'), activation GELU (erf).
+ * replaces: textrecog/encoders/nrtr_encoder.py:67-87, common/layers/transformer_layers.py:57-75
+ */
+int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
+                           const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
+                           const int* valid_len, void* workspace, size_t workspace_bytes,
+                           float* out_cm, float* out_ntc, tpspp_stream_t stream);
+
+/*
+ * NRTRDecoder.forward_test (greedy, forced_tokens == NULL) / forward_train (teacher forcing):
+ *   enc_cm       (C, N*T) channel-major encoder output (tpspp_nrtr_encoder_fwd's out_cm)
+ *   layer_ptrs   n_layers x 22 device pointers, per layer: norm1.weight, norm1.bias,
+ *                self_attn.[q|k|v].weight^T (C, 3C), NULL, self_attn.fc.weight^T, its bias | NULL,
+ *                norm2.weight, norm2.bias, enc_attn.linear_q.weight^T, NULL, enc_attn.linear_k.weight^T,
+ *                its bias | NULL, enc_attn.linear_v.weight^T, NULL, enc_attn.fc.weight^T, its bias | NULL,
+ *                norm3.weight, norm3.bias, mlp.w_1.weight^T, mlp.w_1.bias, mlp.w_2.weight^T, mlp.w_2.bias
+ *                (the slots marked NULL must be NULL: the reference builds these projections without bias)
+ *   ln_g, ln_b   final layer_norm (eps 1e-6);  emb (num_classes, C) trg_word_emb.weight;
+ *   pos_table    (n_position, C) position_enc.position_table;  w_cls (C, num_out) classifier.weight^T,
+ *   b_cls (num_out);  max_seq_len <= 64;  valid_len as above (cross-attention key mask) or NULL
+ *   forced_tokens NULL: greedy decoding from start_idx; out (N, max_seq_len, num_out) = per-step softmax
+ *                scores, tokens_out (N, max_seq_len + 1) int32 (or NULL) = <BOS> followed by the arg-max
+ *                of every step.
+ *                non-NULL (N, max_seq_len) int32 padded targets: out = raw logits of every position
+ *                (keys holding padding_idx are masked out of the self-attention).
+ * One position per step against cached keys/values: same results as the reference's full re-run of the
+ * padded sequence at every step, up to fp32 summation order.  Nothing synchronises with the host.
+ * replaces: textrecog/decoders/nrtr_decoder.py:95-113,131-177, common/layers/transformer_layers.py:133-163
+ */
+int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
+                           const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
+                           const float* emb, const float* pos_table, int n_position,
+                           const float* w_cls, const float* b_cls, int num_out, int max_seq_len,
+                           int start_idx, int padding_idx, const int* valid_len,
+                           const int* forced_tokens, void* workspace, size_t workspace_bytes,
+                           float* out, int* tokens_out, tpspp_stream_t stream);
 
 #ifdef __cplusplus
 }

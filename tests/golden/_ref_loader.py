@@ -13,7 +13,9 @@ behaviour the files rely on:
 * `mmcv.cnn.resnet.BasicBlock` / `conv3x3`: conv3x3-bn-relu-conv3x3-bn (+downsample) -relu.
 * `timm.models.layers.DropPath`: identity at drop_prob 0 (the only use, DGAB.py:67, never
   instantiates it).
-* `mmocr.models.builder.{BACKBONES, PREPROCESSOR}`: dict-backed `register_module()`.
+* `mmocr.models.builder.{BACKBONES, PREPROCESSOR, ENCODERS, DECODERS, CONVERTORS}`: dict-backed
+  `register_module()`; `build_activation_layer`: 'mmcv.GELU' -> nn.GELU(), 'Relu' -> nn.ReLU().
+* `mmcv.runner.ModuleList` == nn.ModuleList.
 
 This file is test tooling for fixture generation; it never travels to the GPU box in a form that
 matters (nothing there reads /root/reference) and is not imported by the product.
@@ -111,6 +113,17 @@ class _MMCVBasicBlock(nn.Module):
         return out
 
 
+def _build_activation_layer(cfg):
+    """mmcv.cnn.build_activation_layer for the two types the transformer blocks ask for
+    ('mmcv.GELU' -> nn.GELU, exact erf form; 'Relu'/'ReLU' -> nn.ReLU)."""
+    t = cfg["type"]
+    if t in ("mmcv.GELU", "GELU"):
+        return nn.GELU()
+    if t in ("Relu", "ReLU"):
+        return nn.ReLU()
+    raise KeyError(t)
+
+
 class _DropPath(nn.Module):
     def __init__(self, drop_prob=0.0):
         super().__init__()
@@ -154,6 +167,7 @@ def load_reference():
     runner = _pkg("mmcv.runner")
     runner.BaseModule = _BaseModule
     runner.Sequential = nn.Sequential
+    runner.ModuleList = nn.ModuleList
     mmcv.cnn, mmcv.runner = cnn, runner
     _pkg("timm")
     _pkg("timm.models")
@@ -167,8 +181,13 @@ def load_reference():
     builder = _pkg("mmocr.models.builder")
     builder.BACKBONES = _Registry("backbone")
     builder.PREPROCESSOR = _Registry("preprocessor")
+    builder.ENCODERS = _Registry("encoder")
+    builder.DECODERS = _Registry("decoder")
+    builder.CONVERTORS = _Registry("convertor")
+    builder.build_activation_layer = _build_activation_layer
     utils = _pkg("mmocr.utils")
     utils.is_type_list = lambda seq, t: isinstance(seq, list) and all(isinstance(x, t) for x in seq)
+    utils.list_from_file = lambda fn, encoding="utf-8": [ln.rstrip("\n\r") for ln in open(fn, encoding=encoding)]
     sys.modules["mmocr"].utils = utils
     # names the backbone file imports but that were never released / are unrelated tooling
     tps = _pkg("mmocr.models.textrecog.backbones.tps")
@@ -199,4 +218,30 @@ def load_reference():
     _loaded["nrtr_modality_transformer"] = _load(
         "mmocr.models.textrecog.backbones.nrtr_modality_transformer",
         f"{base}/backbones/nrtr_modality_transformer.py")
+    # ---- recogniser head: transformer blocks, encoder, decoder, convertor
+    for p in ["mmocr.models.common", "mmocr.models.common.modules", "mmocr.models.common.layers",
+              "mmocr.models.textrecog.encoders", "mmocr.models.textrecog.decoders",
+              "mmocr.models.textrecog.convertors"]:
+        _pkg(p)
+    tm = _load("mmocr.models.common.modules.transformer_module",
+               "mmocr/models/common/modules/transformer_module.py")
+    mods = sys.modules["mmocr.models.common.modules"]
+    for n in ["ScaledDotProductAttention", "MultiHeadAttention", "PositionwiseFeedForward",
+              "PositionalEncoding"]:
+        setattr(mods, n, getattr(tm, n))
+    tl = _load("mmocr.models.common.layers.transformer_layers",
+               "mmocr/models/common/layers/transformer_layers.py")
+    common = sys.modules["mmocr.models.common"]
+    common.TFEncoderLayer, common.TFDecoderLayer = tl.TFEncoderLayer, tl.TFDecoderLayer
+    common.PositionalEncoding = tm.PositionalEncoding
+    _loaded["transformer_module"], _loaded["transformer_layers"] = tm, tl
+    _load("mmocr.models.textrecog.encoders.base_encoder", f"{base}/encoders/base_encoder.py")
+    _loaded["nrtr_encoder"] = _load("mmocr.models.textrecog.encoders.nrtr_encoder",
+                                    f"{base}/encoders/nrtr_encoder.py")
+    _load("mmocr.models.textrecog.decoders.base_decoder", f"{base}/decoders/base_decoder.py")
+    _loaded["nrtr_decoder"] = _load("mmocr.models.textrecog.decoders.nrtr_decoder",
+                                    f"{base}/decoders/nrtr_decoder.py")
+    _load("mmocr.models.textrecog.convertors.base", f"{base}/convertors/base.py")
+    _loaded["attn_convertor"] = _load("mmocr.models.textrecog.convertors.attn",
+                                      f"{base}/convertors/attn.py")
     return _loaded

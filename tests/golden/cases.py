@@ -184,3 +184,46 @@ def nrtr_state_rule(name, shape):
 
 def g8_inputs():
     return dict(img=synth.smooth_image((G8_N, 3, 32, 100), "g8.img", 8))
+
+
+# ---- G9 / G10: recogniser head, small: 2 layers, 2 heads of 64 ------
+HD_SMALL = dict(n_layers=2, n_head=2, d_k=64, d_v=64, d_model=128, d_inner=64)
+HD_N, HD_HW = 3, (2, 10)
+HD_RATIOS = [1.0, 0.6, 0.33]          # valid_ratio per image: key masks of 20, 12 and 7 tokens
+HD_MAXLEN = 8
+HD_KEEP = ("position_enc.position_table",)
+START_IDX, END_IDX, PAD_IDX, NUM_CLASSES = 91, 91, 92, 93   # AttnConvertor(DICT90, with_unknown=True)
+
+
+def head_state_rule(name, shape):
+    if ("norm" in name) and name.endswith(".weight"):
+        return (0.25, 1.0)            # LayerNorm gamma ~ 1
+    if name == "trg_word_emb.weight":
+        return (0.5, 0.0)
+    if name == "classifier.weight":
+        return (4.0 / np.sqrt(shape[1]), 0.0)   # spread the logits: greedy arg-max far from ties
+    return None
+
+
+def g9_inputs(d_model=HD_SMALL["d_model"], n=HD_N, hw=HD_HW, tag="g9"):
+    return dict(feat=synth.dyadic((n, d_model) + tuple(hw), tag + ".feat", 9))
+
+
+def g10_inputs(d_model=HD_SMALL["d_model"], n=HD_N, t=HD_HW[0] * HD_HW[1]):
+    out_enc = synth.dyadic((n, t, d_model), "g10.out_enc", 10)
+    # teacher-forcing targets: <BOS>, a few characters, <EOS>, <PAD>...
+    body = ((synth.dyadic((n, HD_MAXLEN), "g10.tok", 10) + 1.0) * 45.0).astype(np.int64) % 90
+    tgt = np.full((n, HD_MAXLEN), PAD_IDX, dtype=np.int64)
+    for i, ln in enumerate([5, 3, 6][:n]):
+        tgt[i, 0] = START_IDX
+        tgt[i, 1:1 + ln] = body[i, :ln]
+        tgt[i, 1 + ln] = END_IDX
+    return dict(out_enc=out_enc, padded_targets=tgt)
+
+
+# ---- G11: the head at the reference's default size (6+6 layers, 8 heads, d_model 512), N=2 --------
+G11_N, G11_HW = 2, (4, 16)            # backbone output of a 32x128 image with strides [2,1,2,1,2]
+
+
+def g11_inputs():
+    return dict(feat=synth.dyadic((G11_N, 512) + G11_HW, "g11.feat", 11))

@@ -188,7 +188,12 @@ def case_g4(R):
         json.dump({"TPS_PP": {k: list(v.shape) for k, v in m.state_dict().items()},
                    "TPSPreprocessor(20,(32,100),(32,100),3)": {
                        k: list(v.shape) for k, v in R["tps_preprocessor"].TPSPreprocessor(
-                           20, (32, 100), (32, 100), 3).state_dict().items()}}, f, indent=1)
+                           20, (32, 100), (32, 100), 3).state_dict().items()},
+                   "NRTREncoder": {k: list(v.shape)
+                                   for k, v in R["nrtr_encoder"].NRTREncoder().state_dict().items()},
+                   "NRTRDecoder": {k: list(v.shape) for k, v in R["nrtr_decoder"].NRTRDecoder(
+                       num_classes=93, start_idx=91, padding_idx=92, max_seq_len=40).state_dict().items()}},
+                  f, indent=1)
     print("  wrote state_dict_keys.json")
 
 
@@ -243,8 +248,85 @@ def case_g8(R):
     save("nrtr_stem", out=out.numpy())
 
 
+def _head_modules(R, small):
+    cfg = dict(cases.HD_SMALL) if small else {}
+    enc = R["nrtr_encoder"].NRTREncoder(**cfg).eval()
+    dcfg = dict(cfg)
+    if small:
+        dcfg["d_embedding"] = cfg["d_model"]
+    # the recogniser passes these four from the convertor (encode_decode_recognizer.py:62-66)
+    dcfg.update(num_classes=cases.NUM_CLASSES, start_idx=cases.START_IDX, padding_idx=cases.PAD_IDX,
+                max_seq_len=cases.HD_MAXLEN if small else 40)
+    dec = R["nrtr_decoder"].NRTRDecoder(**dcfg).eval()
+    for m, seed in ((enc, 9), (dec, 10)):
+        sd = cases.synth_state(m.state_dict(), seed, cases.head_state_rule, cases.HD_KEEP)
+        m.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    return enc, dec
+
+
+def case_g9(R):
+    """NRTR encoder, small, with and without the valid_ratio key mask."""
+    from oracle import nrtr_oracle as NO
+    enc, _ = _head_modules(R, True)
+    feat = cases.g9_inputs()["feat"]
+    metas = [dict(valid_ratio=r) for r in cases.HD_RATIOS]
+    with torch.no_grad():
+        out_m = enc(t(feat), metas)
+        out_n = enc(t(feat), None)
+    sd = dict(enc.state_dict())
+    o_m = NO.encoder_forward(sd, feat, cases.HD_SMALL["n_head"], cases.HD_RATIOS)
+    o_n = NO.encoder_forward(sd, feat, cases.HD_SMALL["n_head"], None)
+    assert biteq(o_m.numpy(), out_m.numpy()) and biteq(o_n.numpy(), out_n.numpy()), "encoder oracle != reference"
+    save("nrtr_encoder", out_masked=out_m.numpy(), out_nomask=out_n.numpy())
+
+
+def case_g10(R):
+    """NRTR decoder, small: teacher-forced logits and greedy decoding scores."""
+    from oracle import nrtr_oracle as NO
+    _, dec = _head_modules(R, True)
+    inp = cases.g10_inputs()
+    metas = [dict(valid_ratio=r) for r in cases.HD_RATIOS]
+    with torch.no_grad():
+        logits = dec(None, t(inp["out_enc"]), dict(padded_targets=t(inp["padded_targets"])), metas, train_mode=True)
+        probs = dec(None, t(inp["out_enc"]), None, metas, train_mode=False)
+        probs_nomask = dec(None, t(inp["out_enc"]), None, None, train_mode=False)
+    sd = dict(dec.state_dict())
+    nh = cases.HD_SMALL["n_head"]
+    o_l = NO.decoder_forward_train(sd, inp["out_enc"], inp["padded_targets"], nh, cases.PAD_IDX, cases.HD_RATIOS)
+    o_p = NO.decoder_forward_test(sd, inp["out_enc"], nh, cases.HD_MAXLEN, cases.START_IDX, cases.PAD_IDX,
+                                  cases.HD_RATIOS)
+    assert biteq(o_l.numpy(), logits.numpy()) and biteq(o_p.numpy(), probs.numpy()), "decoder oracle != reference"
+    assert biteq(NO.sinusoid_table(200, 128).numpy(), sd["position_enc.position_table"].numpy())
+    save("nrtr_decoder", logits=logits.numpy(), probs=probs.numpy(), probs_nomask=probs_nomask.numpy())
+
+
+def case_g11(R):
+    """Encoder + greedy decoder + convertor at the reference's default size."""
+    from oracle import nrtr_oracle as NO
+    enc, dec = _head_modules(R, False)
+    conv = R["attn_convertor"].AttnConvertor(dict_type="DICT90", with_unknown=True)
+    assert (conv.start_idx, conv.end_idx, conv.padding_idx, conv.num_classes()) == \
+        (cases.START_IDX, cases.END_IDX, cases.PAD_IDX, cases.NUM_CLASSES)
+    feat = cases.g11_inputs()["feat"]
+    with torch.no_grad():
+        out_enc = enc(t(feat), None)
+        out_dec = dec(None, out_enc, None, None, train_mode=False)
+    idx, scores = conv.tensor2idx(out_dec, None)
+    text = conv.idx2str(idx)
+    o = NO.head_simple_test(dict(enc.state_dict()), dict(dec.state_dict()), feat)
+    assert biteq(o["out_enc"].numpy(), out_enc.numpy()) and biteq(o["out_dec"].numpy(), out_dec.numpy())
+    assert o["indexes"] == idx and o["text"] == text
+    assert NO.attn_dictionary()[0] == conv.idx2char
+    tgt = conv.str2tensor(["hello", "W0rld!"])["padded_targets"].numpy()
+    print("  texts:", text)
+    save("nrtr_head_full", out_enc_sub=np.ascontiguousarray(out_enc.numpy()[:, :, ::8]), out_dec=out_dec.numpy(),
+         argmax=out_dec.argmax(-1).numpy().astype(np.int32),
+         text=np.array(text), idx_len=np.array([len(i) for i in idx], dtype=np.int32),
+         str2tensor_targets=tgt)
+
+
 CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1, g1_pin=case_g1_pin,
-             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8)
+             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11)
 
 
 def main(argv):

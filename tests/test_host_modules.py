@@ -171,3 +171,62 @@ def test_nrtr_stem_mirror_layout_and_registry():
         assert m.eval()._forward_torch(torch.zeros(1, 3, 32, 100)).shape == torch.Size([1, 512, 1, 25])
     with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 32, 100))
+
+
+# ---- recogniser head mirrors ----------------------------------------------
+def test_head_state_dict_layout_and_registries():
+    import json
+    import os
+    import tps_pp_amd as P
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")))
+    enc = P.build_encoder(dict(type="NRTREncoder"))
+    dec = P.build_decoder(dict(type="NRTRDecoder", num_classes=93, start_idx=91, padding_idx=92, max_seq_len=40))
+    assert {k: list(v.shape) for k, v in enc.state_dict().items()} == keys["NRTREncoder"]
+    assert {k: list(v.shape) for k, v in dec.state_dict().items()} == keys["NRTRDecoder"]
+    # the config of the reference builds end to end (configs/textrecog/nrtr/nrtr_tps++.py:23-42)
+    label_convertor = dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True)
+    m = P.build_detector(dict(type="NRTR",
+                              backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3],
+                                            strides=[2, 1, 2, 1, 2]),
+                              tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder"),
+                              decoder=dict(type="NRTRDecoder"), loss=dict(type="TFLoss"),
+                              label_convertor=label_convertor, max_seq_len=40))
+    assert (m.decoder.start_idx, m.decoder.padding_idx, m.decoder.max_seq_len) == (91, 92, 40)
+    assert m.decoder.classifier.out_features == 92 and m.decoder.trg_word_emb.num_embeddings == 93
+    with pytest.raises(Exception, match="GPU"):
+        m.simple_test(torch.zeros(1, 3, 32, 128), [dict(resize_shape=(32, 128, 3))])
+    with pytest.raises(NotImplementedError):
+        m.forward_train(torch.zeros(1, 3, 32, 128), [dict()])
+
+
+def test_attn_convertor_matches_the_reference():
+    import tps_pp_amd as P
+    G = cases.load("nrtr_head_full")
+    c = P.build_convertor(dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True, max_seq_len=40))
+    assert (c.unknown_idx, c.start_idx, c.end_idx, c.padding_idx, c.num_classes()) == (90, 91, 91, 92, 93)
+    assert np.array_equal(c.str2tensor(["hello", "W0rld!"])["padded_targets"].numpy(), G["str2tensor_targets"])
+    idx, scores = c.tensor2idx(torch.from_numpy(G["out_dec"]))
+    assert c.idx2str(idx) == [str(s) for s in G["text"]] and [len(i) for i in idx] == G["idx_len"].tolist()
+    assert all(abs(s - float(G["out_dec"][0, j].max())) < 1e-7 for j, s in enumerate(scores[0]))
+    assert c.str2idx(["aé"]) == [[10, 90]]                       # unknown character -> <UKN>
+    c36 = P.AttnConvertor(dict_type="DICT36", with_unknown=False, lower=True, start_end_same=False)
+    assert (c36.start_idx, c36.end_idx, c36.padding_idx) == (36, 37, 38) and c36.str2idx(["AB"]) == [[10, 11]]
+    with pytest.raises(Exception):
+        c36.str2idx(["!"])
+    # <EOS> ends a string, <PAD> is skipped
+    out = torch.zeros(1, 5, 92)
+    for t, k in enumerate([10, 11, 91, 12, 13]):
+        out[0, t, k] = 1.0
+    assert c.idx2str(c.tensor2idx(out)[0]) == ["ab"]
+
+
+def test_head_rejects_unsupported_configurations():
+    import tps_pp_amd as P
+    with pytest.raises(NotImplementedError):
+        P.NRTREncoder(d_k=32, n_head=16)
+    with pytest.raises(NotImplementedError):
+        P.NRTREncoder(operation_order=("self_attn", "norm", "ffn", "norm"))
+    with pytest.raises(NotImplementedError):
+        P.NRTREncoder(act_cfg=dict(type="Relu"))
+    with pytest.raises(Exception, match="GPU"):
+        P.NRTREncoder(n_layers=1)(torch.zeros(1, 512, 2, 4))

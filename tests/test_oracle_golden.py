@@ -187,3 +187,61 @@ def test_oracle_edge_cases(oracle):
     empty = oracle.warp(np.zeros((0, 3, 32, 100), np.float32), np.zeros((0, 20, 2), np.float32),
                         Kc["inv_delta_C"], Kc["P_hat"], (32, 100))
     assert empty["out0"].shape == (0, 3, 32, 100)
+
+
+# ---- recogniser head: oracle/nrtr_oracle.py vs the reference's outputs -----
+def _head_state(kind, small):
+    """The synthetic state_dict the fixtures were generated with, rebuilt without the reference: key
+    names and shapes from the mirror modules (their layout is pinned in tests/test_host_modules.py)."""
+    import tps_pp_amd as P
+    cfg = dict(cases.HD_SMALL) if small else {}
+    if kind == "enc":
+        m, seed = P.NRTREncoder(**cfg), 9
+    else:
+        extra = dict(d_embedding=cfg["d_model"]) if small else {}
+        m, seed = P.NRTRDecoder(num_classes=cases.NUM_CLASSES, start_idx=cases.START_IDX,
+                                padding_idx=cases.PAD_IDX, max_seq_len=cases.HD_MAXLEN if small else 40,
+                                **cfg, **extra), 10
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    for k, v in cases.synth_state(m.state_dict(), seed, cases.head_state_rule, cases.HD_KEEP).items():
+        sd[k] = torch.from_numpy(v)
+    return sd
+
+
+def test_nrtr_encoder_oracle_bit_exact():
+    from oracle import nrtr_oracle as NO
+    G = cases.load("nrtr_encoder")
+    sd = _head_state("enc", True)
+    feat = cases.g9_inputs()["feat"]
+    nh = cases.HD_SMALL["n_head"]
+    assert np.array_equal(NO.encoder_forward(sd, feat, nh, cases.HD_RATIOS).numpy(), G["out_masked"])
+    assert np.array_equal(NO.encoder_forward(sd, feat, nh, None).numpy(), G["out_nomask"])
+
+
+def test_nrtr_decoder_oracle_bit_exact():
+    from oracle import nrtr_oracle as NO
+    G = cases.load("nrtr_decoder")
+    sd = _head_state("dec", True)
+    inp = cases.g10_inputs()
+    nh = cases.HD_SMALL["n_head"]
+    assert np.array_equal(sd["position_enc.position_table"].numpy(), NO.sinusoid_table(200, 128).numpy())
+    lo = NO.decoder_forward_train(sd, inp["out_enc"], inp["padded_targets"], nh, cases.PAD_IDX, cases.HD_RATIOS)
+    assert np.array_equal(lo.numpy(), G["logits"])
+    pr = NO.decoder_forward_test(sd, inp["out_enc"], nh, cases.HD_MAXLEN, cases.START_IDX, cases.PAD_IDX,
+                                 cases.HD_RATIOS)
+    assert np.array_equal(pr.numpy(), G["probs"])
+    pr = NO.decoder_forward_test(sd, inp["out_enc"], nh, cases.HD_MAXLEN, cases.START_IDX, cases.PAD_IDX, None)
+    assert np.array_equal(pr.numpy(), G["probs_nomask"])
+
+
+def test_nrtr_head_full_oracle_and_convertor():
+    from oracle import nrtr_oracle as NO
+    G = cases.load("nrtr_head_full")
+    o = NO.head_simple_test(_head_state("enc", False), _head_state("dec", False), cases.g11_inputs()["feat"])
+    assert np.array_equal(o["out_enc"].numpy()[:, :, ::8], G["out_enc_sub"])
+    assert np.array_equal(o["out_dec"].numpy(), G["out_dec"])
+    assert o["text"] == [str(s) for s in G["text"]]
+    assert [len(i) for i in o["indexes"]] == G["idx_len"].tolist()
+    idx2char, unk, start, end, pad = NO.attn_dictionary()
+    assert (unk, start, end, pad, len(idx2char)) == (90, cases.START_IDX, cases.END_IDX, cases.PAD_IDX,
+                                                     cases.NUM_CLASSES)

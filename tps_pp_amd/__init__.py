@@ -5,14 +5,20 @@ binding), and the host-side mirrors of the reference's module API (`TPSPreproces
 registries).  Importing the package does not touch the GPU or load the native library; the first op
 does, and raises if libtpspp_hip.so is missing (no fallback).
 """
-from .registry import (BACKBONES, PREPROCESSOR, build_backbone, build_preprocessor,  # noqa: F401
-                       register_into_mmocr)
+from .registry import (BACKBONES, PREPROCESSOR, ENCODERS, DECODERS, CONVERTORS, DETECTORS,  # noqa: F401
+                       build_backbone, build_preprocessor, build_encoder, build_decoder, build_convertor,
+                       build_detector, register_into_mmocr)
 from .tps_preprocessor import TPSPreprocessor, LocalizationNetwork, GridGenerator  # noqa: F401
 from .tps_pp import TPS_PP, Attention_Enhanced_TPS  # noqa: F401
 from .resnet_v2_large import ResNetABI_v2_large, BasicBlock  # noqa: F401
 from .nrtr_modality_transformer import NRTRModalityTransform  # noqa: F401
+from .nrtr_head import (NRTREncoder, NRTRDecoder, AttnConvertor, BaseConvertor,  # noqa: F401
+                        EncodeDecodeRecognizer, NRTR, TFEncoderLayer, TFDecoderLayer, MultiHeadAttention,
+                        PositionwiseFeedForward, PositionalEncoding)
 
 __all__ = ["BACKBONES", "PREPROCESSOR", "build_backbone", "build_preprocessor",
            "register_into_mmocr", "TPSPreprocessor", "LocalizationNetwork", "GridGenerator",
            "TPS_PP", "Attention_Enhanced_TPS", "ResNetABI_v2_large", "BasicBlock",
-           "NRTRModalityTransform"]
+           "NRTRModalityTransform", "ENCODERS", "DECODERS", "CONVERTORS", "DETECTORS", "build_encoder",
+           "build_decoder", "build_convertor", "build_detector", "NRTREncoder", "NRTRDecoder", "AttnConvertor",
+           "BaseConvertor", "EncodeDecodeRecognizer", "NRTR"]

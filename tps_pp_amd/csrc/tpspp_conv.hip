@@ -53,7 +53,7 @@ struct ConvParams {
     const float* post_shift;  //                 the activation, nrtr_modality_transformer.py:42-48)
     float* out;               // (N, Cout, Ho, Wo)
     int N, Cin, Cout, Hi, Wi, Ho, Wo, sh, sw, ph, pw;
-    int relu;                 // 1: ReLU
+    int relu;                 // activation: 0 none, 1 ReLU, 2 GELU (exact erf form, nn.GELU default)
     int res_mode;             // 1: out = act(conv + bias) + res; 2: out = act(conv + bias + res)
 };
 
@@ -142,7 +142,8 @@ conv_igemm_f32_kernel(const ConvParams P)
                     if (P.bias) v = v + P.bias[co];
                     const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
                     if (P.res_mode == 2) v = v + P.res[o];
-                    if (P.relu) v = v > 0.0f ? v : 0.0f;
+                    if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+                    else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     if (P.res_mode == 1) v = v + P.res[o];
                     if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
                     P.out[o] = v;
@@ -288,7 +289,8 @@ conv_tiled_f32_kernel(const ConvParams P)
                     if (P.bias) v = v + P.bias[co];
                     const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
                     if (P.res_mode == 2) v = v + P.res[o];
-                    if (P.relu) v = v > 0.0f ? v : 0.0f;
+                    if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+                    else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                     if (P.res_mode == 1) v = v + P.res[o];
                     if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
                     P.out[o] = v;
@@ -394,7 +396,8 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
     TPSPP_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "tpspp_conv2d_fwd: post_scale/post_shift come together");
     P.wt = weight_t; P.bias = bias; P.res = residual; P.out = out;
     P.post_scale = post_scale; P.post_shift = post_shift;
-    P.relu = relu ? 1 : 0; P.res_mode = res_mode;
+    TPSPP_REQUIRE(relu >= 0 && relu <= 2, "tpspp_conv2d_fwd: activation code must be 0 (none), 1 (ReLU) or 2 (GELU)");
+    P.relu = relu; P.res_mode = res_mode;
     if (N == 0) return TPSPP_OK;
     hipStream_t st = tpspp::as_stream(stream);
     if (weight_tiled && g_conv_force_generic == 0) {

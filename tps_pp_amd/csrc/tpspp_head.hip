@@ -1,0 +1,625 @@
+// The recogniser head that consumes the rectified features: NRTR
+// transformer encoder and greedy transformer decoder, fp32, one call per batch each.
+//
+// Replaces (reference, mmocr/models/): textrecog/encoders/nrtr_encoder.py:67-87,
+// textrecog/decoders/nrtr_decoder.py:95-113,131-177, common/layers/transformer_layers.py:57-75,133-163,
+// common/modules/transformer_module.py:24-33,75-99,119-125,155-163.
+//
+// Data layout: every activation is a CHANNEL-MAJOR matrix X[c][m] (row = feature, column = token,
+// m = image*T + token for the encoder, m = image for one decoder step), i.e. exactly the (1, C, 1, M)
+// "image" of a 1x1 convolution.  All projections therefore run on the library's fp32 MFMA
+// convolution kernel (tpspp_conv.hip) with bias / GELU / residual fused in its epilogue and columns
+// contiguous in every load and store; the encoder's NCHW input needs one re-layout on entry.  Where a
+// consumer wants TOKEN-major rows (the decoder's q/k/v of one step, the cross-attention values) the
+// same kernel is called with the operands swapped (the activation as its "weights", the prepared
+// weight as its "image"): D[m][cout] instead of D[cout][m], no transpose kernel.
+//
+// The decoder is incremental: the reference re-runs the whole padded target (41 positions) through all
+// layers at each of its 40 steps and keeps one row; with a causal mask that row depends only on earlier
+// positions, so one position per step against cached self-attention keys/values gives the same numbers
+// (up to summation order) with 1/41 of the arithmetic.  The encoder keys/values of the cross attention
+// are projected once per layer.  The whole loop is enqueued without host synchronisation: the arg-max
+// of step s is written to a device token buffer that step s+1's embedding kernel reads.
+//
+// Bounds: projections: MFMA (fp32 matrix rate); LayerNorm / attention kernels: HBM / L2 (one pass over
+// their operands), LDS-broadcast reads in the encoder attention.
+#include <cmath>
+
+#include "tpspp_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kDK = 64;                 // head width (d_k = d_v = 64: every NRTR config of the reference)
+constexpr int kKRow = kDK + 4;          // LDS row stride of the staged keys / values (16-B aligned rows)
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ---- re-layouts ---------------------------------------------------------------------------------
+// (N, C, T) -> (C, N*T): out[c][b*T + t] = in[b][c][t]   (rows of T stay contiguous on both sides)
+__global__ void __launch_bounds__(256)
+nct_to_cm_kernel(const float* __restrict__ in, int N, int C, int T, float* __restrict__ out)
+{
+    const size_t total = (size_t)N * C * T;
+    const size_t M = (size_t)N * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = i / M, m = i - c * M;
+        const size_t b = m / T, t = m - b * T;
+        out[i] = in[(b * C + c) * T + t];
+    }
+}
+
+// out (cols, rows) = in (rows, cols)^T through a padded 32x32 LDS tile
+__global__ void __launch_bounds__(256)
+transpose2d_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        tile[ty + k][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][ty + k];
+    }
+}
+
+// ---- LayerNorm over the rows of a channel-major matrix ----------------------------------------------
+// y[c][m] = (x[c][m] - mean_m) * rstd_m * gamma[c] + beta[c];  mean / biased variance over c.
+// Workgroup = 64 columns x 4 channel slices; every global access is a 256-B row segment.
+__global__ void __launch_bounds__(256)
+layernorm_cm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                    int C, int M, float eps, float* __restrict__ y)
+{
+    __shared__ float red[4][kWave];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const int m = blockIdx.x * kWave + lane;
+    const bool ok = m < M;
+    const int mm = ok ? m : M - 1;
+    const int cs = (C + 3) / 4;
+    const int c_lo = wv * cs, c_hi = min(C, c_lo + cs);
+    float s = 0.0f;
+    for (int c = c_lo; c < c_hi; ++c) s += x[(size_t)c * M + mm];
+    red[wv][lane] = s;
+    __syncthreads();
+    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    __syncthreads();
+    float v = 0.0f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float d = x[(size_t)c * M + mm] - mean;
+        v = fmaf(d, d, v);
+    }
+    red[wv][lane] = v;
+    __syncthreads();
+    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const size_t o = (size_t)c * M + m;
+        y[o] = (x[o] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// ---- encoder self-attention -------------------------------------------------------------------------
+// qkv (3C, M) channel-major, M = N*T; head h of image b: rows [64h, 64h+64) of each third, columns
+// [bT, bT+T).  Workgroup = one (image, head, block of <=256 queries): the head's keys and values are
+// staged in LDS ([key][feature], read back as wavefront-wide broadcasts), one query per thread with q
+// and the output accumulator in registers.  Two passes over the keys (row maximum, then exp / sum /
+// weighted values): scores are recomputed rather than stored, so T is bounded only by LDS (T <= 256).
+// Keys >= valid_len[b] are masked (nrtr_encoder.py:51-65: the first ceil(T*valid_ratio) tokens count).
+__global__ void __launch_bounds__(256)
+attn_enc_kernel(const float* __restrict__ qkv, int C, int M, int T, const int* __restrict__ valid_len,
+                float* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                         // [T][kKRow]
+    float* Vs = smem + (size_t)T * kKRow;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const size_t col0 = (size_t)b * T;
+    for (int d = wv; d < kDK; d += nw) {
+        const float* kr = qkv + (size_t)(C + kDK * h + d) * M + col0;
+        const float* vr = qkv + (size_t)(2 * C + kDK * h + d) * M + col0;
+        for (int j = lane; j < T; j += kWave) {
+            Ks[j * kKRow + d] = kr[j];
+            Vs[j * kKRow + d] = vr[j];
+        }
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T) return;
+    int nvalid = valid_len ? valid_len[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    float q[kDK];
+#pragma unroll
+    for (int d = 0; d < kDK; ++d) q[d] = qkv[(size_t)(kDK * h + d) * M + col0 + i] * 0.125f;   // q / sqrt(d_k)
+
+    auto score = [&](int j) {
+        const float4* kr = reinterpret_cast<const float4*>(Ks + j * kKRow);
+        float s = 0.0f;
+#pragma unroll
+        for (int d4 = 0; d4 < kDK / 4; ++d4) {
+            const float4 kv = kr[d4];
+            s = fmaf(q[4 * d4 + 0], kv.x, s);
+            s = fmaf(q[4 * d4 + 1], kv.y, s);
+            s = fmaf(q[4 * d4 + 2], kv.z, s);
+            s = fmaf(q[4 * d4 + 3], kv.w, s);
+        }
+        return s;
+    };
+    float mx = -INFINITY;
+    for (int j = 0; j < nvalid; ++j) mx = fmaxf(mx, score(j));
+    float acc[kDK];
+#pragma unroll
+    for (int d = 0; d < kDK; ++d) acc[d] = 0.0f;
+    float l = 0.0f;
+    for (int j = 0; j < nvalid; ++j) {
+        const float p = expf(score(j) - mx);
+        l += p;
+        const float4* vr = reinterpret_cast<const float4*>(Vs + j * kKRow);
+#pragma unroll
+        for (int d4 = 0; d4 < kDK / 4; ++d4) {
+            const float4 vv = vr[d4];
+            acc[4 * d4 + 0] = fmaf(p, vv.x, acc[4 * d4 + 0]);
+            acc[4 * d4 + 1] = fmaf(p, vv.y, acc[4 * d4 + 1]);
+            acc[4 * d4 + 2] = fmaf(p, vv.z, acc[4 * d4 + 2]);
+            acc[4 * d4 + 3] = fmaf(p, vv.w, acc[4 * d4 + 3]);
+        }
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < kDK; ++d) out[(size_t)(kDK * h + d) * M + col0 + i] = acc[d] * inv;
+}
+
+// ---- decoder, one step: embedding + position table ----------------------------------------------------
+// x[c][b] = emb[tokens[b][step]][c] + pos[step][c]      (nrtr_decoder.py:96-98, no scaling)
+__global__ void __launch_bounds__(256)
+dec_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pos, const int* __restrict__ tokens,
+                 int Lt, int step, int C, int Nb, float* __restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * Nb) return;
+    const int c = i / Nb, b = i - c * Nb;
+    const int tok = tokens[(size_t)b * Lt + step];
+    x[i] = emb[(size_t)tok * C + c] + pos[(size_t)step * C + c];
+}
+
+// ---- decoder, one step: masked self-attention against the cache ------------------------------------------
+// qkv_t (Nb, 3C) TOKEN-major (this step's projections).  One wavefront per (image, head); lane = feature
+// while loading / accumulating, lane = position while scoring.  Cache: Kc[b][h][feature][Lmax] (a lane
+// per position reads coalesced), Vc[b][h][position][64] (a lane per feature reads coalesced).  The new
+// position is used from registers, so nothing written by this kernel is read back by it.
+// Key p is valid iff p <= step and tokens[b][p] != <PAD>  (nrtr_decoder.py:100-102).
+__global__ void __launch_bounds__(256)
+attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
+                     float* __restrict__ Kc, float* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
+                     int pad_idx, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair - b * H;
+    const float* base = qkv_t + (size_t)b * 3 * C + kDK * h;
+    const float q = base[lane] * 0.125f;
+    const float k = base[C + lane];
+    const float v = base[2 * C + lane];
+    const size_t bh = (size_t)b * H + h;
+    float* kc = Kc + bh * kDK * Lmax;
+    float* vc = Vc + bh * Lmax * kDK;
+    kc[(size_t)lane * Lmax + step] = k;
+    vc[(size_t)step * kDK + lane] = v;
+
+    const int pl = lane < step ? lane : 0;                // clamped: lanes >= step are masked below
+    float sc = 0.0f;
+    if (step > 0) {
+#pragma unroll 16
+        for (int d = 0; d < kDK; ++d) sc = fmaf(readlane_f(q, d), kc[(size_t)d * Lmax + pl], sc);
+    }
+    const float cur = wave_sum(q * k);
+    if (lane == step) sc = cur;
+    const bool valid = lane <= step && tokens[(size_t)b * Lt + (lane <= step ? lane : 0)] != pad_idx;
+    sc = valid ? sc : -INFINITY;
+    const float mx = wave_max(sc);
+    float p = valid ? expf(sc - mx) : 0.0f;
+    const float l = wave_sum(p);
+    p = p / l;
+    float acc = readlane_f(p, step) * v;
+    for (int pos = 0; pos < step; ++pos) acc = fmaf(readlane_f(p, pos), vc[(size_t)pos * kDK + lane], acc);
+    out[(size_t)(kDK * h + lane) * Nb + b] = acc;
+}
+
+// ---- decoder, one step: cross-attention against the encoder ------------------------------------------------
+// q_t (Nb, C) token-major; Kx (C, Nb*T) channel-major (a lane per encoder token reads coalesced);
+// Vx_t (Nb*T, C) token-major (a lane per feature reads coalesced).  One wavefront per (image, head),
+// T <= 256 (four tokens per lane).  Keys >= valid_len[b] are masked (nrtr_decoder.py:115-129).
+__global__ void __launch_bounds__(256)
+attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ Kx, const float* __restrict__ Vx_t,
+                      int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair - b * H;
+    const float q = q_t[(size_t)b * C + kDK * h + lane] * 0.125f;
+    int nvalid = valid_len ? valid_len[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    const size_t MT = (size_t)Nb * T;
+    const float* kbase = Kx + (size_t)(kDK * h) * MT + (size_t)b * T;
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        sc[jj] = -INFINITY;
+        if (jj * kWave < nvalid) {                         // wave-uniform
+            const int t = jj * kWave + lane;
+            const int tt = t < T ? t : T - 1;
+            float s = 0.0f;
+#pragma unroll 16
+            for (int d = 0; d < kDK; ++d) s = fmaf(readlane_f(q, d), kbase[(size_t)d * MT + tt], s);
+            sc[jj] = t < nvalid ? s : -INFINITY;
+            mx = fmaxf(mx, sc[jj]);
+        }
+    }
+    mx = wave_max(mx);
+    float l = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        sc[jj] = sc[jj] == -INFINITY ? 0.0f : expf(sc[jj] - mx);
+        l += sc[jj];
+    }
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+    const float* vbase = Vx_t + ((size_t)b * T) * C + kDK * h + lane;
+    float acc = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int cnt = min(kWave, nvalid - jj * kWave);   // wave-uniform
+        const float pj = sc[jj] * inv;
+        for (int tl = 0; tl < cnt; ++tl)
+            acc = fmaf(readlane_f(pj, tl), vbase[(size_t)(jj * kWave + tl) * C], acc);
+    }
+    out[(size_t)(kDK * h + lane) * Nb + b] = acc;
+}
+
+// ---- decoder, one step: classifier epilogue ------------------------------------------------------------------
+// logits (Cc, Nb) channel-major.  Greedy: out[b][step][:] = softmax(logits[:, b]) and
+// tokens[b][step+1] = arg-max (first maximum)  (nrtr_decoder.py:168-175).  Forced: out = raw logits.
+__global__ void __launch_bounds__(256)
+dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, int L, int greedy,
+                    float* __restrict__ out, int* __restrict__ tokens, int Lt)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Nb) return;
+    float* o = out + ((size_t)b * L + step) * Cc;
+    if (!greedy) {
+        for (int c = 0; c < Cc; ++c) o[c] = logits[(size_t)c * Nb + b];
+        return;
+    }
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < Cc; ++c) {
+        const float v = logits[(size_t)c * Nb + b];
+        if (v > mx) { mx = v; am = c; }
+    }
+    float sum = 0.0f;
+    for (int c = 0; c < Cc; ++c) sum += expf(logits[(size_t)c * Nb + b] - mx);
+    for (int c = 0; c < Cc; ++c) o[c] = expf(logits[(size_t)c * Nb + b] - mx) / sum;
+    tokens[(size_t)b * Lt + step + 1] = am;
+}
+
+__global__ void __launch_bounds__(256)
+dec_init_tokens_kernel(int* __restrict__ tokens, int Nb, int Lt, int start_idx, int pad_idx,
+                       const int* __restrict__ forced, int Lf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nb * Lt) return;
+    const int b = i / Lt, p = i - b * Lt;
+    if (forced) tokens[i] = p < Lf ? forced[(size_t)b * Lf + p] : pad_idx;
+    else tokens[i] = p == 0 ? start_idx : pad_idx;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+struct Gemm {
+    hipStream_t st;
+    int rc = 0;
+    // out (Co, M) = act(W^T X + bias) [+ res]      W (K, Co) k-major, X (K, M) channel-major
+    void cm(const float* W, const float* bias, const float* X, int K, int Co, int M, float* out, int act,
+            const float* res)
+    {
+        if (rc) return;
+        const float* src[1] = {X};
+        const int dims[5] = {K, 1, M, 1, 1};
+        rc = tpspp_conv2d_fwd(src, dims, 1, W, (K % 32 == 0) ? W : nullptr, bias, res, nullptr, nullptr,
+                              res ? 1 : 0, act, 1, Co, 1, 1, 1, 1, out, 1, M, st);
+    }
+    // out (M, Co) token-major = X^T W           (operands swapped: X plays the weights, W the image)
+    void tm(const float* W, const float* X, int K, int Co, int M, float* out)
+    {
+        if (rc) return;
+        const float* src[1] = {W};
+        const int dims[5] = {K, 1, Co, 1, 1};
+        rc = tpspp_conv2d_fwd(src, dims, 1, X, (K % 32 == 0) ? X : nullptr, nullptr, nullptr, nullptr, nullptr,
+                              0, 0, 1, M, 1, 1, 1, 1, out, 1, Co, st);
+    }
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Carver {
+    char* p;
+    size_t left;
+    bool ok = true;
+    float* f(size_t n)
+    {
+        const size_t bytes = align256(n * sizeof(float));
+        if (bytes > left) { ok = false; return nullptr; }
+        float* r = reinterpret_cast<float*>(p);
+        p += bytes; left -= bytes;
+        return r;
+    }
+};
+
+size_t enc_ws_bytes(int N, int C, int T, int Di)
+{
+    const size_t M = (size_t)N * T;
+    return align256((size_t)C * M * 4) * 3 + align256((size_t)3 * C * M * 4) + align256((size_t)Di * M * 4);
+}
+
+size_t dec_ws_bytes(int N, int C, int T, int Di, int n_layers, int L, int Cc)
+{
+    const size_t MT = (size_t)N * T;
+    size_t s = 0;
+    s += (size_t)n_layers * 2 * align256((size_t)C * MT * 4);                // Kx, Vx_t per layer
+    s += (size_t)n_layers * 2 * align256((size_t)N * C * (size_t)L * 4);      // self-attention caches
+    s += 3 * align256((size_t)C * N * 4);                                    // x, y, a
+    s += align256((size_t)3 * C * N * 4);                                    // qkv_t
+    s += align256((size_t)Di * N * 4);                                       // hidden
+    s += align256((size_t)Cc * N * 4);                                       // logits
+    s += align256((size_t)N * (L + 1) * 4);                                  // tokens
+    return s;
+}
+
+}  // namespace
+
+TPSPP_EXPORT size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner)
+{
+    if (N <= 0 || C <= 0 || T <= 0 || d_inner <= 0) return 0;
+    return enc_ws_bytes(N, C, T, d_inner);
+}
+
+TPSPP_EXPORT size_t tpspp_nrtr_decoder_workspace(int N, int C, int T, int d_inner, int n_layers, int max_seq_len,
+                                                 int num_out)
+{
+    if (N <= 0 || C <= 0 || T <= 0 || d_inner <= 0 || n_layers <= 0 || max_seq_len <= 0 || num_out <= 0) return 0;
+    return dec_ws_bytes(N, C, T, d_inner, n_layers, max_seq_len, num_out);
+}
+
+TPSPP_EXPORT int tpspp_transpose2d(const float* in, int rows, int cols, float* out, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(in && out && rows > 0 && cols > 0, "tpspp_transpose2d: bad argument");
+    const dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    TPSPP_REQUIRE(grid.y <= 65535, "tpspp_transpose2d: too many rows");
+    hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, tpspp::as_stream(stream), in, rows, cols, out);
+    return tpspp::check_launch("tpspp_transpose2d");
+}
+
+TPSPP_EXPORT int tpspp_layernorm_cm_fwd(const float* x, const float* gamma, const float* beta, int C, int M,
+                                        float eps, float* y, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(x && gamma && beta && y && C > 0 && M > 0, "tpspp_layernorm_cm_fwd: bad argument");
+    hipLaunchKernelGGL(layernorm_cm_kernel, dim3((unsigned)((M + kWave - 1) / kWave)), dim3(256), 0,
+                       tpspp::as_stream(stream), x, gamma, beta, C, M, eps, y);
+    return tpspp::check_launch("tpspp_layernorm_cm_fwd");
+}
+
+static int launch_attn_enc(const float* qkv, int N, int C, int T, const int* valid_len, float* out, hipStream_t st)
+{
+    const int H = C / kDK;
+    const size_t M = (size_t)N * T;
+    const size_t lds = (size_t)2 * T * kKRow * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_enc_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    const int threads = kWave * ((T + kWave - 1) / kWave < 4 ? (T + kWave - 1) / kWave : 4);
+    const dim3 grid((unsigned)((T + threads - 1) / threads), (unsigned)H, (unsigned)N);
+    hipLaunchKernelGGL(attn_enc_kernel, grid, dim3(threads), lds, st, qkv, C, (int)M, T, valid_len, out);
+    return tpspp::check_launch("attn_enc_kernel");
+}
+
+TPSPP_EXPORT int tpspp_attn_enc_fwd(const float* qkv, int N, int C, int T, const int* valid_len, float* out,
+                                    tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(qkv && out && N > 0 && T > 0 && C > 0 && C % kDK == 0, "tpspp_attn_enc_fwd: bad argument (C must be a multiple of 64)");
+    TPSPP_REQUIRE(T <= 256, "tpspp_attn_enc_fwd: at most 256 tokens per image");
+    TPSPP_REQUIRE(N <= 65535 && (size_t)N * T < (1u << 31), "tpspp_attn_enc_fwd: batch too large");
+    return launch_attn_enc(qkv, N, C, T, valid_len, out, tpspp::as_stream(stream));
+}
+
+// layer pointer tables: see include/tpspp.h
+enum { E_LN1G, E_LN1B, E_WQKV, E_BQKV, E_WFC, E_BFC, E_LN2G, E_LN2B, E_W1, E_B1, E_W2, E_B2, E_COUNT };
+enum { D_LN1G, D_LN1B, D_WQKV, D_BQKV, D_WFC, D_BFC, D_LN2G, D_LN2B, D_WQ, D_BQ, D_WK, D_BK, D_WV, D_BV, D_WFC2,
+       D_BFC2, D_LN3G, D_LN3B, D_W1, D_B1, D_W2, D_B2, D_COUNT };
+
+TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
+                                        const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
+                                        const int* valid_len, void* workspace, size_t workspace_bytes,
+                                        float* out_cm, float* out_ntc, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(feat && layer_ptrs && ln_g && ln_b && workspace && (out_cm || out_ntc),
+                  "tpspp_nrtr_encoder_fwd: null pointer");
+    TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0,
+                  "tpspp_nrtr_encoder_fwd: bad sizes (d_model must be a multiple of 64 = n_head * 64)");
+    TPSPP_REQUIRE(T <= 256, "tpspp_nrtr_encoder_fwd: at most 256 tokens per image");
+    TPSPP_REQUIRE(N <= 65535 && (size_t)N * T * 3 * C < ((size_t)1 << 40), "tpspp_nrtr_encoder_fwd: batch too large");
+    TPSPP_REQUIRE(workspace_bytes >= enc_ws_bytes(N, C, T, d_inner),
+                  "tpspp_nrtr_encoder_fwd: workspace too small (%zu < %zu)", workspace_bytes,
+                  enc_ws_bytes(N, C, T, d_inner));
+    for (int l = 0; l < n_layers; ++l) {
+        const float* const* w = layer_ptrs + (size_t)l * E_COUNT;
+        TPSPP_REQUIRE(w[E_LN1G] && w[E_LN1B] && w[E_WQKV] && w[E_WFC] && w[E_LN2G] && w[E_LN2B] && w[E_W1] && w[E_W2],
+                      "tpspp_nrtr_encoder_fwd: layer %d has a null weight", l);
+    }
+    hipStream_t st = tpspp::as_stream(stream);
+    const int M = N * T;
+    Carver cv{reinterpret_cast<char*>(workspace), workspace_bytes};
+    float* x = cv.f((size_t)C * M);
+    float* y = cv.f((size_t)C * M);
+    float* a = cv.f((size_t)C * M);
+    float* qkv = cv.f((size_t)3 * C * M);
+    float* hid = cv.f((size_t)d_inner * M);
+    TPSPP_REQUIRE(cv.ok, "tpspp_nrtr_encoder_fwd: workspace carve failed");
+
+    {
+        const size_t total = (size_t)N * C * T;
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
+        hipLaunchKernelGGL(nct_to_cm_kernel, dim3(blocks), dim3(256), 0, st, feat, N, C, T, x);
+    }
+    Gemm g{st};
+    int rc = 0;
+    for (int l = 0; l < n_layers && !rc && !g.rc; ++l) {
+        const float* const* w = layer_ptrs + (size_t)l * E_COUNT;
+        // x = x + fc(attn(LN1(x)))                                   transformer_layers.py:67-70
+        rc = tpspp_layernorm_cm_fwd(x, w[E_LN1G], w[E_LN1B], C, M, 1e-5f, y, stream);
+        if (rc) break;
+        g.cm(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 0, nullptr);
+        if (g.rc) break;
+        rc = launch_attn_enc(qkv, N, C, T, valid_len, a, st);
+        if (rc) break;
+        g.cm(w[E_WFC], w[E_BFC], a, C, C, M, y, 0, x);               // y = x + fc(a)
+        // x = y + w2(gelu(w1(LN2(y))))                                transformer_layers.py:72-75
+        rc = tpspp_layernorm_cm_fwd(y, w[E_LN2G], w[E_LN2B], C, M, 1e-5f, a, stream);
+        if (rc) break;
+        g.cm(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 2, nullptr);
+        g.cm(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 0, y);
+    }
+    if (rc) return rc;
+    if (g.rc) return g.rc;
+    float* fin = out_cm ? out_cm : y;
+    rc = tpspp_layernorm_cm_fwd(x, ln_g, ln_b, C, M, 1e-5f, fin, stream);    // nrtr_encoder.py:85
+    if (rc) return rc;
+    if (out_ntc) return tpspp_transpose2d(fin, C, M, out_ntc, stream);        // (C, N*T) -> (N, T, C)
+    return TPSPP_OK;
+}
+
+TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
+                                        const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
+                                        const float* emb, const float* pos_table, int n_position,
+                                        const float* w_cls, const float* b_cls, int num_out, int max_seq_len,
+                                        int start_idx, int padding_idx, const int* valid_len,
+                                        const int* forced_tokens, void* workspace, size_t workspace_bytes,
+                                        float* out, int* tokens_out, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(enc_cm && layer_ptrs && ln_g && ln_b && emb && pos_table && w_cls && workspace && out,
+                  "tpspp_nrtr_decoder_fwd: null pointer");
+    TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0 && num_out > 0,
+                  "tpspp_nrtr_decoder_fwd: bad sizes (d_model must be a multiple of 64 = n_head * 64)");
+    TPSPP_REQUIRE(T <= 256, "tpspp_nrtr_decoder_fwd: at most 256 encoder tokens per image");
+    TPSPP_REQUIRE(max_seq_len >= 1 && max_seq_len <= kWave, "tpspp_nrtr_decoder_fwd: max_seq_len must be in [1, 64]");
+    TPSPP_REQUIRE(n_position >= max_seq_len, "tpspp_nrtr_decoder_fwd: position table shorter than max_seq_len");
+    TPSPP_REQUIRE(workspace_bytes >= dec_ws_bytes(N, C, T, d_inner, n_layers, max_seq_len, num_out),
+                  "tpspp_nrtr_decoder_fwd: workspace too small");
+    for (int l = 0; l < n_layers; ++l) {
+        const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+        TPSPP_REQUIRE(w[D_LN1G] && w[D_LN1B] && w[D_WQKV] && w[D_WFC] && w[D_LN2G] && w[D_LN2B] && w[D_WQ] &&
+                          w[D_WK] && w[D_WV] && w[D_WFC2] && w[D_LN3G] && w[D_LN3B] && w[D_W1] && w[D_W2],
+                      "tpspp_nrtr_decoder_fwd: layer %d has a null weight", l);
+        TPSPP_REQUIRE(!w[D_BQKV] && !w[D_BQ] && !w[D_BV],
+                      "tpspp_nrtr_decoder_fwd: biases on token-major projections (self q/k/v, cross q, cross v) "
+                      "are not supported (the reference builds them with qkv_bias=False)");
+    }
+    hipStream_t st = tpspp::as_stream(stream);
+    const int H = C / kDK, L = max_seq_len, Lt = L + 1;
+    const int MT = N * T;
+    Carver cv{reinterpret_cast<char*>(workspace), workspace_bytes};
+    float *Kx[64], *Vx[64], *Kc[64], *Vc[64];
+    TPSPP_REQUIRE(n_layers <= 64, "tpspp_nrtr_decoder_fwd: at most 64 layers");
+    for (int l = 0; l < n_layers; ++l) {
+        Kx[l] = cv.f((size_t)C * MT);
+        Vx[l] = cv.f((size_t)C * MT);
+        Kc[l] = cv.f((size_t)N * C * L);
+        Vc[l] = cv.f((size_t)N * C * L);
+    }
+    float* x = cv.f((size_t)C * N);
+    float* y = cv.f((size_t)C * N);
+    float* a = cv.f((size_t)C * N);
+    float* qkv = cv.f((size_t)3 * C * N);
+    float* hid = cv.f((size_t)d_inner * N);
+    float* logits = cv.f((size_t)num_out * N);
+    int* tokens = reinterpret_cast<int*>(cv.f((size_t)N * Lt));
+    TPSPP_REQUIRE(cv.ok, "tpspp_nrtr_decoder_fwd: workspace carve failed");
+
+    Gemm g{st};
+    // encoder keys (channel-major) and values (token-major) of every layer, once
+    for (int l = 0; l < n_layers; ++l) {
+        const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+        g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
+        g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);
+    }
+    if (g.rc) return g.rc;
+    hipLaunchKernelGGL(dec_init_tokens_kernel, dim3((unsigned)((N * Lt + 255) / 256)), dim3(256), 0, st, tokens, N,
+                       Lt, start_idx, padding_idx, forced_tokens, L);
+    const int greedy = forced_tokens ? 0 : 1;
+    const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
+    int rc = 0;
+    for (int s = 0; s < L; ++s) {
+        hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
+                           tokens, Lt, s, C, N, x);
+        for (int l = 0; l < n_layers; ++l) {
+            const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+            // x = x + fc(self_attn(LN1(x)))                          transformer_layers.py:150-154
+            rc = tpspp_layernorm_cm_fwd(x, w[D_LN1G], w[D_LN1B], C, N, 1e-5f, y, stream);
+            if (rc) return rc;
+            g.tm(w[D_WQKV], y, C, 3 * C, N, qkv);
+            hipLaunchKernelGGL(attn_dec_self_kernel, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
+                               Vc[l], tokens, Lt, padding_idx, a);
+            g.cm(w[D_WFC], w[D_BFC], a, C, C, N, y, 0, x);            // y = x + fc(a)
+            // x = y + fc(enc_attn(LN2(y), enc, enc))                   transformer_layers.py:156-159
+            rc = tpspp_layernorm_cm_fwd(y, w[D_LN2G], w[D_LN2B], C, N, 1e-5f, a, stream);
+            if (rc) return rc;
+            g.tm(w[D_WQ], a, C, C, N, qkv);
+            hipLaunchKernelGGL(attn_dec_cross_kernel, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C, N, H,
+                               T, valid_len, a);
+            g.cm(w[D_WFC2], w[D_BFC2], a, C, C, N, x, 0, y);          // x = y + fc(a)
+            // x = x + mlp(LN3(x))                                       transformer_layers.py:161-163
+            rc = tpspp_layernorm_cm_fwd(x, w[D_LN3G], w[D_LN3B], C, N, 1e-5f, a, stream);
+            if (rc) return rc;
+            g.cm(w[D_W1], w[D_B1], a, C, d_inner, N, hid, 2, nullptr);
+            g.cm(w[D_W2], w[D_B2], hid, d_inner, C, N, y, 0, x);      // y = x + w2(...)
+            float* t = x; x = y; y = t;
+            if (g.rc) return g.rc;
+        }
+        rc = tpspp_layernorm_cm_fwd(x, ln_g, ln_b, C, N, 1e-6f, y, stream);   // nrtr_decoder.py:77,111
+        if (rc) return rc;
+        g.cm(w_cls, b_cls, y, C, num_out, N, logits, 0, nullptr);
+        if (g.rc) return g.rc;
+        hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, logits, num_out,
+                           N, s, L, greedy, out, tokens, Lt);
+    }
+    if (tokens_out)
+        (void)hipMemcpyAsync(tokens_out, tokens, (size_t)N * Lt * sizeof(int), hipMemcpyDeviceToDevice, st);
+    return tpspp::check_launch("tpspp_nrtr_decoder_fwd");
+}

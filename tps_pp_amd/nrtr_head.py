@@ -1,0 +1,458 @@
+"""The recogniser head that consumes the rectified features: NRTR encoder, NRTR decoder, the attention
+label convertor and the encode-decode recogniser, behind the reference's API.
+
+Mirrors (mmocr/models/): `common/modules/transformer_module.py:36-163` (MultiHeadAttention,
+PositionwiseFeedForward, PositionalEncoding), `common/layers/transformer_layers.py:9-163`
+(TFEncoderLayer, TFDecoderLayer), `textrecog/encoders/nrtr_encoder.py:12-87`,
+`textrecog/decoders/nrtr_decoder.py:14-177`, `textrecog/convertors/{base,attn}.py`,
+`textrecog/recognizer/encode_decode_recognizer.py:15-221`: same constructor arguments, the same
+`state_dict` keys (released checkpoints load), the same call contracts and return values.
+
+The sub-modules below only HOLD parameters (so `state_dict` matches); the arithmetic of a whole
+encoder / decoder call is one C-ABI call (`tpspp_nrtr_encoder_fwd` / `tpspp_nrtr_decoder_fwd`) that
+enqueues hand-written HIP kernels: there is no CPU or library-kernel path, and the modules raise on CPU
+tensors or under training.  The decoder is incremental (one position per step against cached
+keys/values) where the reference re-runs the padded sequence every step; results agree to fp32
+rounding (see tests/test_gpu_head.py).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import (CONVERTORS, DECODERS, DETECTORS, ENCODERS, build_backbone, build_convertor,
+                       build_decoder, build_encoder, build_preprocessor)
+
+
+def _check_act(act_cfg):
+    if act_cfg.get("type") not in ("mmcv.GELU", "GELU"):
+        raise NotImplementedError(f"activation {act_cfg!r}: the HIP head implements the reference's default "
+                                  "(mmcv.GELU, erf form) only")
+
+
+class MultiHeadAttention(nn.Module):
+    """Parameter holder: `linear_q/k/v` (dim_k -> dim_k), `fc` (dim_v -> d_model)."""
+
+    def __init__(self, n_head=8, d_model=512, d_k=64, d_v=64, dropout=0.1, qkv_bias=False):
+        super().__init__()
+        if d_k != 64 or d_v != 64:
+            raise NotImplementedError("the HIP head is built for d_k = d_v = 64 (every NRTR config of the reference)")
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.dim_k, self.dim_v = n_head * d_k, n_head * d_v
+        self.linear_q = nn.Linear(self.dim_k, self.dim_k, bias=qkv_bias)
+        self.linear_k = nn.Linear(self.dim_k, self.dim_k, bias=qkv_bias)
+        self.linear_v = nn.Linear(self.dim_v, self.dim_v, bias=qkv_bias)
+        self.fc = nn.Linear(self.dim_v, d_model, bias=qkv_bias)
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_in, d_hid, dropout=0.1, act_cfg=dict(type="Relu")):
+        super().__init__()
+        _check_act(act_cfg)
+        self.w_1 = nn.Linear(d_in, d_hid)
+        self.w_2 = nn.Linear(d_hid, d_in)
+
+
+class PositionalEncoding(nn.Module):
+    """Fixed sinusoid table, registered as the buffer `position_table` (1, n_position, d_hid)."""
+
+    def __init__(self, d_hid=512, n_position=200, dropout=0):
+        super().__init__()
+        # float64 powers rounded to fp32, fp32 product with the position, sin / cos
+        # (transformer_module.py:141-153)
+        den = torch.Tensor([1.0 / np.power(10000, 2 * (j // 2) / d_hid) for j in range(d_hid)]).view(1, -1)
+        tab = torch.arange(n_position).unsqueeze(-1).float() * den
+        tab[:, 0::2] = torch.sin(tab[:, 0::2])
+        tab[:, 1::2] = torch.cos(tab[:, 1::2])
+        self.register_buffer("position_table", tab.unsqueeze(0))
+
+
+_ENC_ORDER = ("norm", "self_attn", "norm", "ffn")
+_DEC_ORDER = ("norm", "self_attn", "norm", "enc_dec_attn", "norm", "ffn")
+
+
+class TFEncoderLayer(nn.Module):
+    def __init__(self, d_model=512, d_inner=256, n_head=8, d_k=64, d_v=64, dropout=0.1, qkv_bias=False,
+                 act_cfg=dict(type="mmcv.GELU"), operation_order=None):
+        super().__init__()
+        self.attn = MultiHeadAttention(n_head, d_model, d_k, d_v, qkv_bias=qkv_bias, dropout=dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.mlp = PositionwiseFeedForward(d_model, d_inner, dropout=dropout, act_cfg=act_cfg)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.operation_order = operation_order or _ENC_ORDER
+        if tuple(self.operation_order) != _ENC_ORDER:
+            raise NotImplementedError("the HIP head implements the default pre-norm operation order only")
+
+
+class TFDecoderLayer(nn.Module):
+    def __init__(self, d_model=512, d_inner=256, n_head=8, d_k=64, d_v=64, dropout=0.1, qkv_bias=False,
+                 act_cfg=dict(type="mmcv.GELU"), operation_order=None):
+        super().__init__()
+        if qkv_bias:
+            raise NotImplementedError("decoder projections with bias are not supported by the HIP head")
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.self_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout, qkv_bias=qkv_bias)
+        self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout, qkv_bias=qkv_bias)
+        self.mlp = PositionwiseFeedForward(d_model, d_inner, dropout=dropout, act_cfg=act_cfg)
+        self.operation_order = operation_order or _DEC_ORDER
+        if tuple(self.operation_order) != _DEC_ORDER:
+            raise NotImplementedError("the HIP head implements the default pre-norm operation order only")
+
+
+def _state_key(module):
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def _valid_len(img_metas, n, t, device):
+    """`_get_mask` of encoder and decoder: the first min(T, ceil(T * valid_ratio)) tokens are valid."""
+    if img_metas is None:
+        return None
+    ratios = [m.get("valid_ratio", 1.0) for m in img_metas]
+    if len(ratios) != n:
+        raise ValueError("img_metas must hold one dict per image")
+    return torch.tensor([min(t, math.ceil(t * r)) for r in ratios], dtype=torch.int32, device=device)
+
+
+@ENCODERS.register_module()
+class NRTREncoder(nn.Module):
+    """Transformer encoder; `forward(feat (N, C, H, W), img_metas=None) -> (N, H*W, C)`."""
+
+    def __init__(self, n_layers=6, n_head=8, d_k=64, d_v=64, d_model=512, d_inner=256, dropout=0.1,
+                 init_cfg=None, **kwargs):
+        super().__init__()
+        self.init_cfg = init_cfg
+        if d_model != n_head * d_k:
+            raise ValueError("d_model must equal n_head * d_k (linear_q maps dim_k -> dim_k)")
+        self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
+        self.layer_stack = nn.ModuleList([
+            TFEncoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout, **kwargs) for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d_model)
+
+    def init_weights(self):
+        pass
+
+    def _weights(self):
+        key = _state_key(self)
+        cache = getattr(self, "_w_cache", None)
+        if cache is None or cache[0] != key:
+            ts = []
+            for lyr in self.layer_stack:
+                a = lyr.attn
+                wqkv = torch.cat([ops.kmajor(a.linear_q.weight), ops.kmajor(a.linear_k.weight),
+                                  ops.kmajor(a.linear_v.weight)], dim=1).contiguous()
+                bqkv = None if a.linear_q.bias is None else \
+                    torch.cat([_f32(a.linear_q.bias), _f32(a.linear_k.bias), _f32(a.linear_v.bias)]).contiguous()
+                ts += [_f32(lyr.norm1.weight), _f32(lyr.norm1.bias), wqkv, bqkv, ops.kmajor(a.fc.weight),
+                       None if a.fc.bias is None else _f32(a.fc.bias), _f32(lyr.norm2.weight), _f32(lyr.norm2.bias),
+                       ops.kmajor(lyr.mlp.w_1.weight), _f32(lyr.mlp.w_1.bias), ops.kmajor(lyr.mlp.w_2.weight),
+                       _f32(lyr.mlp.w_2.bias)]
+            cache = (key, ops.PtrTable(ts), _f32(self.layer_norm.weight), _f32(self.layer_norm.bias))
+            self._w_cache = cache
+        return cache[1:]
+
+    def forward(self, feat, img_metas=None):
+        ops.require_gpu(feat, "NRTREncoder", self.training or torch.is_grad_enabled() and feat.requires_grad)
+        table, g, b = self._weights()
+        n, c, h, w = feat.shape
+        if c != self.d_model:
+            raise ValueError(f"NRTREncoder: feature width {c} != d_model {self.d_model}")
+        vl = _valid_len(img_metas, n, h * w, feat.device)
+        out, out_cm = ops.nrtr_encoder(feat.float(), table, len(self.layer_stack), self.d_inner, g, b, vl, holder=self)
+        out._tpspp_cm = out_cm          # lets NRTRDecoder skip the re-layout of its input
+        return out
+
+
+@DECODERS.register_module()
+class NRTRDecoder(nn.Module):
+    """Transformer decoder; `forward(feat, out_enc, targets_dict=None, img_metas=None, train_mode=True)`.
+    `train_mode=False`: greedy decoding -> per-step softmax scores (N, max_seq_len, num_classes - 1).
+    `train_mode=True`: teacher-forced raw logits of `targets_dict['padded_targets']` (inference of the
+    training graph only: no autograd)."""
+
+    def __init__(self, n_layers=6, d_embedding=512, n_head=8, d_k=64, d_v=64, d_model=512, d_inner=256,
+                 n_position=200, dropout=0.1, num_classes=93, max_seq_len=40, start_idx=1, padding_idx=92,
+                 init_cfg=None, **kwargs):
+        super().__init__()
+        self.init_cfg = init_cfg
+        if d_model != n_head * d_k or d_embedding != d_model:
+            raise ValueError("d_model must equal n_head * d_k and d_embedding")
+        self.padding_idx, self.start_idx, self.max_seq_len = padding_idx, start_idx, max_seq_len
+        self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
+        self.trg_word_emb = nn.Embedding(num_classes, d_embedding, padding_idx=padding_idx)
+        self.position_enc = PositionalEncoding(d_embedding, n_position=n_position)
+        self.layer_stack = nn.ModuleList([
+            TFDecoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout, **kwargs) for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
+        self.classifier = nn.Linear(d_model, num_classes - 1)      # <PAD> is never predicted
+
+    def init_weights(self):
+        pass
+
+    def _weights(self):
+        key = _state_key(self)
+        cache = getattr(self, "_w_cache", None)
+        if cache is None or cache[0] != key:
+            ts = []
+            for lyr in self.layer_stack:
+                sa, ea = lyr.self_attn, lyr.enc_attn
+                wqkv = torch.cat([ops.kmajor(sa.linear_q.weight), ops.kmajor(sa.linear_k.weight),
+                                  ops.kmajor(sa.linear_v.weight)], dim=1).contiguous()
+                ts += [_f32(lyr.norm1.weight), _f32(lyr.norm1.bias), wqkv, None, ops.kmajor(sa.fc.weight), None,
+                       _f32(lyr.norm2.weight), _f32(lyr.norm2.bias), ops.kmajor(ea.linear_q.weight), None,
+                       ops.kmajor(ea.linear_k.weight), None, ops.kmajor(ea.linear_v.weight), None,
+                       ops.kmajor(ea.fc.weight), None, _f32(lyr.norm3.weight), _f32(lyr.norm3.bias),
+                       ops.kmajor(lyr.mlp.w_1.weight), _f32(lyr.mlp.w_1.bias), ops.kmajor(lyr.mlp.w_2.weight),
+                       _f32(lyr.mlp.w_2.bias)]
+            cache = (key, ops.PtrTable(ts), _f32(self.layer_norm.weight), _f32(self.layer_norm.bias),
+                     _f32(self.trg_word_emb.weight), _f32(self.position_enc.position_table[0]),
+                     ops.kmajor(self.classifier.weight), _f32(self.classifier.bias))
+            self._w_cache = cache
+        return cache[1:]
+
+    def _run(self, out_enc, img_metas, forced):
+        ops.require_gpu(out_enc, "NRTRDecoder", torch.is_grad_enabled() and out_enc.requires_grad)
+        n, t, c = out_enc.shape
+        if c != self.d_model:
+            raise ValueError(f"NRTRDecoder: encoder width {c} != d_model {self.d_model}")
+        enc_cm = getattr(out_enc, "_tpspp_cm", None)
+        if enc_cm is None or tuple(enc_cm.shape) != (c, n * t):
+            enc_cm = ops.transpose2d(out_enc.float().reshape(n * t, c))
+        table, g, b, emb, pos, wc, bc = self._weights()
+        vl = _valid_len(img_metas, n, t, out_enc.device)
+        seq_len = self.max_seq_len if forced is None else forced.shape[1]
+        out, tokens = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, g, b, emb, pos, wc, bc,
+                                       seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self)
+        self.last_tokens = tokens
+        return out
+
+    def forward_train(self, feat, out_enc, targets_dict, img_metas):
+        targets = targets_dict["padded_targets"].to(out_enc.device).to(torch.int32).contiguous()
+        return self._run(out_enc, img_metas, targets)
+
+    def forward_test(self, feat, out_enc, img_metas):
+        return self._run(out_enc, img_metas, None)
+
+    def forward(self, feat, out_enc, targets_dict=None, img_metas=None, train_mode=True):
+        self.train_mode = train_mode
+        if train_mode:
+            return self.forward_train(feat, out_enc, targets_dict, img_metas)
+        return self.forward_test(feat, out_enc, img_metas)
+
+
+@CONVERTORS.register_module()
+class BaseConvertor:
+    """Text <-> index conversion (`convertors/base.py`)."""
+    start_idx = end_idx = padding_idx = 0
+    unknown_idx = None
+    lower = False
+    DICT36 = tuple("0123456789abcdefghijklmnopqrstuvwxyz")
+    DICT90 = tuple("0123456789abcdefghijklmnopqrstuvwxyz"
+                   "ABCDEFGHIJKLMNOPQRSTUVWXYZ!\"#$%&'()"
+                   "*+,-./:;<=>?@[\\]_`~")
+
+    def __init__(self, dict_type="DICT90", dict_file=None, dict_list=None):
+        assert dict_type in ("DICT36", "DICT90")
+        assert dict_file is None or isinstance(dict_file, str)
+        assert dict_list is None or isinstance(dict_list, list)
+        if dict_file is not None:
+            with open(dict_file, encoding="utf-8") as f:
+                self.idx2char = [ln.strip() for ln in (x.rstrip("\n\r") for x in f) if ln.strip() != ""]
+        elif dict_list is not None:
+            self.idx2char = dict_list
+        else:
+            self.idx2char = list(self.DICT36 if dict_type == "DICT36" else self.DICT90)
+        self.char2idx = {ch: i for i, ch in enumerate(self.idx2char)}
+
+    def num_classes(self):
+        return len(self.idx2char)
+
+    def str2idx(self, strings):
+        assert isinstance(strings, list)
+        indexes = []
+        for string in strings:
+            if self.lower:
+                string = string.lower()
+            index = []
+            for char in string:
+                char_idx = self.char2idx.get(char, self.unknown_idx)
+                if char_idx is None:
+                    raise Exception(f"Chararcter: {char} not in dict, please check gt_label and use custom "
+                                    'dict file, or set "with_unknown=True"')
+                index.append(char_idx)
+            indexes.append(index)
+        return indexes
+
+    def str2tensor(self, strings):
+        raise NotImplementedError
+
+    def idx2str(self, indexes):
+        assert isinstance(indexes, list)
+        return ["".join(self.idx2char[i] for i in index) for index in indexes]
+
+    def tensor2idx(self, output):
+        raise NotImplementedError
+
+
+@CONVERTORS.register_module()
+class AttnConvertor(BaseConvertor):
+    """`convertors/attn.py`: <UKN>, <BOS/EOS>, <PAD> appended to the dictionary; `tensor2idx` takes the
+    per-step arg-max, skips <PAD> and stops at <EOS>."""
+
+    def __init__(self, dict_type="DICT90", dict_file=None, dict_list=None, with_unknown=True, max_seq_len=40,
+                 lower=False, start_end_same=True, **kwargs):
+        super().__init__(dict_type, dict_file, dict_list)
+        assert isinstance(with_unknown, bool) and isinstance(max_seq_len, int) and isinstance(lower, bool)
+        self.with_unknown, self.max_seq_len, self.lower = with_unknown, max_seq_len, lower
+        self.start_end_same = start_end_same
+        self.update_dict()
+
+    def update_dict(self):
+        self.unknown_idx = None
+        if self.with_unknown:
+            self.idx2char.append("<UKN>")
+            self.unknown_idx = len(self.idx2char) - 1
+        self.idx2char.append("<BOS/EOS>")
+        self.start_idx = len(self.idx2char) - 1
+        if not self.start_end_same:
+            self.idx2char.append("<BOS/EOS>")
+        self.end_idx = len(self.idx2char) - 1
+        self.idx2char.append("<PAD>")
+        self.padding_idx = len(self.idx2char) - 1
+        self.char2idx = {ch: i for i, ch in enumerate(self.idx2char)}
+
+    def str2tensor(self, strings):
+        assert isinstance(strings, list) and all(isinstance(s, str) for s in strings)
+        tensors, padded_targets = [], []
+        for index in self.str2idx(strings):
+            tensor = torch.LongTensor(index)
+            tensors.append(tensor)
+            src = torch.LongTensor(tensor.size(0) + 2).fill_(0)
+            src[-1], src[0] = self.end_idx, self.start_idx
+            src[1:-1] = tensor
+            padded = (torch.ones(self.max_seq_len) * self.padding_idx).long()
+            if src.size(0) > self.max_seq_len:
+                padded = src[:self.max_seq_len]
+            else:
+                padded[:src.size(0)] = src
+            padded_targets.append(padded)
+        return {"targets": tensors, "padded_targets": torch.stack(padded_targets, 0).long()}
+
+    def tensor2idx(self, outputs, img_metas=None):
+        # one device->host copy for the batch instead of the reference's two per image
+        max_value, max_idx = torch.max(outputs, -1)
+        max_idx, max_value = max_idx.cpu().numpy().tolist(), max_value.cpu().numpy().tolist()
+        indexes, scores = [], []
+        for row_idx, row_val in zip(max_idx, max_value):
+            str_index, str_score = [], []
+            for char_index, char_score in zip(row_idx, row_val):
+                if char_index == self.padding_idx:
+                    continue
+                if char_index == self.end_idx:
+                    break
+                str_index.append(char_index)
+                str_score.append(char_score)
+            indexes.append(str_index)
+            scores.append(str_score)
+        return indexes, scores
+
+
+@DETECTORS.register_module()
+class EncodeDecodeRecognizer(nn.Module):
+    """`recognizer/encode_decode_recognizer.py`: preprocessor -> backbone (with the TPS++ network called
+    inside it) -> encoder -> decoder -> label convertor.  Inference (`simple_test`, `aug_test`,
+    `forward(..., return_loss=False)`) runs on the HIP kernels; training raises (row F2)."""
+
+    def __init__(self, preprocessor=None, backbone=None, encoder=None, decoder=None, tpsnet=None, loss=None,
+                 label_convertor=None, train_cfg=None, test_cfg=None, max_seq_len=40, pretrained=None,
+                 kd_loss=False, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+        assert label_convertor is not None
+        label_convertor = dict(label_convertor, max_seq_len=max_seq_len)
+        self.label_convertor = build_convertor(label_convertor)
+        self.preprocessor = build_preprocessor(preprocessor) if preprocessor is not None else None
+        assert backbone is not None
+        self.backbone = build_backbone(backbone)
+        self.tpsnet = build_backbone(tpsnet) if tpsnet is not None else None
+        self.kd_loss = kd_loss
+        self.encoder = build_encoder(encoder) if encoder is not None else None
+        if decoder is not None:
+            decoder = dict(decoder, num_classes=self.label_convertor.num_classes(),
+                           start_idx=self.label_convertor.start_idx, padding_idx=self.label_convertor.padding_idx,
+                           max_seq_len=max_seq_len)
+            self.decoder = build_decoder(decoder)
+        else:
+            self.decoder = None
+        self.loss_cfg = None if loss is None else dict(loss, ignore_index=self.label_convertor.padding_idx)
+        self.train_cfg, self.test_cfg, self.max_seq_len = train_cfg, test_cfg, max_seq_len
+
+    def extract_feat(self, img, test=False, **kwargs):
+        if self.preprocessor is not None:
+            img = self.preprocessor(img)
+        if self.tpsnet is not None:
+            return self.backbone(img, self.tpsnet, test)
+        return self.backbone(img)
+
+    def forward_train(self, img, img_metas, **kwargs):
+        raise NotImplementedError("the HIP path is forward-only (SURVEY.md section 8f, row F2)")
+
+    def simple_test(self, img, img_metas, **kwargs):
+        for img_meta in img_metas:
+            img_meta["valid_ratio"] = 1.0 * img_meta["resize_shape"][1] / img.size(-1)
+        feat = self.extract_feat(img, test=True)
+        if isinstance(feat, dict):
+            feat = feat["output"]
+        out_enc = self.encoder(feat, img_metas) if self.encoder is not None else None
+        if self.decoder is not None:
+            out_dec = self.decoder(feat, out_enc, None, img_metas, train_mode=False)
+        else:
+            out_dec = out_enc
+        label_indexes, label_scores = self.label_convertor.tensor2idx(out_dec, img_metas)
+        label_strings = self.label_convertor.idx2str(label_indexes)
+        return [dict(text=s, score=sc) for s, sc in zip(label_strings, label_scores)]
+
+    def merge_aug_results(self, aug_results):
+        out_text, out_score = "", -1
+        for result in aug_results:
+            text = result[0]["text"]
+            score = sum(result[0]["score"]) / max(1, len(text))
+            if score > out_score:
+                out_text, out_score = text, score
+        return [dict(text=out_text, score=out_score)]
+
+    def aug_test(self, imgs, img_metas, **kwargs):
+        return self.merge_aug_results([self.simple_test(i, m, **kwargs) for i, m in zip(imgs, img_metas)])
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """`BaseRecognizer.forward_test` (recognizer/base.py:49-72): a list = test-time augmentation."""
+        if isinstance(imgs, list):
+            assert len(imgs) > 0
+            assert imgs[0].size(0) == 1, f"aug test does not support inference with batch size {imgs[0].size(0)}"
+            assert len(imgs) == len(img_metas)
+            return self.aug_test(imgs, img_metas, **kwargs)
+        return self.simple_test(imgs, img_metas, **kwargs)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """`BaseRecognizer.forward` (recognizer/base.py:74-92)."""
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        if isinstance(img, list):
+            for idx, each_img in enumerate(img):
+                if each_img.dim() == 3:
+                    img[idx] = each_img.unsqueeze(0)
+        elif len(img_metas) == 1 and isinstance(img_metas[0], list):
+            img_metas = img_metas[0]
+        return self.forward_test(img, img_metas, **kwargs)
+
+
+@DETECTORS.register_module()
+class NRTR(EncodeDecodeRecognizer):
+    """`recognizer/nrtr.py`."""

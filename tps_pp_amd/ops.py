@@ -226,7 +226,7 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
 
     srcs: list of 1..3 entries `tensor` or `(tensor, uh, uw)`: channel-concatenated, each nearest-
     upsampled by (uh, uw) on the fly.  cw: ConvWeight from `prep_conv_weight` ("same" padding).
-    residual/res_mode: 1 = act(conv)+res, 2 = act(conv+res)."""
+    residual/res_mode: 1 = act(conv)+res, 2 = act(conv+res).  relu: False/0 none, True/1 ReLU, 2 GELU (erf)."""
     import ctypes
     weight_t, bias, kernel = cw.wt, cw.bias, cw.kernel
     ts, dims = [], []
@@ -261,7 +261,7 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
         rc = _lib.lib().tpspp_conv2d_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
                                          len(ts), _ptr(weight_t), _ptr(cw.tiled), _ptr(bias), _ptr(residual),
                                          _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode),
-                                         int(bool(relu)), N, Cout, kernel, kernel, sh, sw, _ptr(out), Ho, Wo,
+                                         int(relu), N, Cout, kernel, kernel, sh, sw, _ptr(out), Ho, Wo,
                                          _stream(ts[0]))
     _lib.check(rc, "tpspp_conv2d_fwd")
     return out
@@ -451,3 +451,106 @@ def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, ba
     _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group),
                                                 int(kernel_choice), int(bands)),
                "tpspp_warp_set_tuning")
+
+
+# ---- recogniser head (NRTR encoder / decoder): channel-major matrices, K-major weights -------------------
+def transpose2d(x):
+    """(rows, cols) -> (cols, rows) on the device (`tpspp_transpose2d`)."""
+    x = _chk("input", x, 2)
+    r, c = x.shape
+    out = torch.empty((c, r), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_transpose2d(_ptr(x), r, c, _ptr(out), _stream(x))
+    _lib.check(rc, "tpspp_transpose2d")
+    return out
+
+
+def layernorm_cm(x, gamma, beta, eps=1e-5):
+    """LayerNorm over the rows of a channel-major (C, M) matrix (`tpspp_layernorm_cm_fwd`)."""
+    x = _chk("input", x, 2)
+    C, M = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_layernorm_cm_fwd(_ptr(x), _ptr(_chk("gamma", gamma, 1)), _ptr(_chk("beta", beta, 1)),
+                                               C, M, float(eps), _ptr(y), _stream(x))
+    _lib.check(rc, "tpspp_layernorm_cm_fwd")
+    return y
+
+
+def attn_enc(qkv, N, T, valid_len=None):
+    """Encoder multi-head self-attention on projected (3C, N*T) q/k/v (`tpspp_attn_enc_fwd`) -> (C, N*T)."""
+    qkv = _chk("qkv", qkv, 2)
+    C = qkv.shape[0] // 3
+    out = torch.empty((C, N * T), device=qkv.device, dtype=torch.float32)
+    with torch.cuda.device(qkv.device):
+        rc = _lib.lib().tpspp_attn_enc_fwd(_ptr(qkv), N, C, T, _ptr(valid_len), _ptr(out), _stream(qkv))
+    _lib.check(rc, "tpspp_attn_enc_fwd")
+    return out
+
+
+def kmajor(weight):
+    """PyTorch Linear weight (out, in) -> K-major (in, out) fp32 contiguous device copy."""
+    return weight.detach().float().t().contiguous()
+
+
+class PtrTable:
+    """Host array of device pointers (`const float* const*`) + the tensors it points at (kept alive)."""
+
+    def __init__(self, tensors):
+        import ctypes
+        self.keep = list(tensors)
+        self.arr = (ctypes.c_void_p * len(self.keep))(*[None if t is None else t.data_ptr() for t in self.keep])
+        self.ptr = ctypes.cast(self.arr, ctypes.c_void_p)
+
+
+def _workspace(holder, nbytes, device):
+    ws = getattr(holder, "_tpspp_ws", None)
+    if ws is None or ws.numel() < nbytes or ws.device != device:
+        ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        holder._tpspp_ws = ws
+    return ws
+
+
+def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, holder=None, want_ntc=True):
+    """`tpspp_nrtr_encoder_fwd`: feat (N, C, H, W) -> (out (N, T, C) | None, out_cm (C, N*T))."""
+    feat = _chk("feat", feat, 4)
+    N, C, H, W = feat.shape
+    T = H * W
+    L = _lib.lib()
+    nbytes = L.tpspp_nrtr_encoder_workspace(N, C, T, d_inner)
+    ws = _workspace(holder if holder is not None else table, nbytes, feat.device)
+    out_cm = torch.empty((C, N * T), device=feat.device, dtype=torch.float32)
+    out = torch.empty((N, T, C), device=feat.device, dtype=torch.float32) if want_ntc else None
+    with torch.cuda.device(feat.device):
+        rc = L.tpspp_nrtr_encoder_fwd(_ptr(feat), N, C, T, d_inner, n_layers, table.ptr, _ptr(ln_g), _ptr(ln_b),
+                                      _ptr(valid_len), ws.data_ptr(), ws.numel(), _ptr(out_cm), _ptr(out),
+                                      _stream(feat))
+    _lib.check(rc, "tpspp_nrtr_encoder_fwd")
+    return out, out_cm
+
+
+def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, ln_g, ln_b, emb, pos_table, w_cls, b_cls, max_seq_len,
+                 start_idx, padding_idx, valid_len=None, forced_tokens=None, holder=None):
+    """`tpspp_nrtr_decoder_fwd` -> (out (N, L, num_out), tokens (N, L+1) int32)."""
+    enc_cm = _chk("enc_cm", enc_cm, 2)
+    C = enc_cm.shape[0]
+    if enc_cm.shape[1] != N * T:
+        raise ValueError("nrtr_decoder: enc_cm must be (C, N*T)")
+    num_out = w_cls.shape[1]
+    L = _lib.lib()
+    nbytes = L.tpspp_nrtr_decoder_workspace(N, C, T, d_inner, n_layers, max_seq_len, num_out)
+    ws = _workspace(holder if holder is not None else table, nbytes, enc_cm.device)
+    out = torch.empty((N, max_seq_len, num_out), device=enc_cm.device, dtype=torch.float32)
+    tokens = torch.empty((N, max_seq_len + 1), device=enc_cm.device, dtype=torch.int32)
+    if forced_tokens is not None:
+        if forced_tokens.dtype != torch.int32 or tuple(forced_tokens.shape) != (N, max_seq_len) or \
+                not forced_tokens.is_contiguous() or forced_tokens.device != enc_cm.device:
+            raise ValueError("nrtr_decoder: forced_tokens must be a contiguous (N, max_seq_len) int32 device tensor")
+    with torch.cuda.device(enc_cm.device):
+        rc = L.tpspp_nrtr_decoder_fwd(_ptr(enc_cm), N, C, T, d_inner, n_layers, table.ptr, _ptr(ln_g), _ptr(ln_b),
+                                      _ptr(emb), _ptr(pos_table), pos_table.shape[0], _ptr(w_cls), _ptr(b_cls),
+                                      num_out, max_seq_len, int(start_idx), int(padding_idx), _ptr(valid_len),
+                                      _ptr(forced_tokens), ws.data_ptr(), ws.numel(), _ptr(out), _ptr(tokens),
+                                      _stream(enc_cm))
+    _lib.check(rc, "tpspp_nrtr_decoder_fwd")
+    return out, tokens

@@ -75,6 +75,10 @@ class Registry:
 
 BACKBONES = Registry("backbone")
 PREPROCESSOR = Registry("preprocessor")
+ENCODERS = Registry("encoder")
+DECODERS = Registry("decoder")
+CONVERTORS = Registry("convertor")
+DETECTORS = BACKBONES          # builder.py:18-20: recognisers share the 'models' registry with the backbones
 
 
 def build_backbone(cfg):
@@ -87,13 +91,35 @@ def build_preprocessor(cfg):
     return PREPROCESSOR.build(cfg)
 
 
+def build_encoder(cfg):
+    """`mmocr.models.builder.build_encoder` (builder.py:40-42)."""
+    return ENCODERS.build(cfg)
+
+
+def build_decoder(cfg):
+    """`mmocr.models.builder.build_decoder` (builder.py:45-47)."""
+    return DECODERS.build(cfg)
+
+
+def build_convertor(cfg):
+    """`mmocr.models.builder.build_convertor` (builder.py:35-37)."""
+    return CONVERTORS.build(cfg)
+
+
+def build_detector(cfg, train_cfg=None, test_cfg=None):
+    """`mmocr.models.builder.build_detector` / `build_recognizer`: the recogniser from the `model` dict
+    of a config such as configs/textrecog/nrtr/nrtr_tps++.py:26-42."""
+    return DETECTORS.build(cfg, dict(train_cfg=train_cfg, test_cfg=test_cfg))
+
+
 def register_into_mmocr(force=True):
     """If MMOCR is installed, make its own registries build our modules.  Returns True on success."""
     try:
         from mmocr.models import builder as _b  # noqa: WPS433 (optional dependency)
     except Exception:
         return False
-    for reg_name, ours in (("BACKBONES", BACKBONES), ("PREPROCESSOR", PREPROCESSOR)):
+    for reg_name, ours in (("BACKBONES", BACKBONES), ("PREPROCESSOR", PREPROCESSOR), ("ENCODERS", ENCODERS),
+                           ("DECODERS", DECODERS), ("CONVERTORS", CONVERTORS)):
         theirs = getattr(_b, reg_name, None)
         if theirs is None:
             continue
