@@ -216,3 +216,37 @@ def backbone_stem(sd, img, arch=(3, 4), strides=(1, 2)):
             for b in range(nb):
                 x = basic_block(sd, f"layer{li + 1}.{b}", x, st if b == 0 else 1)
     return x, outs
+
+
+def backbone_forward(sd, img, arch=(3, 4, 6, 6, 3), strides=(2, 1, 2, 1, 2), tps_sd=None, variant="ResNet45"):
+    """Whole ResNetABI_v2_large.forward (backbones/resnet_v2_large.py:162-196): stem, then the five
+    stages with the TPS++ network applied to the input of stage index 2 (`outputs = tpsnet(x, outs)`,
+    `x = outputs['output']`).  Returns dict(output, img_ref) like the reference."""
+    x = _t(img)
+    img_ref = None
+    with torch.no_grad():
+        x = F.relu(_bn(sd, "bn1", F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], padding=1)))
+        outs = []
+        for li, (nb, st) in enumerate(zip(arch, strides)):
+            if li == 2 and tps_sd is not None:
+                r = tpspp_forward(tps_sd, x, outs, variant)
+                x = torch.from_numpy(r["output"])
+                img_ref = x
+            outs.append(x)
+            for b in range(nb):
+                x = basic_block(sd, f"layer{li + 1}.{b}", x, st if b == 0 else 1)
+    return dict(output=x, img_ref=img_ref)
+
+
+def recognizer_simple_test(backbone_sd, tps_sd, enc_sd, dec_sd, img, resize_widths=None, variant="ResNet45",
+                           n_head=8, max_seq_len=40):
+    """EncodeDecodeRecognizer.simple_test (recognizer/encode_decode_recognizer.py:186-221) for the
+    NRTR + TPS++ config (configs/textrecog/nrtr/nrtr_tps++.py:26-42): valid_ratio = resize width / batch
+    width, backbone (+TPS++) -> encoder -> greedy decoder -> AttnConvertor."""
+    from . import nrtr_oracle as NO
+    img = _t(img)
+    ratios = None if resize_widths is None else [1.0 * w / img.shape[-1] for w in resize_widths]
+    feat = backbone_forward(backbone_sd, img, tps_sd=tps_sd, variant=variant)["output"]
+    r = NO.head_simple_test(enc_sd, dec_sd, feat, n_head, max_seq_len, ratios)
+    r["feat"] = feat
+    return r

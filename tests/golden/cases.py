@@ -227,3 +227,13 @@ G11_N, G11_HW = 2, (4, 16)            # backbone output of a 32x128 image with s
 
 def g11_inputs():
     return dict(feat=synth.dyadic((G11_N, 512) + G11_HW, "g11.feat", 11))
+
+
+# ---- G12: the whole recogniser (backbone + TPS++ + encoder + decoder + convertor), N=2, 3x32x128 ---
+G12_N = 2
+G12_STRIDES = [2, 1, 2, 1, 2]         # configs/textrecog/nrtr/nrtr_tps++.py:36
+G12_WIDTHS = [128, 96]                # img_meta['resize_shape'][1] of the two images
+
+
+def g12_inputs():
+    return dict(img=synth.smooth_image((G12_N, 3, 32, 128), "g12.img", 12))

@@ -325,8 +325,48 @@ def case_g11(R):
          str2tensor_targets=tgt)
 
 
+def case_g12(R):
+    """Whole recogniser: the reference's backbone (calling the reference's TPS_PP, patched to the
+    geometry its own NRTR config needs -- SURVEY.md section 0 fact 4), encoder, decoder and convertor,
+    composed as EncodeDecodeRecognizer.simple_test composes them (encode_decode_recognizer.py:186-221;
+    the recogniser class itself imports modules that were never released)."""
+    from oracle import tpspp_oracle as TO
+    bb = R["resnet_v2_large"].ResNetABI_v2_large(arch_settings=[3, 4, 6, 6, 3], strides=cases.G12_STRIDES).eval()
+    sd = cases.synth_state(bb.state_dict(), 7, cases.backbone_state_rule)
+    bb.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    tps = quiet(R["tps_pp"].TPS_PP)
+    tps.type = "ResNet45"
+    tps.down0 = sys.modules["mmcv.cnn"].ConvModule(32, tps.img_channel, kernel_size=3, stride=2, padding=1)
+    for n in ("down0_1", "down1_1", "down_feat", "up_sample"):
+        delattr(tps, n)
+    tps.eval()
+    sd = cases.synth_state(tps.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    tps.load_state_dict({k: t(v) for k, v in sd.items()}, strict=False)
+    enc, dec = _head_modules(R, False)
+    conv = R["attn_convertor"].AttnConvertor(dict_type="DICT90", with_unknown=True, max_seq_len=40)
+    img = t(cases.g12_inputs()["img"])
+    metas = [dict(resize_shape=(32, w, 3)) for w in cases.G12_WIDTHS]
+    with torch.no_grad():
+        for m in metas:                                            # simple_test :196-198
+            m["valid_ratio"] = 1.0 * m["resize_shape"][1] / img.size(-1)
+        feat = bb(img, tps, True)["output"]
+        out_enc = enc(feat, metas)
+        out_dec = dec(feat, out_enc, None, metas, train_mode=False)
+    idx, scores = conv.tensor2idx(out_dec, metas)
+    text = conv.idx2str(idx)
+    o = TO.recognizer_simple_test(dict(bb.state_dict()), dict(tps.state_dict()), dict(enc.state_dict()),
+                                  dict(dec.state_dict()), img.numpy(), cases.G12_WIDTHS)
+    assert biteq(o["feat"].numpy(), feat.numpy()), "backbone oracle != reference"
+    assert biteq(o["out_dec"].numpy(), out_dec.numpy()) and o["text"] == text
+    p = np.sort(out_dec.numpy(), -1)
+    print("  texts:", text, " min arg-max margin:", float((p[..., -1] - p[..., -2]).min()),
+          " feat absmax:", float(feat.abs().max()))
+    save("recognizer_e2e", feat_sub=np.ascontiguousarray(feat.numpy()[:, ::8]), out_dec=out_dec.numpy(),
+         text=np.array(text), score0=np.array(scores[0], dtype=np.float32))
+
+
 CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1, g1_pin=case_g1_pin,
-             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11)
+             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12)
 
 
 def main(argv):

@@ -43,6 +43,11 @@ CASES = [
     ("localisation conv 3x3 3->64 @32x100 no bias", [(3, 32, 100, 1, 1)], 64, 3, (1, 1), False, 0, 2),
     ("wide 1x1 64->256 odd pixels", [(64, 7, 9, 1, 1)], 256, 1, (1, 1), False, 0, 2),
     ("Cout not multiple of 64", [(16, 9, 13, 1, 1)], 40, 3, (1, 1), True, 0, 1),
+    # few output pixels -> split-K skinny kernel (decoder steps, batches of feature vectors)
+    ("skinny 1x1 512->512 one row of 512", [(512, 1, 512, 1, 1)], 512, 1, (1, 1), False, 1, 1),
+    ("skinny 1x1 512->92 ragged", [(512, 1, 77, 1, 1)], 92, 1, (1, 1), True, 0, 1),
+    ("skinny 1x1 K=100 odd sizes", [(100, 3, 5, 1, 1)], 37, 1, (1, 1), True, 2, 3),
+    ("skinny 1x1 K=6", [(6, 1, 40, 1, 1)], 8, 1, (1, 1), False, 0, 2),
 ]
 
 

@@ -155,3 +155,37 @@ def test_head_batch_against_oracle(cuda):
     conv = AttnConvertor()
     idx, _ = conv.tensor2idx(out_dec)
     assert idx == o["indexes"] and conv.idx2str(idx) == o["text"]
+
+
+def build_recognizer(cuda):
+    """configs/textrecog/nrtr/nrtr_tps++.py:23-42 (TPS_PP in the geometry that config's strides need)."""
+    import tps_pp_amd as P
+    m = P.build_detector(dict(
+        type="NRTR",
+        backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=cases.G12_STRIDES),
+        tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder"),
+        decoder=dict(type="NRTRDecoder"), loss=dict(type="TFLoss"),
+        label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True), max_seq_len=40)).eval()
+    for mod, seed, rule, keep in ((m.backbone, 7, cases.backbone_state_rule, ()),
+                                  (m.tpsnet, 4, cases.tpspp_state_rule, cases.TPSPP_KEEP),
+                                  (m.encoder, 9, cases.head_state_rule, cases.HD_KEEP),
+                                  (m.decoder, 10, cases.head_state_rule, cases.HD_KEEP)):
+        sd = cases.synth_state(mod.state_dict(), seed, rule, keep)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m.to(cuda)
+
+
+def test_recognizer_end_to_end_against_reference(cuda):
+    """Image batch -> strings through every HIP stage (backbone convs, TPS++ regressor + warp, encoder,
+    greedy decoder, convertor) against the reference's own composition of its modules."""
+    G = cases.load("recognizer_e2e")
+    m = build_recognizer(cuda)
+    img = dev(cases.g12_inputs()["img"], cuda)
+    metas = [dict(resize_shape=(32, w, 3)) for w in cases.G12_WIDTHS]
+    with torch.no_grad():
+        res = m(img, metas, return_loss=False)
+        feat = m.extract_feat(img, test=True)["output"]
+    assert np.abs(feat.cpu().numpy()[:, ::8] - G["feat_sub"]).max() <= TOL
+    assert [r["text"] for r in res] == [str(s) for s in G["text"]]
+    assert np.abs(np.array(res[0]["score"], dtype=np.float32) - G["score0"]).max() <= TOL
+    assert [m_["valid_ratio"] for m_ in metas] == [w / 128 for w in cases.G12_WIDTHS]

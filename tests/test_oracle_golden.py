@@ -245,3 +245,25 @@ def test_nrtr_head_full_oracle_and_convertor():
     idx2char, unk, start, end, pad = NO.attn_dictionary()
     assert (unk, start, end, pad, len(idx2char)) == (90, cases.START_IDX, cases.END_IDX, cases.PAD_IDX,
                                                      cases.NUM_CLASSES)
+
+
+def test_recognizer_end_to_end_oracle():
+    """backbone (+TPS++) -> encoder -> greedy decoder -> convertor, oracle vs the reference's outputs."""
+    import tps_pp_amd as P
+    from oracle import tpspp_oracle as TO
+    G = cases.load("recognizer_e2e")
+
+    def synth_sd(m, seed, rule, keep=()):
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        for k, v in cases.synth_state(m.state_dict(), seed, rule, keep).items():
+            sd[k] = torch.from_numpy(v)
+        return sd
+    bb = synth_sd(P.ResNetABI_v2_large(arch_settings=[3, 4, 6, 6, 3], strides=cases.G12_STRIDES), 7,
+                  cases.backbone_state_rule)
+    tps = synth_sd(P.TPS_PP(variant="ResNet45"), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    o = TO.recognizer_simple_test(bb, tps, _head_state("enc", False), _head_state("dec", False),
+                                  cases.g12_inputs()["img"], cases.G12_WIDTHS)
+    assert np.array_equal(o["feat"].numpy()[:, ::8], G["feat_sub"])
+    assert np.array_equal(o["out_dec"].numpy(), G["out_dec"])
+    assert o["text"] == [str(s) for s in G["text"]]
+    assert np.array_equal(np.array(o["scores"][0], dtype=np.float32), G["score0"])

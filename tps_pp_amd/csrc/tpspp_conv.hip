@@ -300,6 +300,92 @@ conv_tiled_f32_kernel(const ConvParams P)
     }
 }
 
+// ---- skinny 1x1 kernel: few output pixels (one decoder step, a batch of feature vectors) -----------------
+// With M = N*Ho*Wo of a few hundred the 128x64 tiles above leave most CUs idle and every K-chunk pays
+// a full memory latency.  Here a workgroup owns a 32-pixel x 32-channel tile and its four wavefronts
+// SPLIT K: each wavefront streams its quarter of the weight and activation rows straight from L2 into
+// MFMA operands (both are k-major, so a fragment is two 128-B rows per load instruction; no LDS
+// staging, all loads of a wavefront in flight together), the four partial tiles are summed through
+// LDS and every wavefront finishes a quarter of the tile (bias / activation / residual as above).
+__global__ void __launch_bounds__(kThreads)
+conv1x1_skinny_f32_kernel(const ConvParams P)
+{
+    __shared__ float sRed[4][16][kWave];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n = blockIdx.z;
+    const int HoWo = P.Ho * P.Wo;
+    const int m0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int K = P.Cin;
+    const int Kw = ((K + 7) / 8) * 2;                  // k values per wavefront (even)
+    const int k_lo = wv * Kw;
+    const int k_hi = min(K, k_lo + Kw);
+    const int pix = m0 + l31, co = co0 + l31;
+    const bool pix_ok = pix < HoWo, co_ok = co < P.Cout;
+    const float* xp = P.src[0].p + (size_t)n * K * HoWo + (pix_ok ? pix : 0);
+    const float* wp = P.wt + (co_ok ? co : 0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    constexpr int UB = 16;                             // MFMA steps per batch: 2*UB row loads in flight
+    const int nit = (k_hi - k_lo + 1) >> 1;            // wave-uniform trip count
+    for (int it0 = 0; it0 < nit; it0 += UB) {
+        float a[UB], b[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = k_lo + 2 * (it0 + u) + half;
+            const bool k_ok = k < k_hi;
+            const int kk = k_ok ? k : k_lo;
+            const float av = wp[(size_t)kk * P.Cout];
+            const float bv = xp[(size_t)kk * HoWo];
+            a[u] = (k_ok && co_ok) ? av : 0.0f;
+            b[u] = (k_ok && pix_ok) ? bv : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);             // keep every load above the first MFMA
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
+    __syncthreads();
+    // wavefront w finishes registers [4w, 4w+4): channels co0 + {0..3} + 8w + 4*half
+    if (!pix_ok) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wv + q;
+        const int c = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (c < P.Cout) {
+            float v = (sRed[0][r][lane] + sRed[1][r][lane]) + (sRed[2][r][lane] + sRed[3][r][lane]);
+            if (P.bias) v = v + P.bias[c];
+            const size_t o = ((size_t)n * P.Cout + c) * HoWo + pix;
+            if (P.res_mode == 2) v = v + P.res[o];
+            if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+            else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (P.res_mode == 1) v = v + P.res[o];
+            if (P.post_scale) v = v * P.post_scale[c] + P.post_shift[c];
+            P.out[o] = v;
+        }
+    }
+}
+
+// true when the 128x64 tiling would start fewer workgroups than the chip has CUs
+bool skinny_applies(const ConvParams& P, int KH)
+{
+    if (KH != 1 || P.nsrc != 1 || P.sh != 1 || P.sw != 1) return false;
+    if (P.src[0].uh != 1 || P.src[0].uw != 1) return false;
+    const long big = (long)((P.Ho * P.Wo + BM - 1) / BM) * ((P.Cout + BN - 1) / BN) * P.N;
+    return big < 256 && P.N <= 65535 && (P.Cout + 31) / 32 <= 65535;
+}
+
+void launch_skinny(const ConvParams& P, hipStream_t st)
+{
+    const dim3 grid((unsigned)((P.Ho * P.Wo + 31) / 32), (unsigned)((P.Cout + 31) / 32), (unsigned)P.N);
+    hipLaunchKernelGGL(conv1x1_skinny_f32_kernel, grid, dim3(kThreads), 0, st, P);
+}
+
 template <int KH, int SH, int SW, int TH, int TW, int KC>
 void launch_tiled(const ConvParams& P, hipStream_t st)
 {
@@ -400,6 +486,12 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
     P.relu = relu; P.res_mode = res_mode;
     if (N == 0) return TPSPP_OK;
     hipStream_t st = tpspp::as_stream(stream);
+    if (g_conv_force_generic == 0 && skinny_applies(P, KH)) {
+        ConvParams Q = P;
+        Q.wt = weight_t ? weight_t : weight_tiled;         // identical layouts for a 1x1 kernel (k-major)
+        launch_skinny(Q, st);
+        return tpspp::check_launch("tpspp_conv2d_fwd(skinny)");
+    }
     if (weight_tiled && g_conv_force_generic == 0) {
         ConvParams Q = P;
         Q.wt = weight_tiled;

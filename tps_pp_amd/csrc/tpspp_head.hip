@@ -86,37 +86,55 @@ transpose2d_kernel(const float* __restrict__ in, int rows, int cols, float* __re
 
 // ---- LayerNorm over the rows of a channel-major matrix ----------------------------------------------
 // y[c][m] = (x[c][m] - mean_m) * rstd_m * gamma[c] + beta[c];  mean / biased variance over c.
-// Workgroup = 64 columns x 4 channel slices; every global access is a 256-B row segment.
+// Workgroup = 16 columns x 16 interleaved channel slices; a thread keeps its C/16 values in registers
+// (one pass over x, all loads in flight together: a decoder step has only a few hundred columns, so
+// the kernel is latency-bound unless every load is issued up front).  C <= 16 * VPT.
+template <int VPT>
 __global__ void __launch_bounds__(256)
 layernorm_cm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     int C, int M, float eps, float* __restrict__ y)
 {
-    __shared__ float red[4][kWave];
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
-    const int m = blockIdx.x * kWave + lane;
+    __shared__ float red[16][17];
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int m = blockIdx.x * 16 + col;
     const bool ok = m < M;
     const int mm = ok ? m : M - 1;
-    const int cs = (C + 3) / 4;
-    const int c_lo = wv * cs, c_hi = min(C, c_lo + cs);
-    float s = 0.0f;
-    for (int c = c_lo; c < c_hi; ++c) s += x[(size_t)c * M + mm];
-    red[wv][lane] = s;
-    __syncthreads();
-    const float mean = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
-    __syncthreads();
-    float v = 0.0f;
-    for (int c = c_lo; c < c_hi; ++c) {
-        const float d = x[(size_t)c * M + mm] - mean;
-        v = fmaf(d, d, v);
+    float v[VPT], g[VPT], be[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {                    // every load of the thread issued up front
+        const int c = sl + 16 * i;
+        const int cc = c < C ? c : C - 1;
+        v[i] = x[(size_t)cc * M + mm];
+        g[i] = gamma[cc];
+        be[i] = beta[cc];
     }
-    red[wv][lane] = v;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) s += (sl + 16 * i) < C ? v[i] : 0.0f;
+    red[sl][col] = s;
     __syncthreads();
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + eps);
+    float tot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][col];
+    const float mean = tot / (float)C;
+    __syncthreads();
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const float d = (sl + 16 * i) < C ? v[i] - mean : 0.0f;
+        q = fmaf(d, d, q);
+    }
+    red[sl][col] = q;
+    __syncthreads();
+    tot = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tot += red[j][col];
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
     if (!ok) return;
-    for (int c = c_lo; c < c_hi; ++c) {
-        const size_t o = (size_t)c * M + m;
-        y[o] = (x[o] - mean) * rstd * gamma[c] + beta[c];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = sl + 16 * i;
+        if (c < C) y[(size_t)c * M + m] = (v[i] - mean) * rstd * g[i] + be[i];
     }
 }
 
@@ -232,8 +250,11 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
     const int pl = lane < step ? lane : 0;                // clamped: lanes >= step are masked below
     float sc = 0.0f;
     if (step > 0) {
-#pragma unroll 16
-        for (int d = 0; d < kDK; ++d) sc = fmaf(readlane_f(q, d), kc[(size_t)d * Lmax + pl], sc);
+        float kv[kDK];                                     // all 64 cached-key loads in flight together
+#pragma unroll
+        for (int d = 0; d < kDK; ++d) kv[d] = kc[(size_t)d * Lmax + pl];
+#pragma unroll
+        for (int d = 0; d < kDK; ++d) sc = fmaf(readlane_f(q, d), kv[d], sc);
     }
     const float cur = wave_sum(q * k);
     if (lane == step) sc = cur;
@@ -244,7 +265,16 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
     const float l = wave_sum(p);
     p = p / l;
     float acc = readlane_f(p, step) * v;
-    for (int pos = 0; pos < step; ++pos) acc = fmaf(readlane_f(p, pos), vc[(size_t)pos * kDK + lane], acc);
+    for (int p0 = 0; p0 < step; p0 += 8) {                 // 8 cached value rows in flight
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = vc[(size_t)(p0 + u < step ? p0 + u : 0) * kDK + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float pw = p0 + u < step ? readlane_f(p, (p0 + u) & (kWave - 1)) : 0.0f;
+            acc = fmaf(pw, vv[u], acc);
+        }
+    }
     out[(size_t)(kDK * h + lane) * Nb + b] = acc;
 }
 
@@ -273,9 +303,12 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ K
         if (jj * kWave < nvalid) {                         // wave-uniform
             const int t = jj * kWave + lane;
             const int tt = t < T ? t : T - 1;
+            float kv[kDK];                                 // all 64 row loads in flight together
+#pragma unroll
+            for (int d = 0; d < kDK; ++d) kv[d] = kbase[(size_t)d * MT + tt];
             float s = 0.0f;
-#pragma unroll 16
-            for (int d = 0; d < kDK; ++d) s = fmaf(readlane_f(q, d), kbase[(size_t)d * MT + tt], s);
+#pragma unroll
+            for (int d = 0; d < kDK; ++d) s = fmaf(readlane_f(q, d), kv[d], s);
             sc[jj] = t < nvalid ? s : -INFINITY;
             mx = fmaxf(mx, sc[jj]);
         }
@@ -294,9 +327,20 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ K
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const int cnt = min(kWave, nvalid - jj * kWave);   // wave-uniform
-        const float pj = sc[jj] * inv;
-        for (int tl = 0; tl < cnt; ++tl)
-            acc = fmaf(readlane_f(pj, tl), vbase[(size_t)(jj * kWave + tl) * C], acc);
+        const float pj = sc[jj] * inv;                     // 0 for masked tokens
+        for (int t0 = 0; t0 < cnt; t0 += 16) {             // 16 value rows in flight
+            float vv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int tl = t0 + u < cnt ? t0 + u : cnt - 1;
+                vv[u] = vbase[(size_t)(jj * kWave + tl) * C];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float pw = t0 + u < cnt ? readlane_f(pj, (t0 + u) & (kWave - 1)) : 0.0f;
+                acc = fmaf(pw, vv[u], acc);
+            }
+        }
     }
     out[(size_t)(kDK * h + lane) * Nb + b] = acc;
 }
@@ -308,23 +352,32 @@ __global__ void __launch_bounds__(256)
 dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, int L, int greedy,
                     float* __restrict__ out, int* __restrict__ tokens, int Lt)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wavefront per image, lanes over classes
+    const int lane = threadIdx.x & (kWave - 1);
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= Nb) return;
     float* o = out + ((size_t)b * L + step) * Cc;
     if (!greedy) {
-        for (int c = 0; c < Cc; ++c) o[c] = logits[(size_t)c * Nb + b];
+        for (int c = lane; c < Cc; c += kWave) o[c] = logits[(size_t)c * Nb + b];
         return;
     }
     float mx = -INFINITY;
-    int am = 0;
-    for (int c = 0; c < Cc; ++c) {
+    int am = 0x7fffffff;
+    for (int c = lane; c < Cc; c += kWave) {
         const float v = logits[(size_t)c * Nb + b];
         if (v > mx) { mx = v; am = c; }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(mx, off, kWave);
+        const int oi = __shfl_xor(am, off, kWave);
+        if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+    }
     float sum = 0.0f;
-    for (int c = 0; c < Cc; ++c) sum += expf(logits[(size_t)c * Nb + b] - mx);
-    for (int c = 0; c < Cc; ++c) o[c] = expf(logits[(size_t)c * Nb + b] - mx) / sum;
-    tokens[(size_t)b * Lt + step + 1] = am;
+    for (int c = lane; c < Cc; c += kWave) sum += expf(logits[(size_t)c * Nb + b] - mx);
+    sum = wave_sum(sum);
+    for (int c = lane; c < Cc; c += kWave) o[c] = expf(logits[(size_t)c * Nb + b] - mx) / sum;
+    if (lane == 0) tokens[(size_t)b * Lt + step + 1] = am;
 }
 
 __global__ void __launch_bounds__(256)
@@ -427,8 +480,12 @@ TPSPP_EXPORT int tpspp_layernorm_cm_fwd(const float* x, const float* gamma, cons
                                         float eps, float* y, tpspp_stream_t stream)
 {
     TPSPP_REQUIRE(x && gamma && beta && y && C > 0 && M > 0, "tpspp_layernorm_cm_fwd: bad argument");
-    hipLaunchKernelGGL(layernorm_cm_kernel, dim3((unsigned)((M + kWave - 1) / kWave)), dim3(256), 0,
-                       tpspp::as_stream(stream), x, gamma, beta, C, M, eps, y);
+    TPSPP_REQUIRE(C <= 1024, "tpspp_layernorm_cm_fwd: at most 1024 features");
+    const dim3 grid((unsigned)((M + 15) / 16)), block(256);
+    hipStream_t st = tpspp::as_stream(stream);
+    if (C <= 128)      hipLaunchKernelGGL(layernorm_cm_kernel<8>, grid, block, 0, st, x, gamma, beta, C, M, eps, y);
+    else if (C <= 512) hipLaunchKernelGGL(layernorm_cm_kernel<32>, grid, block, 0, st, x, gamma, beta, C, M, eps, y);
+    else               hipLaunchKernelGGL(layernorm_cm_kernel<64>, grid, block, 0, st, x, gamma, beta, C, M, eps, y);
     return tpspp::check_launch("tpspp_layernorm_cm_fwd");
 }
 
@@ -616,7 +673,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         if (rc) return rc;
         g.cm(w_cls, b_cls, y, C, num_out, N, logits, 0, nullptr);
         if (g.rc) return g.rc;
-        hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, logits, num_out,
+        hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, logits, num_out,
                            N, s, L, greedy, out, tokens, Lt);
     }
     if (tokens_out)
