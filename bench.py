@@ -100,12 +100,51 @@ def extra_measurements(dev):
         t_warp = timeit(lambda: m.rectify(fg, x, cp, sc), 20, 3)
     bytes_img = 1966336                                  # SURVEY.md section 8d, G-PP warp stage fp32
     bw = bytes_img * n / (t_warp * 1e-3) / 1e9
-    return {"tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
+    del m, x, o0, o1
+    rec = recognizer_measurement(dev, timeit)
+    return {"nrtr_tpspp_inference_batch512_fp32": rec,
+            "tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
                                            "gflop_per_image": 0.82},
             "tpspp_warp_stage_batch512_fp32": {"us_per_batch": t_warp * 1e3, "achieved_GBps": bw,
                                                "frac_of_hbm_peak": bw / HBM_PEAK_GBS,
                                                "algorithmic_bytes_per_image": bytes_img,
                                                "kernel": "tps_warp_stream_kernel<32,true,true,2>"}}
+
+
+def recognizer_measurement(dev, timeit):
+    """BASELINE.json configs[3]/[4] shape at one GPU: the whole NRTR + TPS++ recogniser (backbone, TPS++,
+    6+6-layer transformer, greedy 40-step decoding, label conversion) on 3x32x128 images, batch 512,
+    random-init weights; plus a string-parity check of a small batch against the CPU oracle."""
+    import tps_pp_amd as P
+    from oracle import tpspp_oracle as TO
+    torch.manual_seed(11)
+    m = P.build_detector(dict(
+        type="NRTR", backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=[2, 1, 2, 1, 2]),
+        tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder"),
+        decoder=dict(type="NRTRDecoder"), loss=dict(type="TFLoss"),
+        label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True), max_seq_len=40)).eval()
+    with torch.no_grad():      # spread the classifier so that the random-init arg-max is far from ties
+        m.decoder.classifier.weight.mul_(8.0)
+    sds = [{k: v.clone() for k, v in mod.state_dict().items()} for mod in (m.backbone, m.tpsnet, m.encoder, m.decoder)]
+    m = m.to(dev)
+    n = 512
+    g = torch.Generator(device=dev).manual_seed(12)
+    img = torch.rand((n, 3, 32, 128), generator=g, device=dev) * 2 - 1
+    metas = [dict(resize_shape=(32, 128, 3)) for _ in range(n)]
+    with torch.no_grad():
+        t_all = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
+        t_feat = timeit(lambda: m.extract_feat(img, test=True), 3, 1)
+        feat = m.extract_feat(img, test=True)["output"]
+        t_enc = timeit(lambda: m.encoder(feat, None), 3, 1)
+        out_enc = m.encoder(feat, None)
+        t_dec = timeit(lambda: m.decoder(feat, out_enc, None, None, train_mode=False), 3, 1)
+        k = 4
+        got = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+    want = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[:k].cpu().numpy(), [128] * k)["text"]
+    return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
+            "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
+            "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
+            "data": "synthetic images, random-init weights"}
 
 
 def main():

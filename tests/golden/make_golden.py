@@ -365,8 +365,40 @@ def case_g12(R):
          text=np.array(text), score0=np.array(scores[0], dtype=np.float32))
 
 
+METRIC_PAIRS = [("hello", "hello"), ("Hello", "hello"), ("he-llo!", "hello"), ("helo", "hello"), ("", "abc"),
+                ("abc", ""), ("W0rld", "world"), ("kitten", "sitting"), ("ICDAR2015", "icdar-2015"),
+                ("~a6666h", "a6666"), ("flaw", "lawn"), ("\u4e2d\u6587ab", "\u4e2d\u6587AB"), ("x", "y")]
+
+
+def case_g13(R):
+    """Word-accuracy / edit-distance metrics from the reference's mmocr/core/evaluation/ocr_metric.py,
+    executed in place; rapidfuzz (absent) is stubbed by the textbook unit-cost Levenshtein DP."""
+    import json
+    import types
+
+    def lev(a, b):
+        d = list(range(len(b) + 1))
+        for i in range(1, len(a) + 1):
+            prev, d[0] = d[0], i
+            for j in range(1, len(b) + 1):
+                prev, d[j] = d[j], min(d[j] + 1, d[j - 1] + 1, prev + (a[i - 1] != b[j - 1]))
+        return d[len(b)]
+    rf = types.ModuleType("rapidfuzz")
+    rf.string_metric = types.SimpleNamespace(levenshtein=lev)
+    sys.modules["rapidfuzz"] = rf
+    from _ref_loader import _load
+    om = _load("mmocr.core.evaluation.ocr_metric", "mmocr/core/evaluation/ocr_metric.py")
+    preds, gts = [p for p, _ in METRIC_PAIRS], [g for _, g in METRIC_PAIRS]
+    out = dict(pairs=METRIC_PAIRS, count_matches=om.count_matches(preds, gts),
+               eval_ocr_metric=om.eval_ocr_metric(preds, gts),
+               per_pair=[om.count_matches([p], [g]) for p, g in METRIC_PAIRS])
+    with open(os.path.join(HERE, "ocr_metric.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("  wrote ocr_metric.json", out["eval_ocr_metric"], out["count_matches"])
+
+
 CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1, g1_pin=case_g1_pin,
-             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12)
+             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12, g13=case_g13)
 
 
 def main(argv):

@@ -70,3 +70,39 @@ def test_all_gather_rows_without_process_group_is_identity():
     assert tdist.all_gather_rows(t, 5) is t
     with pytest.raises(RuntimeError):
         tdist.all_gather_rows(t, 6)
+
+
+def _recognize_worker(rank, world, port, q):
+    """Sharded evaluation step on the reference's golden decoder scores: every rank ends up with the
+    strings of the WHOLE batch, equal to the unsharded conversion."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from tps_pp_amd import AttnConvertor
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G = cases.load("nrtr_head_full")
+        scores = torch.from_numpy(G["out_dec"]).repeat(3, 1, 1)[:5]          # 5 images: ragged shards
+        conv = AttnConvertor()
+        res = tdist.recognize_sharded(lambda lo, hi: scores[lo:hi].clone(), scores.shape[0], conv)
+        want = [str(G["text"][i % 2]) for i in range(5)]
+        q.put((rank, [r["text"] for r in res] == want, len(res)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_recognize_sharded_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_recognize_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res) and all(r[2] == 5 for r in res), res

@@ -62,3 +62,19 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None):
         rlo, rhi = shard_bounds(n_total, r, world)
         pieces.append(recv[r * cap: r * cap + (rhi - rlo)])
     return torch.cat(pieces, dim=0)
+
+
+def recognize_sharded(decode_local, n_total: int, convertor, group=None):
+    """Multi-GPU evaluation step (the role of `multi_gpu_test`'s result gather, tools/test.py:202-207):
+    rank r decodes its contiguous shard, the per-step scores (n_local, max_seq_len, num_classes-1) are
+    all-gathered (the only collective of the inference path), and every rank converts
+    the full tensor to strings.  `decode_local(lo, hi)` returns the local scores tensor."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    lo, hi = shard_bounds(n_total, rank, world)
+    local = decode_local(lo, hi)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank}: decode_local returned {local.shape[0]} rows for a shard of {hi - lo}")
+    scores = all_gather_rows(local, n_total, group)
+    indexes, char_scores = convertor.tensor2idx(scores)
+    return [dict(text=t, score=s) for t, s in zip(convertor.idx2str(indexes), char_scores)]
