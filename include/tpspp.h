@@ -117,6 +117,28 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                    tpspp_stream_t stream);
 
 /*
+ * Backward of tpspp_warp_fwd: given dL/d out0 [, dL/d out1] returns
+ *   g_in0 (N, C0, H0, W0), g_in1 (N, C1, H1, W1)  dL/d input (zeroed here, then accumulated with float
+ *                                                  atomics); either may be NULL (not wanted)
+ *   g_ctrl (N, F, 2)                                dL/d control points
+ *   g_score                                         dL/d score in the layout of `score` ((N, n, F), or
+ *                                                  (N, F, n) with TPSPP_SCORE_TRANSPOSED), or NULL
+ * grid (N, Ho*Wo, 2) is the sampling grid the forward produced (its grid_or_null output) and
+ * T (N, F+3, 2) = tpspp_solve_T(inv_delta_c, ctrl); the tables are the forward's.  Gradients follow
+ * ATen's CPU grid_sampler_2d_backward (bilinear, border, align_corners=True: zero coordinate gradient
+ * where the coordinate was clamped) and the transposes of the two products of build_P_prime.
+ * replaces: autograd through backbones/tps_pp/tps_pp.py:467-496,597-615;
+ *           preprocessor/tps_preprocessor.py:71-83,270-282
+ */
+int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
+                   const float* g_out1, const float* in1, int C1, int H1, int W1,
+                   const float* grid, const float* T, const float* inv_delta_c,
+                   const float* p_hat, int p_hat_ld, const float* p_xy, const float* score,
+                   const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
+                   float* g_in0, float* g_in1, float* g_ctrl, float* g_score,
+                   tpspp_stream_t stream);
+
+/*
  * out = act(conv2d(cat_c(up(src_0), up(src_1), up(src_2)), W) + bias [+ residual]) [+ residual]
  *       [* post_scale + post_shift]
  * fp32, NCHW, 1x1 or 3x3 kernel with "same" padding ((K-1)/2), stride (sh, sw), on the fp32 matrix

@@ -232,3 +232,83 @@ def set_threads(t):
 
 def max_threads():
     return int(lib().tps_oracle_max_threads())
+
+
+def warp_backward(g_out0, in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None, g_out1=None,
+                  chain_grid=False):
+    """Gradients of the warp by PyTorch-CPU autograd through the reference's
+    own composition: T = bmm(inv_delta_C, [C'; 0]); rows [1, P, rbf * (0.5 score + 1)]; grid = bmm(rows, T);
+    F.grid_sample(bilinear, border, align_corners=True) per input
+    (backbones/tps_pp/tps_pp.py:467-496,597-615; preprocessor/tps_preprocessor.py:71-83,270-282).
+    Returns dict(g_in0, g_in1 | None, g_ctrl, g_score | None) as numpy arrays.
+
+    chain_grid=True: the forward grid is taken from the C oracle's k-ascending FMA chain (what the HIP
+    kernels reproduce bit for bit) instead of torch.bmm, whose summation order depends on the BLAS kernel
+    picked for the batch size (an ill-conditioned lattice shows 1e-4 differences between the two); the
+    sampler's backward is still ATen's, the two matrix products are transposed in float64."""
+    import torch
+    with torch.enable_grad():
+        if chain_grid:
+            return _warp_backward_chain(g_out0, in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1, g_out1)
+        return _warp_backward(g_out0, in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1, g_out1)
+
+
+def _warp_backward_chain(g_out0, in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1, g_out1):
+    import torch
+    import torch.nn.functional as Fn
+    tt = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float32)
+    N, F = ctrl.shape[0], ctrl.shape[1]
+    T = solve_T(inv_delta_C, ctrl)
+    grid = build_grid(P_hat, T, P_xy, score)
+    gt = tt(grid).reshape(N, out_hw[0], out_hw[1], 2).requires_grad_(True)
+    in0_t = tt(in0).requires_grad_(True)
+    in1_t = None if in1 is None else tt(in1).requires_grad_(True)
+    loss = (Fn.grid_sample(in0_t, gt, padding_mode="border", align_corners=True) * tt(g_out0)).sum()
+    if in1_t is not None:
+        loss = loss + (Fn.grid_sample(in1_t, gt, padding_mode="border", align_corners=True) * tt(g_out1)).sum()
+    loss.backward()
+    gg = gt.grad.numpy().reshape(N, -1, 2).astype(np.float64)
+    ph = np.asarray(P_hat, dtype=np.float64)
+    n = ph.shape[0]
+    if P_xy is not None:
+        rbf = np.repeat(ph[None], N, 0)
+        fac = np.ones_like(rbf) if score is None else (np.asarray(score, np.float64) * 0.5 + 1)
+        rows = np.concatenate([np.ones((N, n, 1)), np.repeat(np.asarray(P_xy, np.float64)[None], N, 0), rbf * fac], 2)
+    else:
+        rows = np.repeat(ph[None], N, 0)
+    g_T = np.einsum("bnk,bnx->bkx", rows, gg)
+    g_ctrl = np.einsum("kf,bkx->bfx", np.asarray(inv_delta_C, np.float64), g_T)[:, :F]
+    g_score = None
+    if score is not None:
+        g_score = (0.5 * ph[None] * np.einsum("bnx,bkx->bnk", gg, T.astype(np.float64)[:, 3:])).astype(np.float32)
+    return dict(g_in0=in0_t.grad.numpy(), g_in1=None if in1_t is None else in1_t.grad.numpy(),
+                g_ctrl=g_ctrl.astype(np.float32), g_score=g_score)
+
+
+def _warp_backward(g_out0, in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1, g_out1):
+    import torch
+    import torch.nn.functional as Fn
+    tt = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))  # noqa: E731
+    in0_t, ctrl_t, score_t, in1_t = tt(in0), tt(ctrl), tt(score), tt(in1)
+    for v in (in0_t, ctrl_t, score_t, in1_t):
+        if v is not None:
+            v.requires_grad_(True)
+    N, F = ctrl_t.shape[0], ctrl_t.shape[1]
+    inv, ph = tt(inv_delta_C), tt(P_hat)
+    n = ph.shape[0]
+    if P_xy is not None:
+        rbf = ph.unsqueeze(0).repeat(N, 1, 1)
+        if score_t is not None:
+            rbf = rbf * (score_t * 0.5 + 1)
+        rows = torch.cat([torch.ones((N, n, 1)), tt(P_xy).unsqueeze(0).repeat(N, 1, 1), rbf], dim=2)
+    else:
+        rows = ph.unsqueeze(0).repeat(N, 1, 1)
+    cz = torch.cat((ctrl_t, torch.zeros(N, 3, 2)), dim=1)
+    grid = torch.bmm(rows, torch.bmm(inv.unsqueeze(0).repeat(N, 1, 1), cz)).reshape(N, out_hw[0], out_hw[1], 2)
+    loss = (Fn.grid_sample(in0_t, grid, padding_mode="border", align_corners=True) * tt(g_out0)).sum()
+    if in1_t is not None:
+        loss = loss + (Fn.grid_sample(in1_t, grid, padding_mode="border", align_corners=True) * tt(g_out1)).sum()
+    loss.backward()
+    g = lambda v: None if v is None else v.grad.numpy()  # noqa: E731
+    return dict(g_in0=g(in0_t), g_in1=g(in1_t), g_ctrl=g(ctrl_t), g_score=g(score_t))

@@ -237,3 +237,10 @@ G12_WIDTHS = [128, 96]                # img_meta['resize_shape'][1] of the two i
 
 def g12_inputs():
     return dict(img=synth.smooth_image((G12_N, 3, 32, 128), "g12.img", 12))
+
+
+# ---- G14: backward of the warp (row F2): upstream gradients for the G2 / G3 forward cases ----------
+def g14_inputs():
+    return dict(g_out_cl=synth.dyadic((CL_N, CL_C) + CL_HW, "g14.gout_cl", 14),
+                g_out0=synth.dyadic((PP_N, PP_C) + PP_HW, "g14.gout0", 14),
+                g_out1=synth.dyadic((PP_N, PP_C) + PP_HW, "g14.gout1", 14))

@@ -397,8 +397,45 @@ def case_g13(R):
     print("  wrote ocr_metric.json", out["eval_ocr_metric"], out["count_matches"])
 
 
+def case_g14(R):
+    """Backward of the warp: autograd through the reference's own build_P_prime + F.grid_sample."""
+    with torch.enable_grad():
+        _case_g14(R)
+
+
+def _case_g14(R):
+    gi = cases.g14_inputs()
+    # classic geometry (G2 inputs, smooth image)
+    gg = R["tps_preprocessor"].GridGenerator(cases.CL_F, cases.CL_HW)
+    inp = cases.g2_inputs()
+    img, ctrl = t(inp["img_smooth"]).requires_grad_(True), t(inp["ctrl"]).requires_grad_(True)
+    grid = gg.build_P_prime(ctrl, "cpu").reshape(cases.CL_N, cases.CL_HW[0], cases.CL_HW[1], 2)
+    (Fn.grid_sample(img, grid, padding_mode="border", align_corners=True) * t(gi["g_out_cl"])).sum().backward()
+    o = O.warp_backward(gi["g_out_cl"], inp["img_smooth"], inp["ctrl"], gg.inv_delta_C.numpy(), gg.P_hat.numpy(),
+                        cases.CL_HW)
+    assert biteq(o["g_in0"], img.grad.numpy()) and biteq(o["g_ctrl"], ctrl.grad.numpy()), "classic bwd oracle"
+    arrs = dict(cl_g_img=img.grad.numpy(), cl_g_ctrl=ctrl.grad.numpy())
+    # TPS_PP geometry (G3 inputs)
+    at = quiet(R["tps_pp"].Attention_Enhanced_TPS, cases.PP_HW, cases.PP_POINT)
+    inp = cases.g3_inputs()
+    ctrl, score = t(inp["ctrl"]).requires_grad_(True), t(inp["score"]).requires_grad_(True)
+    fg, x = t(inp["feat_grid"]).requires_grad_(True), t(inp["x"]).requires_grad_(True)
+    grid = at.build_P_prime(ctrl, score, "cpu").reshape(cases.PP_N, cases.PP_HW[0], cases.PP_HW[1], 2)
+    loss = (Fn.grid_sample(fg, grid, padding_mode="border", align_corners=True) * t(gi["g_out0"])).sum() + \
+        (Fn.grid_sample(x, grid, padding_mode="border", align_corners=True) * t(gi["g_out1"])).sum()
+    loss.backward()
+    o = O.warp_backward(gi["g_out0"], inp["feat_grid"], inp["ctrl"], at.hat_C.numpy(), at.P_hat.numpy(),
+                        cases.PP_HW, P_xy=at.P.astype(np.float32), score=inp["score"], in1=inp["x"],
+                        g_out1=gi["g_out1"])
+    for k, v in (("g_in0", fg), ("g_in1", x), ("g_ctrl", ctrl), ("g_score", score)):
+        assert biteq(o[k], v.grad.numpy()), "TPS_PP bwd oracle: " + k
+    arrs.update(pp_g_feat_grid_sub=cases.sub(fg.grad.numpy()), pp_g_x_sub=cases.sub(x.grad.numpy()),
+                pp_g_ctrl=ctrl.grad.numpy(), pp_g_score=score.grad.numpy())
+    save("warp_backward", **arrs)
+
+
 CASES = dict(constants=case_constants, g2=case_g2, g3=case_g3, g1=case_g1, g1_pin=case_g1_pin,
-             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12, g13=case_g13)
+             g4=case_g4, g5=case_g5, g7=case_g7, g8=case_g8, g9=case_g9, g10=case_g10, g11=case_g11, g12=case_g12, g13=case_g13, g14=case_g14)
 
 
 def main(argv):

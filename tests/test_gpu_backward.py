@@ -1,0 +1,117 @@
+"""-m gpu: backward of the fused warp against the reference's own autograd
+(golden G14) and the CPU oracle.  Gradients are sums over many taps accumulated with float atomics on
+the GPU (order not fixed), so the bar is a relative tolerance, stated per tensor."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import tps_oracle as O
+from tps_pp_amd import TPS_PP, TPSPreprocessor, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def close(got, want, rtol, what):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max()
+    assert got.shape == want.shape and err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_classic_backward_against_reference(cuda):
+    G = cases.load("warp_backward")
+    inp, gi = cases.g2_inputs(), cases.g14_inputs()
+    c = O.classic_constants(cases.CL_F, cases.CL_HW)
+    inv, ph = dev(c["inv_delta_C"], cuda), dev(c["P_hat"], cuda)
+    img = dev(inp["img_smooth"], cuda).requires_grad_(True)
+    ctrl = dev(inp["ctrl"], cuda).requires_grad_(True)
+    out = ops.warp_autograd(img, ctrl, inv, ph, cases.CL_HW)
+    (out * dev(gi["g_out_cl"], cuda)).sum().backward()
+    close(img.grad, G["cl_g_img"], 2e-5, "dL/d image")
+    close(ctrl.grad, G["cl_g_ctrl"], 1e-4, "dL/d control points")
+    # the transposed-table fast path of the forward gives the same gradients
+    P_hat_t = ops.transpose_p_hat(ph)
+    img2, ctrl2 = img.detach().clone().requires_grad_(True), ctrl.detach().clone().requires_grad_(True)
+    out2 = ops.warp_autograd(img2, ctrl2, inv, ph, cases.CL_HW, P_hat_t=P_hat_t, table_flags=ops.TABLE_MIRROR4)
+    (out2 * dev(gi["g_out_cl"], cuda)).sum().backward()
+    assert torch.equal(out2, out)
+    close(ctrl2.grad, G["cl_g_ctrl"], 1e-4, "dL/d control points (transposed table)")
+
+
+@pytest.mark.parametrize("transposed_score", [False, True])
+def test_tpspp_backward_against_reference(cuda, transposed_score):
+    G = cases.load("warp_backward")
+    inp, gi = cases.g3_inputs(), cases.g14_inputs()
+    c = O.tpspp_constants(cases.PP_HW, cases.PP_POINT)
+    inv, ph, pxy = dev(c["hat_C"], cuda), dev(c["P_hat"], cuda), dev(c["P_xy"], cuda)
+    fg = dev(inp["feat_grid"], cuda).requires_grad_(True)
+    x = dev(inp["x"], cuda).requires_grad_(True)
+    ctrl = dev(inp["ctrl"], cuda).requires_grad_(True)
+    if transposed_score:      # the layout the module hands over: a transposed view of an (N, F, n) buffer
+        base = dev(np.ascontiguousarray(inp["score"].transpose(0, 2, 1)), cuda).requires_grad_(True)
+        score = base.transpose(1, 2)
+    else:
+        base = score = dev(inp["score"], cuda).requires_grad_(True)
+    out0, out1 = ops.warp_autograd(fg, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, score=score, in1=x)
+    ((out0 * dev(gi["g_out0"], cuda)).sum() + (out1 * dev(gi["g_out1"], cuda)).sum()).backward()
+    g_score = base.grad.transpose(1, 2) if transposed_score else base.grad
+    close(fg.grad[:, ::8], G["pp_g_feat_grid_sub"], 2e-5, "dL/d feat_grid")
+    close(x.grad[:, ::8], G["pp_g_x_sub"], 2e-5, "dL/d x")
+    close(ctrl.grad, G["pp_g_ctrl"], 1e-4, "dL/d control points")
+    close(g_score, G["pp_g_score"], 1e-4, "dL/d score")
+
+
+def test_backward_edge_cases_against_oracle(cuda):
+    """Clamped coordinates (zero coordinate gradient), a single input, no score, ragged batch."""
+    from tps_pp_amd import synth
+    N, F, hw = 3, 20, (32, 100)
+    c = O.classic_constants(F, hw)
+    ctrl = O.classic_initial_ctrl(F)[None] + np.array([0.0, 0.6, 3.0], np.float32)[:, None, None] * \
+        synth.dyadic((N, F, 2), "bwd.ctrl", 1)
+    img = synth.smooth_image((N, 2, 16, 40), "bwd.img", 1)           # input size != output size
+    g_out = synth.dyadic((N, 2) + hw, "bwd.gout", 1)
+    # (grid from the FMA chain: at perturbation 3.0 the lattice is ill-conditioned and torch.bmm's own
+    # result moves by 1e-4 with the BLAS kernel it picks for the batch size -- oracle/tps_oracle.py)
+    want = O.warp_backward(g_out, img, ctrl, c["inv_delta_C"], c["P_hat"], hw, chain_grid=True)
+    it, ct = dev(img, cuda).requires_grad_(True), dev(ctrl.astype(np.float32), cuda).requires_grad_(True)
+    out = ops.warp_autograd(it, ct, dev(c["inv_delta_C"], cuda), dev(c["P_hat"], cuda), hw)
+    (out * dev(g_out, cuda)).sum().backward()
+    close(it.grad, want["g_in0"], 2e-5, "dL/d image (clamped grid)")
+    close(ct.grad, want["g_ctrl"], 2e-4, "dL/d control points (clamped grid)")
+    # only the control points need a gradient: the image-gradient buffer is not even allocated
+    ct2 = ct.detach().clone().requires_grad_(True)
+    (ops.warp_autograd(it.detach(), ct2, dev(c["inv_delta_C"], cuda), dev(c["P_hat"], cuda), hw) *
+     dev(g_out, cuda)).sum().backward()
+    close(ct2.grad, want["g_ctrl"], 2e-4, "dL/d control points (image detached)")
+
+
+def test_modules_train_through_the_hip_warp(cuda):
+    """TPS_PP / TPSPreprocessor under autograd: HIP warp forward + backward inside a PyTorch graph; the
+    forward values equal the inference path's, and every parameter that feeds the warp gets a gradient."""
+    m = TPS_PP().to(cuda).train()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    inp = cases.g4_inputs("ResNet45v2")
+    x, outs = dev(inp["x"], cuda), [dev(o, cuda) for o in inp["outs"]]
+    res = m(x, outs)
+    assert res["output"].requires_grad and res["mp_img"].requires_grad
+    (res["output"].square().mean() + res["mp_img"].square().mean()).backward()
+    missing = [k for k, p in m.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    assert m.TPE.localization_fc2.bias.grad.abs().max() > 0
+    with torch.no_grad():
+        ref = m.eval()(x, outs)
+    assert (ref["output"] - res["output"]).abs().max() < 1e-4
+
+    p = TPSPreprocessor(20, (32, 100), (32, 100), 3).to(cuda).train()
+    img = dev(cases.g1_inputs()["img"], cuda).requires_grad_(True)
+    out = p(img)
+    out.square().mean().backward()
+    assert img.grad is not None and torch.isfinite(img.grad).all()
+    assert p.LocalizationNetwork.localization_fc2.bias.grad.abs().max() > 0

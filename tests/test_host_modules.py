@@ -91,8 +91,8 @@ def test_regressor_matches_oracle_on_cpu():
 
 def test_no_cpu_fallback_and_forward_only():
     p = TPSPreprocessor(20, (32, 100), (32, 100), 3)
-    with pytest.raises(NotImplementedError):
-        p(torch.zeros(1, 3, 32, 100))                     # grad mode on, parameters require grad
+    with pytest.raises(_lib.TpsppError, match="no CPU fallback"):
+        p(torch.zeros(1, 3, 32, 100))                     # grad mode on: the training graph needs the GPU too
     with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):
         p(torch.zeros(1, 3, 32, 100))
     m = TPS_PP()

@@ -267,3 +267,25 @@ def test_recognizer_end_to_end_oracle():
     assert np.array_equal(o["out_dec"].numpy(), G["out_dec"])
     assert o["text"] == [str(s) for s in G["text"]]
     assert np.array_equal(np.array(o["scores"][0], dtype=np.float32), G["score0"])
+
+
+def test_warp_backward_oracle_bit_exact(oracle):
+    """Row F2: the backward oracle (PyTorch-CPU autograd through the reference's composition) against
+    the reference's own autograd results (golden G14); its chain-grid variant agrees to rounding."""
+    G = cases.load("warp_backward")
+    gi = cases.g14_inputs()
+    inp = cases.g2_inputs()
+    c = oracle.classic_constants(cases.CL_F, cases.CL_HW)
+    o = oracle.warp_backward(gi["g_out_cl"], inp["img_smooth"], inp["ctrl"], c["inv_delta_C"], c["P_hat"], cases.CL_HW)
+    assert np.array_equal(o["g_in0"], G["cl_g_img"]) and np.array_equal(o["g_ctrl"], G["cl_g_ctrl"])
+    inp = cases.g3_inputs()
+    c = oracle.tpspp_constants(cases.PP_HW, cases.PP_POINT)
+    kw = dict(P_xy=c["P_xy"], score=inp["score"], in1=inp["x"], g_out1=gi["g_out1"])
+    o = oracle.warp_backward(gi["g_out0"], inp["feat_grid"], inp["ctrl"], c["hat_C"], c["P_hat"], cases.PP_HW, **kw)
+    assert np.array_equal(cases.sub(o["g_in0"]), G["pp_g_feat_grid_sub"])
+    assert np.array_equal(cases.sub(o["g_in1"]), G["pp_g_x_sub"])
+    assert np.array_equal(o["g_ctrl"], G["pp_g_ctrl"]) and np.array_equal(o["g_score"], G["pp_g_score"])
+    o2 = oracle.warp_backward(gi["g_out0"], inp["feat_grid"], inp["ctrl"], c["hat_C"], c["P_hat"], cases.PP_HW,
+                              chain_grid=True, **kw)
+    for k in o:
+        assert np.abs(o[k] - o2[k]).max() <= 2e-6 * np.abs(o[k]).max(), k

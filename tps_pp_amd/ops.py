@@ -554,3 +554,93 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, ln_g, ln_b, emb, pos_ta
                                       _stream(enc_cm))
     _lib.check(rc, "tpspp_nrtr_decoder_fwd")
     return out, tokens
+
+
+# ---- backward of the fused warp ------------------------------------------------
+def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
+                  g_out1=None, P_hat_t=None, need_in0=True, need_in1=True, need_score=True):
+    """`tpspp_warp_bwd`: (g_in0 | None, g_in1 | None, g_ctrl, g_score | None) for the call
+    `warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1)`; `grid` is that call's grid output."""
+    g_out0, in0 = _chk("g_out0", g_out0, 4), _chk("in0", in0, 4)
+    grid, ctrl = _chk("grid", grid, 3), _chk("ctrl", ctrl, 3)
+    inv_delta_C, P_hat = _chk("inv_delta_C", inv_delta_C, 2), _chk("P_hat", P_hat, 2)
+    N, C0, H0, W0 = in0.shape
+    F = int(ctrl.shape[1])
+    Ho, Wo = int(out_hw[0]), int(out_hw[1])
+    n = Ho * Wo
+    if tuple(g_out0.shape) != (N, C0, Ho, Wo) or tuple(grid.shape) != (N, n, 2):
+        raise ValueError("warp_backward: g_out0 / grid shape")
+    flags = 0
+    g_score = None
+    if score is not None:
+        if tuple(score.shape) != (N, n, F):
+            raise ValueError("warp_backward: score must be (N, n, F)")
+        if score.stride() == (F * n, 1, n) and n > 1 and F > 1:
+            flags |= SCORE_TRANSPOSED
+            score = _chk("score", score.transpose(1, 2), 3)
+        else:
+            score = _chk("score", score, 3)
+        if need_score:
+            g_score = torch.empty_like(score)
+    if P_xy is not None:
+        P_xy = _chk("P_xy", P_xy, 2)
+    if P_hat_t is not None:
+        P_hat_t = _chk("P_hat_t", P_hat_t, 2)
+    C1 = H1 = W1 = 0
+    if in1 is not None:
+        in1, g_out1 = _chk("in1", in1, 4), _chk("g_out1", g_out1, 4)
+        _, C1, H1, W1 = in1.shape
+        if tuple(g_out1.shape) != (N, C1, Ho, Wo):
+            raise ValueError("warp_backward: g_out1 shape")
+    T = solve_T(inv_delta_C, ctrl)
+    g_in0 = torch.empty_like(in0) if need_in0 else None
+    g_in1 = torch.empty_like(in1) if (in1 is not None and need_in1) else None
+    g_ctrl = torch.empty((N, F, 2), device=in0.device, dtype=torch.float32)
+    with torch.cuda.device(in0.device):
+        rc = _lib.lib().tpspp_warp_bwd(_ptr(g_out0), _ptr(in0), C0, H0, W0, _ptr(g_out1), _ptr(in1), C1, H1, W1,
+                                       _ptr(grid), _ptr(T), _ptr(inv_delta_C), _ptr(P_hat), P_hat.shape[1],
+                                       _ptr(P_xy), _ptr(score), _ptr(P_hat_t), flags, N, F, Ho, Wo,
+                                       _ptr(g_in0), _ptr(g_in1), _ptr(g_ctrl), _ptr(g_score), _stream(in0))
+    _lib.check(rc, "tpspp_warp_bwd")
+    if g_score is not None and (flags & SCORE_TRANSPOSED):
+        g_score = g_score.transpose(1, 2)                  # back to the logical (N, n, F) view
+    return g_in0, g_in1, g_ctrl, g_score
+
+
+class _WarpFunction(torch.autograd.Function):
+    """Differentiable `warp`: HIP forward (`tpspp_warp_fwd`) and HIP backward (`tpspp_warp_bwd`).  The tables
+    (inv_delta_C, P_hat, P_xy) are constants of the module and get no gradient."""
+
+    @staticmethod
+    def forward(ctx, in0, ctrl, score, in1, inv_delta_C, P_hat, P_xy, P_hat_t, out_hw, table_flags):
+        out0, out1, grid, _ = warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=P_xy, score=score, in1=in1,
+                                   want_grid=True, P_hat_t=P_hat_t, table_flags=table_flags)
+        ctx.out_hw = out_hw
+        ctx.has = (score is not None, in1 is not None)
+        ctx.save_for_backward(in0, ctrl, score, in1, inv_delta_C, P_hat, P_xy, P_hat_t, grid)
+        if out1 is None:
+            return out0
+        return out0, out1
+
+    @staticmethod
+    def backward(ctx, *g):
+        in0, ctrl, score, in1, inv_delta_C, P_hat, P_xy, P_hat_t, grid = ctx.saved_tensors
+        g0 = g[0]
+        g1 = g[1] if len(g) > 1 else None
+        if g0 is None:
+            g0 = torch.zeros((in0.shape[0], in0.shape[1]) + tuple(ctx.out_hw), device=in0.device)
+        if in1 is not None and g1 is None:
+            g1 = torch.zeros((in1.shape[0], in1.shape[1]) + tuple(ctx.out_hw), device=in0.device)
+        need = ctx.needs_input_grad
+        g_in0, g_in1, g_ctrl, g_score = warp_backward(
+            g0.float(), in0, grid, ctrl, inv_delta_C, P_hat, ctx.out_hw, P_xy=P_xy, score=score, in1=in1,
+            g_out1=None if g1 is None else g1.float(), P_hat_t=P_hat_t, need_in0=need[0],
+            need_in1=need[3], need_score=need[2])
+        return (g_in0, g_ctrl if need[1] else None, g_score, g_in1, None, None, None, None, None, None)
+
+
+def warp_autograd(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None, P_hat_t=None,
+                  table_flags=0):
+    """`warp` inside an autograd graph: returns out0 or (out0, out1); gradients flow to in0, ctrl, score, in1."""
+    return _WarpFunction.apply(in0, ctrl, score, in1, inv_delta_C, P_hat, P_xy, P_hat_t,
+                               (int(out_hw[0]), int(out_hw[1])), int(table_flags))

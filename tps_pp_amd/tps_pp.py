@@ -458,14 +458,26 @@ class TPS_PP(nn.Module):
                                        in1=batch_img, want_grid=want_grid, P_hat_t=P_hat_t)
         return (out0, out1, grid) if want_grid else (out0, out1)
 
+    def _forward_autograd(self, batch_img, outs):
+        """Training graph: the transformation stage runs on the HIP kernels in both
+        directions (`ops.warp_autograd`: tpspp_warp_fwd / tpspp_warp_bwd); the control-point regressor is
+        the plain PyTorch composition of the same layers, so autograd reaches its parameters (its backward
+        kernels are not part of this path).  GPU tensors only."""
+        ops.require_gpu(batch_img, "TPS_PP")
+        control_point, atten_score, feat_grid = self._regress_torch(batch_img, outs)
+        at = self.atten_tps
+        P_xy, P_hat_t = at.device_constants(batch_img.device)
+        output, mp_img = ops.warp_autograd(feat_grid.float(), control_point.float(), at.hat_C, at.P_hat,
+                                           self.rectified_img_size, P_xy=P_xy, score=atten_score.float(),
+                                           in1=batch_img.float(), P_hat_t=P_hat_t)
+        return {"output": output, "logits": None, "mp_img": mp_img, "pc_score": atten_score}
+
     def forward(self, batch_img, outs, **kwargs):
         """batch_img (N,64,16,64), outs = [stage-0 input, stage-1 input] ->
         dict(output, logits=None, mp_img, pc_score)."""
         if torch.is_grad_enabled() and (batch_img.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "TPS_PP (HIP path) is forward-only: run under torch.no_grad() (backward for the "
-                "warp op is on the roadmap, SURVEY.md section 8f F2)")
+            return self._forward_autograd(batch_img, outs)
         control_point, atten_score, feat_grid = self.regress(batch_img, outs)
         # (the score stays the transposed view of its (N, F, n) buffer: ops.warp reads it in place)
         output, mp_img = self.rectify(feat_grid.float(), batch_img.float(), control_point.float(),

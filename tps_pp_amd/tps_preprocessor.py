@@ -173,8 +173,13 @@ class TPSPreprocessor(BasePreprocessor):
         """(N, C, H, W) -> (N, C, H_r, W_r)."""
         if torch.is_grad_enabled() and (batch_img.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "TPSPreprocessor (HIP path) is forward-only: run under torch.no_grad() / eval "
-                "inference (backward for the warp op is on the roadmap, SURVEY.md section 8f F2)")
+            # training graph (SURVEY.md section 8f row F2): HIP warp forward + backward; the localisation
+            # network is the plain PyTorch composition so that autograd reaches its parameters
+            ops.require_gpu(batch_img, "TPSPreprocessor")
+            gg = self.GridGenerator
+            P_hat_t, flags = gg.prepared_table()
+            ctrl = self.LocalizationNetwork._forward_torch(batch_img)
+            return ops.warp_autograd(batch_img.float(), ctrl.float(), gg.inv_delta_C, gg.P_hat,
+                                     self.rectified_img_size, P_hat_t=P_hat_t, table_flags=flags)
         batch_C_prime = self.LocalizationNetwork(batch_img)
         return self.rectify(batch_img.float(), batch_C_prime.float())
