@@ -74,7 +74,7 @@ def extra_measurements(dev):
       * warp stage at the TPS_PP geometry (batch 512, fp32): HBM roofline fraction;
       * whole TPS++ module forward (regressor + warp, batch 512, fp32): images/s against the
         north-star's >= 50k."""
-    from tps_pp_amd import TPS_PP
+    from tps_pp_amd import TPS_PP, ops
 
     def timeit(fn, iters, warm):
         for _ in range(warm):
@@ -98,11 +98,28 @@ def extra_measurements(dev):
         t_full = timeit(lambda: m(x, [o0, o1]), 10, 4)
         cp, sc, fg = m.regress(x, [o0, o1])
         t_warp = timeit(lambda: m.rectify(fg, x, cp, sc), 20, 3)
+        # row F2: backward of the same warp stage (input, control-point and score gradients)
+        at = m.atten_tps
+        P_xy, P_hat_t = at.device_constants(dev)
+        fgc = fg.contiguous()
+        _, _, grid, _ = ops.warp(fgc, cp, at.hat_C, at.P_hat, (16, 64), P_xy=P_xy, score=sc, in1=x, want_grid=True,
+                                 P_hat_t=P_hat_t)
+        g0 = torch.rand((n, 64, 16, 64), generator=g, device=dev)
+        g1 = torch.rand((n, 64, 16, 64), generator=g, device=dev)
+        t_bwd = timeit(lambda: ops.warp_backward(g0, fgc, grid, cp, at.hat_C, at.P_hat, (16, 64), P_xy=P_xy, score=sc,
+                                                 in1=x, g_out1=g1, P_hat_t=P_hat_t), 10, 3)
+        del g0, g1, grid, fgc
     bytes_img = 1966336                                  # SURVEY.md section 8d, G-PP warp stage fp32
     bw = bytes_img * n / (t_warp * 1e-3) / 1e9
+    # backward: read g_out0, g_out1, both inputs, grid, score; write g_in0, g_in1, g_score (fp32)
+    bwd_bytes_img = 4 * (2 * 64 * 1024 + 2 * (64 * 32 * 128 + 64 * 16 * 64) + 2 * 1024 + 2 * 32 * 1024)
     del m, x, o0, o1
     rec = recognizer_measurement(dev, timeit)
     return {"nrtr_tpspp_inference_batch512_fp32": rec,
+            "tpspp_warp_backward_batch512_fp32": {"us_per_batch": t_bwd * 1e3,
+                                                  "achieved_GBps": bwd_bytes_img * n / (t_bwd * 1e-3) / 1e9,
+                                                  "algorithmic_bytes_per_image": bwd_bytes_img,
+                                                  "kernels": "warp_bwd_sample_lds_kernel + warp_bwd_params_kernel<36>"},
             "tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
                                            "gflop_per_image": 0.82},
             "tpspp_warp_stage_batch512_fp32": {"us_per_batch": t_warp * 1e3, "achieved_GBps": bw,

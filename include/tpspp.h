@@ -123,6 +123,7 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *   g_ctrl (N, F, 2)                                dL/d control points
  *   g_score                                         dL/d score in the layout of `score` ((N, n, F), or
  *                                                  (N, F, n) with TPSPP_SCORE_TRANSPOSED), or NULL
+ *   g_grid_ws (N, Ho*Wo, 2)                         scratch; on return dL/d grid
  * grid (N, Ho*Wo, 2) is the sampling grid the forward produced (its grid_or_null output) and
  * T (N, F+3, 2) = tpspp_solve_T(inv_delta_c, ctrl); the tables are the forward's.  Gradients follow
  * ATen's CPU grid_sampler_2d_backward (bilinear, border, align_corners=True: zero coordinate gradient
@@ -135,7 +136,7 @@ int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0
                    const float* grid, const float* T, const float* inv_delta_c,
                    const float* p_hat, int p_hat_ld, const float* p_xy, const float* score,
                    const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
-                   float* g_in0, float* g_in1, float* g_ctrl, float* g_score,
+                   float* g_in0, float* g_in1, float* g_ctrl, float* g_score, float* g_grid_ws,
                    tpspp_stream_t stream);
 
 /*

@@ -36,7 +36,7 @@ _SIGNATURES = {
     "tpspp_warp_set_tuning": ([_i, _i, _i, _i], _i),
     "tpspp_warp_set_trace": ([_f], _i),
     "tpspp_warp_bwd": ([_f, _f, _i, _i, _i, _f, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _i,
-                        _f, _f, _f, _f, _f], _i),
+                        _f, _f, _f, _f, _f, _f], _i),
     "tpspp_transpose2d": ([_f, _i, _i, _f, _f], _i),
     "tpspp_layernorm_cm_fwd": ([_f, _f, _f, _i, _i, ctypes.c_float, _f, _f], _i),
     "tpspp_attn_enc_fwd": ([_f, _i, _i, _i, _f, _f, _f], _i),
