@@ -189,3 +189,36 @@ def test_recognizer_end_to_end_against_reference(cuda):
     assert [r["text"] for r in res] == [str(s) for s in G["text"]]
     assert np.abs(np.array(res[0]["score"], dtype=np.float32) - G["score0"]).max() <= TOL
     assert [m_["valid_ratio"] for m_ in metas] == [w / 128 for w in cases.G12_WIDTHS]
+
+
+@pytest.mark.parametrize("hw,n", [((4, 20), 5), ((1, 7), 3), ((4, 40), 2)])
+def test_head_other_token_counts_against_oracle(cuda, hw, n):
+    """Token counts other than 64 (wider / narrower images: T = 80, 7, 160 > one wavefront), odd batch."""
+    from tps_pp_amd import synth
+    enc, dec = small_modules(cuda)
+    feat = synth.dyadic((n, cases.HD_SMALL["d_model"]) + hw, f"head.T{hw}", 6)
+    ratios = [1.0, 0.37, 0.81, 0.5, 0.95][:n]
+    metas = [dict(valid_ratio=r) for r in ratios]
+    with torch.no_grad():
+        out_enc = enc(dev(feat, cuda), metas)
+        out_dec = dec(None, out_enc, None, metas, train_mode=False)
+    enc_sd = {k: v.cpu() for k, v in enc.state_dict().items()}
+    dec_sd = {k: v.cpu() for k, v in dec.state_dict().items()}
+    nh = cases.HD_SMALL["n_head"]
+    o_enc = NO.encoder_forward(enc_sd, feat, nh, ratios)
+    o_dec = NO.decoder_forward_test(dec_sd, o_enc, nh, cases.HD_MAXLEN, cases.START_IDX, cases.PAD_IDX, ratios)
+    assert (out_enc.cpu() - o_enc).abs().max() <= TOL
+    assert (out_dec.cpu() - o_dec).abs().max() <= TOL
+    assert torch.equal(out_dec.argmax(-1).cpu(), o_dec.argmax(-1))
+
+
+def test_head_argument_errors(cuda):
+    from tps_pp_amd import _lib
+    enc, dec = small_modules(cuda)
+    with torch.no_grad():
+        with pytest.raises(_lib.TpsppError, match="256"):
+            enc(torch.zeros(1, cases.HD_SMALL["d_model"], 4, 65, device=cuda))       # 260 tokens
+        with pytest.raises(ValueError):
+            enc(torch.zeros(1, 64, 2, 4, device=cuda))                                # wrong width
+        with pytest.raises(ValueError):
+            enc(torch.zeros(2, cases.HD_SMALL["d_model"], 2, 4, device=cuda), [dict(valid_ratio=1.0)])
