@@ -43,6 +43,11 @@ CASES = [
     ("localisation conv 3x3 3->64 @32x100 no bias", [(3, 32, 100, 1, 1)], 64, 3, (1, 1), False, 0, 2),
     ("wide 1x1 64->256 odd pixels", [(64, 7, 9, 1, 1)], 256, 1, (1, 1), False, 0, 2),
     ("Cout not multiple of 64", [(16, 9, 13, 1, 1)], 40, 3, (1, 1), True, 0, 1),
+    # 4x16 outputs (last backbone stage): 128-pixel tiles that span two images, odd batch
+    ("two-image tile 3x3 64->64 @4x16", [(64, 4, 16, 1, 1)], 64, 3, (1, 1), True, 2, 3),
+    ("two-image tile 3x3 s2 32->64 @8x32 -> 4x16", [(32, 8, 32, 1, 1)], 64, 3, (2, 2), True, 0, 5),
+    ("two-image tile 1x1 64->128 @4x16", [(64, 4, 16, 1, 1)], 128, 1, (1, 1), False, 1, 3),
+    ("two-image tile 3x3 @2x16 two sources", [(8, 2, 16, 1, 1), (8, 1, 16, 2, 1)], 64, 3, (1, 1), True, 0, 4),
     # few output pixels -> split-K skinny kernel (decoder steps, batches of feature vectors)
     ("skinny 1x1 512->512 one row of 512", [(512, 1, 512, 1, 1)], 512, 1, (1, 1), False, 1, 1),
     ("skinny 1x1 512->92 ragged", [(512, 1, 77, 1, 1)], 92, 1, (1, 1), True, 0, 1),

@@ -161,7 +161,7 @@ conv_igemm_f32_kernel(const ConvParams P)
 // i.e. one ds_read_b32 with an immediate and no address arithmetic in the MFMA loop.  The next
 // chunk's patch and weight slab are prefetched into registers while the current chunk is multiplied.
 // Requires weights pre-arranged as (chunk, tap, channel-in-chunk, cout) -- tpspp_conv_arrange_weight.
-template <int KH, int SH, int SW, int TH, int TW, int KC>
+template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1>
 struct TileCfg {
     static constexpr int KW = KH;
     static constexpr int TAPS = KH * KW;
@@ -169,19 +169,20 @@ struct TileCfg {
     static constexpr int PW = (TW - 1) * SW + KW;      // patch cols
     static constexpr int PS = PH * PW;                 // floats per channel of the patch
     static constexpr int KCK = KC * TAPS;
-    static constexpr int PATCH = KC * PS;
+    static constexpr int PATCH1 = KC * PS;             // one image's patch
+    static constexpr int PATCH = NI * PATCH1;          // NI images per tile (small maps: 4x16 outputs)
     static constexpr int NP = (PATCH + kThreads - 1) / kThreads;          // patch floats per thread
     static constexpr int NW4 = (KCK * BN / 4 + kThreads - 1) / kThreads;  // weight float4 per thread
 };
 
-template <int KH, int SH, int SW, int TH, int TW, int KC>
+template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_tiled_f32_kernel(const ConvParams P)
 {
-    using Cfg = TileCfg<KH, SH, SW, TH, TW, KC>;
+    using Cfg = TileCfg<KH, SH, SW, TH, TW, KC, NI>;
     constexpr int KW = Cfg::KW, TAPS = Cfg::TAPS, PH = Cfg::PH, PW = Cfg::PW, PS = Cfg::PS;
-    constexpr int KCK = Cfg::KCK, PATCH = Cfg::PATCH, NP = Cfg::NP, NW4 = Cfg::NW4;
-    static_assert(TH * TW == BM, "tile must hold 128 pixels");
+    constexpr int KCK = Cfg::KCK, PATCH = Cfg::PATCH, PATCH1 = Cfg::PATCH1, NP = Cfg::NP, NW4 = Cfg::NW4;
+    static_assert(NI * TH * TW == BM, "tile must hold 128 pixels");
     static_assert(KC % 2 == 0, "channel pairs");
     __shared__ __attribute__((aligned(16))) float sP[PATCH];
     __shared__ __attribute__((aligned(16))) float sW[KCK * BN];
@@ -191,16 +192,19 @@ conv_tiled_f32_kernel(const ConvParams P)
     const int wv = tid / kWave;
     const int half = lane >> 5, l31 = lane & 31;
     const int ctiles = (P.Cout + BN - 1) / BN;
-    const int n = blockIdx.z / ctiles;
-    const int co_base = (blockIdx.z - n * ctiles) * BN;
+    const int ngrp = blockIdx.z / ctiles;
+    const int n0 = ngrp * NI;                                   // first image of this tile
+    const int co_base = (blockIdx.z - ngrp * ctiles) * BN;
     const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const int iy_base = oy0 * SH - P.ph, ix_base = ox0 * SW - P.pw;
     const int HoWo = P.Ho * P.Wo;
 
     // this lane's pixel inside the tile and its B-fragment base address in the patch
     const int tp = wv * 32 + l31;
-    const int ty = tp / TW, tx = tp - ty * TW;
-    const int lane_base = half * PS + ty * SH * PW + tx * SW;
+    const int timg = tp / (TH * TW), tpi = tp - timg * (TH * TW);
+    const int ty = tpi / TW, tx = tpi - ty * TW;
+    const int n = n0 + timg;                                    // the image this lane's pixel belongs to
+    const int lane_base = timg * PATCH1 + half * PS + ty * SH * PW + tx * SW;
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -215,18 +219,20 @@ conv_tiled_f32_kernel(const ConvParams P)
     auto prefetch = [&](int chunk) {
         const int c0 = chunk * KC;
         while (c0 >= cbase + cur.C) { cbase += cur.C; ++s; cur = P.src[s]; }
-        const float* sp = cur.p + ((size_t)n * cur.C + (c0 - cbase)) * cur.H * cur.W;
         const int plane = cur.H * cur.W;
+        const float* sp = cur.p + ((size_t)n0 * cur.C + (c0 - cbase)) * plane;
+        const size_t img_stride = (size_t)cur.C * plane;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int e = tid + i * kThreads;
             float v = 0.0f;
             if (e < PATCH) {
-                const int ci = e / PS, r = e - ci * PS;
+                const int im = NI > 1 ? e / PATCH1 : 0, e1 = e - im * PATCH1;
+                const int ci = e1 / PS, r = e1 - ci * PS;
                 const int py = r / PW, px = r - py * PW;
                 const int iy = iy_base + py, ix = ix_base + px;
-                if (iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (c0 + ci) < P.Cin)
-                    v = sp[(size_t)ci * plane + (iy / cur.uh) * cur.W + (ix / cur.uw)];
+                if (iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (c0 + ci) < P.Cin && (n0 + im) < P.N)
+                    v = sp[im * img_stride + (size_t)ci * plane + (iy / cur.uh) * cur.W + (ix / cur.uw)];
             }
             rp[i] = v;
         }
@@ -277,7 +283,7 @@ conv_tiled_f32_kernel(const ConvParams P)
 
     // ---- epilogue ----
     const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < P.Ho && ox < P.Wo) {
+    if (oy < P.Ho && ox < P.Wo && n < P.N) {
         const int pix = oy * P.Wo + ox;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
@@ -386,12 +392,13 @@ void launch_skinny(const ConvParams& P, hipStream_t st)
     hipLaunchKernelGGL(conv1x1_skinny_f32_kernel, grid, dim3(kThreads), 0, st, P);
 }
 
-template <int KH, int SH, int SW, int TH, int TW, int KC>
+template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1>
 void launch_tiled(const ConvParams& P, hipStream_t st)
 {
     const int ctiles = (P.Cout + BN - 1) / BN;
-    const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH), (unsigned)(P.N * ctiles));
-    hipLaunchKernelGGL((conv_tiled_f32_kernel<KH, SH, SW, TH, TW, KC>), grid, dim3(kThreads), 0, st, P);
+    const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
+                    (unsigned)(((P.N + NI - 1) / NI) * ctiles));
+    hipLaunchKernelGGL((conv_tiled_f32_kernel<KH, SH, SW, TH, TW, KC, NI>), grid, dim3(kThreads), 0, st, P);
 }
 
 // picks a tile for the output width; returns false when no tiled instantiation fits
@@ -400,13 +407,20 @@ bool launch_tiled_any(const ConvParams& P, int KH, hipStream_t st)
     if ((P.Cout % 4) != 0) return false;                          // float4 weight rows
     if ((long)P.N * ((P.Cout + BN - 1) / BN) > 65535) return false;
 #define TPSPP_TILE(KHv, SHv, SWv, THv, TWv, KCv) { launch_tiled<KHv, SHv, SWv, THv, TWv, KCv>(P, st); return true; }
+#define TPSPP_TILE2(KHv, SHv, SWv, THv, TWv, KCv) { launch_tiled<KHv, SHv, SWv, THv, TWv, KCv, 2>(P, st); return true; }
+    // small maps (the last backbone stage: 4x16 outputs): a 128-pixel tile spans TWO images instead of
+    // leaving half of its rows empty
+    const bool small_map = P.Ho <= 4 && P.Wo <= 16 && P.N >= 2;
     if (KH == 1) {
         if (P.sh != 1 || P.sw != 1) return false;
+        if (small_map) TPSPP_TILE2(1, 1, 1, 4, 16, 32)
         if (P.Wo >= 128) TPSPP_TILE(1, 1, 1, 1, 128, 32)
         if (P.Wo >= 64) TPSPP_TILE(1, 1, 1, 2, 64, 32)
         if (P.Wo >= 32) TPSPP_TILE(1, 1, 1, 4, 32, 32)
         TPSPP_TILE(1, 1, 1, 8, 16, 32)
     }
+    if (small_map && P.sh == 1 && P.sw == 1) TPSPP_TILE2(3, 1, 1, 4, 16, kKC3)
+    if (small_map && P.sh == 2 && P.sw == 2) TPSPP_TILE2(3, 2, 2, 4, 16, kKC3)
     if (P.sh == 1 && P.sw == 1) {
         if (P.Wo >= 64) TPSPP_TILE(3, 1, 1, 2, 64, kKC3)
         if (P.Wo >= 32) TPSPP_TILE(3, 1, 1, 4, 32, kKC3)
@@ -419,6 +433,7 @@ bool launch_tiled_any(const ConvParams& P, int KH, hipStream_t st)
     }
     if (P.sh == 2 && P.sw == 1) TPSPP_TILE(3, 2, 1, 8, 16, kKC3)
 #undef TPSPP_TILE
+#undef TPSPP_TILE2
     return false;
 }
 
