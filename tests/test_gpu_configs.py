@@ -1,0 +1,81 @@
+"""-m gpu: the remaining BASELINE.json configurations at their full per-GPU sizes, through
+size-independent properties (the oracle cannot run these sizes in seconds):
+
+* configs[2]  regressor + warp (`TPS_PP.forward`) at batch 1024 (fp32; the bf16 variant is not built);
+* configs[3]  backbone (stem, layer1-2, TPS++, layer3-5) at 256 images per GPU (2048 over 8 GPUs);
+* configs[4]  image -> string at 256 images per GPU.
+
+Property: every image is processed independently, so the rows of a full-size batch equal the same
+images run as a small batch (bit for bit where both batches take the same kernels, to fp32 rounding
+where the launch heuristics pick a different tiling); the small batch in turn is checked against the
+CPU oracle (values within 1e-4, strings identical)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import tpspp_oracle as TO
+from tps_pp_amd import synth
+from test_gpu_head import build_recognizer
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+PICK = [0, 1, 129, 255]
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def tile_batch(a, n):
+    """n images from a small seeded set, each with its own gain so that rows differ."""
+    reps = (n + a.shape[0] - 1) // a.shape[0]
+    out = np.concatenate([a * (1.0 - 0.003 * r) for r in range(reps)], 0)[:n]
+    return np.ascontiguousarray(out.astype(np.float32))
+
+
+def test_config2_regressor_and_warp_batch_1024(cuda):
+    from tps_pp_amd import TPS_PP
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    cpu_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(cuda)
+    n = 1024
+    inp = cases.g4_inputs("ResNet45v2")
+    x = tile_batch(inp["x"], n)
+    outs = [tile_batch(o, n) for o in inp["outs"]]
+    pick = [0, 1, 513, 1023]
+    with torch.no_grad():
+        full = m(dev(x, cuda), [dev(o, cuda) for o in outs])
+        small = m(dev(x[pick], cuda), [dev(o[pick], cuda) for o in outs])
+    for k in ("output", "mp_img", "pc_score"):
+        assert torch.equal(full[k][pick], small[k]), k
+    o = TO.tpspp_forward(cpu_sd, x[pick[:2]], [o_[pick[:2]] for o_ in outs], "ResNet45v2")
+    assert np.abs(small["output"][:2].cpu().numpy() - o["output"]).max() <= TOL
+    assert np.abs(small["mp_img"][:2].cpu().numpy() - o["mp_img"]).max() <= TOL
+
+
+def test_config3_and_4_backbone_and_strings_256_per_gpu(cuda):
+    m = build_recognizer(cuda)
+    n = 256
+    img = tile_batch(synth.smooth_image((8, 3, 32, 128), "cfg34.img", 3), n)
+    widths = [128 if i % 3 else 96 for i in range(n)]
+    metas = [dict(resize_shape=(32, w, 3)) for w in widths]
+    with torch.no_grad():
+        feat_full = m.extract_feat(dev(img, cuda), test=True)["output"]
+        res_full = m(dev(img, cuda), [dict(mm) for mm in metas], return_loss=False)
+        feat_small = m.extract_feat(dev(img[PICK], cuda), test=True)["output"]
+        res_small = m(dev(img[PICK], cuda), [dict(metas[i]) for i in PICK], return_loss=False)
+    assert feat_full.shape == (n, 512, 4, 16)
+    # configs[3]: batch independence (to rounding: the 1x1 projections of a 4-image batch take the split-K
+    # kernel, those of the 256-image batch the tiled one -- different summation order)
+    assert (feat_full[PICK] - feat_small).abs().max() <= 1e-5
+    assert [res_full[i]["text"] for i in PICK] == [r["text"] for r in res_small]
+    for i, r in zip(PICK, res_small):
+        assert np.allclose(res_full[i]["score"], r["score"], rtol=0, atol=1e-5)
+    # the small batch against the CPU oracle (two images: the oracle re-runs the decoder 40 times)
+    sds = [{k: v.cpu() for k, v in mod.state_dict().items()} for mod in (m.backbone, m.tpsnet, m.encoder, m.decoder)]
+    o = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[PICK[:2]], [widths[i] for i in PICK[:2]])
+    assert np.abs(feat_small[:2].cpu().numpy() - o["feat"].numpy()).max() <= TOL
+    assert [r["text"] for r in res_small[:2]] == o["text"]
