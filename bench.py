@@ -272,7 +272,7 @@ def main():
             "max_abs_err_vs_oracle": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
-                         "kernel": "tps_warp_lds_mirror_kernel<20,3,32,100>",
+                         "kernel": "tps_warp_lds_mirror_kernel<20,3,32,100,false>",
                          "launch_us": launch_us,
                          "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH},
         }

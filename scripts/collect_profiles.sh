@@ -19,5 +19,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -o copy -- \
       ./scripts/ubench/copy_bench > $OUT/copy_pmc_$c.log 2>&1
 done
-ls -R $OUT | head -40
+# 3. kernel traces of the wider rows: whole TPS++ module, whole recogniser (F1), warp backward (F2)
+for w in module head backward; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o $w -- \
+      python3 scripts/bench_$w.py > $OUT/$w.log 2>&1
+done
+ls -R $OUT | head -60
 tail -2 $OUT/bench_trace.log

@@ -86,6 +86,19 @@ WRITE_SIZE reads {w_copy:.1f} KiB -> correction x{w_corr:.4f}.
 Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / algorithmic = {traffic / ALGO_BYTES:.3f}
 (the excess is the batch-shared table and inv_delta_C, which the algorithmic figure excludes).
 """)
+    # kernel stats of the wider rows (whole TPS++ module, whole recogniser, warp backward)
+    for w, name in (("module", "module"), ("head", "recognizer"), ("backward", "warp_backward")):
+        src = os.path.join(SRC, f"trace_{w}", f"{w}_kernel_stats.csv")
+        if os.path.exists(src):
+            rows = sorted(csv.DictReader(open(src)), key=lambda r: -float(r["TotalDurationNs"]))
+            with open(os.path.join(DST, f"{TAG}_{name}_kernel_stats.csv"), "w", newline="") as f:
+                wr_ = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+                wr_.writeheader()
+                wr_.writerows(rows[:40])
+            log = os.path.join(SRC, f"{w}.log")
+            if os.path.exists(log):
+                with open(os.path.join(DST, f"{TAG}_{name}_run.txt"), "w") as f:
+                    f.write("".join(l for l in open(log) if "amdgpu.ids" not in l))
     print(json.dumps(js, indent=1))
 
 
