@@ -22,7 +22,9 @@ def ref_conv(srcs, w, b, k, stride, relu, res, res_mode):
     y = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=(k - 1) // 2)
     if res_mode == 2:
         y = y + res
-    if relu:
+    if relu == 2:
+        y = F.gelu(y)
+    elif relu:
         y = F.relu(y)
     if res_mode == 1:
         y = y + res
@@ -48,6 +50,10 @@ CASES = [
     ("two-image tile 3x3 s2 32->64 @8x32 -> 4x16", [(32, 8, 32, 1, 1)], 64, 3, (2, 2), True, 0, 5),
     ("two-image tile 1x1 64->128 @4x16", [(64, 4, 16, 1, 1)], 128, 1, (1, 1), False, 1, 3),
     ("two-image tile 3x3 @2x16 two sources", [(8, 2, 16, 1, 1), (8, 1, 16, 2, 1)], 64, 3, (1, 1), True, 0, 4),
+    # large 1x1 GEMMs -> 128x128 tiles
+    ("wide 1x1 512->1536 one row of 8192", [(512, 1, 8192, 1, 1)], 1536, 1, (1, 1), False, 0, 1),
+    ("wide 1x1 256->512 gelu+res @16x64 x 8", [(256, 16, 64, 1, 1)], 512, 1, (1, 1), 2, 1, 8),
+    ("wide 1x1 K=40 Cout=132 ragged", [(40, 12, 44, 1, 1)], 132, 1, (1, 1), True, 2, 9),
     # few output pixels -> split-K skinny kernel (decoder steps, batches of feature vectors)
     ("skinny 1x1 512->512 one row of 512", [(512, 1, 512, 1, 1)], 512, 1, (1, 1), False, 1, 1),
     ("skinny 1x1 512->92 ragged", [(512, 1, 77, 1, 1)], 92, 1, (1, 1), True, 0, 1),

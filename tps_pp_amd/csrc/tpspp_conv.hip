@@ -306,6 +306,113 @@ conv_tiled_f32_kernel(const ConvParams P)
     }
 }
 
+// ---- wide 1x1 kernel: large GEMMs (transformer projections over N*T tokens, 1x1 convs on big maps) -----------
+// The 128x64 tile moves 24 KB from L2 per 0.5 MFLOP (21 FLOP/B): at the fp32 matrix rate that is more
+// than the L2 can feed, and the 1x1 convolutions sit at ~60 TFLOP/s.  Here a workgroup owns 128 pixels x
+// 128 output channels (wavefront w: pixels [32w, 32w+32) x all 128 channels, four accumulators sharing
+// one B fragment): 32 KB per 1 MFLOP, 1.25 LDS reads per MFMA instead of 1.5.  Both slabs are k-major
+// rows of 128 floats, staged with float4 loads (512-B rows); next chunk prefetched into registers during
+// the multiply.  Needs HoWo % 4 == 0 and Cout % 4 == 0 (vector loads); same k order as the tiled kernel.
+constexpr int WBN = 128;
+
+__global__ void __launch_bounds__(kThreads, 2)
+conv1x1_wide_f32_kernel(const ConvParams P)
+{
+    constexpr int KC = 32;
+    __shared__ __attribute__((aligned(16))) float sX[KC * BM];
+    __shared__ __attribute__((aligned(16))) float sW[KC * WBN];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = tid / kWave;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n = blockIdx.z;
+    const int HoWo = P.Ho * P.Wo;
+    const int m0 = blockIdx.x * BM, co_base = blockIdx.y * WBN;
+    const float* xp = P.src[0].p + (size_t)n * P.Cin * HoWo;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+
+    // staging: thread t loads float4 #(t % 32) of rows t/32 + 8*i  (i = 0..3) of both slabs
+    const int srow = tid >> 5, sc4 = tid & 31;
+    const bool x_ok = m0 + 4 * sc4 + 3 < HoWo, w_ok = co_base + 4 * sc4 + 3 < P.Cout;
+    float4 rx[4], rw[4];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = c0 + srow + 8 * i;
+            const bool k_ok = k < P.Cin;
+            rx[i] = (k_ok && x_ok) ? *reinterpret_cast<const float4*>(xp + (size_t)k * HoWo + m0 + 4 * sc4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = (k_ok && w_ok) ? *reinterpret_cast<const float4*>(P.wt + (size_t)k * P.Cout + co_base + 4 * sc4)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            reinterpret_cast<float4*>(sX)[(srow + 8 * i) * (BM / 4) + sc4] = rx[i];
+            reinterpret_cast<float4*>(sW)[(srow + 8 * i) * (WBN / 4) + sc4] = rw[i];
+        }
+    };
+    prefetch(0);
+    for (int c0 = 0; c0 < P.Cin; c0 += KC) {
+        commit();
+        __syncthreads();
+        if (c0 + KC < P.Cin) prefetch(c0 + KC);
+#pragma unroll
+        for (int k2 = 0; k2 < KC; k2 += 2) {
+            const float b = sX[(k2 + half) * BM + wv * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = sW[(k2 + half) * WBN + 32 * j + l31];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int pix = m0 + wv * 32 + l31;
+    if (pix < HoWo) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < P.Cout) {
+                    float v = acc[j][r];
+                    if (P.bias) v = v + P.bias[co];
+                    const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
+                    if (P.res_mode == 2) v = v + P.res[o];
+                    if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+                    else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                    if (P.res_mode == 1) v = v + P.res[o];
+                    if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
+                    P.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+bool wide_applies(const ConvParams& P, int KH)
+{
+    if (KH != 1 || P.nsrc != 1 || P.sh != 1 || P.sw != 1) return false;
+    if (P.src[0].uh != 1 || P.src[0].uw != 1) return false;
+    const int HoWo = P.Ho * P.Wo;
+    if ((HoWo & 3) || (P.Cout & 3) || HoWo < BM || P.Cout < WBN) return false;
+    const long wgs = (long)((HoWo + BM - 1) / BM) * ((P.Cout + WBN - 1) / WBN) * P.N;
+    return wgs >= 512 && P.N <= 65535 && (P.Cout + WBN - 1) / WBN <= 65535;
+}
+
+void launch_wide(const ConvParams& P, hipStream_t st)
+{
+    const dim3 grid((unsigned)((P.Ho * P.Wo + BM - 1) / BM), (unsigned)((P.Cout + WBN - 1) / WBN), (unsigned)P.N);
+    hipLaunchKernelGGL(conv1x1_wide_f32_kernel, grid, dim3(kThreads), 0, st, P);
+}
+
 // ---- skinny 1x1 kernel: few output pixels (one decoder step, a batch of feature vectors) -----------------
 // With M = N*Ho*Wo of a few hundred the 128x64 tiles above leave most CUs idle and every K-chunk pays
 // a full memory latency.  Here a workgroup owns a 32-pixel x 32-channel tile and its four wavefronts
@@ -506,6 +613,12 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
         Q.wt = weight_t ? weight_t : weight_tiled;         // identical layouts for a 1x1 kernel (k-major)
         launch_skinny(Q, st);
         return tpspp::check_launch("tpspp_conv2d_fwd(skinny)");
+    }
+    if (g_conv_force_generic == 0 && wide_applies(P, KH)) {
+        ConvParams Q = P;
+        Q.wt = weight_t ? weight_t : weight_tiled;
+        launch_wide(Q, st);
+        return tpspp::check_launch("tpspp_conv2d_fwd(wide)");
     }
     if (weight_tiled && g_conv_force_generic == 0) {
         ConvParams Q = P;
