@@ -298,6 +298,22 @@ int tpspp_layernorm_cm_fwd(const float* x, const float* gamma, const float* beta
 int tpspp_attn_enc_fwd(const float* qkv, int N, int C, int T, const int* valid_len, float* out,
                        tpspp_stream_t stream);
 
+/*
+ * Fused LayerNorm -> Linear on a channel-major activation x (K, M), made for the few hundred columns of one
+ * decoder step (any size is accepted; large M is better served by the two separate calls):
+ *   token_major == 0:  out (Cout, M) = act(W^T LN(x) + bias) [+ residual]     act: 0 none, 1 ReLU, 2 GELU(erf)
+ *   token_major != 0:  out (M, Cout) = LN(x)^T W + bias                       (no activation / residual)
+ * The LayerNorm's affine is folded into the weight by the caller, once:
+ *   w_gamma (K, Cout) = diag(gamma) W_kmajor,   w_colsum (Cout) = column sums of w_gamma,
+ *   bias_eff (Cout)   = beta^T W_kmajor (+ bias)  or NULL when that is zero,
+ * so that  W^T LN(x)[:, m] = rstd_m (w_gamma^T x[:, m] - mean_m w_colsum) + bias_eff  and the kernel multiplies
+ * the raw activation (mean / rstd of every column are accumulated from the same loads, biased variance, eps).
+ * replaces: `norm` followed by a projection, common/layers/transformer_layers.py:150-163
+ */
+int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, const float* w_gamma,
+                        const float* w_colsum, int Cout, const float* bias_eff, int act,
+                        const float* residual, int token_major, float* out, tpspp_stream_t stream);
+
 /* Scratch sizes (bytes) for the two calls below; 0 on bad arguments. */
 size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner);
 size_t tpspp_nrtr_decoder_workspace(int N, int C, int T, int d_inner, int n_layers, int max_seq_len,
@@ -323,15 +339,20 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
 /*
  * NRTRDecoder.forward_test (greedy, forced_tokens == NULL) / forward_train (teacher forcing):
  *   enc_cm       (C, N*T) channel-major encoder output (tpspp_nrtr_encoder_fwd's out_cm)
- *   layer_ptrs   n_layers x 22 device pointers, per layer: norm1.weight, norm1.bias,
- *                self_attn.[q|k|v].weight^T (C, 3C), NULL, self_attn.fc.weight^T, its bias | NULL,
- *                norm2.weight, norm2.bias, enc_attn.linear_q.weight^T, NULL, enc_attn.linear_k.weight^T,
- *                its bias | NULL, enc_attn.linear_v.weight^T, NULL, enc_attn.fc.weight^T, its bias | NULL,
- *                norm3.weight, norm3.bias, mlp.w_1.weight^T, mlp.w_1.bias, mlp.w_2.weight^T, mlp.w_2.bias
- *                (the slots marked NULL must be NULL: the reference builds these projections without bias)
- *   ln_g, ln_b   final layer_norm (eps 1e-6);  emb (num_classes, C) trg_word_emb.weight;
- *   pos_table    (n_position, C) position_enc.position_table;  w_cls (C, num_out) classifier.weight^T,
- *   b_cls (num_out);  max_seq_len <= 64;  valid_len as above (cross-attention key mask) or NULL
+ *   layer_ptrs   n_layers x 18 device pointers, per layer (every LayerNorm folded into the projection that
+ *                follows it, see tpspp_linear_ln_fwd: w_gamma = diag(norm.weight) W^T-k-major, colsum its
+ *                column sums, bias_eff = norm.bias^T W (+ bias)):
+ *                  self_attn q|k|v fused (C, 3C): w_gamma, colsum (3C), bias_eff (3C);
+ *                  self_attn.fc.weight^T (C, C), its bias | NULL;
+ *                  enc_attn.linear_q (C, C): w_gamma, colsum (C), bias_eff (C);
+ *                  enc_attn.linear_k.weight^T, its bias | NULL;  enc_attn.linear_v.weight^T (no bias);
+ *                  enc_attn.fc.weight^T, its bias | NULL;
+ *                  mlp.w_1 (C, d_inner): w_gamma, colsum (d_inner), bias_eff (d_inner);
+ *                  mlp.w_2.weight^T (d_inner, C), mlp.w_2.bias
+ *   emb (num_classes, C) trg_word_emb.weight;  pos_table (n_position, C) position_enc.position_table;
+ *   w_cls (C, num_out), cls_colsum (num_out), b_cls (num_out): the classifier with the final layer_norm
+ *                (eps 1e-6) folded in the same way;  max_seq_len <= 64;  valid_len as above (cross-attention
+ *                key mask) or NULL
  *   forced_tokens NULL: greedy decoding from start_idx; out (N, max_seq_len, num_out) = per-step softmax
  *                scores, tokens_out (N, max_seq_len + 1) int32 (or NULL) = <BOS> followed by the arg-max
  *                of every step.
@@ -342,9 +363,10 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
  * replaces: textrecog/decoders/nrtr_decoder.py:95-113,131-177, common/layers/transformer_layers.py:133-163
  */
 int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
-                           const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
+                           const float* const* layer_ptrs,
                            const float* emb, const float* pos_table, int n_position,
-                           const float* w_cls, const float* b_cls, int num_out, int max_seq_len,
+                           const float* w_cls, const float* cls_colsum, const float* b_cls, int num_out,
+                           int max_seq_len,
                            int start_idx, int padding_idx, const int* valid_len,
                            const int* forced_tokens, void* workspace, size_t workspace_bytes,
                            float* out, int* tokens_out, tpspp_stream_t stream);

@@ -62,6 +62,23 @@ def test_layernorm_transpose_and_gelu_kernels(cuda):
     assert (got - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("K,M,Co", [(512, 512, 512), (512, 77, 92), (128, 33, 384), (96, 200, 40)])
+def test_fused_layernorm_projection(cuda, K, M, Co):
+    g = torch.Generator().manual_seed(K + M)
+    x = torch.randn(K, M, generator=g) * 2 + 0.5
+    ga, be = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w, b = torch.randn(Co, K, generator=g) / K ** 0.5, torch.randn(Co, generator=g)
+    r = torch.randn(Co, M, generator=g)
+    ln = F.layer_norm(x.t(), (K,), ga, be, 1e-5)                       # (M, K)
+    d = lambda t: t.to(cuda)  # noqa: E731
+    folded = ops.fold_layernorm(d(ga), d(be), ops.kmajor(d(w)), d(b))
+    got = ops.linear_ln(d(x), folded, 1e-5, act=2, residual=d(r)).cpu()
+    assert (got - (F.gelu(ln @ w.t() + b).t() + r)).abs().max() < 5e-5
+    folded = ops.fold_layernorm(d(ga), d(be), ops.kmajor(d(w)))
+    got_t = ops.linear_ln(d(x), folded, 1e-5, token_major=True).cpu()
+    assert (got_t - ln @ w.t()).abs().max() < 5e-5
+
+
 @pytest.mark.parametrize("T", [20, 64, 100, 256])
 def test_encoder_attention_kernel(cuda, T):
     g = torch.Generator().manual_seed(T)

@@ -484,6 +484,115 @@ conv1x1_skinny_f32_kernel(const ConvParams P)
     }
 }
 
+// ---- LayerNorm fused into the skinny projection --------------------------------------------------------------------
+// out = act(W^T LN(x) + bias) [+ res] for a channel-major x (K, M) with few columns (a decoder step).
+// With gamma folded into the weight rows on the host (Wg = diag(gamma) W) the normalisation commutes with
+// the product:   W^T LN(x)[:, m] = rstd_m (Wg^T x[:, m] - mean_m colsum(Wg)) + W^T beta,
+// so the MFMAs run on the RAW activation while the same loads feed sum / sum-of-squares per column
+// (two VALU FMAs per value); mean and rstd meet the accumulators in the epilogue.  The split-K workgroup
+// touches all K values of its 32 columns exactly once (4 wavefronts x 2 k-parities), so the statistics
+// cost one extra LDS row per wavefront in the reduction that is there anyway: no separate LayerNorm
+// launch, no normalised copy of x in HBM.  var = E[x^2] - mean^2 in fp32 (inputs are O(1) activations).
+// LN_ON_A = false: x is the B operand, output (Cout, M) channel-major;
+// LN_ON_A = true : operands swapped, x is the A operand, output (M, Cout') token-major.
+struct LnArgs {
+    const float* colsum;       // (Cout): column sums of Wg
+    float eps;
+};
+
+template <bool LN_ON_A>
+__global__ void __launch_bounds__(kThreads)
+conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
+{
+    __shared__ float sRed[4][16][kWave];
+    __shared__ float sSum[8][32], sSq[8][32];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int n = blockIdx.z;
+    const int HoWo = P.Ho * P.Wo;
+    const int m0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int K = P.Cin;
+    const int Kw = ((K + 7) / 8) * 2;
+    const int k_lo = wv * Kw;
+    const int k_hi = min(K, k_lo + Kw);
+    const int pix = m0 + l31, co = co0 + l31;
+    const bool pix_ok = pix < HoWo, co_ok = co < P.Cout;
+    const float* xp = P.src[0].p + (size_t)n * K * HoWo + (pix_ok ? pix : 0);
+    const float* wp = P.wt + (co_ok ? co : 0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float s1 = 0.0f, s2 = 0.0f;
+    constexpr int UB = 16;
+    const int nit = (k_hi - k_lo + 1) >> 1;
+    for (int it0 = 0; it0 < nit; it0 += UB) {
+        float a[UB], b[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = k_lo + 2 * (it0 + u) + half;
+            const bool k_ok = k < k_hi;
+            const int kk = k_ok ? k : k_lo;
+            const float av = wp[(size_t)kk * P.Cout];
+            const float bv = xp[(size_t)kk * HoWo];
+            a[u] = (k_ok && co_ok) ? av : 0.0f;
+            b[u] = (k_ok && pix_ok) ? bv : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const float xv = LN_ON_A ? a[u] : b[u];
+            s1 += xv;
+            s2 = fmaf(xv, xv, s2);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
+    sSum[wv * 2 + half][l31] = s1;
+    sSq[wv * 2 + half][l31] = s2;
+    __syncthreads();
+    if (!pix_ok) return;
+    float mean_l = 0.0f, rstd_l = 0.0f;
+    if (!LN_ON_A) {                                        // statistics of this lane's pixel column
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t1 += sSum[j][l31]; t2 += sSq[j][l31]; }
+        mean_l = t1 / (float)K;
+        rstd_l = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean_l * mean_l, 0.0f) + L.eps);
+    }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        const int r = 4 * wv + qd;
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;    // row inside the tile
+        const int c = co0 + cl;
+        if (c < P.Cout) {
+            float mean = mean_l, rstd = rstd_l, csum;
+            if (LN_ON_A) {                                 // statistics belong to the ROW (a column of x)
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { t1 += sSum[j][cl]; t2 += sSq[j][cl]; }
+                mean = t1 / (float)K;
+                rstd = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean * mean, 0.0f) + L.eps);
+                csum = L.colsum[pix];
+            } else {
+                csum = L.colsum[c];
+            }
+            float val = (sRed[0][r][lane] + sRed[1][r][lane]) + (sRed[2][r][lane] + sRed[3][r][lane]);
+            val = rstd * (val - mean * csum);
+            if (P.bias) val = val + P.bias[LN_ON_A ? pix : c];
+            const size_t o = ((size_t)n * P.Cout + c) * HoWo + pix;
+            if (P.res_mode == 2) val = val + P.res[o];
+            if (P.relu == 1) val = val > 0.0f ? val : 0.0f;
+            else if (P.relu == 2) val = 0.5f * val * (1.0f + erff(val * 0.70710678118654752440f));
+            if (P.res_mode == 1) val = val + P.res[o];
+            P.out[o] = val;
+        }
+    }
+}
+
 // true when the 128x64 tiling would start fewer workgroups than the chip has CUs
 bool skinny_applies(const ConvParams& P, int KH)
 {
@@ -629,4 +738,36 @@ TPSPP_EXPORT int tpspp_conv2d_fwd(const float* const* src_ptrs, const int* src_d
     if (KH == 1) launch_conv<1, 1, 32>(P, st);
     else         launch_conv<3, 3, 8>(P, st);
     return tpspp::check_launch("tpspp_conv2d_fwd");
+}
+
+TPSPP_EXPORT int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, const float* w_gamma,
+                                     const float* w_colsum, int Cout, const float* bias_eff, int act,
+                                     const float* residual, int token_major, float* out, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(x && w_gamma && w_colsum && out, "tpspp_linear_ln_fwd: null pointer");
+    TPSPP_REQUIRE(K > 0 && M > 0 && Cout > 0 && act >= 0 && act <= 2, "tpspp_linear_ln_fwd: bad sizes / activation");
+    TPSPP_REQUIRE(!token_major || (act == 0 && !residual),
+                  "tpspp_linear_ln_fwd: the token-major form takes no activation / residual");
+    ConvParams P;
+    P.nsrc = 1;
+    P.src[0].C = K; P.src[0].H = 1; P.src[0].uh = 1; P.src[0].uw = 1;
+    P.Cin = K; P.N = 1; P.Hi = 1; P.Ho = 1; P.sh = P.sw = 1; P.ph = P.pw = 0;
+    P.bias = bias_eff; P.res = residual; P.res_mode = residual ? 1 : 0; P.relu = act;
+    P.post_scale = nullptr; P.post_shift = nullptr; P.out = out;
+    const LnArgs L{w_colsum, eps};
+    hipStream_t st = tpspp::as_stream(stream);
+    if (!token_major) {                    // out (Cout, M)
+        P.src[0].p = x; P.src[0].W = M; P.Wi = M; P.Wo = M; P.Cout = Cout; P.wt = w_gamma;
+        P.src[1] = P.src[0]; P.src[2] = P.src[0];
+        const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Cout + 31) / 32), 1);
+        TPSPP_REQUIRE(grid.y <= 65535, "tpspp_linear_ln_fwd: too many output features");
+        hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false>), grid, dim3(kThreads), 0, st, P, L);
+    } else {                               // out (M, Cout): the weight plays the image, x the weights
+        P.src[0].p = w_gamma; P.src[0].W = Cout; P.Wi = Cout; P.Wo = Cout; P.Cout = M; P.wt = x;
+        P.src[1] = P.src[0]; P.src[2] = P.src[0];
+        const dim3 grid((unsigned)((Cout + 31) / 32), (unsigned)((M + 31) / 32), 1);
+        TPSPP_REQUIRE(grid.y <= 65535, "tpspp_linear_ln_fwd: too many columns");
+        hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true>), grid, dim3(kThreads), 0, st, P, L);
+    }
+    return tpspp::check_launch("tpspp_linear_ln_fwd");
 }

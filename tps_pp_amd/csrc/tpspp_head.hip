@@ -518,8 +518,9 @@ TPSPP_EXPORT int tpspp_attn_enc_fwd(const float* qkv, int N, int C, int T, const
 
 // layer pointer tables: see include/tpspp.h
 enum { E_LN1G, E_LN1B, E_WQKV, E_BQKV, E_WFC, E_BFC, E_LN2G, E_LN2B, E_W1, E_B1, E_W2, E_B2, E_COUNT };
-enum { D_LN1G, D_LN1B, D_WQKV, D_BQKV, D_WFC, D_BFC, D_LN2G, D_LN2B, D_WQ, D_BQ, D_WK, D_BK, D_WV, D_BV, D_WFC2,
-       D_BFC2, D_LN3G, D_LN3B, D_W1, D_B1, D_W2, D_B2, D_COUNT };
+// decoder: the three LayerNorms are folded into the projections that follow them (tpspp_linear_ln_fwd)
+enum { D_QKV_W, D_QKV_CS, D_QKV_B, D_WFC, D_BFC, D_Q_W, D_Q_CS, D_Q_B, D_WK, D_BK, D_WV, D_WFC2, D_BFC2, D_W1_W, D_W1_CS,
+       D_W1_B, D_W2, D_B2, D_COUNT };
 
 TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
                                         const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
@@ -583,14 +584,15 @@ TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, 
 }
 
 TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
-                                        const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
+                                        const float* const* layer_ptrs,
                                         const float* emb, const float* pos_table, int n_position,
-                                        const float* w_cls, const float* b_cls, int num_out, int max_seq_len,
+                                        const float* w_cls, const float* cls_colsum, const float* b_cls, int num_out,
+                                        int max_seq_len,
                                         int start_idx, int padding_idx, const int* valid_len,
                                         const int* forced_tokens, void* workspace, size_t workspace_bytes,
                                         float* out, int* tokens_out, tpspp_stream_t stream)
 {
-    TPSPP_REQUIRE(enc_cm && layer_ptrs && ln_g && ln_b && emb && pos_table && w_cls && workspace && out,
+    TPSPP_REQUIRE(enc_cm && layer_ptrs && emb && pos_table && w_cls && cls_colsum && workspace && out,
                   "tpspp_nrtr_decoder_fwd: null pointer");
     TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0 && num_out > 0,
                   "tpspp_nrtr_decoder_fwd: bad sizes (d_model must be a multiple of 64 = n_head * 64)");
@@ -601,12 +603,9 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                   "tpspp_nrtr_decoder_fwd: workspace too small");
     for (int l = 0; l < n_layers; ++l) {
         const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
-        TPSPP_REQUIRE(w[D_LN1G] && w[D_LN1B] && w[D_WQKV] && w[D_WFC] && w[D_LN2G] && w[D_LN2B] && w[D_WQ] &&
-                          w[D_WK] && w[D_WV] && w[D_WFC2] && w[D_LN3G] && w[D_LN3B] && w[D_W1] && w[D_W2],
+        TPSPP_REQUIRE(w[D_QKV_W] && w[D_QKV_CS] && w[D_WFC] && w[D_Q_W] && w[D_Q_CS] && w[D_WK] && w[D_WV] && w[D_WFC2] &&
+                          w[D_W1_W] && w[D_W1_CS] && w[D_W2],
                       "tpspp_nrtr_decoder_fwd: layer %d has a null weight", l);
-        TPSPP_REQUIRE(!w[D_BQKV] && !w[D_BQ] && !w[D_BV],
-                      "tpspp_nrtr_decoder_fwd: biases on token-major projections (self q/k/v, cross q, cross v) "
-                      "are not supported (the reference builds them with qkv_bias=False)");
     }
     hipStream_t st = tpspp::as_stream(stream);
     const int H = C / kDK, L = max_seq_len, Lt = L + 1;
@@ -634,7 +633,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     for (int l = 0; l < n_layers; ++l) {
         const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
         g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
-        g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);
+        g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);            // (a value bias would be per channel = per column here: not supported)
     }
     if (g.rc) return g.rc;
     hipLaunchKernelGGL(dec_init_tokens_kernel, dim3((unsigned)((N * Lt + 255) / 256)), dim3(256), 0, st, tokens, N,
@@ -648,31 +647,27 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         for (int l = 0; l < n_layers; ++l) {
             const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
             // x = x + fc(self_attn(LN1(x)))                          transformer_layers.py:150-154
-            rc = tpspp_layernorm_cm_fwd(x, w[D_LN1G], w[D_LN1B], C, N, 1e-5f, y, stream);
+            rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_QKV_W], w[D_QKV_CS], 3 * C, w[D_QKV_B], 0, nullptr, 1, qkv, stream);
             if (rc) return rc;
-            g.tm(w[D_WQKV], y, C, 3 * C, N, qkv);
             hipLaunchKernelGGL(attn_dec_self_kernel, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
                                Vc[l], tokens, Lt, padding_idx, a);
             g.cm(w[D_WFC], w[D_BFC], a, C, C, N, y, 0, x);            // y = x + fc(a)
             // x = y + fc(enc_attn(LN2(y), enc, enc))                   transformer_layers.py:156-159
-            rc = tpspp_layernorm_cm_fwd(y, w[D_LN2G], w[D_LN2B], C, N, 1e-5f, a, stream);
+            rc = tpspp_linear_ln_fwd(y, C, N, 1e-5f, w[D_Q_W], w[D_Q_CS], C, w[D_Q_B], 0, nullptr, 1, qkv, stream);
             if (rc) return rc;
-            g.tm(w[D_WQ], a, C, C, N, qkv);
             hipLaunchKernelGGL(attn_dec_cross_kernel, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C, N, H,
                                T, valid_len, a);
             g.cm(w[D_WFC2], w[D_BFC2], a, C, C, N, x, 0, y);          // x = y + fc(a)
             // x = x + mlp(LN3(x))                                       transformer_layers.py:161-163
-            rc = tpspp_layernorm_cm_fwd(x, w[D_LN3G], w[D_LN3B], C, N, 1e-5f, a, stream);
+            rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_W1_W], w[D_W1_CS], d_inner, w[D_W1_B], 2, nullptr, 0, hid, stream);
             if (rc) return rc;
-            g.cm(w[D_W1], w[D_B1], a, C, d_inner, N, hid, 2, nullptr);
             g.cm(w[D_W2], w[D_B2], hid, d_inner, C, N, y, 0, x);      // y = x + w2(...)
             float* t = x; x = y; y = t;
             if (g.rc) return g.rc;
         }
-        rc = tpspp_layernorm_cm_fwd(x, ln_g, ln_b, C, N, 1e-6f, y, stream);   // nrtr_decoder.py:77,111
+        // final LayerNorm (eps 1e-6) folded into the classifier     nrtr_decoder.py:77,111 + :78
+        rc = tpspp_linear_ln_fwd(x, C, N, 1e-6f, w_cls, cls_colsum, num_out, b_cls, 0, nullptr, 0, logits, stream);
         if (rc) return rc;
-        g.cm(w_cls, b_cls, y, C, num_out, N, logits, 0, nullptr);
-        if (g.rc) return g.rc;
         hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, logits, num_out,
                            N, s, L, greedy, out, tokens, Lt);
     }

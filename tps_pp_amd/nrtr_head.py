@@ -205,15 +205,18 @@ class NRTRDecoder(nn.Module):
                 sa, ea = lyr.self_attn, lyr.enc_attn
                 wqkv = torch.cat([ops.kmajor(sa.linear_q.weight), ops.kmajor(sa.linear_k.weight),
                                   ops.kmajor(sa.linear_v.weight)], dim=1).contiguous()
-                ts += [_f32(lyr.norm1.weight), _f32(lyr.norm1.bias), wqkv, None, ops.kmajor(sa.fc.weight), None,
-                       _f32(lyr.norm2.weight), _f32(lyr.norm2.bias), ops.kmajor(ea.linear_q.weight), None,
-                       ops.kmajor(ea.linear_k.weight), None, ops.kmajor(ea.linear_v.weight), None,
-                       ops.kmajor(ea.fc.weight), None, _f32(lyr.norm3.weight), _f32(lyr.norm3.bias),
-                       ops.kmajor(lyr.mlp.w_1.weight), _f32(lyr.mlp.w_1.bias), ops.kmajor(lyr.mlp.w_2.weight),
-                       _f32(lyr.mlp.w_2.bias)]
-            cache = (key, ops.PtrTable(ts), _f32(self.layer_norm.weight), _f32(self.layer_norm.bias),
-                     _f32(self.trg_word_emb.weight), _f32(self.position_enc.position_table[0]),
-                     ops.kmajor(self.classifier.weight), _f32(self.classifier.bias))
+                # each LayerNorm is folded into the projection that follows it (tpspp_linear_ln_fwd)
+                qkv = ops.fold_layernorm(lyr.norm1.weight, lyr.norm1.bias, wqkv)
+                q = ops.fold_layernorm(lyr.norm2.weight, lyr.norm2.bias, ops.kmajor(ea.linear_q.weight))
+                w1 = ops.fold_layernorm(lyr.norm3.weight, lyr.norm3.bias, ops.kmajor(lyr.mlp.w_1.weight), lyr.mlp.w_1.bias)
+                ts += [qkv[0], qkv[1], qkv[2], ops.kmajor(sa.fc.weight), None,
+                       q[0], q[1], q[2], ops.kmajor(ea.linear_k.weight), None, ops.kmajor(ea.linear_v.weight),
+                       ops.kmajor(ea.fc.weight), None, w1[0], w1[1], w1[2],
+                       ops.kmajor(lyr.mlp.w_2.weight), _f32(lyr.mlp.w_2.bias)]
+            cls = ops.fold_layernorm(self.layer_norm.weight, self.layer_norm.bias, ops.kmajor(self.classifier.weight),
+                                     self.classifier.bias)
+            cache = (key, ops.PtrTable(ts), _f32(self.trg_word_emb.weight), _f32(self.position_enc.position_table[0]),
+                     cls)
             self._w_cache = cache
         return cache[1:]
 
@@ -225,10 +228,10 @@ class NRTRDecoder(nn.Module):
         enc_cm = getattr(out_enc, "_tpspp_cm", None)
         if enc_cm is None or tuple(enc_cm.shape) != (c, n * t):
             enc_cm = ops.transpose2d(out_enc.float().reshape(n * t, c))
-        table, g, b, emb, pos, wc, bc = self._weights()
+        table, emb, pos, cls = self._weights()
         vl = _valid_len(img_metas, n, t, out_enc.device)
         seq_len = self.max_seq_len if forced is None else forced.shape[1]
-        out, tokens = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, g, b, emb, pos, wc, bc,
+        out, tokens = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, emb, pos, cls,
                                        seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self)
         self.last_tokens = tokens
         return out

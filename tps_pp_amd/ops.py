@@ -477,6 +477,33 @@ def layernorm_cm(x, gamma, beta, eps=1e-5):
     return y
 
 
+def fold_layernorm(gamma, beta, w_kmajor, bias=None):
+    """LayerNorm affine folded into the following projection (done once per weight):
+    -> (w_gamma = diag(gamma) W, w_colsum = column sums of w_gamma, bias_eff = beta^T W (+ bias))."""
+    w = w_kmajor.detach().float()
+    wg = (gamma.detach().float()[:, None] * w).contiguous()
+    be = beta.detach().float() @ w
+    if bias is not None:
+        be = be + bias.detach().float()
+    return wg, wg.sum(0).contiguous(), be.contiguous()
+
+
+def linear_ln(x, folded, eps=1e-5, act=0, residual=None, token_major=False):
+    """Fused LayerNorm -> Linear on a channel-major (K, M) activation (`tpspp_linear_ln_fwd`);
+    `folded` = fold_layernorm(gamma, beta, w_kmajor, bias)."""
+    wg, colsum, bias_eff = folded
+    x, wg = _chk("x", x, 2), _chk("w_gamma", wg, 2)
+    K, M = x.shape
+    Cout = wg.shape[1]
+    out = torch.empty((M, Cout) if token_major else (Cout, M), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().tpspp_linear_ln_fwd(_ptr(x), K, M, float(eps), _ptr(wg), _ptr(_chk("w_colsum", colsum, 1)), Cout,
+                                            _ptr(bias_eff), int(act), _ptr(residual), int(bool(token_major)),
+                                            _ptr(out), _stream(x))
+    _lib.check(rc, "tpspp_linear_ln_fwd")
+    return out
+
+
 def attn_enc(qkv, N, T, valid_len=None):
     """Encoder multi-head self-attention on projected (3C, N*T) q/k/v (`tpspp_attn_enc_fwd`) -> (C, N*T)."""
     qkv = _chk("qkv", qkv, 2)
@@ -529,13 +556,14 @@ def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, hol
     return out, out_cm
 
 
-def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, ln_g, ln_b, emb, pos_table, w_cls, b_cls, max_seq_len,
+def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_folded, max_seq_len,
                  start_idx, padding_idx, valid_len=None, forced_tokens=None, holder=None):
     """`tpspp_nrtr_decoder_fwd` -> (out (N, L, num_out), tokens (N, L+1) int32)."""
     enc_cm = _chk("enc_cm", enc_cm, 2)
     C = enc_cm.shape[0]
     if enc_cm.shape[1] != N * T:
         raise ValueError("nrtr_decoder: enc_cm must be (C, N*T)")
+    w_cls, cls_colsum, b_cls = cls_folded              # fold_layernorm(final layer_norm, classifier)
     num_out = w_cls.shape[1]
     L = _lib.lib()
     nbytes = L.tpspp_nrtr_decoder_workspace(N, C, T, d_inner, n_layers, max_seq_len, num_out)
@@ -547,9 +575,9 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, ln_g, ln_b, emb, pos_ta
                 not forced_tokens.is_contiguous() or forced_tokens.device != enc_cm.device:
             raise ValueError("nrtr_decoder: forced_tokens must be a contiguous (N, max_seq_len) int32 device tensor")
     with torch.cuda.device(enc_cm.device):
-        rc = L.tpspp_nrtr_decoder_fwd(_ptr(enc_cm), N, C, T, d_inner, n_layers, table.ptr, _ptr(ln_g), _ptr(ln_b),
-                                      _ptr(emb), _ptr(pos_table), pos_table.shape[0], _ptr(w_cls), _ptr(b_cls),
-                                      num_out, max_seq_len, int(start_idx), int(padding_idx), _ptr(valid_len),
+        rc = L.tpspp_nrtr_decoder_fwd(_ptr(enc_cm), N, C, T, d_inner, n_layers, table.ptr,
+                                      _ptr(emb), _ptr(pos_table), pos_table.shape[0], _ptr(w_cls), _ptr(cls_colsum),
+                                      _ptr(b_cls), num_out, max_seq_len, int(start_idx), int(padding_idx), _ptr(valid_len),
                                       _ptr(forced_tokens), ws.data_ptr(), ws.numel(), _ptr(out), _ptr(tokens),
                                       _stream(enc_cm))
     _lib.check(rc, "tpspp_nrtr_decoder_fwd")
