@@ -265,12 +265,12 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
     const float l = wave_sum(p);
     p = p / l;
     float acc = readlane_f(p, step) * v;
-    for (int p0 = 0; p0 < step; p0 += 8) {                 // 8 cached value rows in flight
-        float vv[8];
+    for (int p0 = 0; p0 < step; p0 += 16) {                // 16 cached value rows in flight
+        float vv[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) vv[u] = vc[(size_t)(p0 + u < step ? p0 + u : 0) * kDK + lane];
+        for (int u = 0; u < 16; ++u) vv[u] = vc[(size_t)(p0 + u < step ? p0 + u : 0) * kDK + lane];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const float pw = p0 + u < step ? readlane_f(p, (p0 + u) & (kWave - 1)) : 0.0f;
             acc = fmaf(pw, vv[u], acc);
         }
