@@ -271,6 +271,7 @@ struct LdsParams {
     int compute_waves;  // wavefronts [0, compute_waves) own pixels, the rest load
     int band_px;        // output pixels per band (a workgroup = one image pair x one band)
     int bands;
+    int zero_off;       // mirror kernel: float offset (from the staged pair) of the zero words for OOB taps
     long long* trace;   // optional: 8 shader-clock stamps per workgroup (tpspp_warp_set_trace)
 };
 
@@ -524,6 +525,7 @@ tps_warp_lds_mirror_kernel(const LdsParams P)
     float4* sT = reinterpret_cast<float4*>(smem);          // K x (TxA, TyA, TxB, TyB)
     float* sInv = smem + 4 * K;                            // K*K (padded to 4)
     float* sImg = sInv + ((K * K + 3) & ~3);               // image pair, contiguous, + slack
+    float* sZero = sImg + P.zero_off;                      // C zero words, H*W apart, behind the DMA pieces
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -626,6 +628,7 @@ tps_warp_lds_mirror_kernel(const LdsParams P)
             dst[0] = ax; dst[1] = ay;
         }
     }
+    if (tid < C) sZero[tid * HW] = 0.0f;                           // read by out-of-image taps
     lds_only_barrier();
     if (wv == 0) stamp(P.trace, 1);                               // T ready
 
@@ -679,6 +682,7 @@ tps_warp_lds_mirror_kernel(const LdsParams P)
             if (im == 1 && !hasB) break;                   // wave-uniform
             const int b = b0 + im;
             const float* img = sImg + im * img_elems;
+            const float* zero_im = sZero;                  // + ch*HW: this image's zero words
             typedef __attribute__((address_space(1))) char gchar;
             typedef __attribute__((address_space(1))) float gfloat;
             gchar* oc[C];                                  // per-plane bases, kept in SGPR pairs
@@ -689,6 +693,13 @@ tps_warp_lds_mirror_kernel(const LdsParams P)
             }
             char* og = AUX ? reinterpret_cast<char*>(P.grid) + (size_t)b * 2 * row_bytes : nullptr;
             char* oi = AUX ? reinterpret_cast<char*>(P.idx) + (size_t)b * 2 * row_bytes : nullptr;
+            // Four tap pointers per pixel; a tap outside the image points at a zero word kept behind the
+            // staged pair (one per channel plane, HW apart), so a channel is four LDS reads with immediate
+            // offsets and no per-channel select or address arithmetic.  All 16*C reads of the image's four
+            // mirror pixels are issued before the first is consumed: with ~3 wavefronts per SIMD the
+            // LDS latency would otherwise be paid once per pixel.
+            const float* tp[4][4];
+            float tw[4][4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const Taps t = make_taps(gx[m][im], gy[m][im], H, W);
@@ -697,20 +708,28 @@ tps_warp_lds_mirror_kernel(const LdsParams P)
                     if (P.idx) *reinterpret_cast<int2*>(oi + 2u * poff[m]) = make_int2(t.x0, t.y0);
                 }
                 const bool inxy = t.inx && t.iny;
+                tp[m][0] = img + t.o00;
+                tp[m][1] = t.inx ? tp[m][0] + 1 : zero_im;
+                tp[m][2] = t.iny ? img + t.o10 : zero_im;
+                tp[m][3] = inxy ? img + t.o10 + 1 : zero_im;
+                tw[m][0] = t.nw; tw[m][1] = t.ne; tw[m][2] = t.sw; tw[m][3] = t.se;
+            }
+            float tv[4][C][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tv[m][ch][q] = tp[m][q][ch * HW];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                    const float* pl = img + ch * HW;
-                    const float v00 = pl[t.o00];
-                    float v01 = pl[t.o00 + 1];             // over-read masked below (slack after pair)
-                    float v10 = pl[t.o10];
-                    float v11 = pl[t.o10 + 1];
-                    v01 = t.inx ? v01 : 0.0f;
-                    v10 = t.iny ? v10 : 0.0f;
-                    v11 = inxy ? v11 : 0.0f;
-                    float acc = v00 * t.nw;
-                    acc = fmaf(v01, t.ne, acc);
-                    acc = fmaf(v10, t.sw, acc);
-                    acc = fmaf(v11, t.se, acc);
+                    float acc = tv[m][ch][0] * tw[m][0];
+                    acc = fmaf(tv[m][ch][1], tw[m][1], acc);
+                    acc = fmaf(tv[m][ch][2], tw[m][2], acc);
+                    acc = fmaf(tv[m][ch][3], tw[m][3], acc);
                     *(gfloat*)(oc[ch] + poff[m]) = acc;
                 }
             }
@@ -974,10 +993,17 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                 const int mcw = qpb / kWave < 2 ? 2 : qpb / kWave;
                 L.compute_waves = mcw; L.band_px = qpb; L.bands = mb;
                 const int threads = (mcw + kLdsLoaders) * kWave;
-                if (C0 == 1) launch_lds_mirror<20, 1>(L, threads, lds, st);
-                else         launch_lds_mirror<20, 3>(L, threads, lds, st);
+                // zero words for out-of-image taps: one per channel plane, H*W apart, behind the DMA pieces
+                L.zero_off = pieces * 256;
+                const size_t mlds = (size_t)(4 * K + ((K * K + 3) & ~3)) * sizeof(float) + (size_t)pieces * 1024 +
+                                    ((size_t)(C0 - 1) * H0 * W0 + 4) * sizeof(float);
+                if (mlds > 160 * 1024) goto no_mirror;
+                if (C0 == 1) launch_lds_mirror<20, 1>(L, threads, mlds, st);
+                else         launch_lds_mirror<20, 3>(L, threads, mlds, st);
                 return tpspp::check_launch("tpspp_warp_fwd(lds-mirror)");
             }
+        no_mirror:
+            L.compute_waves = cw; L.band_px = band_px; L.bands = bands; L.zero_off = 0;
             const int threads = (cw + kLdsLoaders) * kWave;
             const bool ok = (C0 == 1) ? launch_lds<20, 1>(L, ppt, threads, lds, st)
                                       : launch_lds<20, 3>(L, ppt, threads, lds, st);
