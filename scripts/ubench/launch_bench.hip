@@ -11,13 +11,13 @@ __global__ void __launch_bounds__(1024) empty_k(float* sink)
 __global__ void __launch_bounds__(1024) write_k(float4* out, int per_block4)
 {
     float4* o = out + (size_t)blockIdx.x * per_block4;
-    for (int i = threadIdx.x; i < per_block4; i += 1024) o[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+    for (int i = threadIdx.x; i < per_block4; i += blockDim.x) o[i] = make_float4(1.f, 2.f, 3.f, (float)i);
 }
 __global__ void __launch_bounds__(1024) copy_k(const float4* in, float4* out, int per_block4)
 {
     const float4* s = in + (size_t)blockIdx.x * per_block4;
     float4* o = out + (size_t)blockIdx.x * per_block4;
-    for (int i = threadIdx.x; i < per_block4; i += 1024) o[i] = s[i];
+    for (int i = threadIdx.x; i < per_block4; i += blockDim.x) o[i] = s[i];
 }
 template <class F> float period_us(F launch, int n)
 {
