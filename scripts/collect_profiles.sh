@@ -24,5 +24,10 @@ for w in module head backward; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o $w -- \
       python3 scripts/bench_$w.py > $OUT/$w.log 2>&1
 done
+# 4. MFMA-busy counters (own pass) for the regressor kernels + the calibration kernel (pure MFMA)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc -o module -- \
+    python3 scripts/bench_module.py > $OUT/mfma_module.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_cal -o cal -- \
+    ./scripts/ubench/mfma_bench > $OUT/mfma_cal.log 2>&1
 ls -R $OUT | head -60
 tail -2 $OUT/bench_trace.log

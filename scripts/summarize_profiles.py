@@ -32,6 +32,48 @@ def mean_counter(path, kernel_substr, counter):
     return sum(vals) / len(vals), len(vals)
 
 
+def mfma_summary():
+    """MFMA-busy fraction per kernel of the TPS++ module run: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128),
+    the denominator calibrated on a kernel that does nothing but fp32 MFMAs (scripts/ubench/mfma_bench.hip)."""
+    def load(path):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(path)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return agg
+    mod = os.path.join(SRC, "mfma_pmc", "module_counter_collection.csv")
+    cal = os.path.join(SRC, "mfma_cal", "cal_counter_collection.csv")
+    if not (os.path.exists(mod) and os.path.exists(cal)):
+        return
+    c = next(v for k, v in load(cal).items() if "mfma_only" in k)
+    busy, act = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"]), sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+    per_active = busy / act                       # counter units of a saturated matrix pipe per GUI_ACTIVE tick
+    tf = [l for l in open(os.path.join(SRC, "mfma_cal.log")) if "TFLOP/s" in l]
+    rows = []
+    for k, v in load(mod).items():
+        b = v.get("SQ_VALU_MFMA_BUSY_CYCLES")
+        a = v.get("GRBM_GUI_ACTIVE")
+        if not b or not a or sum(b) == 0:
+            continue
+        rows.append((sum(b), k, len(b), sum(b) / sum(a) / per_active))
+    rows.sort(reverse=True)
+    with open(os.path.join(DST, f"{TAG}_mfma_util.md"), "w") as f:
+        f.write(f"""# {TAG}: fp32 matrix-pipe utilisation of the TPS++ regressor kernels (MI355X, 1 GPU)
+
+`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 scripts/bench_module.py` (batch 512, own pass).
+
+Calibration (`scripts/ubench/mfma_bench.hip`: every SIMD issues only `v_mfma_f32_32x32x2_f32`):
+{tf[-1].strip() if tf else ""}
+-> SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE = {per_active:.2f} at saturation (64 busy cycles per MFMA, 1024 SIMDs,
+GRBM_GUI_ACTIVE summed over the 8 XCDs); utilisation below = the same ratio of a kernel / {per_active:.2f}.
+
+| kernel | dispatches | MFMA pipe busy |
+|---|---|---|
+""")
+        for _, k, n, u in rows:
+            f.write(f"| `{k[:100]}` | {n} | {100 * u:.1f} % |\n")
+        f.write("\n(counter collection serialises dispatches and slows kernels slightly; un-profiled rates are in DESIGN.md section 4b)\n")
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"),
@@ -99,6 +141,7 @@ Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / 
             if os.path.exists(log):
                 with open(os.path.join(DST, f"{TAG}_{name}_run.txt"), "w") as f:
                     f.write("".join(l for l in open(log) if "amdgpu.ids" not in l))
+    mfma_summary()
     print(json.dumps(js, indent=1))
 
 
