@@ -63,9 +63,32 @@ def cpu_baseline(img, ctrl, inv, p_hat, budget_s=12.0):
         if time.perf_counter() - t0 >= budget_s or reps >= 2000:
             break
     dt = time.perf_counter() - t0
+    # the same arithmetic as the reference composes it, on PyTorch's CPU kernels (torch.bmm x2 +
+    # F.grid_sample; tps_preprocessor.py:71-83,270-282), all host threads, ~6 s sample
+    import torch.nn.functional as Fn
+    with torch.no_grad():
+        ti, tc = torch.from_numpy(img), torch.from_numpy(ctrl)
+        tinv = torch.from_numpy(inv).unsqueeze(0).repeat(BATCH, 1, 1)
+        tph = torch.from_numpy(p_hat).unsqueeze(0).repeat(BATCH, 1, 1)
+
+        def ref_step():
+            cz = torch.cat((tc, torch.zeros(BATCH, 3, 2)), dim=1)
+            grid = torch.bmm(tph, torch.bmm(tinv, cz)).reshape(BATCH, H, W, 2)
+            return Fn.grid_sample(ti, grid, padding_mode="border", align_corners=True)
+        ref_step()
+        t1 = time.perf_counter()
+        treps = 0
+        while time.perf_counter() - t1 < 6.0 and treps < 2000:
+            ref_step()
+            treps += 1
+        tdt = time.perf_counter() - t1
     return {"value": reps * BATCH / dt, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"{reps} batches of {BATCH} images (3x32x100, F=20) in {dt:.1f} s, "
-                      f"oracle/tps_oracle.c with {threads} OpenMP threads"}
+                      f"oracle/tps_oracle.c with {threads} OpenMP threads",
+            "pytorch_cpu_composition": {"value": treps * BATCH / tdt, "unit": "images/s",
+                                        "threads": torch.get_num_threads(),
+                                        "sample": f"{treps} batches of {BATCH} in {tdt:.1f} s: torch.bmm x2 + "
+                                                  "F.grid_sample as the reference composes them"}}
 
 
 def extra_measurements(dev):
