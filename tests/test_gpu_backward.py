@@ -115,3 +115,62 @@ def test_modules_train_through_the_hip_warp(cuda):
     out.square().mean().backward()
     assert img.grad is not None and torch.isfinite(img.grad).all()
     assert p.LocalizationNetwork.localization_fc2.bias.grad.abs().max() > 0
+
+
+def test_backward_full_size_properties(cuda):
+    """TPS_PP geometry at batch 512 (the oracle cannot run this in seconds): the HIP backward against the
+    HIP forward itself.  L = <out0, g0> + <out1, g1> is LINEAR in the sampled inputs, so
+    <dL/d in, d> = L(in + d) - L(in) exactly (to rounding); the parameter gradients of a few rows are
+    compared with float64 autograd of the reference's composition."""
+    from tps_pp_amd import constants
+    n = 512
+    g = torch.Generator(device=cuda).manual_seed(5)
+    c = O.tpspp_constants(cases.PP_HW, cases.PP_POINT)
+    inv, ph, pxy = dev(c["hat_C"], cuda), dev(c["P_hat"], cuda), dev(c["P_xy"], cuda)
+    # band-limited images (low-resolution noise, bilinearly upsampled): the loss is then smooth enough in
+    # the control points for a finite difference to mean something
+    up = lambda t, hw: torch.nn.functional.interpolate(t, size=hw, mode="bilinear", align_corners=True)  # noqa: E731
+    fg = up(torch.rand((n, 64, 4, 16), generator=g, device=cuda), (32, 128)).contiguous()
+    x = up(torch.rand((n, 64, 2, 8), generator=g, device=cuda), (16, 64)).contiguous()
+    ctrl = dev(constants.tpspp_initial_ctrl((2, 16)), cuda)[None].repeat(n, 1, 1) + \
+        0.02 * (torch.rand((n, 32, 2), generator=g, device=cuda) - 0.5)
+    score = 0.5 * (torch.rand((n, 1024, 32), generator=g, device=cuda) - 0.5)
+    g0 = torch.rand((n, 64, 16, 64), generator=g, device=cuda) - 0.5
+    g1 = torch.rand((n, 64, 16, 64), generator=g, device=cuda) - 0.5
+
+    def loss(fg_, x_, ctrl_, score_):
+        o0, o1, _, _ = ops.warp(fg_, ctrl_, inv, ph, cases.PP_HW, P_xy=pxy, score=score_, in1=x_)
+        return float((o0.double() * g0.double()).sum() + (o1.double() * g1.double()).sum())
+
+    _, _, grid, _ = ops.warp(fg, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, score=score, in1=x, want_grid=True)
+    g_fg, g_x, g_ctrl, g_score = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, score=score,
+                                                   in1=x, g_out1=g1)
+    base = loss(fg, x, ctrl, score)
+    # linear in the inputs
+    d_fg = torch.rand(fg.shape, generator=g, device=cuda) - 0.5
+    d_x = torch.rand(x.shape, generator=g, device=cuda) - 0.5
+    want = loss(fg + d_fg, x + d_x, ctrl, score) - base
+    got = float((g_fg.double() * d_fg.double()).sum() + (g_x.double() * d_x.double()).sum())
+    assert abs(got - want) <= 2e-4 * max(abs(want), 1.0), (got, want)
+    # control-point and score gradients of a few rows of the batch against float64 autograd of the
+    # reference's composition (a finite difference of the fp32 forward is too noisy here: the sampled
+    # function has a kink at every pixel boundary and wherever the grid leaves [-1, 1])
+    import torch.nn.functional as Fn
+    pick = [0, 1, 255, 511]
+    k = len(pick)
+    with torch.enable_grad():
+        cd = ctrl[pick].cpu().double().requires_grad_(True)
+        sd = score[pick].cpu().double().requires_grad_(True)
+        rows = torch.cat([torch.ones(k, 1024, 1, dtype=torch.float64),
+                          torch.from_numpy(c["P_xy"]).double()[None].repeat(k, 1, 1),
+                          torch.from_numpy(c["P_hat"]).double()[None] * (sd * 0.5 + 1)], 2)
+        T = torch.bmm(torch.from_numpy(c["hat_C"]).double()[None].repeat(k, 1, 1),
+                      torch.cat((cd, torch.zeros(k, 3, 2, dtype=torch.float64)), 1))
+        gr = torch.bmm(rows, T).reshape(k, 16, 64, 2)
+        L = (Fn.grid_sample(fg[pick].cpu().double(), gr, padding_mode="border", align_corners=True) *
+             g0[pick].cpu().double()).sum() + \
+            (Fn.grid_sample(x[pick].cpu().double(), gr, padding_mode="border", align_corners=True) *
+             g1[pick].cpu().double()).sum()
+        L.backward()
+    close(g_ctrl[pick], cd.grad.float().numpy(), 2e-4, "dL/d control points (rows of batch 512)")
+    close(g_score[pick], sd.grad.float().numpy(), 2e-4, "dL/d score (rows of batch 512)")
