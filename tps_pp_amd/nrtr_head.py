@@ -407,6 +407,7 @@ class EncodeDecodeRecognizer(nn.Module):
     def forward_train(self, img, img_metas, **kwargs):
         raise NotImplementedError("the HIP path is forward-only (SURVEY.md section 8f, row F2)")
 
+    @torch.no_grad()          # the callers (mmdet's single/multi_gpu_test) run it under no_grad as well
     def simple_test(self, img, img_metas, **kwargs):
         for img_meta in img_metas:
             img_meta["valid_ratio"] = 1.0 * img_meta["resize_shape"][1] / img.size(-1)
