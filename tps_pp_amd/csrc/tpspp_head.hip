@@ -155,12 +155,27 @@ attn_enc_kernel(const float* __restrict__ qkv, int C, int M, int T, const int* _
     const int b = blockIdx.z, h = blockIdx.y;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const size_t col0 = (size_t)b * T;
-    for (int d = wv; d < kDK; d += nw) {
-        const float* kr = qkv + (size_t)(C + kDK * h + d) * M + col0;
-        const float* vr = qkv + (size_t)(2 * C + kDK * h + d) * M + col0;
-        for (int j = lane; j < T; j += kWave) {
-            Ks[j * kKRow + d] = kr[j];
-            Vs[j * kKRow + d] = vr[j];
+    // staging: 8 key rows + 8 value rows per wavefront in flight (a one-wavefront workgroup would
+    // otherwise pay a full memory latency for each of its 128 rows)
+    for (int j0 = 0; j0 < T; j0 += kWave) {
+        const int j = j0 + lane;
+        const int jj = j < T ? j : T - 1;
+        for (int d0 = wv; d0 < kDK; d0 += 8 * nw) {
+            float kk[8], vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u * nw < kDK ? d0 + u * nw : wv;
+                kk[u] = qkv[(size_t)(C + kDK * h + d) * M + col0 + jj];
+                vv[u] = qkv[(size_t)(2 * C + kDK * h + d) * M + col0 + jj];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u * nw;
+                if (d < kDK && j < T) {
+                    Ks[j * kKRow + d] = kk[u];
+                    Vs[j * kKRow + d] = vv[u];
+                }
+            }
         }
     }
     __syncthreads();
