@@ -224,6 +224,111 @@ attn_enc_kernel(const float* __restrict__ qkv, int C, int M, int T, const int* _
     for (int d = 0; d < kDK; ++d) out[(size_t)(kDK * h + d) * M + col0 + i] = acc[d] * inv;
 }
 
+// ---- encoder self-attention on the fp32 matrix cores (T <= 128) ----------------------------------------------------
+// One wavefront = 32 queries of one (image, head).  Both products are v_mfma_f32_32x32x2_f32 with operands
+// taken straight from the channel-major rows (a fragment = two 128-B row segments), nothing staged:
+//   S^T tile (32 keys x 32 queries) = sum_d K[d][j] Q[d][i]   -> in the C/D layout a LANE is a QUERY and its
+//     16 registers are 16 keys (the other 16 keys of the tile sit in lane^32), so the softmax is a
+//     per-lane reduction plus one exchange with lane^32;
+//   O^T tile (32 features x 32 queries) = sum_j V[d][j] P^T[j][i]: the probabilities are consumed as the B
+//     operand IN PLACE -- register r of lane (i, half) holds key 8*(r>>2) + (r&3) + 4*half of its tile, and
+//     those two keys (half = 0, 1) are taken as the k-pair of MFMA step r; the A operand reads V at the
+//     same two keys.  No LDS, no barrier.
+// NJ = ceil(T / 32) key tiles (template, <= 4).  Scores are scaled by 1/8 through q, keys >= valid_len[b]
+// get probability 0.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int NJ>
+__global__ void __launch_bounds__(256)
+attn_enc_mfma_kernel(const float* __restrict__ qkv, int C, int M, int T, const int* __restrict__ valid_len,
+                     float* __restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nib = (T + 31) >> 5;                           // query blocks per (image, head)
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int H = C / kDK;
+    const int ib = w % nib, bh = w / nib;
+    if (bh >= (M / T) * H) return;                           // wave-uniform (M / T = images)
+    const int h = bh % H, b = bh / H;
+    const size_t col0 = (size_t)b * T;
+    int nvalid = valid_len ? valid_len[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    const int i = ib * 32 + l31;                             // this lane's query (B-operand column)
+    const int ic = i < T ? i : T - 1;
+    const float* qp = qkv + (size_t)(kDK * h) * M + col0;
+    const float* kp = qkv + (size_t)(C + kDK * h) * M + col0;
+    const float* vp = qkv + (size_t)(2 * C + kDK * h) * M + col0;
+
+    // B fragments of Q for all 32 k-steps (k = feature pair 2*ks + half), scaled
+    float qf[32];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) qf[ks] = qp[(size_t)(2 * ks + half) * M + ic] * 0.125f;
+
+    f32x16_t sc[NJ];
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[jb][r] = 0.0f;
+        const int j = jb * 32 + l31;                         // A-operand row: key
+        const int jc = j < T ? j : T - 1;
+        float kf[32];
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) kf[ks] = kp[(size_t)(2 * ks + half) * M + jc];
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) sc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[ks], qf[ks], sc[jb], 0, 0, 0);
+    }
+    // softmax over the keys of query i: registers of this lane + the complementary keys in lane^32
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            sc[jb][r] = j < nvalid ? sc[jb][r] : -INFINITY;
+            mx = fmaxf(mx, sc[jb][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, kWave));
+    float l = 0.0f;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = sc[jb][r] == -INFINITY ? 0.0f : expf(sc[jb][r] - mx);
+            sc[jb][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32, kWave);
+    const float inv = 1.0f / l;
+
+    // O^T = V P^T, two feature tiles of 32
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        f32x16_t o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+        const float* vrow = vp + (size_t)(dt * 32 + l31) * M;   // A-operand row: feature
+#pragma unroll
+        for (int jb = 0; jb < NJ; ++jb) {
+            float vf[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                vf[r] = vrow[j < T ? j : T - 1];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], sc[jb][r], o, 0, 0, 0);
+        }
+        if (i < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(size_t)(kDK * h + d) * M + col0 + i] = o[r] * inv;
+            }
+        }
+    }
+}
+
 // ---- decoder, one step: embedding + position table ----------------------------------------------------
 // x[c][b] = emb[tokens[b][step]][c] + pos[step][c]      (nrtr_decoder.py:96-98, no scaling)
 __global__ void __launch_bounds__(256)
@@ -515,6 +620,18 @@ static int launch_attn_enc(const float* qkv, int N, int C, int T, const int* val
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         attr_done = true;
+    }
+    if (T <= 128) {                                          // matrix-core kernel: a wavefront per 32 queries
+        const int nj = (T + 31) / 32;
+        const long waves = (long)N * H * nj;
+        const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+        switch (nj) {
+        case 1: hipLaunchKernelGGL(attn_enc_mfma_kernel<1>, grid, block, 0, st, qkv, C, (int)M, T, valid_len, out); break;
+        case 2: hipLaunchKernelGGL(attn_enc_mfma_kernel<2>, grid, block, 0, st, qkv, C, (int)M, T, valid_len, out); break;
+        case 3: hipLaunchKernelGGL(attn_enc_mfma_kernel<3>, grid, block, 0, st, qkv, C, (int)M, T, valid_len, out); break;
+        default: hipLaunchKernelGGL(attn_enc_mfma_kernel<4>, grid, block, 0, st, qkv, C, (int)M, T, valid_len, out); break;
+        }
+        return tpspp::check_launch("attn_enc_mfma_kernel");
     }
     const int threads = kWave * ((T + kWave - 1) / kWave < 4 ? (T + kWave - 1) / kWave : 4);
     const dim3 grid((unsigned)((T + threads - 1) / threads), (unsigned)H, (unsigned)N);
