@@ -1,0 +1,25 @@
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import tps_pp_amd as P
+from tps_pp_amd import _lib  # (tpspp_head_set_graphs existed only in the experiment described in DESIGN.md section 7)
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+enc = P.NRTREncoder().eval().to(dev)
+dec = P.NRTRDecoder(num_classes=93, start_idx=91, padding_idx=92).eval().to(dev)
+feat = torch.rand(512, 512, 4, 16, device=dev)
+with torch.no_grad():
+    out_enc = enc(feat, None)
+    for on in (0, 1):
+        _lib.lib().tpspp_head_set_graphs(on)
+        for _ in range(3):
+            dec(None, out_enc, None, None, train_mode=False)
+        torch.cuda.synchronize()
+        hs, ws = [], []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            dec(None, out_enc, None, None, train_mode=False)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            hs.append(t1 - t0); ws.append(t2 - t0)
+        print(f"graphs {'on ' if on else 'off'}: host returns after {1e3 * min(hs):.2f} ms, batch done after {1e3 * min(ws):.1f} ms")
