@@ -9,8 +9,7 @@ dec = P.NRTRDecoder(num_classes=93, start_idx=91, padding_idx=92).eval().to(dev)
 feat = torch.rand(512, 512, 4, 16, device=dev)
 with torch.no_grad():
     out_enc = enc(feat, None)
-    for on in (0, 1):
-        _lib.lib().tpspp_head_set_graphs(on)
+    for on in (0,):          # (the graph-replay variant measured next to it is described in DESIGN.md section 7)
         for _ in range(3):
             dec(None, out_enc, None, None, train_mode=False)
         torch.cuda.synchronize()
@@ -22,4 +21,4 @@ with torch.no_grad():
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             hs.append(t1 - t0); ws.append(t2 - t0)
-        print(f"graphs {'on ' if on else 'off'}: host returns after {1e3 * min(hs):.2f} ms, batch done after {1e3 * min(ws):.1f} ms")
+        print(f"eager launches: host returns after {1e3 * min(hs):.2f} ms, batch done after {1e3 * min(ws):.1f} ms")
