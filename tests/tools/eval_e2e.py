@@ -2,13 +2,15 @@
 process per GPU, the per-step scores all-gathered over RCCL (the only collective of the path), strings and
 word accuracy computed from the gathered tensor.
 
-    python scripts/eval_e2e.py --batch 256                       # one GPU
+    python tests/tools/eval_e2e.py --batch 256                       # one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        --master-port 29500 scripts/eval_e2e.py --batch 2048     # configs[3]: 256 images per GPU
+        --master-port 29500 tests/tools/eval_e2e.py --batch 2048     # configs[3]: 256 images per GPU
 
 Synthetic IC15-shaped crops (3x32x128, ImageNet normalisation) and seeded random-init weights (there is no
 network for datasets or checkpoints; pass --checkpoint for a released .pth).  "Ground truth" for the word
-accuracy is the CPU oracle's decoding of the first --check images (the parity check of configs[4])."""
+accuracy is the CPU oracle's decoding of the first --check images (the parity check of configs[4]).
+
+Lives under tests/ because it calls the oracle (as the checker); the product never does."""
 import argparse
 import os
 import sys
@@ -17,7 +19,7 @@ import time
 import torch
 import torch.distributed as dist
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import tps_pp_amd as P  # noqa: E402
 from tps_pp_amd import dist as tdist, metrics, synth  # noqa: E402
 
