@@ -19,6 +19,29 @@ def load(name):
     return np.load(os.path.join(HERE, name + ".npz"))
 
 
+def host_fingerprint():
+    """What decides which MKL / oneDNN kernels PyTorch-CPU picks: CPU model, torch build, thread count."""
+    import torch
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"cpu": model, "torch": torch.__version__, "threads": torch.get_num_threads()}
+
+
+def on_generating_host():
+    """True on a host like the one make_golden.py ran on (HOST.json): there the PyTorch-CPU oracles must
+    reproduce the fixtures bit for bit; elsewhere they are held to rounding."""
+    import json
+    try:
+        with open(os.path.join(HERE, "HOST.json")) as f:
+            return json.load(f) == host_fingerprint()
+    except OSError:
+        return False
+
+
 # ---- G2: classic grid + sampler, F=20, 32x100 -> 32x100, N=8 -----------------------------------
 CL_F, CL_HW, CL_C, CL_N = 20, (32, 100), 3, 8
 # per-image perturbation of the control points: 0 = the module's initial lattice, large values

@@ -443,6 +443,8 @@ def main(argv):
     for name in (argv or list(CASES)):
         print(f"[{name}]")
         CASES[name](R)
+    with open(os.path.join(HERE, "HOST.json"), "w") as f:      # see cases.on_generating_host()
+        json.dump(cases.host_fingerprint(), f, indent=1)
 
 
 if __name__ == "__main__":

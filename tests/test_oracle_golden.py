@@ -12,6 +12,16 @@ import cases
 from oracle import tpspp_oracle as TO
 
 CONV_TOL = 2e-5
+EXACT_HOST = cases.on_generating_host()
+
+
+def close(a, b, tol=CONV_TOL, pinned=True):
+    """PyTorch-CPU oracles: bit-identical to the fixtures in the container that generated them (make_golden.py
+    asserts it), to rounding on other hosts (MKL / oneDNN pick other kernels per CPU model and thread count)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if EXACT_HOST and pinned:
+        return np.array_equal(a, b)
+    return a.shape == b.shape and float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max()))
 
 
 def bits(a):
@@ -208,17 +218,17 @@ def _head_state(kind, small):
     return sd
 
 
-def test_nrtr_encoder_oracle_bit_exact():
+def test_nrtr_encoder_oracle():
     from oracle import nrtr_oracle as NO
     G = cases.load("nrtr_encoder")
     sd = _head_state("enc", True)
     feat = cases.g9_inputs()["feat"]
     nh = cases.HD_SMALL["n_head"]
-    assert np.array_equal(NO.encoder_forward(sd, feat, nh, cases.HD_RATIOS).numpy(), G["out_masked"])
-    assert np.array_equal(NO.encoder_forward(sd, feat, nh, None).numpy(), G["out_nomask"])
+    assert close(NO.encoder_forward(sd, feat, nh, cases.HD_RATIOS).numpy(), G["out_masked"])
+    assert close(NO.encoder_forward(sd, feat, nh, None).numpy(), G["out_nomask"])
 
 
-def test_nrtr_decoder_oracle_bit_exact():
+def test_nrtr_decoder_oracle():
     from oracle import nrtr_oracle as NO
     G = cases.load("nrtr_decoder")
     sd = _head_state("dec", True)
@@ -226,20 +236,20 @@ def test_nrtr_decoder_oracle_bit_exact():
     nh = cases.HD_SMALL["n_head"]
     assert np.array_equal(sd["position_enc.position_table"].numpy(), NO.sinusoid_table(200, 128).numpy())
     lo = NO.decoder_forward_train(sd, inp["out_enc"], inp["padded_targets"], nh, cases.PAD_IDX, cases.HD_RATIOS)
-    assert np.array_equal(lo.numpy(), G["logits"])
+    assert close(lo.numpy(), G["logits"])
     pr = NO.decoder_forward_test(sd, inp["out_enc"], nh, cases.HD_MAXLEN, cases.START_IDX, cases.PAD_IDX,
                                  cases.HD_RATIOS)
-    assert np.array_equal(pr.numpy(), G["probs"])
+    assert close(pr.numpy(), G["probs"]) and np.array_equal(pr.numpy().argmax(-1), G["probs"].argmax(-1))
     pr = NO.decoder_forward_test(sd, inp["out_enc"], nh, cases.HD_MAXLEN, cases.START_IDX, cases.PAD_IDX, None)
-    assert np.array_equal(pr.numpy(), G["probs_nomask"])
+    assert close(pr.numpy(), G["probs_nomask"])
 
 
 def test_nrtr_head_full_oracle_and_convertor():
     from oracle import nrtr_oracle as NO
     G = cases.load("nrtr_head_full")
     o = NO.head_simple_test(_head_state("enc", False), _head_state("dec", False), cases.g11_inputs()["feat"])
-    assert np.array_equal(o["out_enc"].numpy()[:, :, ::8], G["out_enc_sub"])
-    assert np.array_equal(o["out_dec"].numpy(), G["out_dec"])
+    assert close(o["out_enc"].numpy()[:, :, ::8], G["out_enc_sub"])
+    assert close(o["out_dec"].numpy(), G["out_dec"])
     assert o["text"] == [str(s) for s in G["text"]]
     assert [len(i) for i in o["indexes"]] == G["idx_len"].tolist()
     idx2char, unk, start, end, pad = NO.attn_dictionary()
@@ -263,29 +273,37 @@ def test_recognizer_end_to_end_oracle():
     tps = synth_sd(P.TPS_PP(variant="ResNet45"), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
     o = TO.recognizer_simple_test(bb, tps, _head_state("enc", False), _head_state("dec", False),
                                   cases.g12_inputs()["img"], cases.G12_WIDTHS)
-    assert np.array_equal(o["feat"].numpy()[:, ::8], G["feat_sub"])
-    assert np.array_equal(o["out_dec"].numpy(), G["out_dec"])
+    assert close(o["feat"].numpy()[:, ::8], G["feat_sub"])
+    assert close(o["out_dec"].numpy(), G["out_dec"], 1e-4)
     assert o["text"] == [str(s) for s in G["text"]]
-    assert np.array_equal(np.array(o["scores"][0], dtype=np.float32), G["score0"])
+    assert close(np.array(o["scores"][0], dtype=np.float32), G["score0"], 1e-4)
 
 
-def test_warp_backward_oracle_bit_exact(oracle):
-    """Row F2: the backward oracle (PyTorch-CPU autograd through the reference's composition) against
-    the reference's own autograd results (golden G14); its chain-grid variant agrees to rounding."""
+def test_warp_backward_oracle_against_reference(oracle):
+    """Row F2: the backward oracle against the reference's own autograd results (golden G14): both variants
+    of the oracle (grid through torch.bmm -- bit-identical to the fixtures where they were generated, host
+    dependent elsewhere -- and grid through the FMA chain with the two products transposed in float64).
+    The parameter gradients are sums of 1024-3200 terms amplified by inv_delta_C (+-223), so an fp32
+    accumulation differs from a float64 one by ~1e-4 of the largest entry."""
     G = cases.load("warp_backward")
     gi = cases.g14_inputs()
     inp = cases.g2_inputs()
     c = oracle.classic_constants(cases.CL_F, cases.CL_HW)
-    o = oracle.warp_backward(gi["g_out_cl"], inp["img_smooth"], inp["ctrl"], c["inv_delta_C"], c["P_hat"], cases.CL_HW)
-    assert np.array_equal(o["g_in0"], G["cl_g_img"]) and np.array_equal(o["g_ctrl"], G["cl_g_ctrl"])
+    for chain in (False, True):
+        o = oracle.warp_backward(gi["g_out_cl"], inp["img_smooth"], inp["ctrl"], c["inv_delta_C"], c["P_hat"],
+                                 cases.CL_HW, chain_grid=chain)
+        # (G2 holds lattices perturbed by up to +-2: there the grid out of torch.bmm itself moves by 1e-4
+        # between hosts, and so does every gradient that is scattered through it)
+        assert close(o["g_in0"], G["cl_g_img"], 1e-2 if not chain else CONV_TOL, not chain), chain
+        assert close(o["g_ctrl"], G["cl_g_ctrl"], 1e-2 if not chain else 5e-4, not chain), chain
     inp = cases.g3_inputs()
     c = oracle.tpspp_constants(cases.PP_HW, cases.PP_POINT)
     kw = dict(P_xy=c["P_xy"], score=inp["score"], in1=inp["x"], g_out1=gi["g_out1"])
-    o = oracle.warp_backward(gi["g_out0"], inp["feat_grid"], inp["ctrl"], c["hat_C"], c["P_hat"], cases.PP_HW, **kw)
-    assert np.array_equal(cases.sub(o["g_in0"]), G["pp_g_feat_grid_sub"])
-    assert np.array_equal(cases.sub(o["g_in1"]), G["pp_g_x_sub"])
-    assert np.array_equal(o["g_ctrl"], G["pp_g_ctrl"]) and np.array_equal(o["g_score"], G["pp_g_score"])
-    o2 = oracle.warp_backward(gi["g_out0"], inp["feat_grid"], inp["ctrl"], c["hat_C"], c["P_hat"], cases.PP_HW,
-                              chain_grid=True, **kw)
-    for k in o:
-        assert np.abs(o[k] - o2[k]).max() <= 2e-6 * np.abs(o[k]).max(), k
+    for chain in (False, True):
+        o = oracle.warp_backward(gi["g_out0"], inp["feat_grid"], inp["ctrl"], c["hat_C"], c["P_hat"], cases.PP_HW,
+                                 chain_grid=chain, **kw)
+        t_in, t_par = (CONV_TOL, 5e-4) if chain else (1e-3, 1e-2)      # the bmm variant is host dependent
+        assert close(cases.sub(o["g_in0"]), G["pp_g_feat_grid_sub"], t_in, not chain), chain
+        assert close(cases.sub(o["g_in1"]), G["pp_g_x_sub"], t_in, not chain), chain
+        assert close(o["g_ctrl"], G["pp_g_ctrl"], t_par, not chain), chain
+        assert close(o["g_score"], G["pp_g_score"], t_par, not chain), chain
