@@ -132,6 +132,14 @@ def extra_measurements(dev):
         t_bwd = timeit(lambda: ops.warp_backward(g0, fgc, grid, cp, at.hat_C, at.P_hat, (16, 64), P_xy=P_xy, score=sc,
                                                  in1=x, g_out1=g1, P_hat_t=P_hat_t), 10, 3)
         del g0, g1, grid, fgc
+        # BASELINE.json configs[2]: the same module at batch 1024 on bf16 activations (bf16 MFMA convolutions;
+        # control points, TPS solve, grid and sampling stay fp32)
+        n2 = 1024
+        xb = torch.rand((n2, 64, 16, 64), generator=g, device=dev).to(torch.bfloat16)
+        o0b = torch.rand((n2, 32, 32, 128), generator=g, device=dev).to(torch.bfloat16)
+        o1b = torch.rand((n2, 32, 32, 128), generator=g, device=dev).to(torch.bfloat16)
+        t_bf16 = timeit(lambda: m(xb, [o0b, o1b]), 10, 4)
+        del xb, o0b, o1b
     bytes_img = 1966336                                  # SURVEY.md section 8d, G-PP warp stage fp32
     bw = bytes_img * n / (t_warp * 1e-3) / 1e9
     # backward: read g_out0, g_out1, both inputs, grid, score; write g_in0, g_in1, g_score (fp32)
@@ -145,6 +153,9 @@ def extra_measurements(dev):
                                                   "kernels": "warp_bwd_sample_lds_kernel + warp_bwd_params_kernel<36>"},
             "tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
                                            "gflop_per_image": 0.82},
+            "tpspp_module_batch1024_bf16": {"images_per_s": n2 / (t_bf16 * 1e-3), "ms_per_batch": t_bf16,
+                                            "gflop_per_image": 0.82,
+                                            "note": "BASELINE.json configs[2]: bf16 tensors at the module boundary"},
             "tpspp_warp_stage_batch512_fp32": {"us_per_batch": t_warp * 1e3, "achieved_GBps": bw,
                                                "frac_of_hbm_peak": bw / HBM_PEAK_GBS,
                                                "algorithmic_bytes_per_image": bytes_img,

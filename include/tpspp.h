@@ -247,6 +247,32 @@ int tpspp_global_avgpool_fwd(const float* in, int N, int C, int H, int W, float*
 /* Channels per K-chunk of the tiled conv kernel for a 1x1 / 3x3 kernel (layout of weight_tiled). */
 int tpspp_conv_chunk_channels(int kernel_size);
 
+/*
+ * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32
+ * accumulation; bias / residual / activation / affine in fp32) for the bf16 configurations
+ * (BASELINE.json configs[2], configs[4]).  Every tensor is NCHW and independently bf16 or fp32 in memory.
+ *   src_ptrs[i]      (N, C_i, H_i, W_i); src_dims + 6*i = {C_i, H_i, W_i, uh_i, uw_i, is_f32_i}; uh, uw in
+ *                    {1, 2, 4}; with nsrc > 1 every C_i must be a multiple of
+ *                    KC = tpspp_conv_bf16_chunk_channels(K)
+ *   weight_arranged  bf16, the PyTorch weight (Cout, Cin, KH, KW) (BatchNorm folded) zero-padded to
+ *                    Cout % 64 == 0 and Cin % KC == 0 and laid out
+ *                    [Cout/64][Cin/KC][KH*KW][KC/8][64 cout][8 cin]  (the LDS image of each K-chunk)
+ *   bias, post_scale, post_shift   (Cout) fp32 or NULL
+ *   residual         (N, Cout, Ho, Wo), fp32 when residual_f32 else bf16, or NULL; res_mode as above
+ *   relu             0 none, 1 ReLU
+ *   out              (N, Cout, Ho, Wo), fp32 when out_f32 else bf16 (round to nearest even)
+ * replaces: the call sites listed for tpspp_conv2d_fwd when the module runs in bf16.
+ */
+int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* src_dims, int nsrc,
+                          const void* weight_arranged, const float* bias,
+                          const void* residual, int residual_f32,
+                          const float* post_scale, const float* post_shift,
+                          int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
+                          void* out, int out_f32, int Ho, int Wo, tpspp_stream_t stream);
+
+/* Channels per K-chunk of the bf16 conv kernel for a 1x1 / 3x3 kernel (layout of weight_arranged). */
+int tpspp_conv_bf16_chunk_channels(int kernel_size);
+
 /* Tuning / testing: non-zero forces the generic conv kernel even when weight_tiled is given. */
 int tpspp_conv_set_tuning(int force_generic);
 

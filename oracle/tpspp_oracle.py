@@ -25,11 +25,21 @@ def _t(a):
     return a if isinstance(a, torch.Tensor) else torch.from_numpy(a)
 
 
-def conv_module(sd, prefix, x, stride=1, padding=0):
+def rb(x):
+    """Round to bfloat16 (nearest even), keep float32 storage."""
+    return x.to(torch.bfloat16).float()
+
+
+def conv_module(sd, prefix, x, stride=1, padding=0, bf16=False):
     """mmcv ConvModule as used by the reference: conv (+bias) then ReLU
-    (backbones/tps_pp/tps_pp.py:126-131,149-154,538-552)."""
-    return F.relu(F.conv2d(x, sd[prefix + ".conv.weight"], sd[prefix + ".conv.bias"], stride=stride,
-                           padding=padding))
+    (backbones/tps_pp/tps_pp.py:126-131,149-154,538-552).
+    bf16=True restates the bf16 configuration of the build (BASELINE.json configs[2]): operands rounded to
+    bfloat16, products and sums in fp32, bias / ReLU in fp32; the CALLER rounds the result where the build
+    stores it as bfloat16."""
+    w = sd[prefix + ".conv.weight"]
+    if bf16:
+        x, w = rb(x), rb(w)
+    return F.relu(F.conv2d(x, w, sd[prefix + ".conv.bias"], stride=stride, padding=padding))
 
 
 def cbam(sd, prefix, x):
@@ -50,14 +60,19 @@ def cbam(sd, prefix, x):
     return sa * out
 
 
-def msfa(sd, feat_cat, p_stride=2):
+def msfa(sd, feat_cat, p_stride=2, bf16=False):
     """Encoder_Decoder_Feature_Extractor.forward (tps_pp.py:156-169) with the layer list of
-    :94-119: encoder strides 1, 2, p_stride, (2,1); decoder upsample (2,1), p_stride, 2, 1."""
+    :94-119: encoder strides 1, 2, p_stride, (2,1); decoder upsample (2,1), p_stride, 2, 1.
+    bf16: every map is stored as bfloat16 except the bottleneck (feeds CBAM and the control points) and
+    the last decoder output (feeds DGAB / the score), which stay fp32."""
     inter = {}
     k = feat_cat
     feats = []
+    q = rb if bf16 else (lambda v: v)
     for i, st in enumerate([1, 2, p_stride, (2, 1)]):
-        k = conv_module(sd, f"MSFA.conv.k_encoder.{i}", k, stride=st, padding=1)
+        k = conv_module(sd, f"MSFA.conv.k_encoder.{i}", k, stride=st, padding=1, bf16=bf16)
+        if i < 3:
+            k = q(k)
         feats.append(k)
         inter[f"enc{i}"] = k
     point = feats[-1]
@@ -66,11 +81,11 @@ def msfa(sd, feat_cat, p_stride=2):
     scales = [(2, 1), p_stride, 2, 1]
     for i in range(3):
         k = F.interpolate(k, scale_factor=scales[i], mode="nearest")
-        k = conv_module(sd, f"MSFA.conv.k_decoder.{i}.1", k, padding=1)
-        k = k + feats[2 - i]
+        k = conv_module(sd, f"MSFA.conv.k_decoder.{i}.1", k, padding=1, bf16=bf16)
+        k = q(k + feats[2 - i])
         inter[f"dec{i}"] = k
     k = F.interpolate(k, scale_factor=scales[3], mode="nearest")
-    k = conv_module(sd, "MSFA.conv.k_decoder.3.1", k, padding=1)
+    k = conv_module(sd, "MSFA.conv.k_decoder.3.1", k, padding=1, bf16=bf16)
     inter["dec3"] = k
     return point, k, inter
 
@@ -116,38 +131,43 @@ def tpe(sd, en_feat, de_feat, scale=64 ** -0.5):
     return ctrl, score, de
 
 
-def tpspp_regress(sd, x, outs, variant="ResNet45v2", p_stride=2):
+def tpspp_regress(sd, x, outs, variant="ResNet45v2", p_stride=2, bf16=False):
     """TPS_PP.forward up to the control points (tps_pp.py:572-594).  Returns
-    (ctrl, score, feat_grid, intermediates)."""
+    (ctrl, score, feat_grid, intermediates).
+    bf16=True: the build's bf16 configuration -- convolutions on bfloat16 operands with fp32 accumulation,
+    feature maps between convolutions stored as bfloat16, `feat_grid` / `en_feat` / `de_feat` and everything
+    after them (CBAM, DGAB, control points, score, TPS solve, grid, sampling) in fp32."""
     x, outs = _t(x), [_t(o) for o in outs]
     inter = {}
+    q = rb if bf16 else (lambda v: v)
+    cm = lambda *a, **k: conv_module(*a, bf16=bf16, **k)          # noqa: E731
     if variant == "ResNet45v2":                                   # :580-585
-        feat0 = conv_module(sd, "down0", outs[0])
-        feat1 = conv_module(sd, "down1", outs[1])
-        feat2 = conv_module(sd, "down2", x)
-        feat_cat = torch.cat((conv_module(sd, "down0_1", feat0, stride=2, padding=1),
-                              conv_module(sd, "down1_1", feat1, stride=2, padding=1), feat2), dim=1)
+        feat0 = q(cm(sd, "down0", outs[0]))
+        feat1 = q(cm(sd, "down1", outs[1]))
+        feat2 = q(cm(sd, "down2", x))
+        feat_cat = torch.cat((q(cm(sd, "down0_1", feat0, stride=2, padding=1)),
+                              q(cm(sd, "down1_1", feat1, stride=2, padding=1)), feat2), dim=1)
         up = F.interpolate(feat2, scale_factor=2, mode="nearest")
-        feat_grid = conv_module(sd, "down_feat", torch.cat((feat0, feat1, up), dim=1))   # :560-562
+        feat_grid = cm(sd, "down_feat", torch.cat((feat0, feat1, up), dim=1))   # :560-562
     else:                                                         # 'ResNet45', :574-579
-        feat0 = conv_module(sd, "down0", outs[0], stride=2, padding=1)
-        feat1 = conv_module(sd, "down1", outs[1])
-        feat2 = conv_module(sd, "down2", x)
+        feat0 = q(cm(sd, "down0", outs[0], stride=2, padding=1))
+        feat1 = q(cm(sd, "down1", outs[1]))
+        feat2 = q(cm(sd, "down2", x))
         feat_cat = torch.cat((feat0, feat1, feat2), dim=1)
         feat_grid = x
     inter["feat_cat"], inter["feat_grid"] = feat_cat, feat_grid
-    en, de, m_inter = msfa(sd, feat_cat, p_stride)
+    en, de, m_inter = msfa(sd, feat_cat, p_stride, bf16=bf16)
     inter.update(m_inter)
     ctrl, score, de2 = tpe(sd, en, de)
     inter["dgab"] = de2
     return ctrl, score, feat_grid, inter
 
 
-def tpspp_forward(sd, x, outs, variant="ResNet45v2", rectified_img_size=(16, 64), point_size=(2, 16)):
+def tpspp_forward(sd, x, outs, variant="ResNet45v2", rectified_img_size=(16, 64), point_size=(2, 16), bf16=False):
     """Whole TPS_PP.forward (tps_pp.py:564-625): regressor (above) + grid + two grid_samples (the C
     oracle).  Returns dict(output, mp_img, pc_score, ctrl, grid)."""
     with torch.no_grad():
-        ctrl, score, feat_grid, _ = tpspp_regress(sd, x, outs, variant)
+        ctrl, score, feat_grid, _ = tpspp_regress(sd, x, outs, variant, bf16=bf16)
     P_xy = sd.get("_P_xy")
     if P_xy is None:
         P_xy = tps_oracle.tpspp_constants(rectified_img_size, point_size)["P_xy"]

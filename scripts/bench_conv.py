@@ -33,7 +33,7 @@ SHAPES = [
     ("k_decoder.3 3x3 64->64 @16x64", 64, 16, 64, 64, 3, (1, 1)),
     ("k_encoder.1 3x3 s2 64->64 @16x64", 64, 16, 64, 64, 3, (2, 2)),
 ]
-tot_ours = tot_torch = 0.0
+tot_ours = tot_torch = tot_b16 = tot_tb16 = 0.0
 for name, cin, h, w, cout, k, st in SHAPES:
     x = torch.rand(N, cin, h, w, device=dev)
     wgt = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
@@ -45,7 +45,17 @@ for name, cin, h, w, cout, k, st in SHAPES:
         t_torch = timeit(lambda: F.relu(F.conv2d(x, wgt, b, stride=st, padding=(k - 1) // 2)))
     ho, wo = out.shape[2], out.shape[3]
     flop = 2.0 * N * cout * ho * wo * cin * k * k
-    print(f"{name:36s} ours {t_ours:7.3f} ms {flop / t_ours / 1e9:6.1f} TF | torch {t_torch:7.3f} ms {flop / t_torch / 1e9:6.1f} TF")
+    # bf16 MFMA kernel (tpspp_conv_bf16.hip): bf16 tensors in and out
+    cwb = ops.prep_conv_weight_bf16(wgt, conv_bias=b)
+    xb = x.to(torch.bfloat16)
+    t_b16 = timeit(lambda: ops.conv2d_bf16([xb], cwb, st, True))
+    with torch.no_grad():
+        wb, bb = wgt.to(torch.bfloat16), b.to(torch.bfloat16)
+        t_tb16 = timeit(lambda: F.relu(F.conv2d(xb, wb, bb, stride=st, padding=(k - 1) // 2)))
+    print(f"{name:36s} fp32 ours {t_ours:7.3f} ms {flop / t_ours / 1e9:6.1f} TF | torch {t_torch:7.3f} ms {flop / t_torch / 1e9:6.1f} TF"
+          f" || bf16 ours {t_b16:7.3f} ms {flop / t_b16 / 1e9:6.1f} TF | torch {t_tb16:7.3f} ms {flop / t_tb16 / 1e9:6.1f} TF")
     tot_ours += t_ours
     tot_torch += t_torch
-print(f"sum: ours {tot_ours:.2f} ms, torch {tot_torch:.2f} ms")
+    tot_b16 += t_b16
+    tot_tb16 += t_tb16
+print(f"sum: fp32 ours {tot_ours:.2f} ms, torch {tot_torch:.2f} ms; bf16 ours {tot_b16:.2f} ms, torch {tot_tb16:.2f} ms")

@@ -45,3 +45,14 @@ with torch.no_grad():
     t_full = timeit(lambda: p(img))
     t_loc = timeit(lambda: p.LocalizationNetwork(img))
 print(f"TPSPreprocessor batch {N}: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | localisation net {t_loc:.2f} ms")
+
+
+# bf16 configuration (BASELINE.json configs[2]): bf16 tensors at the module boundary, bf16 MFMA convolutions
+xb, o0b, o1b = x.to(torch.bfloat16), o0.to(torch.bfloat16), o1.to(torch.bfloat16)
+with torch.no_grad():
+    timeit(lambda: m(xb, [o0b, o1b]), iters=3)
+    t_reg16 = timeit(lambda: m.regress(xb, [o0b, o1b]))
+    t_full16 = timeit(lambda: m(xb, [o0b, o1b]))
+print(f"TPS_PP batch {N} bf16: full {t_full16:.2f} ms = {N / t_full16 * 1e3:,.0f} img/s | regressor {t_reg16:.2f} ms "
+      f"({0.82 * N / t_reg16:.1f} TFLOP/s)")
+del xb, o0b, o1b

@@ -1,7 +1,8 @@
 """-m gpu: the remaining BASELINE.json configurations at their full per-GPU sizes, through
 size-independent properties (the oracle cannot run these sizes in seconds):
 
-* configs[2]  regressor + warp (`TPS_PP.forward`) at batch 1024 (fp32; the bf16 variant is not built);
+* configs[2]  regressor + warp (`TPS_PP.forward`) at batch 1024, fp32 and bf16 (bf16 tensors at the module boundary,
+  bf16 MFMA convolutions; checked against the bf16-emulating CPU oracle and, loosely, the fp32 one);
 * configs[3]  backbone (stem, layer1-2, TPS++, layer3-5) at 256 images per GPU (2048 over 8 GPUs);
 * configs[4]  image -> string at 256 images per GPU.
 
@@ -54,6 +55,43 @@ def test_config2_regressor_and_warp_batch_1024(cuda):
     o = TO.tpspp_forward(cpu_sd, x[pick[:2]], [o_[pick[:2]] for o_ in outs], "ResNet45v2")
     assert np.abs(small["output"][:2].cpu().numpy() - o["output"]).max() <= TOL
     assert np.abs(small["mp_img"][:2].cpu().numpy() - o["mp_img"]).max() <= TOL
+
+
+def test_config2_bf16_regressor_and_warp_batch_1024(cuda):
+    """BASELINE.json configs[2] as named: batch 1024, bf16.  Rows of the full batch equal the same images run
+    as a small batch bit for bit; the small batch is checked against the CPU oracle that rounds to bfloat16
+    at the same places (outputs within one bf16 ulp of the oracle's rounded value, control points to 1e-5)
+    and against the fp32 oracle at bf16 resolution."""
+    from tps_pp_amd import TPS_PP
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    cpu_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(cuda)
+    n = 1024
+    inp = cases.g4_inputs("ResNet45v2")
+    b16 = lambda a: torch.from_numpy(a).to(torch.bfloat16)      # noqa: E731
+    x = b16(tile_batch(inp["x"], n))
+    outs = [b16(tile_batch(o, n)) for o in inp["outs"]]
+    pick = [0, 1, 513, 1023]
+    with torch.no_grad():
+        full = m(x.to(cuda), [o.to(cuda) for o in outs])
+        small = m(x[pick].to(cuda), [o[pick].to(cuda) for o in outs])
+        ctrl, score, _ = m.regress(x[pick[:2]].to(cuda), [o[pick[:2]].to(cuda) for o in outs])
+    assert full["output"].dtype == torch.bfloat16 and full["mp_img"].dtype == torch.bfloat16
+    for k in ("output", "mp_img", "pc_score"):
+        assert torch.equal(full[k][pick], small[k]), k
+    xs, os_ = x[pick[:2]].float().numpy(), [o[pick[:2]].float().numpy() for o in outs]
+    ob = TO.tpspp_forward(cpu_sd, xs, os_, "ResNet45v2", bf16=True)
+    of = TO.tpspp_forward(cpu_sd, xs, os_, "ResNet45v2", bf16=False)
+    assert np.abs(ctrl.cpu().numpy() - ob["ctrl"]).max() <= 1e-5
+    assert np.abs(score.float().cpu().numpy() - ob["pc_score"]).max() <= 5e-4
+    assert np.abs(ctrl.cpu().numpy() - of["ctrl"]).max() <= 1e-4
+    for k in ("output", "mp_img"):
+        got = small[k][:2].float().cpu().numpy()
+        for o, slack in ((ob, 1e-4), (of, 1e-2)):
+            ref = o[k]
+            assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -8 + slack * np.abs(ref).max()).all(), k
 
 
 def test_config3_and_4_backbone_and_strings_256_per_gpu(cuda):

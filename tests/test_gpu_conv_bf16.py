@@ -1,0 +1,106 @@
+"""-m gpu: the bf16 MFMA convolution (tpspp_conv2d_bf16_fwd) against PyTorch-CPU.
+
+bf16 x bf16 products are exact in fp32, so with the operands rounded to bf16 on both sides the only
+differences are the fp32 summation order (fp32 outputs: 1e-5 of the tensor's scale) and, for bf16
+outputs, an occasional flip of the final rounding (one bf16 ulp = 2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tps_pp_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def rb(x):
+    """round to bf16, keep fp32 storage"""
+    return x.to(torch.bfloat16).float()
+
+
+def ref_conv(srcs, w, b, k, stride, relu, res, res_mode):
+    xs = []
+    for x, uh, uw in srcs:
+        x = rb(x).double()
+        xs.append(F.interpolate(x, scale_factor=(uh, uw), mode="nearest") if (uh, uw) != (1, 1) else x)
+    y = F.conv2d(torch.cat(xs, 1), rb(w).double(), None if b is None else b.double(), stride=stride,
+                 padding=(k - 1) // 2)
+    if res_mode == 2:
+        y = y + res.double()
+    if relu:
+        y = F.relu(y)
+    if res_mode == 1:
+        y = y + res.double()
+    return y.float()
+
+
+CASES = [
+    # name, sources [(C,H,W,uh,uw,dtype)], Cout, k, stride, relu, res_mode, res dtype, N
+    ("down0 1x1 32->64 @32x128", [(32, 32, 128, 1, 1, "bf16")], 64, 1, (1, 1), True, 0, None, 3),
+    ("down0_1 3x3 s2 64->64 @32x128", [(64, 32, 128, 1, 1, "bf16")], 64, 3, (2, 2), True, 0, None, 2),
+    ("down_feat 1x1 cat(64,64,up 64)->64", [(64, 32, 128, 1, 1, "bf16"), (64, 32, 128, 1, 1, "bf16"),
+                                            (64, 16, 64, 2, 2, "bf16")], 64, 1, (1, 1), True, 0, None, 2),
+    ("k_encoder.0 3x3 192->64 @16x64", [(64, 16, 64, 1, 1, "bf16")] * 3, 64, 3, (1, 1), True, 0, None, 2),
+    ("k_encoder.1 3x3 s2 @16x64 -> 8x32", [(64, 16, 64, 1, 1, "bf16")], 64, 3, (2, 2), True, 0, None, 3),
+    ("k_encoder.2 3x3 s2 @8x32 -> 4x16", [(64, 8, 32, 1, 1, "bf16")], 64, 3, (2, 2), True, 0, None, 5),
+    ("k_encoder.3 3x3 s(2,1) @4x16 -> 2x16", [(64, 4, 16, 1, 1, "bf16")], 64, 3, (2, 1), True, 0, None, 9),
+    ("k_decoder.0 up(2,1)+3x3 + skip, f32 source", [(64, 2, 16, 2, 1, "f32")], 64, 3, (1, 1), True, 1, "bf16", 5),
+    ("k_decoder.1 up2+3x3 + skip @8x32", [(64, 4, 16, 2, 2, "bf16")], 64, 3, (1, 1), True, 1, "bf16", 3),
+    ("k_decoder.2 up2+3x3 + skip @16x64", [(64, 8, 32, 2, 2, "bf16")], 64, 3, (1, 1), True, 1, "f32", 2),
+    ("stem 3x3 3->32 @32x128 f32 image", [(3, 32, 128, 1, 1, "f32")], 32, 3, (1, 1), True, 0, None, 2),
+    ("BasicBlock conv2 3x3 s2 + residual before relu", [(64, 32, 128, 1, 1, "bf16")], 128, 3, (2, 2), True, 2, "bf16", 2),
+    ("ragged 3x3 16->40 @9x13", [(16, 9, 13, 1, 1, "bf16")], 40, 3, (1, 1), True, 0, None, 3),
+    ("ragged 1x1 40->132 @12x44", [(40, 12, 44, 1, 1, "f32")], 132, 1, (1, 1), False, 2, "f32", 3),
+    ("1x1 256->512 @4x16", [(256, 4, 16, 1, 1, "bf16")], 512, 1, (1, 1), True, 0, None, 7),
+    ("3x3 @16x16 odd channels 24->64", [(24, 16, 16, 1, 1, "bf16")], 64, 3, (1, 1), False, 0, None, 2),
+]
+
+
+@pytest.mark.parametrize("out_dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("name,srcs,cout,k,stride,relu,res_mode,res_dt,N", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16_matches_cpu_reference(cuda, name, srcs, cout, k, stride, relu, res_mode, res_dt, N, out_dtype):
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}
+    xs = [(t(synth.dyadic((N, c, h, w), f"{name}.x{i}", 1)), uh, uw) for i, (c, h, w, uh, uw, _) in enumerate(srcs)]
+    cin = sum(s_[0] for s_ in srcs)
+    w = t(synth.dyadic((cout, cin, k, k), name + ".w", 1, 1.0 / np.sqrt(cin * k * k)))
+    b = t(synth.dyadic((cout,), name + ".b", 1, 0.1))
+    y0 = ref_conv(xs, w, b, k, stride, relu, None, 0)
+    res = None
+    if res_mode:
+        res = t(synth.dyadic(tuple(y0.shape), name + ".r", 1))
+        if res_dt == "bf16":
+            res = rb(res)
+    ref = ref_conv(xs, w, b, k, stride, relu, res, res_mode)
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    dsrcs = [(x.to(cuda).to(dt[s_[5]]), uh, uw) for (x, uh, uw), s_ in zip(xs, srcs)]
+    got = ops.conv2d_bf16(dsrcs, cw, stride, relu, None if res is None else res.to(cuda).to(dt[res_dt]),
+                          res_mode, out_dtype=dt[out_dtype])
+    assert got.dtype == dt[out_dtype] and tuple(got.shape) == tuple(ref.shape)
+    got = got.float().cpu()
+    scale = float(ref.abs().max())
+    if out_dtype == "f32":
+        assert float((got - ref).abs().max()) <= 1e-5 * scale, name
+    else:
+        # within one bf16 ulp of the exactly rounded value
+        err = (got - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6 * scale).all()), (name, float(err.max()))
+        # and mostly the exactly rounded value itself
+        assert float((got == rb(ref)).float().mean()) > 0.98, name
+
+
+def test_conv_bf16_argument_errors(cuda):
+    from tps_pp_amd import _lib
+    w = torch.zeros((64, 32, 3, 3), device=cuda)
+    cw = ops.prep_conv_weight_bf16(w)
+    with pytest.raises(ValueError):
+        ops.conv2d_bf16([torch.zeros((1, 16, 8, 8), device=cuda)], cw)          # Cin mismatch
+    with pytest.raises(TypeError):
+        ops.conv2d_bf16([torch.zeros((1, 32, 8, 8), device=cuda, dtype=torch.float16)], cw)
+    with pytest.raises(_lib.TpsppError):
+        ops.conv2d_bf16([torch.zeros((1, 32, 8, 8))], cw)                       # CPU tensor
+    with pytest.raises(_lib.TpsppError):
+        ops.conv2d_bf16([torch.zeros((1, 32, 8, 8), device=cuda)], cw, stride=(1, 2))   # no such kernel

@@ -85,6 +85,38 @@ def test_tpspp_module_against_reference(cuda, variant, fname):
     assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])
 
 
+@pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"), ("ResNet45", "tpspp_module_v1")])
+def test_tpspp_module_bf16(cuda, variant, fname):
+    """The bf16 configuration (bf16 inputs -> bf16 MFMA convolutions, fp32 from the control points on) against
+    the reference's fp32 outputs (golden G4 / G5) at bf16 resolution, fp32 inputs with `compute_dtype` set, and
+    the refusal of a module cast to bfloat16."""
+    G = cases.load(fname)
+    m = build_backbone(dict(type="TPS_PP", variant=variant)).eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    inp = cases.g4_inputs(variant)
+    xb, outsb = dev(inp["x"], cuda).to(torch.bfloat16), [dev(o, cuda).to(torch.bfloat16) for o in inp["outs"]]
+    with torch.no_grad():
+        ctrl, score, _ = m.regress(xb, outsb)
+        res = m(xb, outsb)
+    assert res["output"].dtype == torch.bfloat16 and res["mp_img"].dtype == torch.bfloat16
+    assert ctrl.dtype == torch.float32 and np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 1e-4
+    assert np.abs(score.float().cpu().numpy() - G["pc_score"]).max() < 2e-3
+    for k in ("output", "mp_img"):       # inputs rounded to bf16 (2^-9 relative) + outputs rounded to bf16
+        ref = G[k]
+        assert np.abs(res[k].float().cpu().numpy() - ref).max() <= 2.0 ** -6 * np.abs(ref).max(), k
+    # fp32 tensors, bf16 convolutions: fp32 outputs
+    m.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        res32 = m(dev(inp["x"], cuda), [dev(o, cuda) for o in inp["outs"]])
+    assert res32["output"].dtype == torch.float32
+    assert np.abs(res32["output"].cpu().numpy() - G["output"]).max() <= 2.0 ** -7 * np.abs(G["output"]).max()
+    m.compute_dtype = None
+    with pytest.raises(TypeError):
+        m.to(torch.bfloat16)(xb, outsb)
+
+
 def test_backbone_stem_and_tps_call_site(cuda):
     """Stem + layer1 + layer2 of ResNetABI_v2_large on the MFMA conv kernels (BatchNorm folded) against
     the reference's outputs, and the `tpsnet(x, outs)` call contract (resnet_v2_large.py:183-191)."""

@@ -1,0 +1,366 @@
+// bf16 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands,
+// fp32 accumulation) for BASELINE.json configs[2] / [4] (the bf16 variants of the TPS++ regressor and the
+// conv stem).  Same fusion surface as the fp32 kernel (tpspp_conv.hip): 1x1 / 3x3, strides 1 / 2 / (2,1),
+// "same" padding, up to three channel-concatenated sources each nearest-upsampled by a power of two on the
+// fly, bias + ReLU, residual before or after the activation, optional per-channel affine last.  Every
+// source / the residual / the output is independently bf16 or fp32 in memory (NCHW), so the layers around
+// the convolutions that must stay fp32 (control points, TPS solve, grid) exchange tensors without a
+// conversion pass.
+//
+// GEMM view:  D[cout][pixel] = W[cout][k] X[k][pixel];  weights are the A operand, the image the B operand,
+// so a half-wavefront holds 32 consecutive pixels of one output channel (coalesced NCHW rows).
+//
+// The 16x faster matrix pipe moves the bottleneck to operand delivery, hence three differences from the
+// fp32 kernel:
+//  * workgroup tile = 256 pixels x 64 channels, wavefront = 64 pixels x 64 channels (four 32x32
+//    accumulators): one LDS fragment read per MFMA instead of 1.5;
+//  * the LDS patch is CHANNEL-INNERMOST, [channel group of 8][position][8 channels]: the B fragment of a
+//    lane (pixel p, k-half h) for one tap is ONE ds_read_b128 at lane_base + immediate (8 consecutive k =
+//    8 channels of the tap), conflict-free because consecutive pixels are 16 B apart.  The NCHW -> channel-
+//    innermost transposition happens in the staging registers: a thread owns patch positions, loads the
+//    chunk's channels of that position (coalesced 2-B loads along the row, packed in pairs) and writes 16 B;
+//  * weights are pre-arranged on the host as [cout tile][chunk][tap][k group][64 cout][8 k] bf16, i.e. the
+//    global image of a chunk's slab IS its LDS image and an A fragment is one ds_read_b128.
+// Next chunk's patch and slab are prefetched into registers during the multiply (one barrier pair per chunk).
+//
+// Replaces (reference, mmocr/models/textrecog/): the same call sites as tpspp_conv2d_fwd --
+// backbones/tps_pp/tps_pp.py:126-131,149-154,156-169,538-552,560-562; backbones/resnet_v2_large.py:131-135;
+// layers/conv_layer.py:12-33 -- when the module runs in bf16.
+// Bound: operand delivery (LDS bandwidth) below the bf16 MFMA peak (2.5 PFLOP/s); 1x1 layers HBM.
+#include "tpspp_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;
+constexpr int BM = 256;       // output pixels per workgroup
+constexpr int BN = 64;        // output channels per workgroup
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct BSrc {
+    const void* p;
+    int C, H, W;              // stored size
+    int lh, lw;               // log2 of the nearest upsampling factors
+    int f32;                  // element type: 1 fp32, 0 bf16
+};
+
+struct BParams {
+    BSrc src[3];
+    int nsrc;
+    const u32x4* wt;          // [ctile][chunk][tap][k group][64][8] bf16, 16-B units
+    const float* bias;        // (Cout) fp32 or null
+    const void* res;          // (N, Cout, Ho, Wo) or null
+    const float* post_scale;
+    const float* post_shift;
+    void* out;
+    int res_f32, out_f32;
+    int N, Cin, Cout, Hi, Wi, Ho, Wo, ph, pw;
+    int relu, res_mode;
+    int nchunks;
+};
+
+__device__ __forceinline__ unsigned f32_to_bf16_bits(float f)
+{
+    // round to nearest even (inputs are finite activations)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h)
+{
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
+struct BCfg {
+    static constexpr int KW = KH;
+    static constexpr int TAPS = KH * KW;
+    static constexpr int PH = (TH - 1) * SH + KH;
+    static constexpr int PW = (TW - 1) * SW + KW;
+    static constexpr int PS = PH * PW;                 // positions per image
+    static constexpr int PSN = NI * PS;                // positions per tile
+    static constexpr int NPOS = (PSN + kThreads - 1) / kThreads;
+    static constexpr int KG = KC / 8;                  // channel groups of 8
+    static constexpr int WSLAB = TAPS * KG * BN;       // 16-B units of a chunk's weight slab
+    static constexpr int NW = (WSLAB + kThreads - 1) / kThreads;
+};
+
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
+__global__ void __launch_bounds__(kThreads, 2)
+conv_tiled_bf16_kernel(const BParams P)
+{
+    using Cfg = BCfg<KH, SH, SW, TH, TW, NI, KC>;
+    constexpr int KW = Cfg::KW, TAPS = Cfg::TAPS, PW = Cfg::PW, PS = Cfg::PS, PSN = Cfg::PSN;
+    constexpr int NPOS = Cfg::NPOS, KG = Cfg::KG, WSLAB = Cfg::WSLAB, NW = Cfg::NW;
+    static_assert(NI * TH * TW == BM, "tile must hold 256 pixels");
+    static_assert(KC % 16 == 0, "whole MFMA k-steps");
+    __shared__ u32x4 sP[KG * PSN];                     // [k group][position] x 8 bf16
+    __shared__ u32x4 sW[WSLAB];                        // [tap][k group][cout] x 8 bf16
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = tid / kWave;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ctiles = (P.Cout + BN - 1) / BN;
+    const int ngrp = blockIdx.z / ctiles;
+    const int ctile = blockIdx.z - ngrp * ctiles;
+    const int n0 = ngrp * NI;
+    const int co_base = ctile * BN;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int iy_base = oy0 * SH - P.ph, ix_base = ox0 * SW - P.pw;
+    const int HoWo = P.Ho * P.Wo;
+
+    // the two 32-pixel fragments of this wavefront: tile-linear pixel -> (image, row, column)
+    int fimg[2], fty[2], ftx[2], fpos[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int tp = (wv * 2 + f) * 32 + l31;
+        fimg[f] = tp / (TH * TW);
+        const int tpi = tp - fimg[f] * (TH * TW);
+        fty[f] = tpi / TW;
+        ftx[f] = tpi - fty[f] * TW;
+        fpos[f] = half * PSN + fimg[f] * PS + fty[f] * SH * PW + ftx[f] * SW;
+    }
+
+    // staging: this thread's patch positions (fixed over the chunks): logical input coordinates, or -1
+    int piy[NPOS], pix[NPOS], pim[NPOS];
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+        const int e = tid + i * kThreads;
+        const int im = e / PS, e1 = e - im * PS;
+        const int py = e1 / PW, px = e1 - py * PW;
+        const int iy = iy_base + py, ix = ix_base + px;
+        const bool ok = e < PSN && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
+        piy[i] = ok ? iy : -1;
+        pix[i] = ix;
+        pim[i] = im;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[f][h2][i] = 0.0f;
+
+    unsigned rp[NPOS][KC / 2];          // packed channel pairs of each position
+    u32x4 rw[NW];
+    int cbase = 0, s = 0;
+    BSrc cur = P.src[0];
+    const u32x4* wbase = P.wt + (size_t)ctile * P.nchunks * WSLAB;
+
+    auto prefetch = [&](int chunk) {
+        const int c0 = chunk * KC;
+        while (c0 >= cbase + cur.C) { cbase += cur.C; ++s; cur = P.src[s]; }
+        const int plane = cur.H * cur.W;
+        const int cleft = min(KC, cur.C - (c0 - cbase));           // channels of this chunk that exist
+        const size_t img_stride = (size_t)cur.C * plane;
+        const size_t chan0 = (size_t)n0 * img_stride + (size_t)(c0 - cbase) * plane;
+        // every load is unconditional (a predicate per load would put each one in its own basic block and
+        // serialise them behind s_waitcnt): channels beyond the source's last one re-read that last channel
+        // and are zeroed by a select, padding positions read the chunk's first element
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+            const bool ok = piy[i] >= 0;
+            const size_t off = ok ? chan0 + pim[i] * img_stride + (size_t)(piy[i] >> cur.lh) * cur.W + (pix[i] >> cur.lw) : chan0;
+            if (cur.f32) {
+                const float* sp = reinterpret_cast<const float*>(cur.p) + off;
+                float v[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) v[c] = sp[(size_t)min(c, cleft - 1) * plane];
+#pragma unroll
+                for (int c2 = 0; c2 < KC / 2; ++c2) {
+                    const unsigned lo = (2 * c2 < cleft) ? f32_to_bf16_bits(v[2 * c2]) : 0u;
+                    const unsigned hi = (2 * c2 + 1 < cleft) ? f32_to_bf16_bits(v[2 * c2 + 1]) : 0u;
+                    rp[i][c2] = ok ? (lo | (hi << 16)) : 0u;
+                }
+            } else {
+                const unsigned short* sp = reinterpret_cast<const unsigned short*>(cur.p) + off;
+                unsigned short v[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) v[c] = sp[(size_t)min(c, cleft - 1) * plane];
+#pragma unroll
+                for (int c2 = 0; c2 < KC / 2; ++c2) {
+                    const unsigned lo = (2 * c2 < cleft) ? (unsigned)v[2 * c2] : 0u;
+                    const unsigned hi = (2 * c2 + 1 < cleft) ? (unsigned)v[2 * c2 + 1] : 0u;
+                    rp[i][c2] = ok ? (lo | (hi << 16)) : 0u;
+                }
+            }
+        }
+        const u32x4* wp = wbase + (size_t)chunk * WSLAB;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = tid + i * kThreads;
+            rw[i] = wp[e < WSLAB ? e : 0];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPOS; ++i) {
+            const int e = tid + i * kThreads;
+            if (e < PSN) {
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    u32x4 v;
+                    v[0] = rp[i][4 * g]; v[1] = rp[i][4 * g + 1]; v[2] = rp[i][4 * g + 2]; v[3] = rp[i][4 * g + 3];
+                    sP[g * PSN + e] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int e = tid + i * kThreads;
+            if (e < WSLAB) sW[e] = rw[i];
+        }
+    };
+
+    prefetch(0);
+    for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+        commit();
+        __syncthreads();
+        if (chunk + 1 < P.nchunks) prefetch(chunk + 1);       // in flight during the MFMA phase
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KW, kx = tap - ky * KW;
+#pragma unroll
+            for (int ks = 0; ks < KC / 16; ++ks) {
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, sP[fpos[0] + (2 * ks) * PSN + ky * PW + kx]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, sP[fpos[1] + (2 * ks) * PSN + ky * PW + kx]);
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + l31]);
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + 32 + l31]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, residual, ReLU, affine; half-wavefronts store rows of 32 consecutive pixels ----
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
+        if (oy < P.Ho && ox < P.Wo && n < P.N) {
+            const int pixel = oy * P.Wo + ox;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_base + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < P.Cout) {
+                        float v = acc[f][h2][r];
+                        if (P.bias) v = v + P.bias[co];
+                        const size_t o = ((size_t)n * P.Cout + co) * HoWo + pixel;
+                        float rv = 0.0f;
+                        if (P.res_mode)
+                            rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
+                                           : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
+                        if (P.res_mode == 2) v = v + rv;
+                        if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+                        if (P.res_mode == 1) v = v + rv;
+                        if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
+                        if (P.out_f32) reinterpret_cast<float*>(P.out)[o] = v;
+                        else reinterpret_cast<unsigned short*>(P.out)[o] = (unsigned short)f32_to_bf16_bits(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
+void launch_b(const BParams& P, hipStream_t st)
+{
+    const int ctiles = (P.Cout + BN - 1) / BN;
+    const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
+                    (unsigned)(((P.N + NI - 1) / NI) * ctiles));
+    hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC>), grid, dim3(kThreads), 0, st, P);
+}
+
+constexpr int kKC3 = 16;      // channels per chunk, 3x3 kernels
+constexpr int kKC1 = 32;      // channels per chunk, 1x1 kernels
+
+// picks the tile by output width / height; false when no instantiation fits
+template <int KH, int SH, int SW, int KC>
+bool launch_by_shape(const BParams& P, hipStream_t st)
+{
+    if (P.Wo > 64)      launch_b<KH, SH, SW, 2, 128, 1, KC>(P, st);
+    else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC>(P, st);
+    else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC>(P, st);
+    else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC>(P, st);
+    else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC>(P, st);
+    else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 4, KC>(P, st);
+    else                launch_b<KH, SH, SW, 2, 16, 8, KC>(P, st);
+    return true;
+}
+
+}  // namespace
+
+TPSPP_EXPORT int tpspp_conv_bf16_chunk_channels(int kernel_size)
+{
+    return kernel_size == 1 ? kKC1 : kKC3;
+}
+
+TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* src_dims, int nsrc,
+                                       const void* weight_arranged, const float* bias,
+                                       const void* residual, int residual_f32,
+                                       const float* post_scale, const float* post_shift,
+                                       int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
+                                       void* out, int out_f32, int Ho, int Wo, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(src_ptrs && src_dims && weight_arranged && out, "tpspp_conv2d_bf16_fwd: null pointer");
+    TPSPP_REQUIRE(nsrc >= 1 && nsrc <= 3, "tpspp_conv2d_bf16_fwd: 1..3 sources");
+    TPSPP_REQUIRE((KH == 1 && KW == 1) || (KH == 3 && KW == 3), "tpspp_conv2d_bf16_fwd: kernel must be 1x1 or 3x3");
+    TPSPP_REQUIRE(N >= 0 && Cout > 0 && sh >= 1 && sw >= 1 && Ho > 0 && Wo > 0, "tpspp_conv2d_bf16_fwd: bad sizes");
+    TPSPP_REQUIRE(res_mode >= 0 && res_mode <= 2 && (res_mode == 0) == (residual == nullptr),
+                  "tpspp_conv2d_bf16_fwd: residual / res_mode mismatch");
+    TPSPP_REQUIRE(relu == 0 || relu == 1, "tpspp_conv2d_bf16_fwd: activation code must be 0 (none) or 1 (ReLU)");
+    TPSPP_REQUIRE((post_scale == nullptr) == (post_shift == nullptr),
+                  "tpspp_conv2d_bf16_fwd: post_scale/post_shift come together");
+    BParams P;
+    P.nsrc = nsrc;
+    const int KC = (KH == 1) ? kKC1 : kKC3;
+    int cin = 0, Hi = -1, Wi = -1;
+    for (int i = 0; i < nsrc; ++i) {
+        const int* d = src_dims + 6 * i;                      // C, H, W, uh, uw, is_f32
+        TPSPP_REQUIRE(src_ptrs[i] && d[0] > 0 && d[1] > 0 && d[2] > 0, "tpspp_conv2d_bf16_fwd: bad source %d", i);
+        TPSPP_REQUIRE((d[3] == 1 || d[3] == 2 || d[3] == 4) && (d[4] == 1 || d[4] == 2 || d[4] == 4),
+                      "tpspp_conv2d_bf16_fwd: upsampling factors must be 1, 2 or 4");
+        TPSPP_REQUIRE(nsrc == 1 || d[0] % KC == 0,
+                      "tpspp_conv2d_bf16_fwd: concatenated sources need channel counts that are multiples of %d", KC);
+        P.src[i].p = src_ptrs[i];
+        P.src[i].C = d[0]; P.src[i].H = d[1]; P.src[i].W = d[2];
+        P.src[i].lh = d[3] >> 1; P.src[i].lw = d[4] >> 1;      // 1,2,4 -> 0,1,2
+        P.src[i].f32 = d[5] ? 1 : 0;
+        const int lh = d[1] * d[3], lw = d[2] * d[4];
+        TPSPP_REQUIRE(Hi < 0 || (Hi == lh && Wi == lw), "tpspp_conv2d_bf16_fwd: sources disagree on the logical size");
+        Hi = lh; Wi = lw;
+        cin += d[0];
+    }
+    for (int i = nsrc; i < 3; ++i) P.src[i] = P.src[nsrc - 1];
+    P.Cin = cin; P.Cout = Cout; P.N = N; P.Hi = Hi; P.Wi = Wi; P.Ho = Ho; P.Wo = Wo;
+    P.ph = (KH - 1) / 2; P.pw = (KW - 1) / 2;
+    TPSPP_REQUIRE(Ho == (Hi + 2 * P.ph - KH) / sh + 1 && Wo == (Wi + 2 * P.pw - KW) / sw + 1,
+                  "tpspp_conv2d_bf16_fwd: output size does not match input size / stride ('same' padding)");
+    P.wt = reinterpret_cast<const u32x4*>(weight_arranged);
+    P.bias = bias; P.res = residual; P.res_f32 = residual_f32 ? 1 : 0; P.out = out; P.out_f32 = out_f32 ? 1 : 0;
+    P.post_scale = post_scale; P.post_shift = post_shift;
+    P.relu = relu; P.res_mode = res_mode;
+    P.nchunks = (cin + KC - 1) / KC;
+    if (N == 0) return TPSPP_OK;
+    TPSPP_REQUIRE((long)N * ((Cout + BN - 1) / BN) <= 65535, "tpspp_conv2d_bf16_fwd: grid too large");
+    hipStream_t st = tpspp::as_stream(stream);
+    bool ok = false;
+    if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1>(P, st);
+    else if (KH == 3 && sh == 1 && sw == 1) ok = launch_by_shape<3, 1, 1, kKC3>(P, st);
+    else if (KH == 3 && sh == 2 && sw == 2) ok = launch_by_shape<3, 2, 2, kKC3>(P, st);
+    else if (KH == 3 && sh == 2 && sw == 1) ok = launch_by_shape<3, 2, 1, kKC3>(P, st);
+    TPSPP_REQUIRE(ok, "tpspp_conv2d_bf16_fwd: no kernel for a %dx%d kernel with stride (%d,%d)", KH, KW, sh, sw);
+    return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
+}

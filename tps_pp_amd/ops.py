@@ -267,6 +267,96 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
     return out
 
 
+def _chk16(name, t, ndim=None):
+    """bf16 path: a GPU tensor that is float32 or bfloat16."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise _lib.TpsppError(f"{name}: tensor is on {t.device}; the HIP path needs a GPU tensor "
+                              "(no CPU fallback)")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"{name}: expected float32 or bfloat16, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class ConvWeightBf16:
+    """Device-side weights of one fused bf16 convolution: `arranged` bf16
+    [Cout/64][Cin/KC][taps][KC/8][64][8] (include/tpspp.h, tpspp_conv2d_bf16_fwd), fp32 `bias` | None."""
+
+    def __init__(self, arranged, bias, kernel, cin, cout, post_scale=None, post_shift=None):
+        self.arranged, self.bias, self.kernel, self.cin, self.cout = arranged, bias, kernel, cin, cout
+        self.post_scale, self.post_shift = post_scale, post_shift
+
+
+def prep_conv_weight_bf16(weight, bn=None, conv_bias=None, eps=1e-5, post_bn=None):
+    """PyTorch conv weight (Cout, Cin, KH, KW) [+ eval-mode BatchNorm folded in fp32, then rounded] ->
+    ConvWeightBf16.  Same folding rules as `prep_conv_weight`."""
+    w = weight.detach().float()
+    b = None if conv_bias is None else conv_bias.detach().float()
+    if bn is not None:
+        gamma, beta, mean, var = (t.detach().float() for t in bn)
+        scale = gamma / torch.sqrt(var + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = beta - mean * scale if b is None else beta + (b - mean) * scale
+    cout, cin, kh, kw = w.shape
+    kc = int(_lib.lib().tpspp_conv_bf16_chunk_channels(int(kh)))
+    ct, nch = (cout + 63) // 64, (cin + kc - 1) // kc
+    wp = torch.zeros((ct * 64, nch * kc, kh, kw), device=w.device, dtype=torch.float32)
+    wp[:cout, :cin] = w
+    # (ctile, co, chunk, kgroup, k8, ky, kx) -> (ctile, chunk, ky, kx, kgroup, co, k8)
+    arranged = wp.view(ct, 64, nch, kc // 8, 8, kh, kw).permute(0, 2, 5, 6, 3, 1, 4).contiguous().to(torch.bfloat16)
+    ps = pb = None
+    if post_bn is not None:
+        gamma, beta, mean, var = (t.detach().float() for t in post_bn)
+        ps = (gamma / torch.sqrt(var + eps)).contiguous()
+        pb = (beta - mean * ps).contiguous()
+    return ConvWeightBf16(arranged, None if b is None else b.contiguous(), kh, cin, cout, ps, pb)
+
+
+def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out_dtype=torch.bfloat16):
+    """Fused conv on the bf16 matrix cores (`tpspp_conv2d_bf16_fwd`): same call shape as `conv2d`; every
+    source / the residual may be float32 or bfloat16, the output is `out_dtype`."""
+    import ctypes
+    ts, dims = [], []
+    for e in srcs:
+        t, uh, uw = (e, 1, 1) if isinstance(e, torch.Tensor) else e
+        t = _chk16("conv source", t, 4)
+        ts.append(t)
+        dims += [t.shape[1], t.shape[2], t.shape[3], int(uh), int(uw), int(t.dtype == torch.float32)]
+    N = ts[0].shape[0]
+    if sum(t.shape[1] for t in ts) != cw.cin:
+        raise ValueError("conv2d_bf16: source channels != Cin of the weight")
+    Hi, Wi = ts[0].shape[2] * dims[3], ts[0].shape[3] * dims[4]
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    kernel, Cout = cw.kernel, cw.cout
+    pad = (kernel - 1) // 2
+    Ho = (Hi + 2 * pad - kernel) // sh + 1
+    Wo = (Wi + 2 * pad - kernel) // sw + 1
+    res_f32 = 0
+    if residual is not None:
+        residual = _chk16("residual", residual, 4)
+        if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2):
+            raise ValueError("conv2d_bf16: residual shape / res_mode")
+        res_f32 = int(residual.dtype == torch.float32)
+    elif res_mode != 0:
+        raise ValueError("conv2d_bf16: res_mode without residual")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("conv2d_bf16: out_dtype must be float32 or bfloat16")
+    out = torch.empty((N, Cout, Ho, Wo), device=ts[0].device, dtype=out_dtype)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    dim_arr = (ctypes.c_int * len(dims))(*dims)
+    with torch.cuda.device(ts[0].device):
+        rc = _lib.lib().tpspp_conv2d_bf16_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
+                                              len(ts), _ptr(cw.arranged), _ptr(cw.bias), _ptr(residual), res_f32,
+                                              _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode), int(bool(relu)),
+                                              N, Cout, kernel, kernel, sh, sw, _ptr(out),
+                                              int(out_dtype == torch.float32), Ho, Wo, _stream(ts[0]))
+    _lib.check(rc, "tpspp_conv2d_bf16_fwd")
+    return out
+
+
 def _mfma_feature_perm(device):
     """slot 2*ks + half -> input feature held by (accumulator register ks, half-wavefront `half`) in the
     C/D layout of v_mfma_f32_32x32x2_f32 (see tpspp_dgab.hip)."""

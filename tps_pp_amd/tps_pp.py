@@ -306,6 +306,7 @@ class TPS_PP(nn.Module):
         self.init_cfg = init_cfg
         self.heads = 16
         self.type = variant
+        self.compute_dtype = None          # None: follow the input dtype; torch.bfloat16: bf16 convolutions
         self.visual_point = visual_point
         self.num_fiducial = point_size[0] * point_size[1]
         self.img_size = img_size
@@ -371,6 +372,53 @@ class TPS_PP(nn.Module):
         k = ops.conv2d([k], cw["dec3"], 1)
         return e3, k
 
+    # ---- bf16 path (BASELINE.json configs[2]): bf16 MFMA convolutions, tpspp_conv_bf16.hip ------------
+    def _conv_weights_bf16(self):
+        convs = {"down0": self.down0, "down1": self.down1, "down2": self.down2}
+        if self.type == "ResNet45v2":
+            convs.update(down0_1=self.down0_1, down1_1=self.down1_1, down_feat=self.down_feat)
+        for i in range(4):
+            convs[f"enc{i}"] = self.MSFA.conv.k_encoder[i]
+            convs[f"dec{i}"] = self.MSFA.conv.k_decoder[i][1]
+        key = tuple((n, m.conv.weight._version, m.conv.bias._version, m.conv.weight.data_ptr())
+                    for n, m in convs.items())
+        cache = getattr(self, "_cw16_cache", None)
+        if cache is None or cache[0] != key:
+            cw = {n: ops.prep_conv_weight_bf16(m.conv.weight, conv_bias=m.conv.bias) for n, m in convs.items()}
+            self._cw16_cache = cache = (key, cw)
+        return cache[1]
+
+    def _regress_hip_bf16(self, batch_img, outs):
+        """The regressor with every convolution on the bf16 matrix cores.  Activations between convolutions
+        are bf16 in HBM; the three tensors that feed fp32 arithmetic -- `en_feat` (CBAM, control points:
+        amplified ~223x by the TPS solve), `de_feat` (DGAB, score) and `feat_grid` (sampled by the warp) --
+        leave their convolution in fp32 (fp32 accumulators, never rounded).  Inputs may be bf16 or fp32."""
+        cw = self._conv_weights_bf16()
+        bf, f32 = torch.bfloat16, torch.float32
+        c16 = ops.conv2d_bf16
+        x, o0, o1 = batch_img, outs[0], outs[1]
+        if self.type == "ResNet45v2":
+            feat0 = c16([o0], cw["down0"], 1)
+            feat1 = c16([o1], cw["down1"], 1)
+            feat2 = c16([x], cw["down2"], 1)
+            feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1, out_dtype=f32)
+            cat_srcs = [c16([feat0], cw["down0_1"], 2), c16([feat1], cw["down1_1"], 2), feat2]
+        else:
+            cat_srcs = [c16([o0], cw["down0"], 2), c16([o1], cw["down1"], 1), c16([x], cw["down2"], 1)]
+            feat_grid = x.float()
+        p = self.MSFA.conv.stride
+        e0 = c16(cat_srcs, cw["enc0"], 1)
+        e1 = c16([e0], cw["enc1"], 2)
+        e2 = c16([e1], cw["enc2"], p)
+        e3 = c16([e2], cw["enc3"], (2, 1), out_dtype=f32)
+        k = ops.cbam(e3, self.MSFA.conv.atten)
+        k = c16([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1)
+        k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
+        k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
+        de_feat = c16([k], cw["dec3"], 1, out_dtype=f32)
+        control_point, atten_score = self._tpe_hip(e3, de_feat)
+        return control_point, atten_score, feat_grid
+
     def grid(self, a1, a2, a3):
         return self.down_feat(torch.cat((a1, a2, self.up_sample(a3)), dim=1))
 
@@ -386,7 +434,18 @@ class TPS_PP(nn.Module):
                     "[2,1,2,1,2] (configs/textrecog/nrtr/nrtr_tps++.py) produce the 'ResNet45' "
                     "geometry -- build with variant='ResNet45' (the reference itself fails here)")
         ops.require_gpu(batch_img, "TPS_PP")
+        if self._bf16(batch_img):
+            return self._regress_hip_bf16(batch_img, outs)
         return self._regress_hip(batch_img, outs)
+
+    def _bf16(self, batch_img):
+        """bf16 compute when the caller hands over bf16 activations or sets `compute_dtype`.  The module's
+        own parameters and TPS constants stay fp32 (`module.bfloat16()` would round `hat_C`, whose entries
+        reach +-223: refused)."""
+        if self.atten_tps.hat_C.dtype != torch.float32:
+            raise TypeError("TPS_PP: keep the module in float32 (its TPS constants do not survive bf16); bf16 "
+                            "compute is selected by a bfloat16 input or `module.compute_dtype = torch.bfloat16`")
+        return batch_img.dtype == torch.bfloat16 or self.compute_dtype == torch.bfloat16
 
     def _regress_torch(self, batch_img, outs):
         """TEST HOOK, never called by forward(): the same layers composed with plain PyTorch ops, so that
@@ -482,6 +541,8 @@ class TPS_PP(nn.Module):
         # (the score stays the transposed view of its (N, F, n) buffer: ops.warp reads it in place)
         output, mp_img = self.rectify(feat_grid.float(), batch_img.float(), control_point.float(),
                                       atten_score.float())
+        if batch_img.dtype == torch.bfloat16:          # bf16 module boundary
+            output, mp_img = output.to(torch.bfloat16), mp_img.to(torch.bfloat16)
         return {"output": output, "logits": None, "mp_img": mp_img, "pc_score": atten_score}
 
 
