@@ -191,10 +191,19 @@ def recognizer_measurement(dev, timeit):
         t_dec = timeit(lambda: m.decoder(feat, out_enc, None, None, train_mode=False), 3, 1)
         k = 4
         got = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+        # BASELINE.json configs[4]: backbone + TPS++ convolutions on the bf16 matrix cores (head stays fp32)
+        m.backbone.compute_dtype = torch.bfloat16
+        t_all16 = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
+        t_feat16 = timeit(lambda: m.extract_feat(img, test=True), 3, 1)
+        got16 = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+        m.backbone.compute_dtype = None
     want = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[:k].cpu().numpy(), [128] * k)["text"]
     return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
             "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
             "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
+            "bf16_backbone": {"images_per_s": n / (t_all16 * 1e-3), "ms_per_batch": t_all16,
+                              "ms_backbone_tpspp": t_feat16,
+                              "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(got16, want))}/{k}"},
             "data": "synthetic images, random-init weights"}
 
 

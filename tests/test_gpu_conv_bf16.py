@@ -53,6 +53,8 @@ CASES = [
     ("k_decoder.2 up2+3x3 + skip @16x64", [(64, 8, 32, 2, 2, "bf16")], 64, 3, (1, 1), True, 1, "f32", 2),
     ("stem 3x3 3->32 @32x128 f32 image", [(3, 32, 128, 1, 1, "f32")], 32, 3, (1, 1), True, 0, None, 2),
     ("BasicBlock conv2 3x3 s2 + residual before relu", [(64, 32, 128, 1, 1, "bf16")], 128, 3, (2, 2), True, 2, "bf16", 2),
+    ("downsample 1x1 s2 64->128 @32x128", [(64, 32, 128, 1, 1, "bf16")], 128, 1, (2, 2), False, 0, None, 3),
+    ("downsample 1x1 s2 ragged 40->72 @9x13", [(40, 9, 13, 1, 1, "bf16")], 72, 1, (2, 2), False, 0, None, 2),
     ("ragged 3x3 16->40 @9x13", [(16, 9, 13, 1, 1, "bf16")], 40, 3, (1, 1), True, 0, None, 3),
     ("ragged 1x1 40->132 @12x44", [(40, 12, 44, 1, 1, "f32")], 132, 1, (1, 1), False, 2, "f32", 3),
     ("1x1 256->512 @4x16", [(256, 4, 16, 1, 1, "bf16")], 512, 1, (1, 1), True, 0, None, 7),

@@ -208,6 +208,25 @@ def test_recognizer_end_to_end_against_reference(cuda):
     assert [m_["valid_ratio"] for m_ in metas] == [w / 128 for w in cases.G12_WIDTHS]
 
 
+def test_recognizer_bf16_backbone_against_reference(cuda):
+    """BASELINE.json configs[4]: the recogniser with backbone + TPS++ convolutions on the bf16 matrix cores
+    (`backbone.compute_dtype = torch.bfloat16`; the transformer head stays fp32) against the reference's fp32
+    run (golden G12): the feature map within bf16 resolution, the decoded strings identical."""
+    G = cases.load("recognizer_e2e")
+    m = build_recognizer(cuda)
+    m.backbone.compute_dtype = torch.bfloat16
+    img = dev(cases.g12_inputs()["img"], cuda)
+    metas = [dict(resize_shape=(32, w, 3)) for w in cases.G12_WIDTHS]
+    with torch.no_grad():
+        res = m(img, metas, return_loss=False)
+        feat = m.extract_feat(img, test=True)["output"]
+    assert feat.dtype == torch.float32
+    ref = G["feat_sub"]
+    err = np.abs(feat.cpu().numpy()[:, ::8] - ref)
+    assert err.max() <= 0.05 * np.abs(ref).max() and err.mean() <= 0.005 * np.abs(ref).max()
+    assert [r["text"] for r in res] == [str(s) for s in G["text"]]
+
+
 @pytest.mark.parametrize("hw,n", [((4, 20), 5), ((1, 7), 3), ((4, 40), 2)])
 def test_head_other_token_counts_against_oracle(cuda, hw, n):
     """Token counts other than 64 (wider / narrower images: T = 80, 7, 160 > one wavefront), odd batch."""

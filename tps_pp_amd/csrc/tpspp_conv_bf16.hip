@@ -79,8 +79,12 @@ template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
 struct BCfg {
     static constexpr int KW = KH;
     static constexpr int TAPS = KH * KW;
-    static constexpr int PH = (TH - 1) * SH + KH;
-    static constexpr int PW = (TW - 1) * SW + KW;
+    // a 1x1 kernel stages exactly the pixels it reads (one patch position per output pixel, input step =
+    // stride); a 3x3 kernel stages the dense patch (input step 1, output pixels `stride` positions apart)
+    static constexpr int OSH = KH == 1 ? 1 : SH, OSW = KH == 1 ? 1 : SW;   // patch positions per output step
+    static constexpr int ISH = KH == 1 ? SH : 1, ISW = KH == 1 ? SW : 1;   // input pixels per patch position
+    static constexpr int PH = (TH - 1) * OSH + KH;
+    static constexpr int PW = (TW - 1) * OSW + KW;
     static constexpr int PS = PH * PW;                 // positions per image
     static constexpr int PSN = NI * PS;                // positions per tile
     static constexpr int NPOS = (PSN + kThreads - 1) / kThreads;
@@ -123,7 +127,7 @@ conv_tiled_bf16_kernel(const BParams P)
         const int tpi = tp - fimg[f] * (TH * TW);
         fty[f] = tpi / TW;
         ftx[f] = tpi - fty[f] * TW;
-        fpos[f] = half * PSN + fimg[f] * PS + fty[f] * SH * PW + ftx[f] * SW;
+        fpos[f] = half * PSN + fimg[f] * PS + fty[f] * Cfg::OSH * PW + ftx[f] * Cfg::OSW;
     }
 
     // staging: this thread's patch positions (fixed over the chunks): logical input coordinates, or -1
@@ -133,7 +137,7 @@ conv_tiled_bf16_kernel(const BParams P)
         const int e = tid + i * kThreads;
         const int im = e / PS, e1 = e - im * PS;
         const int py = e1 / PW, px = e1 - py * PW;
-        const int iy = iy_base + py, ix = ix_base + px;
+        const int iy = iy_base + py * Cfg::ISH, ix = ix_base + px * Cfg::ISW;
         const bool ok = e < PSN && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
         piy[i] = ok ? iy : -1;
         pix[i] = ix;
@@ -358,6 +362,7 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     hipStream_t st = tpspp::as_stream(stream);
     bool ok = false;
     if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1>(P, st);
+    else if (KH == 1 && sh == 2 && sw == 2) ok = launch_by_shape<1, 2, 2, kKC1>(P, st);
     else if (KH == 3 && sh == 1 && sw == 1) ok = launch_by_shape<3, 1, 1, kKC3>(P, st);
     else if (KH == 3 && sh == 2 && sw == 2) ok = launch_by_shape<3, 2, 2, kKC3>(P, st);
     else if (KH == 3 && sh == 2 && sw == 1) ok = launch_by_shape<3, 2, 1, kKC3>(P, st);

@@ -63,6 +63,29 @@ class BasicBlock(nn.Module):
             self._cw_cache = cache = (key, cw)
         return cache[1]
 
+    def _weights_bf16(self):
+        mods = [self.conv1, self.bn1, self.conv2, self.bn2] + \
+            ([self.downsample[0], self.downsample[1]] if self.downsample is not None else [])
+        key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        cache = getattr(self, "_cw16_cache", None)
+        if cache is None or cache[0] != key:
+            def fold(conv, bn):
+                return ops.prep_conv_weight_bf16(conv.weight, eps=bn.eps,
+                                                 bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            cw = [fold(self.conv1, self.bn1), fold(self.conv2, self.bn2),
+                  fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None]
+            self._cw16_cache = cache = (key, cw)
+        return cache[1]
+
+    def _forward_hip_bf16(self, x, out_dtype=torch.bfloat16):
+        """The block on the bf16 matrix cores (BatchNorm folded in fp32, then rounded): activations bf16 in
+        HBM, accumulation / bias / residual add / ReLU in fp32."""
+        c1, c2, cd = self._weights_bf16()
+        out = ops.conv2d_bf16([x], c1, self.conv1.stride, True)
+        residual = x if cd is None else ops.conv2d_bf16([x], cd, self.downsample[0].stride, False)
+        return ops.conv2d_bf16([out], c2, self.conv2.stride, True, residual=residual, res_mode=2,
+                               out_dtype=out_dtype)
+
     def _forward_hip(self, x):
         c1, c2, cd = self._weights()
         x = x.float().contiguous()
@@ -89,6 +112,7 @@ class ResNetABI_v2_large(nn.Module):
         assert out_indices is None or isinstance(out_indices, (list, tuple))
         assert isinstance(last_stage_pool, bool)
         self.init_cfg = init_cfg
+        self.compute_dtype = None          # None: follow the input dtype; torch.bfloat16: bf16 convolutions
         self.out_indices = out_indices
         self.last_stage_pool = last_stage_pool
         self.block = BasicBlock
@@ -136,7 +160,25 @@ class ResNetABI_v2_large(nn.Module):
         """(N, 3, H, W) -> dict(output, img_ref); `tpsnet(x, outs, **kwargs)` runs before stage 2 and
         its 'output' replaces x (`resnet_v2_large.py:183-191`)."""
         ops.require_gpu(x, "ResNetABI_v2_large", self.training)
+        if x.dtype == torch.bfloat16 or self.compute_dtype == torch.bfloat16:
+            # bf16 configuration (BASELINE.json configs[4]): every convolution on the bf16 matrix cores, bf16
+            # activations in HBM (also through `tpsnet`, which follows its input dtype); the feature map handed
+            # to the encoder leaves the last block in fp32
+            last = getattr(self, self.res_layers[-1])[-1]
+            return self._run(x, tpsnet, self._stem_bf16, lambda blk, t: blk._forward_hip_bf16(
+                t, torch.float32 if blk is last else torch.bfloat16), **kwargs)
         return self._run(x, tpsnet, self._stem, lambda blk, t: blk(t), **kwargs)
+
+    def _stem_bf16(self, x):
+        mods = [self.conv1, self.bn1]
+        key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        cache = getattr(self, "_cw16_cache", None)
+        if cache is None or cache[0] != key:
+            bn = self.bn1
+            cw = ops.prep_conv_weight_bf16(self.conv1.weight, conv_bias=self.conv1.bias, eps=bn.eps,
+                                           bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            self._cw16_cache = cache = (key, cw)
+        return ops.conv2d_bf16([x], cache[1], 1, True)
 
     def _run(self, x, tpsnet, stem, apply_block, **kwargs):
         x = stem(x)
