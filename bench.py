@@ -251,10 +251,13 @@ def main():
         ctrls.append(ident_d[None] + 0.05 * (torch.rand((BATCH, F, 2), generator=g, device=dev) * 2 - 1))
     outs = [torch.empty((BATCH, C, H, W), device=dev) for _ in range(nbuf)]
 
+    # one validated, pre-marshalled tpspp_warp_fwd call per buffer set (ops.WarpPlan): a step is exactly one
+    # foreign call = one kernel launch; per-call tensor checks in Python would cost about a launch period
+    plans = [ops.WarpPlan(imgs[j], ctrls[j], gg.inv_delta_C, gg.P_hat, (H, W), outs[j], P_hat_t=p_hat_t,
+                          table_flags=flags) for j in range(nbuf)]
+
     def step(i):
-        j = i % nbuf
-        ops.warp(imgs[j], ctrls[j], gg.inv_delta_C, gg.P_hat, (H, W), out0=outs[j],
-                 P_hat_t=p_hat_t, table_flags=flags)
+        plans[i % nbuf].run()
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -218,6 +218,15 @@ def test_full_size_batch512_properties(cuda, oracle):
     sel = np.array([0, 1, 63, 64, 255, 256, 300, 511])
     ref = oracle.warp(x[sel], ctrl[sel], Kc["inv_delta_C"], Kc["P_hat"], (32, 100))["out0"]
     assert_biteq(ox[sel], ref, "batch-512 sample vs oracle")
+    # the pre-marshalled call bench.py times (ops.WarpPlan) is the same launch
+    out_p = torch.empty((N, 3, 32, 100), device=cuda)
+    plan = ops.WarpPlan(dev(x, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100), out_p, P_hat_t=P_hat_t,
+                        table_flags=ops.TABLE_MIRROR4)
+    plan.run()
+    plan.run()
+    assert_biteq(out_p, ox, "WarpPlan vs ops.warp")
+    with pytest.raises(ValueError):
+        ops.WarpPlan(dev(x, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100), out_p[:, :2])
 
 
 def test_mirror_symmetry_check_rejects_perturbed_table(oracle):

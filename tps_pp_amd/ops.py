@@ -182,6 +182,66 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
     return out0, out1, grid, idx
 
 
+class WarpPlan:
+    """A validated, pre-marshalled `tpspp_warp_fwd` call on fixed buffers: `ops.warp` checks its tensors and
+    marshals 25 arguments on every call (~12 us of Python, about one launch period of the classic geometry);
+    a caller that rectifies batch after batch into the same buffers (a serving loop, bench.py) builds the
+    plan once and pays one foreign call per batch.  The tensors are kept alive by the plan; the launch goes to
+    the stream that was current on `in0.device` when the plan was built, and that device must be the
+    thread's current device when `run()` is called (one process per GPU: always true)."""
+
+    def __init__(self, in0, ctrl, inv_delta_C, P_hat, out_hw, out0, P_xy=None, score=None, in1=None, out1=None,
+                 P_hat_t=None, table_flags=0):
+        import ctypes
+        in0, ctrl = _chk("in0", in0, 4), _chk("ctrl", ctrl, 3)
+        inv_delta_C, P_hat = _chk("inv_delta_C", inv_delta_C, 2), _chk("P_hat", P_hat, 2)
+        N, C0, H0, W0 = in0.shape
+        F = int(ctrl.shape[1])
+        Ho, Wo = int(out_hw[0]), int(out_hw[1])
+        n = Ho * Wo
+        if ctrl.shape[0] != N or ctrl.shape[2] != 2 or tuple(inv_delta_C.shape) != (F + 3, F + 3):
+            raise ValueError("WarpPlan: ctrl must be (N, F, 2), inv_delta_C (F+3, F+3)")
+        if P_xy is not None:
+            P_xy = _chk("P_xy", P_xy, 2)
+        if tuple(P_hat.shape) != (n, F if P_xy is not None else F + 3):
+            raise ValueError(f"WarpPlan: P_hat has shape {tuple(P_hat.shape)}")
+        if score is not None:
+            if tuple(score.shape) != (N, n, F):
+                raise ValueError("WarpPlan: score must be (N, n, F)")
+            if score.stride() == (F * n, 1, n) and n > 1 and F > 1:
+                table_flags = int(table_flags) | SCORE_TRANSPOSED
+                score = _chk("score", score.transpose(1, 2), 3)
+            else:
+                score = _chk("score", score, 3)
+        if P_hat_t is not None:
+            P_hat_t = _chk("P_hat_t", P_hat_t, 2)
+            if tuple(P_hat_t.shape) != (P_hat.shape[1], n):
+                raise ValueError("WarpPlan: P_hat_t must be P_hat transposed")
+        C1 = H1 = W1 = 0
+        if in1 is not None:
+            in1 = _chk("in1", in1, 4)
+            _, C1, H1, W1 = in1.shape
+            if in1.shape[0] != N or out1 is None or tuple(out1.shape) != (N, C1, Ho, Wo) or not out1.is_contiguous():
+                raise ValueError("WarpPlan: in1 needs a contiguous out1 (N, C1, Ho, Wo)")
+        if tuple(out0.shape) != (N, C0, Ho, Wo) or out0.dtype != torch.float32 or not out0.is_contiguous() \
+                or out0.device != in0.device:
+            raise ValueError("WarpPlan: out0 must be a contiguous float32 (N, C0, Ho, Wo) tensor on in0's device")
+        self._keep = (in0, in1, ctrl, score, inv_delta_C, P_hat, P_xy, P_hat_t, out0, out1)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        self._args = (vp(_ptr(in0)), ci(C0), ci(H0), ci(W0), vp(_ptr(in1)), ci(C1), ci(H1), ci(W1), vp(_ptr(ctrl)),
+                      vp(_ptr(score)), vp(_ptr(inv_delta_C)), vp(_ptr(P_hat)), ci(P_hat.shape[1]), vp(_ptr(P_xy)),
+                      vp(_ptr(P_hat_t)), ci(int(table_flags)), ci(N), ci(F), ci(Ho), ci(Wo), vp(_ptr(out0)),
+                      vp(_ptr(out1)), vp(0), vp(0), vp(_stream(in0)))
+        self._fn = _lib.lib().tpspp_warp_fwd
+        self.out0, self.out1 = out0, out1
+
+    def run(self):
+        rc = self._fn(*self._args)
+        if rc != 0:
+            _lib.check(rc, "tpspp_warp_fwd")
+        return self.out0, self.out1
+
+
 class ConvWeight:
     """Device-side weights of one fused convolution, prepared once: `wt` (K, Cout) for the generic
     kernel, `tiled` [chunk][tap][channel-in-chunk][Cout] for the tiled kernel, `bias` (Cout) | None."""
