@@ -94,6 +94,11 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
 #define TPSPP_SCORE_TRANSPOSED 2   /* table_flags bit: `score` is laid out (N, F, n) instead of the
                                       reference's (N, n, F): lanes that own consecutive pixels then read
                                       it coalesced.  Same values, same results. */
+#define TPSPP_IO_BF16 4            /* table_flags bit: in0 / in1 / out0 / out1 hold bfloat16 (the pointers are
+                                      reinterpreted; everything else stays fp32).  The bf16 configuration
+                                      (BASELINE.json configs[2]): T, grid and interpolation in fp32 exactly as
+                                      without the flag, one round-to-nearest-even at the store.  Shapes the
+                                      plane-streaming kernel takes only (TPS_PP geometry); else TPSPP_EINVAL. */
 
 /*
  * The fused hot path: T-solve -> grid -> bilinear warp of in0 (and in1 when non-NULL) in ONE kernel;
@@ -102,8 +107,8 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
  *   ctrl (N,F,2); score (N,Ho*Wo,F) or NULL; inv_delta_c (F+3,F+3); p_hat / p_hat_ld / p_xy as in
  *   tpspp_build_grid; p_hat_t_or_null = tpspp_transpose_p_hat(p_hat) (same values, enables the
  *   coalesced / LDS-staged fast kernels; NULL selects the generic kernel -- identical results);
- *   table_flags: OR of TPSPP_TABLE_MIRROR4 (only meaningful with p_hat_t) and
- *   TPSPP_SCORE_TRANSPOSED; neither changes results;
+ *   table_flags: OR of TPSPP_TABLE_MIRROR4 (only meaningful with p_hat_t), TPSPP_SCORE_TRANSPOSED
+ *   (neither changes results) and TPSPP_IO_BF16 (bf16 images in and out);
  *   grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
  * replaces: GridGenerator.build_P_prime + F.grid_sample   tps_preprocessor.py:71-83
  *           Attention_Enhanced_TPS.build_P_prime + 2x F.grid_sample   tps_pp.py:597-615

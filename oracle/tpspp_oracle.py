@@ -135,8 +135,9 @@ def tpspp_regress(sd, x, outs, variant="ResNet45v2", p_stride=2, bf16=False):
     """TPS_PP.forward up to the control points (tps_pp.py:572-594).  Returns
     (ctrl, score, feat_grid, intermediates).
     bf16=True: the build's bf16 configuration -- convolutions on bfloat16 operands with fp32 accumulation,
-    feature maps between convolutions stored as bfloat16, `feat_grid` / `en_feat` / `de_feat` and everything
-    after them (CBAM, DGAB, control points, score, TPS solve, grid, sampling) in fp32."""
+    feature maps between convolutions (and `feat_grid`, which the warp samples) stored as bfloat16, `en_feat` /
+    `de_feat` and everything after them (CBAM, DGAB, control points, score, TPS solve, grid, interpolation) in
+    fp32; the caller rounds the two warped outputs to bfloat16 (the module boundary is bf16)."""
     x, outs = _t(x), [_t(o) for o in outs]
     inter = {}
     q = rb if bf16 else (lambda v: v)
@@ -148,7 +149,7 @@ def tpspp_regress(sd, x, outs, variant="ResNet45v2", p_stride=2, bf16=False):
         feat_cat = torch.cat((q(cm(sd, "down0_1", feat0, stride=2, padding=1)),
                               q(cm(sd, "down1_1", feat1, stride=2, padding=1)), feat2), dim=1)
         up = F.interpolate(feat2, scale_factor=2, mode="nearest")
-        feat_grid = cm(sd, "down_feat", torch.cat((feat0, feat1, up), dim=1))   # :560-562
+        feat_grid = q(cm(sd, "down_feat", torch.cat((feat0, feat1, up), dim=1)))   # :560-562
     else:                                                         # 'ResNet45', :574-579
         feat0 = q(cm(sd, "down0", outs[0], stride=2, padding=1))
         feat1 = q(cm(sd, "down1", outs[1]))

@@ -93,6 +93,41 @@ def test_tpspp_warp_matches_reference_golden(cuda):
         ops.set_warp_tuning(0, 0, 0, 0)
 
 
+def test_tpspp_warp_bf16_io(cuda, oracle):
+    """TPSPP_IO_BF16: bf16 planes in and out, fp32 grid and interpolation.  On bf16-valued inputs the result
+    must be the oracle's fp32 result rounded once to bfloat16 (nearest even), bit for bit; the grid is the
+    fp32 one.  Odd batch, with and without the second input / score / transposed table."""
+    K = cases.load("constants")
+    G = cases.load("tpspp_warp")
+    inp = cases.g3_inputs()
+    P_xy = K["pp_P"].astype(np.float32)
+    P_hat = dev(K["pp_P_hat"], cuda)
+    rb = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)      # noqa: E731
+    fg, x = rb(inp["feat_grid"]), rb(inp["x"])
+    ref = oracle.warp(fg.float().numpy(), inp["ctrl"], K["pp_hat_C"], K["pp_P_hat"], cases.PP_HW, P_xy=P_xy,
+                      score=inp["score"], in1=x.float().numpy(), want_grid=True)
+    for P_hat_t in (None, ops.transpose_p_hat(P_hat)):
+        out0, out1, grid, _ = ops.warp(fg.to(cuda), dev(inp["ctrl"], cuda), dev(K["pp_hat_C"], cuda), P_hat,
+                                       cases.PP_HW, P_xy=dev(P_xy, cuda), score=dev(inp["score"], cuda),
+                                       in1=x.to(cuda), want_grid=True, P_hat_t=P_hat_t)
+        assert out0.dtype == torch.bfloat16 and out1.dtype == torch.bfloat16
+        assert_biteq(grid, G["grid"], "grid (fp32, as without the flag)")
+        assert torch.equal(out0.cpu(), torch.from_numpy(ref["out0"]).to(torch.bfloat16))
+        assert torch.equal(out1.cpu(), torch.from_numpy(ref["out1"]).to(torch.bfloat16))
+    # single input, no score, one image
+    ref1 = oracle.warp(x.float().numpy()[:1], inp["ctrl"][:1], K["pp_hat_C"], K["pp_P_hat"], cases.PP_HW, P_xy=P_xy)
+    o1 = ops.warp(x[:1].to(cuda), dev(inp["ctrl"][:1], cuda), dev(K["pp_hat_C"], cuda), P_hat, cases.PP_HW,
+                  P_xy=dev(P_xy, cuda))[0]
+    assert torch.equal(o1.cpu(), torch.from_numpy(ref1["out0"]).to(torch.bfloat16))
+    with pytest.raises(TypeError):
+        ops.warp(fg.to(cuda), dev(inp["ctrl"], cuda), dev(K["pp_hat_C"], cuda), P_hat, cases.PP_HW,
+                 P_xy=dev(P_xy, cuda), in1=dev(inp["x"], cuda))                   # mixed dtypes
+    from tps_pp_amd import _lib
+    with pytest.raises(_lib.TpsppError):                                          # classic 32x100: 3200 output pixels
+        ops.warp(torch.zeros((2, 3, 32, 100), device=cuda, dtype=torch.bfloat16), torch.zeros((2, 20, 2), device=cuda),
+                 torch.zeros((23, 23), device=cuda), torch.zeros((3200, 23), device=cuda), (32, 100))
+
+
 # ---------------------------------------------------------------- oracle on fresh inputs ---------
 @pytest.mark.parametrize("N,C,H,W,Ho,Wo,F,perturb", [
     (1, 1, 32, 100, 32, 100, 20, 0.05),     # the reference's own test shape (test_ocr_preprocessor.py:19-29)

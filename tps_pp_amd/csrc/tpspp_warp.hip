@@ -953,6 +953,22 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
     if (in1) TPSPP_REQUIRE(C1 > 0 && H1 > 0 && W1 > 0, "tpspp_warp_fwd: bad in1 sizes");
     if (N == 0) return TPSPP_OK;
     hipStream_t st = tpspp::as_stream(stream);
+    if (table_flags & TPSPP_IO_BF16) {
+        // bf16 images in and out (the bf16 configuration): plane-streaming kernel only
+        tpspp::StreamArgs A;
+        A.in0 = in0; A.C0 = C0; A.H0 = H0; A.W0 = W0;
+        A.in1 = in1; A.C1 = C1; A.H1 = H1; A.W1 = W1;
+        A.ctrl = ctrl; A.score = score; A.inv_delta_c = inv_delta_c;
+        A.score_t = (score && (table_flags & TPSPP_SCORE_TRANSPOSED)) ? 1 : 0;
+        A.io_bf16 = 1;
+        A.p_hat = p_hat; A.p_hat_ld = p_hat_ld; A.p_xy = p_xy; A.p_hat_t = p_hat_t;
+        A.N = N; A.F = F; A.Ho = Ho; A.Wo = Wo;
+        A.out0 = out0; A.out1 = out1; A.grid = grid_or_null; A.idx = idx_or_null;
+        if (!tpspp::stream_kernel_applicable(A))
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: TPSPP_IO_BF16 needs a shape the plane-streaming kernel "
+                               "takes (F = 20 or 32, <= 1024 output pixels, planes that fit the LDS ring)");
+        return tpspp::launch_stream_kernel(A, g_trace, st);
+    }
 
     // ---- LDS-staged kernel: single small input, classic layout, transposed table available ----
     {
@@ -1018,6 +1034,7 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
         A.in1 = in1; A.C1 = C1; A.H1 = H1; A.W1 = W1;
         A.ctrl = ctrl; A.score = score; A.inv_delta_c = inv_delta_c;
         A.score_t = (score && (table_flags & TPSPP_SCORE_TRANSPOSED)) ? 1 : 0;
+        A.io_bf16 = 0;
         A.p_hat = p_hat; A.p_hat_ld = p_hat_ld; A.p_xy = p_xy; A.p_hat_t = p_hat_t;
         A.N = N; A.F = F; A.Ho = Ho; A.Wo = Wo;
         A.out0 = out0; A.out1 = out1; A.grid = grid_or_null; A.idx = idx_or_null;

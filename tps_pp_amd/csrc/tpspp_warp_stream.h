@@ -13,6 +13,7 @@ struct StreamArgs {
     const float* p_hat; int p_hat_ld; const float* p_xy; const float* p_hat_t;
     int N, F, Ho, Wo;
     int score_t;               // 1: score is (N, F, n)
+    int io_bf16;               // 1: in0 / in1 / out0 / out1 are bf16 in memory (pointers reinterpreted)
     float* out0; float* out1; float* grid; int32_t* idx;
 };
 

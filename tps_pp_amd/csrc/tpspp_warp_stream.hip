@@ -23,6 +23,8 @@
 #include "tpspp_warp_dev.h"
 #include "tpspp_warp_stream.h"
 
+#include <type_traits>
+
 using namespace tpspp_dev;
 
 namespace {
@@ -30,7 +32,8 @@ namespace {
 constexpr int kComputeWaves = 8;
 constexpr int kLoaders = 4;
 constexpr int kRing = 3;
-constexpr int kCPS = 2;                                     // channels of each input per stage
+constexpr int kCPS32 = 2;                                   // channels of each input per stage (fp32 planes)
+constexpr int kCPS16 = 4;                                   // ... for bf16 planes (same bytes per stage)
 constexpr int kThreads = (kComputeWaves + kLoaders) * kWave;
 constexpr int kCT = kComputeWaves * kWave;                 // pixel stride between a thread's slots
 
@@ -78,13 +81,31 @@ __device__ __forceinline__ TapRegs to_regs(const Taps& t)
     return r;
 }
 
-__device__ __forceinline__ float lds_bilerp(const float* pl, const TapRegs& t)
+__device__ __forceinline__ float lds_elem(const float* pl, int o) { return pl[o]; }
+__device__ __forceinline__ float lds_elem(const unsigned short* pl, int o)
+{
+    return __builtin_bit_cast(float, (unsigned)pl[o] << 16);          // bf16 -> fp32, exact
+}
+
+__device__ __forceinline__ void store_elem(char* base, unsigned pix, float v, float*)
+{
+    *reinterpret_cast<float*>(base + 4u * pix) = v;
+}
+__device__ __forceinline__ void store_elem(char* base, unsigned pix, float v, unsigned short*)
+{
+    unsigned u = __builtin_bit_cast(unsigned, v);                       // round to nearest even
+    u += 0x7fffu + ((u >> 16) & 1u);
+    *reinterpret_cast<unsigned short*>(base + 2u * pix) = (unsigned short)(u >> 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float lds_bilerp(const T* pl, const TapRegs& t)
 {
     // the east neighbour is read unconditionally (slots end with slack) and masked afterwards
-    const float v00 = pl[t.o00];
-    float v01 = pl[t.o00 + 1];
-    float v10 = pl[t.o10];
-    float v11 = pl[t.o10 + 1];
+    const float v00 = lds_elem(pl, t.o00);
+    float v01 = lds_elem(pl, t.o00 + 1);
+    float v10 = lds_elem(pl, t.o10);
+    float v11 = lds_elem(pl, t.o10 + 1);
     v01 = t.inx ? v01 : 0.0f;
     v10 = t.iny ? v10 : 0.0f;
     v11 = (t.inx && t.iny) ? v11 : 0.0f;
@@ -95,11 +116,16 @@ __device__ __forceinline__ float lds_bilerp(const float* pl, const TapRegs& t)
     return acc;
 }
 
-// FCT: F at compile time (table row in registers); PPT: pixels per compute thread
-template <int FCT, bool PXY, bool SCORE, int PPT>
+// FCT: F at compile time (table row in registers); PPT: pixels per compute thread; B16: the inputs and
+// outputs are bf16 in memory (the bf16 configuration: half the bytes, interpolation still in fp32 with the
+// fp32 grid, one rounding at the store)
+template <int FCT, bool PXY, bool SCORE, int PPT, bool B16 = false>
 __global__ void __launch_bounds__(kThreads)
 tps_warp_stream_kernel(const StreamParams P)
 {
+    constexpr int kCPS = B16 ? kCPS16 : kCPS32;
+    constexpr int ES = B16 ? 2 : 4;                           // bytes per element of in0 / in1 / out0 / out1
+    using elem_t = typename std::conditional<B16, unsigned short, float>::type;
     constexpr int F = FCT;
     constexpr int K = F + 3;
     constexpr int KK = K * K;
@@ -122,8 +148,8 @@ tps_warp_stream_kernel(const StreamParams P)
         const int ld = wv - kComputeWaves;
         const char* base0 = reinterpret_cast<const char*>(P.in0);
         const char* base1 = reinterpret_cast<const char*>(P.in1);
-        const long long end0 = (long long)P.N * P.C0 * HW0 * 4;
-        const long long end1 = (long long)P.N * P.C1 * HW1 * 4;
+        const long long end0 = (long long)P.N * P.C0 * HW0 * ES;
+        const long long end1 = (long long)P.N * P.C1 * HW1 * ES;
         const int per_ch = P.pieces0 + P.pieces1;           // slot layout: [in0 c | in1 c] x kCPS
         const int total = per_ch * kCPS;
         auto issue_stage = [&](int s) {
@@ -139,7 +165,7 @@ tps_warp_stream_kernel(const StreamParams P)
                 const int HW = second ? HW1 : HW0;
                 const int ch = s * kCPS + sub;
                 const int c = ch < C ? ch : C - 1;         // an exhausted input re-reads its last plane
-                long long off = ((long long)b * C + c) * HW * 4 + (long long)pp * 1024 + lane * 16;
+                long long off = ((long long)b * C + c) * HW * ES + (long long)pp * 1024 + lane * 16;
                 const long long end = second ? end1 : end0;
                 if (off + 16 > end) off = end - 16;        // tail of the tensor: stay inside it
                 const char* src = (second ? base1 : base0) + off;
@@ -307,9 +333,9 @@ tps_warp_stream_kernel(const StreamParams P)
 
     // ---- stream the channel planes ----
     const int off1 = P.pieces0 * 1024;                            // in1's plane inside a slot
-    char* o0 = reinterpret_cast<char*>(P.out0 + (size_t)b * P.C0 * P.n);
-    char* o1 = reinterpret_cast<char*>(P.out1 ? P.out1 + (size_t)b * P.C1 * P.n : nullptr);
-    const size_t row_bytes = (size_t)P.n * 4;
+    char* o0 = reinterpret_cast<char*>(P.out0) + (size_t)b * P.C0 * P.n * ES;
+    char* o1 = P.out1 ? reinterpret_cast<char*>(P.out1) + (size_t)b * P.C1 * P.n * ES : nullptr;
+    const size_t row_bytes = (size_t)P.n * ES;
     const int ch_bytes = (P.pieces0 + P.pieces1) * 1024;
     for (int s = 0; s < stages; ++s) {
         lds_only_barrier();                                       // A(s)
@@ -317,20 +343,20 @@ tps_warp_stream_kernel(const StreamParams P)
 #pragma unroll
         for (int sub = 0; sub < kCPS; ++sub) {
             const int ch = s * kCPS + sub;
-            const float* pl0 = reinterpret_cast<const float*>(slot + sub * ch_bytes);
-            const float* pl1 = reinterpret_cast<const float*>(slot + sub * ch_bytes + off1);
+            const elem_t* pl0 = reinterpret_cast<const elem_t*>(slot + sub * ch_bytes);
+            const elem_t* pl1 = reinterpret_cast<const elem_t*>(slot + sub * ch_bytes + off1);
             if (ch < P.C0) {
 #pragma unroll
                 for (int j = 0; j < PPT; ++j) {
                     const float r = lds_bilerp(pl0, t0[j]);
-                    if (live[j]) *reinterpret_cast<float*>(o0 + ch * row_bytes + 4u * (unsigned)pix[j]) = r;
+                    if (live[j]) store_elem(o0 + ch * row_bytes, (unsigned)pix[j], r, (elem_t*)nullptr);
                 }
             }
             if (P.in1 && ch < P.C1) {
 #pragma unroll
                 for (int j = 0; j < PPT; ++j) {
                     const float r = lds_bilerp(pl1, t1[j]);
-                    if (live[j]) *reinterpret_cast<float*>(o1 + ch * row_bytes + 4u * (unsigned)pix[j]) = r;
+                    if (live[j]) store_elem(o1 + ch * row_bytes, (unsigned)pix[j], r, (elem_t*)nullptr);
                 }
             }
         }
@@ -341,7 +367,7 @@ tps_warp_stream_kernel(const StreamParams P)
     }
 }
 
-template <int F, bool PXY, bool SCORE>
+template <int F, bool PXY, bool SCORE, bool B16>
 void launch_ppt(const StreamParams& P, int ppt, size_t lds, hipStream_t st)
 {
     const dim3 grid((unsigned)P.N), block(kThreads);
@@ -350,26 +376,26 @@ void launch_ppt(const StreamParams& P, int ppt, size_t lds, hipStream_t st)
         static bool attr_done = false;                                                              \
         if (!attr_done) {                                                                           \
             (void)hipFuncSetAttribute(                                                              \
-                reinterpret_cast<const void*>(&tps_warp_stream_kernel<F, PXY, SCORE, PP>),          \
+                reinterpret_cast<const void*>(&tps_warp_stream_kernel<F, PXY, SCORE, PP, B16>),          \
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
             (void)hipGetLastError();                                                                \
             attr_done = true;                                                                       \
         }                                                                                           \
-        hipLaunchKernelGGL((tps_warp_stream_kernel<F, PXY, SCORE, PP>), grid, block, lds, st, P);   \
+        hipLaunchKernelGGL((tps_warp_stream_kernel<F, PXY, SCORE, PP, B16>), grid, block, lds, st, P);   \
     }
     if (ppt == 1) TPSPP_LAUNCH(1)
     else TPSPP_LAUNCH(2)
 #undef TPSPP_LAUNCH
 }
 
-template <int F>
+template <int F, bool B16>
 void launch_f(const StreamParams& P, int ppt, size_t lds, hipStream_t st)
 {
     const bool pxy = P.p_xy != nullptr, sc = P.score != nullptr;
-    if (pxy && sc)       launch_ppt<F, true, true>(P, ppt, lds, st);
-    else if (pxy && !sc) launch_ppt<F, true, false>(P, ppt, lds, st);
-    else if (!pxy && sc) launch_ppt<F, false, true>(P, ppt, lds, st);
-    else                 launch_ppt<F, false, false>(P, ppt, lds, st);
+    if (pxy && sc)       launch_ppt<F, true, true, B16>(P, ppt, lds, st);
+    else if (pxy && !sc) launch_ppt<F, true, false, B16>(P, ppt, lds, st);
+    else if (!pxy && sc) launch_ppt<F, false, true, B16>(P, ppt, lds, st);
+    else                 launch_ppt<F, false, false, B16>(P, ppt, lds, st);
 }
 
 }  // namespace
@@ -383,12 +409,13 @@ bool stream_kernel_applicable(const StreamArgs& a)
     const int ppt = (n + kCT - 1) / kCT;
     if (ppt < 1 || ppt > 2) return false;      // 3 pixels per thread spills (168-VGPR budget)
     if (reinterpret_cast<uintptr_t>(a.in0) % 16 || (a.in1 && reinterpret_cast<uintptr_t>(a.in1) % 16)) return false;
-    if ((a.H0 * a.W0) % 4 || (a.in1 && (a.H1 * a.W1) % 4)) return false;        // 16-B DMA granules
-    if ((long long)a.N * a.C0 * a.H0 * a.W0 * 4 < 1024) return false;
-    if (a.in1 && (long long)a.N * a.C1 * a.H1 * a.W1 * 4 < 1024) return false;
-    const int p0 = (a.H0 * a.W0 * 4 + 1023) / 1024;
-    const int p1 = a.in1 ? (a.H1 * a.W1 * 4 + 1023) / 1024 : 0;
-    const int per_loader = ((p0 + p1) * kCPS + kLoaders - 1) / kLoaders;
+    const int es = a.io_bf16 ? 2 : 4, cps = a.io_bf16 ? kCPS16 : kCPS32;
+    if ((a.H0 * a.W0 * es) % 16 || (a.in1 && (a.H1 * a.W1 * es) % 16)) return false;   // 16-B DMA granules
+    if ((long long)a.N * a.C0 * a.H0 * a.W0 * es < 1024) return false;
+    if (a.in1 && (long long)a.N * a.C1 * a.H1 * a.W1 * es < 1024) return false;
+    const int p0 = (a.H0 * a.W0 * es + 1023) / 1024;
+    const int p1 = a.in1 ? (a.H1 * a.W1 * es + 1023) / 1024 : 0;
+    const int per_loader = ((p0 + p1) * cps + kLoaders - 1) / kLoaders;
     if (per_loader * (kRing - 2) > 32) return false;                            // counted vmcnt range
     const int K = a.F + 3;
     const size_t slot = (size_t)per_loader * kLoaders * 1024 + 16;
@@ -405,16 +432,22 @@ int launch_stream_kernel(const StreamArgs& a, long long* trace, hipStream_t st)
     P.p_hat = a.p_hat; P.p_hat_ld = a.p_hat_ld; P.p_xy = a.p_xy; P.p_hat_t = a.p_hat_t;
     P.N = a.N; P.n = a.Ho * a.Wo; P.score_t = a.score_t;
     P.out0 = a.out0; P.out1 = a.out1; P.grid = a.grid; P.idx = a.idx;
-    P.pieces0 = (a.H0 * a.W0 * 4 + 1023) / 1024;
-    P.pieces1 = a.in1 ? (a.H1 * a.W1 * 4 + 1023) / 1024 : 0;
-    P.per_loader = ((P.pieces0 + P.pieces1) * kCPS + kLoaders - 1) / kLoaders;
+    const int es = a.io_bf16 ? 2 : 4, cps = a.io_bf16 ? kCPS16 : kCPS32;
+    P.pieces0 = (a.H0 * a.W0 * es + 1023) / 1024;
+    P.pieces1 = a.in1 ? (a.H1 * a.W1 * es + 1023) / 1024 : 0;
+    P.per_loader = ((P.pieces0 + P.pieces1) * cps + kLoaders - 1) / kLoaders;
     P.slot_bytes = P.per_loader * kLoaders * 1024 + 16;
     P.trace = trace;
     const int K = a.F + 3;
     const size_t lds = (size_t)(((2 * K + 3) & ~3) + ((K * K + 3) & ~3)) * 4 + (size_t)kRing * P.slot_bytes;
     const int ppt = (P.n + kCT - 1) / kCT;
-    if (a.F == 20) launch_f<20>(P, ppt, lds, st);
-    else           launch_f<32>(P, ppt, lds, st);
+    if (a.io_bf16) {
+        if (a.F == 20) launch_f<20, true>(P, ppt, lds, st);
+        else           launch_f<32, true>(P, ppt, lds, st);
+    } else {
+        if (a.F == 20) launch_f<20, false>(P, ppt, lds, st);
+        else           launch_f<32, false>(P, ppt, lds, st);
+    }
     return check_launch("tpspp_warp_fwd(stream)");
 }
 

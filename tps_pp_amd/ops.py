@@ -106,6 +106,7 @@ def transpose_p_hat(P_hat):
 
 TABLE_MIRROR4 = 1
 SCORE_TRANSPOSED = 2
+IO_BF16 = 4              # TPSPP_IO_BF16: in0 / in1 / out0 / out1 are bfloat16
 
 
 def table_mirror_symmetry(P_hat_host, out_hw, F):
@@ -129,7 +130,16 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
     TPS_PP :  in0 = feat_grid, in1 = x, P_hat (n, F) + P_xy (n, 2) + score (N, n, F)
                                                                      (tps_pp.py:597-615)
     """
-    in0, ctrl = _chk("in0", in0, 4), _chk("ctrl", ctrl, 3)
+    io16 = isinstance(in0, torch.Tensor) and in0.dtype == torch.bfloat16
+    if io16:          # bf16 images in and out (TPSPP_IO_BF16): T, grid and interpolation stay fp32
+        if in1 is not None and in1.dtype != torch.bfloat16:
+            raise TypeError("warp: in0 and in1 must share their dtype")
+        in0 = _chk16("in0", in0, 4)
+        table_flags = int(table_flags) | IO_BF16
+    else:
+        in0 = _chk("in0", in0, 4)
+    io_dtype = torch.bfloat16 if io16 else torch.float32
+    ctrl = _chk("ctrl", ctrl, 3)
     inv_delta_C, P_hat = _chk("inv_delta_C", inv_delta_C, 2), _chk("P_hat", P_hat, 2)
     N, C0, H0, W0 = in0.shape
     F = int(ctrl.shape[1])
@@ -161,15 +171,18 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
             raise ValueError("warp: P_hat_t must be P_hat transposed")
     C1 = H1 = W1 = 0
     if in1 is not None:
-        in1 = _chk("in1", in1, 4)
+        in1 = _chk16("in1", in1, 4) if io16 else _chk("in1", in1, 4)
         if in1.shape[0] != N:
             raise ValueError("warp: in1 batch mismatch")
         _, C1, H1, W1 = in1.shape
     dev = in0.device
     if out0 is None:
-        out0 = torch.empty((N, C0, Ho, Wo), device=dev, dtype=torch.float32)
+        out0 = torch.empty((N, C0, Ho, Wo), device=dev, dtype=io_dtype)
     if in1 is not None and out1 is None:
-        out1 = torch.empty((N, C1, Ho, Wo), device=dev, dtype=torch.float32)
+        out1 = torch.empty((N, C1, Ho, Wo), device=dev, dtype=io_dtype)
+    for o in (out0, out1):
+        if o is not None and (o.dtype != io_dtype or not o.is_contiguous()):
+            raise TypeError("warp: out0 / out1 must be contiguous and of the inputs' dtype")
     grid = torch.empty((N, n, 2), device=dev, dtype=torch.float32) if want_grid else None
     idx = torch.empty((N, n, 2), device=dev, dtype=torch.int32) if want_idx else None
     with torch.cuda.device(dev):

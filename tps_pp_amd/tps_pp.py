@@ -401,11 +401,14 @@ class TPS_PP(nn.Module):
             feat0 = c16([o0], cw["down0"], 1)
             feat1 = c16([o1], cw["down1"], 1)
             feat2 = c16([x], cw["down2"], 1)
-            feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1, out_dtype=f32)
+            # (sampled by the warp: bf16 when the module boundary is bf16 -- the warp then moves half the
+            #  bytes and rounds once at its store --, fp32 when the caller's tensors are fp32)
+            feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1,
+                            out_dtype=bf if x.dtype == bf else f32)
             cat_srcs = [c16([feat0], cw["down0_1"], 2), c16([feat1], cw["down1_1"], 2), feat2]
         else:
             cat_srcs = [c16([o0], cw["down0"], 2), c16([o1], cw["down1"], 1), c16([x], cw["down2"], 1)]
-            feat_grid = x.float()
+            feat_grid = x
         p = self.MSFA.conv.stride
         e0 = c16(cat_srcs, cw["enc0"], 1)
         e1 = c16([e0], cw["enc1"], 2)
@@ -539,10 +542,12 @@ class TPS_PP(nn.Module):
             return self._forward_autograd(batch_img, outs)
         control_point, atten_score, feat_grid = self.regress(batch_img, outs)
         # (the score stays the transposed view of its (N, F, n) buffer: ops.warp reads it in place)
-        output, mp_img = self.rectify(feat_grid.float(), batch_img.float(), control_point.float(),
-                                      atten_score.float())
-        if batch_img.dtype == torch.bfloat16:          # bf16 module boundary
-            output, mp_img = output.to(torch.bfloat16), mp_img.to(torch.bfloat16)
+        if batch_img.dtype == torch.bfloat16:
+            # bf16 module boundary: the warp reads and writes bf16 planes
+            output, mp_img = self.rectify(feat_grid, batch_img, control_point.float(), atten_score.float())
+        else:
+            output, mp_img = self.rectify(feat_grid.float(), batch_img.float(), control_point.float(),
+                                          atten_score.float())
         return {"output": output, "logits": None, "mp_img": mp_img, "pc_score": atten_score}
 
 
