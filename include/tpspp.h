@@ -253,6 +253,22 @@ int tpspp_global_avgpool_fwd(const float* in, int N, int C, int H, int W, float*
 int tpspp_conv_chunk_channels(int kernel_size);
 
 /*
+ * tpspp_front_fwd on the bf16 matrix cores (the bf16 configuration): inputs and feat0 / feat1 / feat2 are bf16,
+ * feat_grid bf16 or fp32 (feat_grid_f32); accumulation, bias and ReLU in fp32; feat_grid is computed from the
+ * bf16-rounded feat0 / feat1 / feat2 (what the separate convolutions would read back).
+ *   w0 / w1  [2 k-steps][2 halves][64 cout][8] bf16 with value W[cout][16 j + 8 h + e];  w2 the same with 4 k-steps;
+ *   wg       [12][2][64][8] with value Wg[cout][16 j + perm[8 h + e]], perm = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15}
+ *            (the order in which the matrix core's result registers come back as the next operand);
+ *   b0 / b1 / b2 / bg (64) fp32.  Needs H even and W a multiple of 32.
+ * replaces: backbones/tps_pp/tps_pp.py:560-562,581-585
+ */
+int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
+                         const void* w0, const float* b0, const void* w1, const float* b1,
+                         const void* w2, const float* b2, const void* wg, const float* bg,
+                         void* feat0, void* feat1, void* feat2, void* feat_grid, int feat_grid_f32,
+                         int N, int H, int W, tpspp_stream_t stream);
+
+/*
  * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32
  * accumulation; bias / residual / activation / affine in fp32) for the bf16 configurations
  * (BASELINE.json configs[2], configs[4]).  Every tensor is NCHW and independently bf16 or fp32 in memory.

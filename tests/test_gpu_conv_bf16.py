@@ -106,3 +106,40 @@ def test_conv_bf16_argument_errors(cuda):
         ops.conv2d_bf16([torch.zeros((1, 32, 8, 8))], cw)                       # CPU tensor
     with pytest.raises(_lib.TpsppError):
         ops.conv2d_bf16([torch.zeros((1, 32, 8, 8), device=cuda)], cw, stride=(1, 2))   # no such kernel
+
+
+@pytest.mark.parametrize("fg_dtype", ["bf16", "f32"])
+def test_front_bf16_fused_against_cpu_reference(cuda, fg_dtype):
+    """tpspp_front_bf16_fwd (down0 / down1 / down2 / cat + Upsample + down_feat in one register-chained kernel)
+    against PyTorch-CPU on bf16-rounded operands, feat_grid computed from the rounded feat0 / feat1 / feat2; odd
+    batch, a width of three 32-pixel segments (partial last workgroup)."""
+    from tps_pp_amd import TPS_PP
+    import cases
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N, H, W = 3, 6, 96
+    o0 = rb(t(synth.dyadic((N, 32, H, W), "fb.o0", 1)))
+    o1 = rb(t(synth.dyadic((N, 32, H, W), "fb.o1", 1)))
+    x = rb(t(synth.dyadic((N, 64, H // 2, W // 2), "fb.x", 1)))
+
+    def cm(mod, v):
+        return F.relu(F.conv2d(v.double(), rb(mod.conv.weight.detach()).double(), mod.conv.bias.detach().double())).float()
+    f0, f1, f2 = cm(m.down0, o0), cm(m.down1, o1), cm(m.down2, x)
+    up = F.interpolate(rb(f2), scale_factor=2, mode="nearest")
+    fg = cm(m.down_feat, torch.cat((rb(f0), rb(f1), up), 1))
+    m.to(cuda)
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}[fg_dtype]
+    fw = ops.FrontWeightsBf16(m)
+    g0, g1, g2, gg = ops.front_bf16(o0.to(cuda).bfloat16(), o1.to(cuda).bfloat16(), x.to(cuda).bfloat16(), fw, dt)
+    assert gg.dtype == dt and g0.dtype == torch.bfloat16
+    for got, ref, name in ((g0, f0, "feat0"), (g1, f1, "feat1"), (g2, f2, "feat2")):
+        got = got.float().cpu()
+        err = (got - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-6).all()), (name, float(err.max()))
+        assert float((got == rb(ref)).float().mean()) > 0.98, name
+    # feat_grid sees the occasional one-ulp flip of its inputs
+    got = gg.float().cpu()
+    scale = float(fg.abs().max())
+    assert float((got - fg).abs().max()) <= 2.0 ** -7 * scale
+    assert float((got - fg).abs().mean()) <= (2e-3 if fg_dtype == "bf16" else 2e-4) * scale

@@ -398,13 +398,22 @@ class TPS_PP(nn.Module):
         c16 = ops.conv2d_bf16
         x, o0, o1 = batch_img, outs[0], outs[1]
         if self.type == "ResNet45v2":
-            feat0 = c16([o0], cw["down0"], 1)
-            feat1 = c16([o1], cw["down1"], 1)
-            feat2 = c16([x], cw["down2"], 1)
-            # (sampled by the warp: bf16 when the module boundary is bf16 -- the warp then moves half the
-            #  bytes and rounds once at its store --, fp32 when the caller's tensors are fp32)
-            feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1,
-                            out_dtype=bf if x.dtype == bf else f32)
+            # feat_grid is sampled by the warp: bf16 when the module boundary is bf16 (the warp then moves half
+            # the bytes and rounds once at its store), fp32 when the caller's tensors are fp32
+            fg_dtype = bf if x.dtype == bf else f32
+            if ops.front_bf16_applicable(o0, o1, x):
+                # the four pointwise convolutions fused, register-chained (tpspp_front_bf16.hip)
+                fkey = tuple((t.data_ptr(), t._version) for mdl in (self.down0, self.down1, self.down2, self.down_feat)
+                             for t in mdl.parameters())
+                fc = getattr(self, "_front16_cache", None)
+                if fc is None or fc[0] != fkey:
+                    self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self))
+                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype)
+            else:
+                feat0 = c16([o0], cw["down0"], 1)
+                feat1 = c16([o1], cw["down1"], 1)
+                feat2 = c16([x], cw["down2"], 1)
+                feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1, out_dtype=fg_dtype)
             cat_srcs = [c16([feat0], cw["down0_1"], 2), c16([feat1], cw["down1_1"], 2), feat2]
         else:
             cat_srcs = [c16([o0], cw["down0"], 2), c16([o1], cw["down1"], 1), c16([x], cw["down2"], 1)]
