@@ -70,6 +70,16 @@ __device__ __forceinline__ unsigned f32_to_bf16_bits(float f)
     return u >> 16;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// v_cvt_pk_bf16_f32: two fp32 -> packed bf16, round to nearest even
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi)
+{
+    f32x2 v; v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h)
 {
     return __builtin_bit_cast(float, (unsigned)h << 16);
@@ -164,35 +174,36 @@ conv_tiled_bf16_kernel(const BParams P)
         const int plane = cur.H * cur.W;
         const int cleft = min(KC, cur.C - (c0 - cbase));           // channels of this chunk that exist
         const size_t img_stride = (size_t)cur.C * plane;
-        const size_t chan0 = (size_t)n0 * img_stride + (size_t)(c0 - cbase) * plane;
+        const size_t chan0 = (size_t)n0 * img_stride + (size_t)(c0 - cbase) * plane;   // uniform
         // every load is unconditional (a predicate per load would put each one in its own basic block and
         // serialise them behind s_waitcnt): channels beyond the source's last one re-read that last channel
-        // and are zeroed by a select, padding positions read the chunk's first element
+        // and are zeroed by a select, padding positions read the chunk's first element.  Addresses are
+        // wave-uniform channel base + one 32-bit lane offset per position (no 64-bit vector arithmetic).
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
             const bool ok = piy[i] >= 0;
-            const size_t off = ok ? chan0 + pim[i] * img_stride + (size_t)(piy[i] >> cur.lh) * cur.W + (pix[i] >> cur.lw) : chan0;
+            const unsigned lo = ok ? (unsigned)(pim[i] * (int)img_stride + (piy[i] >> cur.lh) * cur.W + (pix[i] >> cur.lw)) : 0u;
             if (cur.f32) {
-                const float* sp = reinterpret_cast<const float*>(cur.p) + off;
+                const float* sp = reinterpret_cast<const float*>(cur.p) + chan0;
                 float v[KC];
 #pragma unroll
-                for (int c = 0; c < KC; ++c) v[c] = sp[(size_t)min(c, cleft - 1) * plane];
+                for (int c = 0; c < KC; ++c) v[c] = (sp + (size_t)min(c, cleft - 1) * plane)[lo];
 #pragma unroll
                 for (int c2 = 0; c2 < KC / 2; ++c2) {
-                    const unsigned lo = (2 * c2 < cleft) ? f32_to_bf16_bits(v[2 * c2]) : 0u;
-                    const unsigned hi = (2 * c2 + 1 < cleft) ? f32_to_bf16_bits(v[2 * c2 + 1]) : 0u;
-                    rp[i][c2] = ok ? (lo | (hi << 16)) : 0u;
+                    const unsigned pk = pack2_bf16(v[2 * c2], v[2 * c2 + 1]);
+                    const unsigned m = (2 * c2 + 1 < cleft) ? 0xffffffffu : ((2 * c2 < cleft) ? 0x0000ffffu : 0u);
+                    rp[i][c2] = ok ? (pk & m) : 0u;
                 }
             } else {
-                const unsigned short* sp = reinterpret_cast<const unsigned short*>(cur.p) + off;
+                const unsigned short* sp = reinterpret_cast<const unsigned short*>(cur.p) + chan0;
                 unsigned short v[KC];
 #pragma unroll
-                for (int c = 0; c < KC; ++c) v[c] = sp[(size_t)min(c, cleft - 1) * plane];
+                for (int c = 0; c < KC; ++c) v[c] = (sp + (size_t)min(c, cleft - 1) * plane)[lo];
 #pragma unroll
                 for (int c2 = 0; c2 < KC / 2; ++c2) {
-                    const unsigned lo = (2 * c2 < cleft) ? (unsigned)v[2 * c2] : 0u;
-                    const unsigned hi = (2 * c2 + 1 < cleft) ? (unsigned)v[2 * c2 + 1] : 0u;
-                    rp[i][c2] = ok ? (lo | (hi << 16)) : 0u;
+                    const unsigned lo16 = (2 * c2 < cleft) ? (unsigned)v[2 * c2] : 0u;
+                    const unsigned hi16 = (2 * c2 + 1 < cleft) ? (unsigned)v[2 * c2 + 1] : 0u;
+                    rp[i][c2] = ok ? (lo16 | (hi16 << 16)) : 0u;
                 }
             }
         }
