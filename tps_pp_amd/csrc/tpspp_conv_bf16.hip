@@ -258,31 +258,69 @@ conv_tiled_bf16_kernel(const BParams P)
     }
 
     // ---- epilogue: bias, residual, ReLU, affine; half-wavefronts store rows of 32 consecutive pixels ----
+    // For a 1x1 layer with 32 input channels the epilogue IS the kernel (8 MFMAs against 64 outputs per lane),
+    // so it is kept off the vector ALU: addresses are a wave-uniform base (image group, channel tile, channel:
+    // scalar arithmetic) plus ONE 32-bit lane offset per fragment, the bias arrives as eight float4 per lane,
+    // bf16 pairs are rounded by v_cvt_pk_bf16_f32 and stored from the two halves of one register.
+    const bool full_c = co_base + BN <= P.Cout;                  // uniform
+    float bq[2][4][4];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = co_base + 32 * h2 + 8 * g + 4 * half;
+            if (P.bias && full_c) {
+                const float4 b4 = *reinterpret_cast<const float4*>(P.bias + co);
+                bq[h2][g][0] = b4.x; bq[h2][g][1] = b4.y; bq[h2][g][2] = b4.z; bq[h2][g][3] = b4.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[h2][g][e] = (P.bias && co + e < P.Cout) ? P.bias[co + e] : 0.0f;
+            }
+        }
+    const size_t ubase = ((size_t)n0 * P.Cout + co_base) * HoWo;  // uniform: first image / channel of the tile
+    const bool simple = P.res_mode == 0 && P.post_scale == nullptr;
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
-        if (oy < P.Ho && ox < P.Wo && n < P.N) {
-            const int pixel = oy * P.Wo + ox;
+        const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
+        const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
+        for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co_base + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < P.Cout) {
-                        float v = acc[f][h2][r];
-                        if (P.bias) v = v + P.bias[co];
-                        const size_t o = ((size_t)n * P.Cout + co) * HoWo + pixel;
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+                const int cu = 32 * h2 + 8 * g;                   // + 4*half (in `lo`) + e
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[f][h2][4 * g + e] + bq[h2][g][e];
+                    if (!simple) {
+                        const size_t o = ubase + (size_t)(cu + e) * HoWo + lo;
+                        const int co = co_base + cu + 4 * half + e;
                         float rv = 0.0f;
-                        if (P.res_mode)
+                        if (P.res_mode && valid && co < P.Cout)
                             rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
                                            : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
-                        if (P.res_mode == 2) v = v + rv;
-                        if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
-                        if (P.res_mode == 1) v = v + rv;
-                        if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
-                        if (P.out_f32) reinterpret_cast<float*>(P.out)[o] = v;
-                        else reinterpret_cast<unsigned short*>(P.out)[o] = (unsigned short)f32_to_bf16_bits(v);
+                        if (P.res_mode == 2) v[e] = v[e] + rv;
+                        if (P.relu == 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                        if (P.res_mode == 1) v[e] = v[e] + rv;
+                        if (P.post_scale && co < P.Cout) v[e] = v[e] * P.post_scale[co] + P.post_shift[co];
+                    } else if (P.relu == 1) {
+                        v[e] = v[e] > 0.0f ? v[e] : 0.0f;
                     }
+                }
+                const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
+                if (P.out_f32) {
+                    float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (valid && (full_c || co4 + e < P.Cout)) (ob + (size_t)e * HoWo)[lo] = v[e];
+                } else {
+                    unsigned short* ob = reinterpret_cast<unsigned short*>(P.out) + ubase + (size_t)cu * HoWo;
+                    const unsigned p01 = pack2_bf16(v[0], v[1]), p23 = pack2_bf16(v[2], v[3]);
+                    if (valid && (full_c || co4 < P.Cout)) ob[lo] = (unsigned short)(p01 & 0xffffu);
+                    if (valid && (full_c || co4 + 1 < P.Cout)) (ob + (size_t)HoWo)[lo] = (unsigned short)(p01 >> 16);
+                    if (valid && (full_c || co4 + 2 < P.Cout)) (ob + (size_t)2 * HoWo)[lo] = (unsigned short)(p23 & 0xffffu);
+                    if (valid && (full_c || co4 + 3 < P.Cout)) (ob + (size_t)3 * HoWo)[lo] = (unsigned short)(p23 >> 16);
                 }
             }
         }
