@@ -194,6 +194,23 @@ int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const flo
                    tpspp_stream_t stream);
 
 /*
+ * tpspp_dgab_fwd with the three Linear layers of the chain on the bf16 matrix cores (the bf16 configuration):
+ * x, LayerNorms, gates, softmaxes, GELU and both residual sums in fp32; the gated map, the normalised x1 and the
+ * GELU output are rounded to bf16 once each as matrix operands; erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7).
+ *   proj_slab [4 k-steps][2][64 out][8] bf16 = Wp[out][16 j + 8 h + e];
+ *   fc1_slab  [4 blocks][4][2][64][8] = W1[64 b + m][16 j + perm[8 h + e]];
+ *   fc2_slab  [4 blocks][4][2][64][8] = W2[m][64 b + 16 j + perm[8 h + e]];  perm as in tpspp_front_bf16_fwd;
+ *   scratch   (N,C,16,64) bf16;  everything else as tpspp_dgab_fwd.
+ * replaces: backbones/tps_pp/DGAB.py:25-77
+ */
+int tpspp_dgab_bf16_fwd(const float* x, const float* y, const float* ln1_w, const float* ln1_b,
+                        const float* mlp_w_t, const float* mlp_h_t, const void* proj_slab,
+                        const float* proj_b, const float* ln2_w, const float* ln2_b,
+                        const void* fc1_slab, const float* fc1_b, const void* fc2_slab,
+                        const float* fc2_b, void* scratch, float* out, int N, int C,
+                        tpspp_stream_t stream);
+
+/*
  * The pointwise front of TPS_PP (ResNet45v2 wiring) fused: feat0 = relu(W0 outs0 + b0),
  * feat1 = relu(W1 outs1 + b1) at (H, W); feat2 = relu(W2 x + b2) at (H/2, W/2);
  * feat_grid = relu(Wg cat(feat0, feat1, Upsample2(feat2)) + bg).

@@ -90,9 +90,12 @@ def msfa(sd, feat_cat, p_stride=2, bf16=False):
     return point, k, inter
 
 
-def dgab(sd, prefix, x, y):
+def dgab(sd, prefix, x, y, bf16=False):
     """DGAB.forward (backbones/tps_pp/DGAB.py:74-77) with DGAB_Block.forward (:39-55) and Mlp
-    (:17-23).  LayerNorm is over the trailing (H, W); proj / fc1 / fc2 act along W."""
+    (:17-23).  LayerNorm is over the trailing (H, W); proj / fc1 / fc2 act along W.
+    bf16: the operands of proj / fc1 / fc2 (gated map, normalised x1, GELU output; weights) rounded to bfloat16,
+    everything else fp32 -- the build's bf16 configuration."""
+    q = rb if bf16 else (lambda v: v)
     hw = tuple(x.shape[-2:])
     xn = F.layer_norm(x, hw, sd[prefix + ".norm1.weight"], sd[prefix + ".norm1.bias"])
     yt = y.transpose(1, 2)
@@ -102,21 +105,21 @@ def dgab(sd, prefix, x, y):
     v_h = h[:, :, :-1].softmax(dim=-1).unsqueeze(3)
     a = v_h * xn * h[:, :, -1].unsqueeze(-1).unsqueeze(-1) + \
         v_w * xn * w[:, :, -1].unsqueeze(-1).unsqueeze(-1)
-    a = F.linear(a, sd[prefix + ".attn.proj.weight"], sd[prefix + ".attn.proj.bias"])
+    a = F.linear(q(a), q(sd[prefix + ".attn.proj.weight"]), sd[prefix + ".attn.proj.bias"])
     x = x + a
     xn2 = F.layer_norm(x, hw, sd[prefix + ".norm2.weight"], sd[prefix + ".norm2.bias"])
-    m = F.linear(xn2, sd[prefix + ".mlp.fc1.weight"], sd[prefix + ".mlp.fc1.bias"])
+    m = F.linear(q(xn2), q(sd[prefix + ".mlp.fc1.weight"]), sd[prefix + ".mlp.fc1.bias"])
     m = F.gelu(m)
-    m = F.linear(m, sd[prefix + ".mlp.fc2.weight"], sd[prefix + ".mlp.fc2.bias"])
+    m = F.linear(q(m), q(sd[prefix + ".mlp.fc2.weight"]), sd[prefix + ".mlp.fc2.bias"])
     return x + m
 
 
-def tpe(sd, en_feat, de_feat, scale=64 ** -0.5):
+def tpe(sd, en_feat, de_feat, scale=64 ** -0.5, bf16=False):
     """Transformation_Parameter_Estimation.forward (tps_pp.py:315-325), get_score / atten_score
     (:293-312): control points and tanh attention score."""
     n = en_feat.size(0)
     en = en_feat.flatten(2).transpose(1, 2)
-    de = dgab(sd, "TPE.atten.0", de_feat, en)
+    de = dgab(sd, "TPE.atten.0", de_feat, en, bf16=bf16)
     f1 = F.relu(F.linear(en, sd["TPE.localization_fc1.0.weight"], sd["TPE.localization_fc1.0.bias"]))
     f1 = F.relu(F.linear(f1, sd["TPE.localization_fc1.2.weight"], sd["TPE.localization_fc1.2.bias"]))
     ctrl = F.linear(f1.reshape(n, -1), sd["TPE.localization_fc2.weight"],
@@ -159,7 +162,7 @@ def tpspp_regress(sd, x, outs, variant="ResNet45v2", p_stride=2, bf16=False):
     inter["feat_cat"], inter["feat_grid"] = feat_cat, feat_grid
     en, de, m_inter = msfa(sd, feat_cat, p_stride, bf16=bf16)
     inter.update(m_inter)
-    ctrl, score, de2 = tpe(sd, en, de)
+    ctrl, score, de2 = tpe(sd, en, de, bf16=bf16)
     inter["dgab"] = de2
     return ctrl, score, feat_grid, inter
 

@@ -31,6 +31,29 @@ def test_dgab_matches_oracle(cuda):
     assert (got - ref2).abs().max().item() <= 1e-4
 
 
+def test_dgab_bf16_matches_bf16_oracle(cuda):
+    """tpspp_dgab_bf16_fwd (proj / fc1 / fc2 on the bf16 matrix cores, everything else fp32) against the oracle
+    that rounds the same operands to bfloat16; and, at bf16 resolution, against the fp32 oracle.  Odd batch."""
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N = 5
+    from tps_pp_amd import synth
+    x = torch.from_numpy(synth.dyadic((N, 64, 16, 64), "dgab16.x"))
+    en = torch.from_numpy(synth.dyadic((N, 64, 2, 16), "dgab16.en"))
+    with torch.no_grad():
+        ref16 = TO.dgab(dict(m.state_dict()), "TPE.atten.0", x, en.flatten(2).transpose(1, 2), bf16=True)
+        ref32 = TO.dgab(dict(m.state_dict()), "TPE.atten.0", x, en.flatten(2).transpose(1, 2))
+    m.to(cuda)
+    dw = ops.DgabWeightsBf16(m.TPE.atten[0])
+    got = ops.dgab_bf16(x.to(cuda), en.to(cuda).view(N, 64, 32), dw).cpu()
+    scale = ref32.abs().max().item()
+    e16, e32 = (got - ref16).abs(), (got - ref32).abs()
+    # same roundings, different summation order / a flipped operand rounding here and there
+    assert e16.max().item() <= 2e-3 * scale and e16.mean().item() <= 1e-4 * scale, (e16.max().item(), e16.mean().item())
+    assert e32.max().item() <= 2e-2 * scale and e32.mean().item() <= 2e-3 * scale, (e32.max().item(), e32.mean().item())
+
+
 def test_score_matches_oracle(cuda):
     from tps_pp_amd import synth
     m = TPS_PP().eval()

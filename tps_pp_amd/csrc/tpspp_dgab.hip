@@ -26,6 +26,17 @@ constexpr int H = 16, W = 64, PT = 32, HID = 256;       // plane, points, MLP hi
 constexpr float kEps = 1e-5f;                            // nn.LayerNorm default
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// v_cvt_pk_bf16_f32: two fp32 -> packed bf16, round to nearest even
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    f32x2 v; v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
 
 __device__ __forceinline__ float readlane_f(float v, int lane)
 {
@@ -54,10 +65,12 @@ struct GateParams {
     const float* g1; const float* b1;       // LayerNorm affine (16, 64)
     const float* mw_t;     // (96, 65): mlp_w weight transposed  [input][output]
     const float* mh_t;     // (48, 17): mlp_h weight transposed
-    float* a;              // (N, C, 16, 64)
+    void* a;               // (N, C, 16, 64), fp32 or bf16 (A16)
     int planes;
 };
 
+// A16: the gated map is written as bf16 (the bf16 chain kernel reads it straight into MFMA operands)
+template <bool A16>
 __global__ void __launch_bounds__(256)
 dgab_gate_kernel(const GateParams P)
 {
@@ -121,7 +134,6 @@ dgab_gate_kernel(const GateParams P)
     const float hlast = readlane_f(ho, H);
 
     // A = (v_h * xn) * h_last + (v_w * xn) * w_last      (op order of DGAB.py:50)
-    float* ap = P.a + (size_t)pl * H * W;
 #pragma unroll
     for (int r = 0; r < H; ++r) {
         const float vhr = readlane_f(vh, r);
@@ -129,7 +141,9 @@ dgab_gate_kernel(const GateParams P)
         t1 = t1 * hlast;
         float t2 = vw * v[r];
         t2 = t2 * wlast;
-        ap[r * W + lane] = t1 + t2;
+        const size_t o = (size_t)pl * H * W + r * W + lane;
+        if (A16) reinterpret_cast<unsigned short*>(P.a)[o] = (unsigned short)(pack_bf16(t1 + t2, 0.0f) & 0xffffu);
+        else reinterpret_cast<float*>(P.a)[o] = t1 + t2;
     }
 }
 
@@ -270,6 +284,179 @@ dgab_chain_kernel(const ChainParams P)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// chain kernel on the bf16 matrix cores (the bf16 configuration, BASELINE.json configs[2])
+//
+// Same structure -- a lane owns a tensor row in the C/D register pattern, activations never go through LDS --
+// with v_mfma_f32_32x32x16_bf16: a lane supplies 8 consecutive k per step, and two consecutive result groups
+// (channels 8g + 4h + {0..3}, 8(g+1) + 4h + {0..3}) are exactly such an operand once the next layer's weight
+// slab is permuted on the host to that k-slot order (tpspp_front_bf16.hip uses the same chain).  Operands are
+// rounded to bf16 once each (gated map, normalised x1, GELU output); x, x1, LayerNorm, GELU and both residual
+// sums stay fp32.  The matrix work shrinks 16x (72 instead of 576 MFMAs per 32 rows), which leaves the vector
+// ALU as the bound -- mostly the 128 GELUs per lane --, so erf is evaluated with Abramowitz-Stegun 7.1.26
+// (|error| < 1.5e-7: invisible even before the bf16 rounding of its result) on v_rcp_f32 / v_exp_f32.
+// LDS holds the bf16 weight slabs: 72 KB, two workgroups per CU.
+struct ChainBParams {
+    const float* x;              // (rows, 64) fp32 residual input
+    const unsigned short* a;     // (rows, 64) bf16 gated map
+    const u32x4* wp_s;           // [4 k-steps][2][64 out][8]            proj, natural k order
+    const u32x4* w1_s;           // [4 blocks][4][2][64 hidden][8]       fc1, chain k order
+    const u32x4* w2_s;           // [4 blocks][4][2][64 out][8]          fc2, chain k order (hidden units of the block)
+    const float* bp; const float* b1; const float* b2;
+    const float* g2; const float* be2;
+    float* out;
+    int tiles;
+};
+
+__device__ __forceinline__ float gelu_as(float z)
+{
+    const float u = z * 0.70710678118654752440f;
+    const float ax = fabsf(u);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f(-(ax * ax) * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p, e, 1.0f);
+    const float erf_u = __builtin_copysignf(erf_abs, u);
+    return 0.5f * z * (1.0f + erf_u);
+}
+
+// acc[t] += slab^T in over 4 k-steps (64 k), both 32-row tiles of the 64 outputs
+__device__ __forceinline__ void gemm64b(const u32x4* __restrict__ slab, const u32x4 (&in)[4], int half, int l31,
+                                        f32x16 (&acc)[2])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, slab[(2 * j + half) * 64 + l31]);
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, slab[(2 * j + half) * 64 + 32 + l31]);
+        const bf16x8 bb = __builtin_bit_cast(bf16x8, in[j]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1], 0, 0, 0);
+    }
+}
+
+// 32 fp32 values in the C/D pattern (index 16t + 4g + e <-> feature 32t + 8g + 4h + e) -> chain-ordered operands
+__device__ __forceinline__ void to_operands(const float (&v)[32], u32x4 (&out)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            out[2 * t + (g >> 1)][2 * (g & 1)] = pack_bf16(v[16 * t + 4 * g], v[16 * t + 4 * g + 1]);
+            out[2 * t + (g >> 1)][2 * (g & 1) + 1] = pack_bf16(v[16 * t + 4 * g + 2], v[16 * t + 4 * g + 3]);
+        }
+}
+
+__global__ void __launch_bounds__(256, 2)
+dgab_chain_bf16_kernel(const ChainBParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    u32x4* sWp = reinterpret_cast<u32x4*>(smem);        // 512
+    u32x4* sW1 = sWp + 512;                              // 4 x 512
+    u32x4* sW2 = sW1 + 4 * 512;                          // 4 x 512
+    float* sB = reinterpret_cast<float*>(sW2 + 4 * 512); // bp (64) | b1 (256) | b2 (64)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 512; i += 256) sWp[i] = P.wp_s[i];
+    for (int i = tid; i < 4 * 512; i += 256) { sW1[i] = P.w1_s[i]; sW2[i] = P.w2_s[i]; }
+    for (int i = tid; i < 64; i += 256) { sB[i] = P.bp[i]; sB[64 + HID + i] = P.b2[i]; }
+    for (int i = tid; i < HID; i += 256) sB[64 + i] = P.b1[i];
+    __syncthreads();
+
+    const int lane = tid & (kWave - 1);
+    const int wv = tid / kWave;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int prow = l31 & (H - 1);
+
+    for (int tile = blockIdx.x; tile < P.tiles; tile += gridDim.x) {
+        const size_t row = (size_t)tile * 128 + wv * 32 + l31;
+        const float* xr = P.x + row * W;
+        // the gated map is already the operand: 8 consecutive bf16 per k-step
+        u32x4 ab[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ab[j] = *reinterpret_cast<const u32x4*>(P.a + row * W + 16 * j + 8 * half);
+        float x1[32];
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {                 // g8 = 4t + g
+            const float4 vx = *reinterpret_cast<const float4*>(xr + 32 * (g8 >> 2) + 8 * (g8 & 3) + 4 * half);
+            x1[4 * g8] = vx.x; x1[4 * g8 + 1] = vx.y; x1[4 * g8 + 2] = vx.z; x1[4 * g8 + 3] = vx.w;
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        gemm64b(sWp, ab, half, l31, acc);
+        // ---- x1 = x + proj(A) ----
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int f = 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3) + 4 * half;
+            x1[i] = x1[i] + (acc[i >> 4][i & 15] + sB[f]);
+        }
+        // ---- LayerNorm over each 16x64 plane (32 lanes x 32 registers), two-pass, fp32 ----
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += x1[i];
+        const float mean = plane_sum(s) * (1.0f / (H * W));
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const float d = x1[i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(plane_sum(q) * (1.0f / (H * W)) + kEps);
+        u32x4 xb[4];
+        {
+            float xn[32];
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) {
+                const int f = 32 * (g8 >> 2) + 8 * (g8 & 3) + 4 * half;
+                const float4 gg = *reinterpret_cast<const float4*>(P.g2 + prow * W + f);
+                const float4 bb = *reinterpret_cast<const float4*>(P.be2 + prow * W + f);
+                xn[4 * g8] = (x1[4 * g8] - mean) * rstd * gg.x + bb.x;
+                xn[4 * g8 + 1] = (x1[4 * g8 + 1] - mean) * rstd * gg.y + bb.y;
+                xn[4 * g8 + 2] = (x1[4 * g8 + 2] - mean) * rstd * gg.z + bb.z;
+                xn[4 * g8 + 3] = (x1[4 * g8 + 3] - mean) * rstd * gg.w + bb.w;
+            }
+            to_operands(xn, xb);
+        }
+        // ---- out = x1 + fc2(gelu(fc1(xn))): hidden units in 4 blocks of 64, never leaving registers ----
+        f32x16 o[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[t][i] = 0.0f;
+#pragma unroll 1
+        for (int hb = 0; hb < 4; ++hb) {
+            f32x16 hh[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hh[t][i] = 0.0f;
+            gemm64b(sW1 + hb * 512, xb, half, l31, hh);
+            float hid[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int f = 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3) + 4 * half;
+                hid[i] = gelu_as(hh[i >> 4][i & 15] + sB[64 + hb * 64 + f]);
+            }
+            u32x4 hb4[4];
+            to_operands(hid, hb4);
+            gemm64b(sW2 + hb * 512, hb4, half, l31, o);
+        }
+        float* orow = P.out + row * W;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) {
+            const int f = 32 * (g8 >> 2) + 8 * (g8 & 3) + 4 * half;
+            float4 v;
+            v.x = x1[4 * g8] + (o[g8 >> 2][4 * (g8 & 3)] + sB[64 + HID + f]);
+            v.y = x1[4 * g8 + 1] + (o[g8 >> 2][4 * (g8 & 3) + 1] + sB[64 + HID + f + 1]);
+            v.z = x1[4 * g8 + 2] + (o[g8 >> 2][4 * (g8 & 3) + 2] + sB[64 + HID + f + 2]);
+            v.w = x1[4 * g8 + 3] + (o[g8 >> 2][4 * (g8 & 3) + 3] + sB[64 + HID + f + 3]);
+            *reinterpret_cast<float4*>(orow + f) = v;
+        }
+    }
+}
+
 }  // namespace
 
 TPSPP_EXPORT int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const float* ln1_b,
@@ -288,7 +475,7 @@ TPSPP_EXPORT int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1
     GateParams G;
     G.x = x; G.y = y; G.g1 = ln1_w; G.b1 = ln1_b; G.mw_t = mlp_w_t; G.mh_t = mlp_h_t; G.a = scratch;
     G.planes = planes;
-    hipLaunchKernelGGL(dgab_gate_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
+    hipLaunchKernelGGL(dgab_gate_kernel<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
     int rc = tpspp::check_launch("tpspp_dgab_fwd(gate)");
     if (rc) return rc;
     ChainParams Q;
@@ -306,4 +493,42 @@ TPSPP_EXPORT int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1
     const int grid = Q.tiles < 256 ? Q.tiles : 256;                 // persistent: one workgroup per CU
     hipLaunchKernelGGL(dgab_chain_kernel, dim3((unsigned)grid), dim3(256), lds, st, Q);
     return tpspp::check_launch("tpspp_dgab_fwd(chain)");
+}
+
+TPSPP_EXPORT int tpspp_dgab_bf16_fwd(const float* x, const float* y, const float* ln1_w, const float* ln1_b,
+                                     const float* mlp_w_t, const float* mlp_h_t, const void* proj_slab,
+                                     const float* proj_b, const float* ln2_w, const float* ln2_b,
+                                     const void* fc1_slab, const float* fc1_b, const void* fc2_slab,
+                                     const float* fc2_b, void* scratch, float* out, int N, int C,
+                                     tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(x && y && ln1_w && ln1_b && mlp_w_t && mlp_h_t && proj_slab && proj_b && ln2_w && ln2_b &&
+                  fc1_slab && fc1_b && fc2_slab && fc2_b && scratch && out, "tpspp_dgab_bf16_fwd: null pointer");
+    TPSPP_REQUIRE(N >= 0 && C > 0 && (C % 8) == 0, "tpspp_dgab_bf16_fwd: channels must be a multiple of 8");
+    if (N == 0) return TPSPP_OK;
+    hipStream_t st = tpspp::as_stream(stream);
+    const int planes = N * C;
+    GateParams G;
+    G.x = x; G.y = y; G.g1 = ln1_w; G.b1 = ln1_b; G.mw_t = mlp_w_t; G.mh_t = mlp_h_t; G.a = scratch;
+    G.planes = planes;
+    hipLaunchKernelGGL(dgab_gate_kernel<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
+    int rc = tpspp::check_launch("tpspp_dgab_bf16_fwd(gate)");
+    if (rc) return rc;
+    ChainBParams Q;
+    Q.x = x; Q.a = static_cast<const unsigned short*>(scratch);
+    Q.wp_s = static_cast<const u32x4*>(proj_slab); Q.w1_s = static_cast<const u32x4*>(fc1_slab);
+    Q.w2_s = static_cast<const u32x4*>(fc2_slab);
+    Q.bp = proj_b; Q.b1 = fc1_b; Q.b2 = fc2_b; Q.g2 = ln2_w; Q.be2 = ln2_b; Q.out = out;
+    Q.tiles = planes / 8;
+    const size_t lds = (size_t)(9 * 512) * 16 + (size_t)(64 + HID + 64) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_bf16_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+        attr_done = true;
+    }
+    const int grid = Q.tiles < 512 ? Q.tiles : 512;                 // persistent: two workgroups per CU
+    hipLaunchKernelGGL(dgab_chain_bf16_kernel, dim3((unsigned)grid), dim3(256), lds, st, Q);
+    return tpspp::check_launch("tpspp_dgab_bf16_fwd(chain)");
 }
