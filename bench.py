@@ -196,6 +196,14 @@ def recognizer_measurement(dev, timeit):
         t_all16 = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
         t_feat16 = timeit(lambda: m.extract_feat(img, test=True), 3, 1)
         got16 = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+        # ... and the head's wide projections + encoder keys / values in bf16 (TPSPP_HEAD_BF16)
+        m.encoder.compute_dtype = m.decoder.compute_dtype = torch.bfloat16
+        t_all16h = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
+        t_enc16 = timeit(lambda: m.encoder(feat, None), 3, 1)
+        out_enc16 = m.encoder(feat, None)
+        t_dec16 = timeit(lambda: m.decoder(feat, out_enc16, None, None, train_mode=False), 3, 1)
+        got16h = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+        m.encoder.compute_dtype = m.decoder.compute_dtype = None
         m.backbone.compute_dtype = None
     want = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[:k].cpu().numpy(), [128] * k)["text"]
     return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
@@ -204,6 +212,10 @@ def recognizer_measurement(dev, timeit):
             "bf16_backbone": {"images_per_s": n / (t_all16 * 1e-3), "ms_per_batch": t_all16,
                               "ms_backbone_tpspp": t_feat16,
                               "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(got16, want))}/{k}"},
+            "bf16_backbone_and_head": {"images_per_s": n / (t_all16h * 1e-3), "ms_per_batch": t_all16h,
+                                       "ms_encoder": t_enc16, "ms_greedy_decoder_40_steps": t_dec16,
+                                       "strings_equal_to_fp32_cpu_oracle":
+                                           f"{sum(a == b for a, b in zip(got16h, want))}/{k}"},
             "data": "synthetic images, random-init weights"}
 
 

@@ -297,7 +297,7 @@ int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
  *                    [Cout/64][Cin/KC][KH*KW][KC/8][64 cout][8 cin]  (the LDS image of each K-chunk)
  *   bias, post_scale, post_shift   (Cout) fp32 or NULL
  *   residual         (N, Cout, Ho, Wo), fp32 when residual_f32 else bf16, or NULL; res_mode as above
- *   relu             0 none, 1 ReLU
+ *   relu             0 none, 1 ReLU, 2 GELU (exact erf form)
  *   out              (N, Cout, Ho, Wo), fp32 when out_f32 else bf16 (round to nearest even)
  * replaces: the call sites listed for tpspp_conv2d_fwd when the module runs in bf16.
  */
@@ -378,6 +378,16 @@ int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, const float* w_
                         const float* w_colsum, int Cout, const float* bias_eff, int act,
                         const float* residual, int token_major, float* out, tpspp_stream_t stream);
 
+/*
+ * flags bit of tpspp_nrtr_encoder_fwd / tpspp_nrtr_decoder_fwd (the bf16 configuration, BASELINE.json configs[4]):
+ * the wide projections run on the bf16 matrix cores -- encoder: wqkv / fc / w1 / w2; decoder: the one-off key / value
+ * projections of the encoder output -- and their entries of layer_ptrs then point to bf16 weights arranged as
+ * tpspp_conv2d_bf16_fwd wants a 1x1 kernel; the decoder keeps the encoder keys / values as bf16 (they are the only
+ * HBM-bound operand of a decoding step).  Residual stream, LayerNorms, softmaxes, the per-step projections and the
+ * classifier stay fp32.
+ */
+#define TPSPP_HEAD_BF16 1
+
 /* Scratch sizes (bytes) for the two calls below; 0 on bad arguments. */
 size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner);
 size_t tpspp_nrtr_decoder_workspace(int N, int C, int T, int d_inner, int n_layers, int max_seq_len,
@@ -398,7 +408,7 @@ size_t tpspp_nrtr_decoder_workspace(int N, int C, int T, int d_inner, int n_laye
 int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
                            const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
                            const int* valid_len, void* workspace, size_t workspace_bytes,
-                           float* out_cm, float* out_ntc, tpspp_stream_t stream);
+                           float* out_cm, float* out_ntc, int flags, tpspp_stream_t stream);
 
 /*
  * NRTRDecoder.forward_test (greedy, forced_tokens == NULL) / forward_train (teacher forcing):
@@ -433,7 +443,7 @@ int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner
                            int max_seq_len,
                            int start_idx, int padding_idx, const int* valid_len,
                            const int* forced_tokens, void* workspace, size_t workspace_bytes,
-                           float* out, int* tokens_out, tpspp_stream_t stream);
+                           float* out, int* tokens_out, int flags, tpspp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -26,11 +26,17 @@ def timeit(fn, iters=10, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+ONLY16 = len(sys.argv) > 2 and sys.argv[2] == "bf16only"      # profile runs: only the bf16 configuration
 m = TPS_PP().eval().to(dev)
 x = torch.rand(N, 64, 16, 64, device=dev)
 o0 = torch.rand(N, 32, 32, 128, device=dev)
 o1 = torch.rand(N, 32, 32, 128, device=dev)
 with torch.no_grad():
+    if ONLY16:
+        xb, o0b, o1b = x.to(torch.bfloat16), o0.to(torch.bfloat16), o1.to(torch.bfloat16)
+        t16 = timeit(lambda: m(xb, [o0b, o1b]), iters=20)
+        print(f"TPS_PP batch {N} bf16: full {t16:.2f} ms = {N / t16 * 1e3:,.0f} img/s")
+        sys.exit(0)
     timeit(lambda: m(x, [o0, o1]), iters=3)            # settle allocator / library caches
     t_reg = timeit(lambda: m.regress(x, [o0, o1]))
     t_full = timeit(lambda: m(x, [o0, o1]))

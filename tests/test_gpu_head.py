@@ -225,6 +225,32 @@ def test_recognizer_bf16_backbone_against_reference(cuda):
     err = np.abs(feat.cpu().numpy()[:, ::8] - ref)
     assert err.max() <= 0.05 * np.abs(ref).max() and err.mean() <= 0.005 * np.abs(ref).max()
     assert [r["text"] for r in res] == [str(s) for s in G["text"]]
+    # ... and with the head's wide projections on the bf16 matrix cores and bf16 encoder keys / values
+    # (TPSPP_HEAD_BF16): same strings, per-character scores at bf16 resolution
+    m.encoder.compute_dtype = m.decoder.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        res16 = m(img, [dict(mm) for mm in metas], return_loss=False)
+    assert [r["text"] for r in res16] == [str(s) for s in G["text"]]
+    assert np.abs(np.array(res16[0]["score"], dtype=np.float32) - G["score0"]).max() <= 2e-2
+
+
+def test_head_bf16_flag_against_fp32_head(cuda):
+    """TPSPP_HEAD_BF16 on the small head (odd sizes, key masks): encoder output and decoder probabilities against
+    the fp32 HIP head at bf16 resolution; greedy tokens identical."""
+    enc, dec = small_modules(cuda)
+    feat = dev(cases.g9_inputs()["feat"], cuda)
+    metas = [dict(valid_ratio=r) for r in cases.HD_RATIOS]
+    with torch.no_grad():
+        e32 = enc(feat, metas)
+        p32 = dec(feat, e32, None, metas, train_mode=False)
+        t32 = dec.last_tokens.clone()
+        enc.compute_dtype = dec.compute_dtype = torch.bfloat16
+        e16 = enc(feat, metas)
+        p16 = dec(feat, e16, None, metas, train_mode=False)
+        t16 = dec.last_tokens.clone()
+    assert (e16 - e32).abs().max().item() <= 3e-2 * e32.abs().max().item()
+    assert (p16 - p32).abs().max().item() <= 2e-2
+    assert torch.equal(t16, t32)
 
 
 @pytest.mark.parametrize("hw,n", [((4, 20), 5), ((1, 7), 3), ((4, 40), 2)])

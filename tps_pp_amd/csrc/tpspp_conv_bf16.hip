@@ -302,10 +302,13 @@ conv_tiled_bf16_kernel(const BParams P)
                                            : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
                         if (P.res_mode == 2) v[e] = v[e] + rv;
                         if (P.relu == 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                        else if (P.relu == 2) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
                         if (P.res_mode == 1) v[e] = v[e] + rv;
                         if (P.post_scale && co < P.Cout) v[e] = v[e] * P.post_scale[co] + P.post_shift[co];
                     } else if (P.relu == 1) {
                         v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                    } else if (P.relu == 2) {
+                        v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
                     }
                 }
                 const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
@@ -343,7 +346,8 @@ constexpr int kKC1 = 32;      // channels per chunk, 1x1 kernels
 template <int KH, int SH, int SW, int KC>
 bool launch_by_shape(const BParams& P, hipStream_t st)
 {
-    if (P.Wo > 64)      launch_b<KH, SH, SW, 2, 128, 1, KC>(P, st);
+    if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC>(P, st);   // a row of tokens
+    else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC>(P, st);
     else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC>(P, st);
     else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC>(P, st);
     else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC>(P, st);
@@ -373,7 +377,7 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     TPSPP_REQUIRE(N >= 0 && Cout > 0 && sh >= 1 && sw >= 1 && Ho > 0 && Wo > 0, "tpspp_conv2d_bf16_fwd: bad sizes");
     TPSPP_REQUIRE(res_mode >= 0 && res_mode <= 2 && (res_mode == 0) == (residual == nullptr),
                   "tpspp_conv2d_bf16_fwd: residual / res_mode mismatch");
-    TPSPP_REQUIRE(relu == 0 || relu == 1, "tpspp_conv2d_bf16_fwd: activation code must be 0 (none) or 1 (ReLU)");
+    TPSPP_REQUIRE(relu >= 0 && relu <= 2, "tpspp_conv2d_bf16_fwd: activation code must be 0 (none), 1 (ReLU) or 2 (GELU)");
     TPSPP_REQUIRE((post_scale == nullptr) == (post_shift == nullptr),
                   "tpspp_conv2d_bf16_fwd: post_scale/post_shift come together");
     BParams P;

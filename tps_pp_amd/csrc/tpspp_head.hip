@@ -402,8 +402,14 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
 // q_t (Nb, C) token-major; Kx (C, Nb*T) channel-major (a lane per encoder token reads coalesced);
 // Vx_t (Nb*T, C) token-major (a lane per feature reads coalesced).  One wavefront per (image, head),
 // T <= 256 (four tokens per lane).  Keys >= valid_len[b] are masked (nrtr_decoder.py:115-129).
+__device__ __forceinline__ float kv_elem(float v) { return v; }
+__device__ __forceinline__ float kv_elem(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+
+// KV = float, or unsigned short: bf16 keys / values (TPSPP_HEAD_BF16: the 128 MB of encoder K/V per layer are the
+// only HBM-bound operand of a decoder step; scores, softmax and the weighted sum stay fp32)
+template <typename KV>
 __global__ void __launch_bounds__(256)
-attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ Kx, const float* __restrict__ Vx_t,
+attn_dec_cross_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx, const KV* __restrict__ Vx_t,
                       int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -414,7 +420,7 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ K
     int nvalid = valid_len ? valid_len[b] : T;
     nvalid = nvalid < T ? nvalid : T;
     const size_t MT = (size_t)Nb * T;
-    const float* kbase = Kx + (size_t)(kDK * h) * MT + (size_t)b * T;
+    const KV* kbase = Kx + (size_t)(kDK * h) * MT + (size_t)b * T;
     float sc[4];
     float mx = -INFINITY;
 #pragma unroll
@@ -425,7 +431,7 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ K
             const int tt = t < T ? t : T - 1;
             float kv[kDK];                                 // all 64 row loads in flight together
 #pragma unroll
-            for (int d = 0; d < kDK; ++d) kv[d] = kbase[(size_t)d * MT + tt];
+            for (int d = 0; d < kDK; ++d) kv[d] = kv_elem(kbase[(size_t)d * MT + tt]);
             float s = 0.0f;
 #pragma unroll
             for (int d = 0; d < kDK; ++d) s = fmaf(readlane_f(q, d), kv[d], s);
@@ -442,7 +448,7 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ K
     }
     l = wave_sum(l);
     const float inv = 1.0f / l;
-    const float* vbase = Vx_t + ((size_t)b * T) * C + kDK * h + lane;
+    const KV* vbase = Vx_t + ((size_t)b * T) * C + kDK * h + lane;
     float acc = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -453,7 +459,7 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const float* __restrict__ K
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int tl = t0 + u < cnt ? t0 + u : cnt - 1;
-                vv[u] = vbase[(size_t)(jj * kWave + tl) * C];
+                vv[u] = kv_elem(vbase[(size_t)(jj * kWave + tl) * C]);
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -512,9 +518,38 @@ dec_init_tokens_kernel(int* __restrict__ tokens, int Nb, int Lt, int start_idx, 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+// (rows, cols) bf16 -> (cols, rows) bf16, 64x64 tiles through LDS
+__global__ void __launch_bounds__(256)
+transpose2d_b16_kernel(const unsigned short* __restrict__ in, int rows, int cols, unsigned short* __restrict__ out)
+{
+    __shared__ unsigned short tile[64][66];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
 struct Gemm {
     hipStream_t st;
     int rc = 0;
+    // the same product on the bf16 matrix cores: W16 = the weight arranged for tpspp_conv2d_bf16_fwd (1x1),
+    // X / res fp32 (rounded to bf16 as they are staged), out fp32 or bf16
+    void cm16(const void* W16, const float* bias, const float* X, int K, int Co, int M, void* out, int out_f32, int act,
+              const float* res)
+    {
+        if (rc) return;
+        const void* src[1] = {X};
+        const int dims[6] = {K, 1, M, 1, 1, 1};
+        rc = tpspp_conv2d_bf16_fwd(src, dims, 1, W16, bias, res, 1, nullptr, nullptr, res ? 1 : 0, act, 1, Co, 1, 1, 1, 1,
+                                   out, out_f32, 1, M, st);
+    }
     // out (Co, M) = act(W^T X + bias) [+ res]      W (K, Co) k-major, X (K, M) channel-major
     void cm(const float* W, const float* bias, const float* X, int K, int Co, int M, float* out, int act,
             const float* res)
@@ -657,8 +692,9 @@ enum { D_QKV_W, D_QKV_CS, D_QKV_B, D_WFC, D_BFC, D_Q_W, D_Q_CS, D_Q_B, D_WK, D_B
 TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
                                         const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
                                         const int* valid_len, void* workspace, size_t workspace_bytes,
-                                        float* out_cm, float* out_ntc, tpspp_stream_t stream)
+                                        float* out_cm, float* out_ntc, int flags, tpspp_stream_t stream)
 {
+    const bool b16 = (flags & TPSPP_HEAD_BF16) != 0;
     TPSPP_REQUIRE(feat && layer_ptrs && ln_g && ln_b && workspace && (out_cm || out_ntc),
                   "tpspp_nrtr_encoder_fwd: null pointer");
     TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0,
@@ -695,16 +731,23 @@ TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, 
         // x = x + fc(attn(LN1(x)))                                   transformer_layers.py:67-70
         rc = tpspp_layernorm_cm_fwd(x, w[E_LN1G], w[E_LN1B], C, M, 1e-5f, y, stream);
         if (rc) break;
-        g.cm(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 0, nullptr);
+        if (b16) g.cm16(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 1, 0, nullptr);
+        else g.cm(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 0, nullptr);
         if (g.rc) break;
         rc = launch_attn_enc(qkv, N, C, T, valid_len, a, st);
         if (rc) break;
-        g.cm(w[E_WFC], w[E_BFC], a, C, C, M, y, 0, x);               // y = x + fc(a)
+        if (b16) g.cm16(w[E_WFC], w[E_BFC], a, C, C, M, y, 1, 0, x);
+        else g.cm(w[E_WFC], w[E_BFC], a, C, C, M, y, 0, x);          // y = x + fc(a)
         // x = y + w2(gelu(w1(LN2(y))))                                transformer_layers.py:72-75
         rc = tpspp_layernorm_cm_fwd(y, w[E_LN2G], w[E_LN2B], C, M, 1e-5f, a, stream);
         if (rc) break;
-        g.cm(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 2, nullptr);
-        g.cm(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 0, y);
+        if (b16) {
+            g.cm16(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 1, 2, nullptr);
+            g.cm16(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 1, 0, y);
+        } else {
+            g.cm(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 2, nullptr);
+            g.cm(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 0, y);
+        }
     }
     if (rc) return rc;
     if (g.rc) return g.rc;
@@ -722,8 +765,9 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                                         int max_seq_len,
                                         int start_idx, int padding_idx, const int* valid_len,
                                         const int* forced_tokens, void* workspace, size_t workspace_bytes,
-                                        float* out, int* tokens_out, tpspp_stream_t stream)
+                                        float* out, int* tokens_out, int flags, tpspp_stream_t stream)
 {
+    const bool b16 = (flags & TPSPP_HEAD_BF16) != 0;
     TPSPP_REQUIRE(enc_cm && layer_ptrs && emb && pos_table && w_cls && cls_colsum && workspace && out,
                   "tpspp_nrtr_decoder_fwd: null pointer");
     TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0 && num_out > 0,
@@ -764,8 +808,19 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     // encoder keys (channel-major) and values (token-major) of every layer, once
     for (int l = 0; l < n_layers; ++l) {
         const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
-        g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
-        g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);            // (a value bias would be per channel = per column here: not supported)
+        if (b16) {
+            // bf16 matrix cores, bf16 keys / values: K channel-major straight from the epilogue; V channel-major
+            // into the upper half of its own (fp32-sized) slot, then transposed to token-major rows
+            unsigned short* vt = reinterpret_cast<unsigned short*>(Vx[l]) + (size_t)C * MT;
+            g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, 0, nullptr);
+            g.cm16(w[D_WV], nullptr, enc_cm, C, C, MT, vt, 0, 0, nullptr);
+            if (g.rc) return g.rc;
+            hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
+                               0, st, vt, C, MT, reinterpret_cast<unsigned short*>(Vx[l]));
+        } else {
+            g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
+            g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);        // (a value bias would be per channel = per column here: not supported)
+        }
     }
     if (g.rc) return g.rc;
     hipLaunchKernelGGL(dec_init_tokens_kernel, dim3((unsigned)((N * Lt + 255) / 256)), dim3(256), 0, st, tokens, N,
@@ -787,8 +842,13 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             // x = y + fc(enc_attn(LN2(y), enc, enc))                   transformer_layers.py:156-159
             rc = tpspp_linear_ln_fwd(y, C, N, 1e-5f, w[D_Q_W], w[D_Q_CS], C, w[D_Q_B], 0, nullptr, 1, qkv, stream);
             if (rc) return rc;
-            hipLaunchKernelGGL(attn_dec_cross_kernel, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C, N, H,
-                               T, valid_len, a);
+            if (b16)
+                hipLaunchKernelGGL(attn_dec_cross_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
+                                   reinterpret_cast<const unsigned short*>(Kx[l]),
+                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a);
+            else
+                hipLaunchKernelGGL(attn_dec_cross_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
+                                   N, H, T, valid_len, a);
             g.cm(w[D_WFC2], w[D_BFC2], a, C, C, N, x, 0, y);          // x = y + fc(a)
             // x = x + mlp(LN3(x))                                       transformer_layers.py:161-163
             rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_W1_W], w[D_W1_CS], d_inner, w[D_W1_B], 2, nullptr, 0, hid, stream);

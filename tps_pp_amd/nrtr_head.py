@@ -121,6 +121,12 @@ def _valid_len(img_metas, n, t, device):
     return torch.tensor([min(t, math.ceil(t * r)) for r in ratios], dtype=torch.int32, device=device)
 
 
+def _arranged16(weight):
+    """nn.Linear weight (out, in) -> bf16, arranged as a 1x1 kernel for tpspp_conv2d_bf16_fwd."""
+    w = weight.detach().float()
+    return ops.prep_conv_weight_bf16(w.view(w.shape[0], w.shape[1], 1, 1)).arranged
+
+
 @ENCODERS.register_module()
 class NRTREncoder(nn.Module):
     """Transformer encoder; `forward(feat (N, C, H, W), img_metas=None) -> (N, H*W, C)`."""
@@ -132,6 +138,7 @@ class NRTREncoder(nn.Module):
         if d_model != n_head * d_k:
             raise ValueError("d_model must equal n_head * d_k (linear_q maps dim_k -> dim_k)")
         self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
+        self.compute_dtype = None          # torch.bfloat16: the wide projections on the bf16 matrix cores
         self.layer_stack = nn.ModuleList([
             TFEncoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout, **kwargs) for _ in range(n_layers)])
         self.layer_norm = nn.LayerNorm(d_model)
@@ -140,19 +147,25 @@ class NRTREncoder(nn.Module):
         pass
 
     def _weights(self):
-        key = _state_key(self)
+        b16 = self.compute_dtype == torch.bfloat16
+        key = (_state_key(self), b16)
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != key:
             ts = []
+            # fp32: k-major (in, out); bf16 (TPSPP_HEAD_BF16): arranged for the bf16 1x1 convolution kernel
+            km = _arranged16 if b16 else ops.kmajor
             for lyr in self.layer_stack:
                 a = lyr.attn
-                wqkv = torch.cat([ops.kmajor(a.linear_q.weight), ops.kmajor(a.linear_k.weight),
-                                  ops.kmajor(a.linear_v.weight)], dim=1).contiguous()
+                if b16:
+                    wqkv = _arranged16(torch.cat([a.linear_q.weight, a.linear_k.weight, a.linear_v.weight], dim=0))
+                else:
+                    wqkv = torch.cat([ops.kmajor(a.linear_q.weight), ops.kmajor(a.linear_k.weight),
+                                      ops.kmajor(a.linear_v.weight)], dim=1).contiguous()
                 bqkv = None if a.linear_q.bias is None else \
                     torch.cat([_f32(a.linear_q.bias), _f32(a.linear_k.bias), _f32(a.linear_v.bias)]).contiguous()
-                ts += [_f32(lyr.norm1.weight), _f32(lyr.norm1.bias), wqkv, bqkv, ops.kmajor(a.fc.weight),
+                ts += [_f32(lyr.norm1.weight), _f32(lyr.norm1.bias), wqkv, bqkv, km(a.fc.weight),
                        None if a.fc.bias is None else _f32(a.fc.bias), _f32(lyr.norm2.weight), _f32(lyr.norm2.bias),
-                       ops.kmajor(lyr.mlp.w_1.weight), _f32(lyr.mlp.w_1.bias), ops.kmajor(lyr.mlp.w_2.weight),
+                       km(lyr.mlp.w_1.weight), _f32(lyr.mlp.w_1.bias), km(lyr.mlp.w_2.weight),
                        _f32(lyr.mlp.w_2.bias)]
             cache = (key, ops.PtrTable(ts), _f32(self.layer_norm.weight), _f32(self.layer_norm.bias))
             self._w_cache = cache
@@ -165,7 +178,8 @@ class NRTREncoder(nn.Module):
         if c != self.d_model:
             raise ValueError(f"NRTREncoder: feature width {c} != d_model {self.d_model}")
         vl = _valid_len(img_metas, n, h * w, feat.device)
-        out, out_cm = ops.nrtr_encoder(feat.float(), table, len(self.layer_stack), self.d_inner, g, b, vl, holder=self)
+        out, out_cm = ops.nrtr_encoder(feat.float(), table, len(self.layer_stack), self.d_inner, g, b, vl, holder=self,
+                                       flags=ops.HEAD_BF16 if self.compute_dtype == torch.bfloat16 else 0)
         out._tpspp_cm = out_cm          # lets NRTRDecoder skip the re-layout of its input
         return out
 
@@ -186,6 +200,7 @@ class NRTRDecoder(nn.Module):
             raise ValueError("d_model must equal n_head * d_k and d_embedding")
         self.padding_idx, self.start_idx, self.max_seq_len = padding_idx, start_idx, max_seq_len
         self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
+        self.compute_dtype = None          # torch.bfloat16: encoder K/V projected on the bf16 matrix cores, kept as bf16
         self.trg_word_emb = nn.Embedding(num_classes, d_embedding, padding_idx=padding_idx)
         self.position_enc = PositionalEncoding(d_embedding, n_position=n_position)
         self.layer_stack = nn.ModuleList([
@@ -197,10 +212,12 @@ class NRTRDecoder(nn.Module):
         pass
 
     def _weights(self):
-        key = _state_key(self)
+        b16 = self.compute_dtype == torch.bfloat16
+        key = (_state_key(self), b16)
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != key:
             ts = []
+            kv = _arranged16 if b16 else ops.kmajor        # the one-off key / value projections of the encoder output
             for lyr in self.layer_stack:
                 sa, ea = lyr.self_attn, lyr.enc_attn
                 wqkv = torch.cat([ops.kmajor(sa.linear_q.weight), ops.kmajor(sa.linear_k.weight),
@@ -210,7 +227,7 @@ class NRTRDecoder(nn.Module):
                 q = ops.fold_layernorm(lyr.norm2.weight, lyr.norm2.bias, ops.kmajor(ea.linear_q.weight))
                 w1 = ops.fold_layernorm(lyr.norm3.weight, lyr.norm3.bias, ops.kmajor(lyr.mlp.w_1.weight), lyr.mlp.w_1.bias)
                 ts += [qkv[0], qkv[1], qkv[2], ops.kmajor(sa.fc.weight), None,
-                       q[0], q[1], q[2], ops.kmajor(ea.linear_k.weight), None, ops.kmajor(ea.linear_v.weight),
+                       q[0], q[1], q[2], kv(ea.linear_k.weight), None, kv(ea.linear_v.weight),
                        ops.kmajor(ea.fc.weight), None, w1[0], w1[1], w1[2],
                        ops.kmajor(lyr.mlp.w_2.weight), _f32(lyr.mlp.w_2.bias)]
             cls = ops.fold_layernorm(self.layer_norm.weight, self.layer_norm.bias, ops.kmajor(self.classifier.weight),
@@ -232,7 +249,8 @@ class NRTRDecoder(nn.Module):
         vl = _valid_len(img_metas, n, t, out_enc.device)
         seq_len = self.max_seq_len if forced is None else forced.shape[1]
         out, tokens = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, emb, pos, cls,
-                                       seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self)
+                                       seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self,
+                                       flags=ops.HEAD_BF16 if self.compute_dtype == torch.bfloat16 else 0)
         self.last_tokens = tokens
         return out
 

@@ -423,7 +423,7 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
     with torch.cuda.device(ts[0].device):
         rc = _lib.lib().tpspp_conv2d_bf16_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
                                               len(ts), _ptr(cw.arranged), _ptr(cw.bias), _ptr(residual), res_f32,
-                                              _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode), int(bool(relu)),
+                                              _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode), int(relu),
                                               N, Cout, kernel, kernel, sh, sw, _ptr(out),
                                               int(out_dtype == torch.float32), Ho, Wo, _stream(ts[0]))
     _lib.check(rc, "tpspp_conv2d_bf16_fwd")
@@ -795,7 +795,10 @@ def _workspace(holder, nbytes, device):
     return ws
 
 
-def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, holder=None, want_ntc=True):
+HEAD_BF16 = 1            # TPSPP_HEAD_BF16
+
+
+def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, holder=None, want_ntc=True, flags=0):
     """`tpspp_nrtr_encoder_fwd`: feat (N, C, H, W) -> (out (N, T, C) | None, out_cm (C, N*T))."""
     feat = _chk("feat", feat, 4)
     N, C, H, W = feat.shape
@@ -808,13 +811,13 @@ def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, hol
     with torch.cuda.device(feat.device):
         rc = L.tpspp_nrtr_encoder_fwd(_ptr(feat), N, C, T, d_inner, n_layers, table.ptr, _ptr(ln_g), _ptr(ln_b),
                                       _ptr(valid_len), ws.data_ptr(), ws.numel(), _ptr(out_cm), _ptr(out),
-                                      _stream(feat))
+                                      int(flags), _stream(feat))
     _lib.check(rc, "tpspp_nrtr_encoder_fwd")
     return out, out_cm
 
 
 def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_folded, max_seq_len,
-                 start_idx, padding_idx, valid_len=None, forced_tokens=None, holder=None):
+                 start_idx, padding_idx, valid_len=None, forced_tokens=None, holder=None, flags=0):
     """`tpspp_nrtr_decoder_fwd` -> (out (N, L, num_out), tokens (N, L+1) int32)."""
     enc_cm = _chk("enc_cm", enc_cm, 2)
     C = enc_cm.shape[0]
@@ -836,7 +839,7 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_fol
                                       _ptr(emb), _ptr(pos_table), pos_table.shape[0], _ptr(w_cls), _ptr(cls_colsum),
                                       _ptr(b_cls), num_out, max_seq_len, int(start_idx), int(padding_idx), _ptr(valid_len),
                                       _ptr(forced_tokens), ws.data_ptr(), ws.numel(), _ptr(out), _ptr(tokens),
-                                      _stream(enc_cm))
+                                      int(flags), _stream(enc_cm))
     _lib.check(rc, "tpspp_nrtr_decoder_fwd")
     return out, tokens
 
