@@ -24,6 +24,10 @@ for w in module head backward; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o $w -- \
       python3 scripts/bench_$w.py > $OUT/$w.log 2>&1
 done
+# 3b. the bf16 configuration: TPS_PP on bf16 tensors (BASELINE.json configs[2]) and the bf16 conv kernel beside MIOpen
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_bf16 -o module_bf16 -- \
+    python3 scripts/bench_module.py 512 bf16only > $OUT/module_bf16.log 2>&1
+python3 scripts/bench_conv.py > $OUT/conv_bf16.log 2>&1
 # 4. MFMA-busy counters (own pass) for the regressor kernels + the calibration kernel (pure MFMA)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc -o module -- \
     python3 scripts/bench_module.py > $OUT/mfma_module.log 2>&1

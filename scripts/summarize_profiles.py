@@ -129,7 +129,8 @@ Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / 
 (the excess is the batch-shared table and inv_delta_C, which the algorithmic figure excludes).
 """)
     # kernel stats of the wider rows (whole TPS++ module, whole recogniser, warp backward)
-    for w, name in (("module", "module"), ("head", "recognizer"), ("backward", "warp_backward")):
+    for w, name in (("module", "module"), ("head", "recognizer"), ("backward", "warp_backward"),
+                    ("module_bf16", "module_bf16")):
         src = os.path.join(SRC, f"trace_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(src):
             rows = sorted(csv.DictReader(open(src)), key=lambda r: -float(r["TotalDurationNs"]))
@@ -141,6 +142,10 @@ Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / 
             if os.path.exists(log):
                 with open(os.path.join(DST, f"{TAG}_{name}_run.txt"), "w") as f:
                     f.write("".join(l for l in open(log) if "amdgpu.ids" not in l))
+    cl = os.path.join(SRC, "conv_bf16.log")
+    if os.path.exists(cl):
+        with open(os.path.join(DST, f"{TAG}_conv_fp32_bf16_vs_miopen.txt"), "w") as f:
+            f.write("".join(l for l in open(cl) if "amdgpu.ids" not in l))
     mfma_summary()
     print(json.dumps(js, indent=1))
 
