@@ -282,25 +282,48 @@ conv_tiled_f32_kernel(const ConvParams P)
     }
 
     // ---- epilogue ----
+    // Kept off the vector ALU where it can be (the lesson of the bf16 kernel, tpspp_conv_bf16.hip): wave-uniform base
+    // (image group, channel tile: scalar arithmetic) + one 32-bit lane offset, the bias as float4 quads, and a common
+    // path (no residual, no affine, no GELU) without per-element branches.
     const int oy = oy0 + ty, ox = ox0 + tx;
-    if (oy < P.Ho && ox < P.Wo && n < P.N) {
-        const int pix = oy * P.Wo + ox;
+    const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
+    const bool full_c = co_base + BN <= P.Cout;                  // uniform
+    const bool simple = P.res_mode == 0 && P.post_scale == nullptr && P.relu != 2;
+    const unsigned lo = valid ? (unsigned)((timg * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
+    float* obase = P.out + ((size_t)n0 * P.Cout + co_base) * HoWo;     // uniform
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+    for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co_base + 32 * h2 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < P.Cout) {
-                    float v = h2 ? acc1[r] : acc0[r];
-                    if (P.bias) v = v + P.bias[co];
-                    const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
-                    if (P.res_mode == 2) v = v + P.res[o];
+        for (int g = 0; g < 4; ++g) {
+            const int cu = 32 * h2 + 8 * g;                       // + 4*half (in `lo`) + e
+            const int co4 = co_base + cu + 4 * half;
+            float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (P.bias) {
+                if (full_c) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(P.bias + co4);
+                    b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = co4 + e < P.Cout ? P.bias[co4 + e] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = (h2 ? acc1[4 * g + e] : acc0[4 * g + e]) + b[e];
+                float* op = obase + (size_t)(cu + e) * HoWo;       // uniform
+                const bool ok = valid && (full_c || co4 + e < P.Cout);
+                if (simple) {
+                    if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+                } else {
+                    const int co = co4 + e;
+                    const float rv = (P.res_mode && ok) ? (P.res + ((size_t)n0 * P.Cout + co_base + cu + e) * HoWo)[lo] : 0.0f;
+                    if (P.res_mode == 2) v = v + rv;
                     if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
                     else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (P.res_mode == 1) v = v + P.res[o];
-                    if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
-                    P.out[o] = v;
+                    if (P.res_mode == 1) v = v + rv;
+                    if (P.post_scale && co < P.Cout) v = v * P.post_scale[co] + P.post_shift[co];
                 }
+                if (ok) op[lo] = v;
             }
         }
     }
