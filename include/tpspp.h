@@ -379,6 +379,21 @@ int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, const float* w_
                         const float* residual, int token_major, float* out, tpspp_stream_t stream);
 
 /*
+ * ResizeOCR + ToTensorOCR + NormalizeOCR on the GPU: N uint8 HWC crops of different
+ * sizes, packed in one device buffer, -> out (N, C, H, W) fp32.  Image n (src_h[n] x src_w[n] x C at
+ * src_packed + src_offsets[n]) is resized to H x resize_w[n] with OpenCV's 8-bit INTER_LINEAR arithmetic
+ * (11-bit fixed-point weights; INTER_AREA for an exact 2x2 shrink), columns >= resize_w[n] hold pad_value, and every
+ * byte v of channel c becomes lut[c*256 + v] (the caller tabulates (v/255 - mean[c]) / std[c] in fp32).
+ * The widths come from the host logic of ResizeOCR.__call__ (tps_pp_amd/ocr_transforms.py).
+ * PARITY UNPINNED against OpenCV (absent at build time); bit-exact against oracle/resize_oracle.py.
+ * replaces: mmocr/datasets/pipelines/ocr_transforms.py:67-156 (mmcv.imresize + mmcv.impad, TF.to_tensor, TF.normalize)
+ */
+int tpspp_resize_normalize_fwd(const unsigned char* src_packed, const long long* src_offsets,
+                               const int* src_h, const int* src_w, const int* resize_w,
+                               const float* lut, int pad_value, int N, int C, int H, int W,
+                               float* out, tpspp_stream_t stream);
+
+/*
  * flags bit of tpspp_nrtr_encoder_fwd / tpspp_nrtr_decoder_fwd (the bf16 configuration, BASELINE.json configs[4]):
  * the wide projections run on the bf16 matrix cores -- encoder: wqkv / fc / w1 / w2; decoder: the one-off key / value
  * projections of the encoder output -- and their entries of layer_ptrs then point to bf16 weights arranged as

@@ -1,0 +1,108 @@
+"""SURVEY.md section 8f row F4 (GPU ResizeOCR + ToTensorOCR + NormalizeOCR).
+
+CPU part: the host logic and the normalisation against the reference's own known answers
+(tests/test_dataset/test_ocr_transforms.py:13-57 of the reference) -- for the oracle and for the mirror;
+GPU part: the kernel bit for bit against the oracle on ragged batches.  The interpolation arithmetic itself is
+"parity unpinned" (OpenCV is not installed here): see oracle/resize_oracle.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import resize_oracle as RO
+from tps_pp_amd import NormalizeOCR, OCRBatchPreprocessor, ResizeOCR, synth
+
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]      # crnn_pp_pipeline.py:1
+
+
+def test_reference_known_answers_oracle_and_mirror():
+    # test_resize_ocr of the reference: ones (64, 256, 3), height 32, widths 32..160
+    img = np.ones((64, 256, 3), dtype=np.uint8)
+    out, p = RO.resize_ocr(img, 32, 32, 160, True)
+    m = ResizeOCR(32, min_width=32, max_width=160, keep_aspect_ratio=True).plan(img.shape)
+    for q in (p, m):
+        assert np.allclose([32, 160, 3], q["pad_shape"]) and math.isclose(q["valid_ratio"], 0.8)
+        assert q["resize_w"] == 128 and tuple(q["resize_shape"]) == (32, 128, 3)
+    assert out.shape == (32, 160, 3) and math.isclose(np.sum(out[:, 129:, :]), 0) and (out[:, :128] == 1).all()
+    assert math.isclose(RO.resize_plan(img.shape, 32, 32, 160, False)["valid_ratio"], 1)
+    assert math.isclose(ResizeOCR(32, min_width=32, max_width=160, keep_aspect_ratio=False).plan(img.shape)["valid_ratio"], 1)
+    # test_normalize / test_to_tensor of the reference
+    z = RO.to_tensor_normalize(np.zeros((10, 10, 3), dtype=np.uint8), [0.5] * 3, [0.5] * 3)
+    assert np.allclose(z, -1)
+    lut = NormalizeOCR([0.5] * 3, [0.5] * 3).table("cpu")
+    assert lut.shape == (3, 256) and float(lut[0, 0]) == -1.0 and float(lut[2, 255]) == 1.0
+    v = torch.arange(256, dtype=torch.float32).div(255)
+    assert torch.equal(NormalizeOCR(MEAN, STD).table("cpu")[1], (v - 0.456) / 0.224)
+
+
+def test_resize_plan_mirror_equals_oracle_on_many_shapes():
+    for keep in (True, False):
+        for h, w in [(19, 35), (25, 119), (64, 256), (31, 900), (48, 48), (7, 3), (32, 128), (100, 17)]:
+            for mn, mx in [(32, 128), (32, 160), (None, 128), (48, 100)]:
+                a = RO.resize_plan((h, w, 3), 32, mn, mx, keep)
+                b = ResizeOCR(32, min_width=mn, max_width=mx, keep_aspect_ratio=keep).plan((h, w, 3))
+                assert all(a[k] == b[k] for k in a), (keep, h, w, mn, mx, a, b)
+
+
+def test_constructor_assertions():
+    with pytest.raises(AssertionError):
+        ResizeOCR(32.0)
+    with pytest.raises(AssertionError):
+        ResizeOCR(32, keep_aspect_ratio=False)                 # max_width missing
+    with pytest.raises(AssertionError):
+        ResizeOCR((32, 48), min_width=32, max_width=128)
+
+
+def test_oracle_bilinear_properties():
+    g = np.random.default_rng(5)
+    img = g.integers(0, 256, (23, 57, 3), dtype=np.uint8)
+    assert np.array_equal(RO.imresize_bilinear_u8(img, (57, 23)), img)                     # same size: copy
+    c = np.full((9, 11, 3), 77, dtype=np.uint8)
+    assert (RO.imresize_bilinear_u8(c, (40, 32)) == 77).all()                              # constants stay constant
+    big = RO.imresize_bilinear_u8(img, (114, 46))
+    assert big.shape == (46, 114, 3) and big.min() >= img.min() and big.max() <= img.max() # convex weights
+    half = RO.imresize_bilinear_u8(big, (57, 23))                                          # exact 2x2 shrink: area mean
+    s = big.astype(np.int32)
+    assert np.array_equal(half, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2))
+
+
+def ragged_images(n, seed):
+    g = np.random.default_rng(seed)
+    shapes = [(64, 256), (19, 35), (25, 119), (32, 128), (31, 400), (48, 48), (7, 3), (100, 17), (33, 77), (16, 64)]
+    return [np.ascontiguousarray((synth.dyadic((h, w, 3), f"ocr.{seed}.{i}", seed) * 127.5 + 127.5).astype(np.uint8)
+                                 if i % 2 else g.integers(0, 256, (h, w, 3), dtype=np.uint8))
+            for i, (h, w) in enumerate((shapes * ((n + 9) // 10))[:n])]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep,mn,mx,pad", [(False, 32, 128, 0), (True, 32, 128, 0), (True, 32, 160, 7), (False, None, 100, 255)])
+def test_gpu_batch_preprocessor_equals_oracle(cuda, keep, mn, mx, pad):
+    imgs = ragged_images(23, 3)
+    pre = OCRBatchPreprocessor(ResizeOCR(32, min_width=mn, max_width=mx, keep_aspect_ratio=keep, img_pad_value=pad),
+                               NormalizeOCR(MEAN, STD), cuda)
+    out, metas = pre(imgs)
+    ref, plans = RO.preprocess_batch(imgs, 32, mn, mx, keep, pad, MEAN, STD)
+    assert out.dtype == torch.float32 and tuple(out.shape) == ref.shape
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    for m, p in zip(metas, plans):
+        assert m["valid_ratio"] == p["valid_ratio"] and tuple(m["resize_shape"]) == tuple(p["resize_shape"])
+        assert tuple(m["pad_shape"]) == tuple(p["pad_shape"])
+
+
+@pytest.mark.gpu
+def test_gpu_preprocessor_feeds_the_recogniser(cuda):
+    """Crops -> GPU preprocessing -> recogniser, equal to the oracle's preprocessing fed to the same recogniser."""
+    from test_gpu_head import build_recognizer
+    m = build_recognizer(cuda)
+    imgs = ragged_images(6, 8)
+    pre = OCRBatchPreprocessor(ResizeOCR(32, min_width=32, max_width=128, keep_aspect_ratio=False),
+                               NormalizeOCR(MEAN, STD), cuda)
+    x, metas = pre(imgs)
+    ref, _ = RO.preprocess_batch(imgs, 32, 32, 128, False, 0, MEAN, STD)
+    with torch.no_grad():
+        a = m(x, metas, return_loss=False)
+        b = m(torch.from_numpy(ref).to(cuda), [dict(mm) for mm in metas], return_loss=False)
+    assert [r["text"] for r in a] == [r["text"] for r in b]
+    with pytest.raises(ValueError):
+        OCRBatchPreprocessor(ResizeOCR(32, min_width=32, max_width=None), NormalizeOCR(MEAN, STD), cuda)(imgs)

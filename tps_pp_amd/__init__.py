@@ -16,7 +16,10 @@ from .nrtr_head import (NRTREncoder, NRTRDecoder, AttnConvertor, BaseConvertor, 
                         EncodeDecodeRecognizer, NRTR, TFEncoderLayer, TFDecoderLayer, MultiHeadAttention,
                         PositionwiseFeedForward, PositionalEncoding)
 
-__all__ = ["BACKBONES", "PREPROCESSOR", "build_backbone", "build_preprocessor",
+from .ocr_transforms import PIPELINES, ResizeOCR, NormalizeOCR, OCRBatchPreprocessor  # noqa: F401
+
+__all__ = ["PIPELINES", "ResizeOCR", "NormalizeOCR", "OCRBatchPreprocessor",
+           "BACKBONES", "PREPROCESSOR", "build_backbone", "build_preprocessor",
            "register_into_mmocr", "TPSPreprocessor", "LocalizationNetwork", "GridGenerator",
            "TPS_PP", "Attention_Enhanced_TPS", "ResNetABI_v2_large", "BasicBlock",
            "NRTRModalityTransform", "ENCODERS", "DECODERS", "CONVERTORS", "DETECTORS", "build_encoder",

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "tpspp_layernorm_cm_fwd": ([_f, _f, _f, _i, _i, ctypes.c_float, _f, _f], _i),
     "tpspp_attn_enc_fwd": ([_f, _i, _i, _i, _f, _f, _f], _i),
     "tpspp_linear_ln_fwd": ([_f, _i, _i, ctypes.c_float, _f, _f, _i, _f, _i, _f, _i, _f, _f], _i),
+    "tpspp_resize_normalize_fwd": ([_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f], _i),
     "tpspp_nrtr_encoder_workspace": ([_i, _i, _i, _i], ctypes.c_size_t),
     "tpspp_nrtr_decoder_workspace": ([_i] * 7, ctypes.c_size_t),
     "tpspp_nrtr_encoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, ctypes.c_size_t, _f, _f, _i, _f], _i),

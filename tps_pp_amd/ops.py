@@ -844,6 +844,26 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_fol
     return out, tokens
 
 
+def resize_normalize(packed, offsets, src_h, src_w, resize_w, lut, pad_value, N, C, H, W):
+    """`tpspp_resize_normalize_fwd`: packed uint8 HWC images -> (N, C, H, W) fp32 (ocr_transforms.py:67-156)."""
+    for name, t, dt in (("packed", packed, torch.uint8), ("offsets", offsets, torch.int64), ("src_h", src_h, torch.int32),
+                        ("src_w", src_w, torch.int32), ("resize_w", resize_w, torch.int32), ("lut", lut, torch.float32)):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise _lib.TpsppError(f"resize_normalize: {name} must be a GPU tensor (no CPU fallback)")
+        if t.dtype != dt or not t.is_contiguous():
+            raise TypeError(f"resize_normalize: {name} must be a contiguous {dt} tensor")
+    if offsets.numel() != N or src_h.numel() != N or src_w.numel() != N or resize_w.numel() != N or \
+            tuple(lut.shape) != (C, 256):
+        raise ValueError("resize_normalize: per-image arrays need N entries, lut must be (C, 256)")
+    out = torch.empty((N, C, H, W), device=packed.device, dtype=torch.float32)
+    with torch.cuda.device(packed.device):
+        rc = _lib.lib().tpspp_resize_normalize_fwd(_ptr(packed), _ptr(offsets), _ptr(src_h), _ptr(src_w), _ptr(resize_w),
+                                                   _ptr(lut), int(pad_value), int(N), int(C), int(H), int(W), _ptr(out),
+                                                   _stream(packed))
+    _lib.check(rc, "tpspp_resize_normalize_fwd")
+    return out
+
+
 # ---- backward of the fused warp (SURVEY.md section 8f, row F2) ------------------------------------------------
 def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
                   g_out1=None, P_hat_t=None, need_in0=True, need_in1=True, need_score=True):
