@@ -117,3 +117,30 @@ def test_config3_and_4_backbone_and_strings_256_per_gpu(cuda):
     o = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[PICK[:2]], [widths[i] for i in PICK[:2]])
     assert np.abs(feat_small[:2].cpu().numpy() - o["feat"].numpy()).max() <= TOL
     assert [r["text"] for r in res_small[:2]] == o["text"]
+
+
+def test_config3_and_4_bf16_256_per_gpu(cuda):
+    """BASELINE.json configs[3] / [4] in the bf16 configuration at 256 images per GPU: backbone + TPS++ convolutions and
+    the head's wide projections on the bf16 matrix cores.  Rows of the full batch equal the same images run as a small
+    batch (feature map bit for bit: every layer takes the same kernel at both sizes; strings identical); the feature
+    map stays within bf16 resolution of the fp32 CPU oracle's and the strings of the checked images are the oracle's."""
+    m = build_recognizer(cuda)
+    m.backbone.compute_dtype = m.encoder.compute_dtype = m.decoder.compute_dtype = torch.bfloat16
+    n = 256
+    img = tile_batch(synth.smooth_image((8, 3, 32, 128), "cfg34.img", 3), n)
+    widths = [128 if i % 3 else 96 for i in range(n)]
+    metas = [dict(resize_shape=(32, w, 3)) for w in widths]
+    with torch.no_grad():
+        feat_full = m.extract_feat(dev(img, cuda), test=True)["output"]
+        res_full = m(dev(img, cuda), [dict(mm) for mm in metas], return_loss=False)
+        feat_small = m.extract_feat(dev(img[PICK], cuda), test=True)["output"]
+        res_small = m(dev(img[PICK], cuda), [dict(metas[i]) for i in PICK], return_loss=False)
+    assert feat_full.shape == (n, 512, 4, 16) and feat_full.dtype == torch.float32
+    assert (feat_full[PICK] - feat_small).abs().max() <= 2e-3 * feat_small.abs().max()
+    assert [res_full[i]["text"] for i in PICK] == [r["text"] for r in res_small]
+    sds = [{k: v.cpu() for k, v in mod.state_dict().items()} for mod in (m.backbone, m.tpsnet, m.encoder, m.decoder)]
+    o = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[PICK[:2]], [widths[i] for i in PICK[:2]])
+    ref = o["feat"].numpy()
+    err = np.abs(feat_small[:2].cpu().numpy() - ref)
+    assert err.max() <= 0.05 * np.abs(ref).max() and err.mean() <= 0.005 * np.abs(ref).max()
+    assert [r["text"] for r in res_small[:2]] == o["text"]

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--check", type=int, default=4, help="images decoded by the CPU oracle as well")
     ap.add_argument("--checkpoint", default=None)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--bf16", action="store_true",
+                    help="BASELINE.json configs[4]: backbone / TPS++ convolutions and the head's wide projections on the "
+                         "bf16 matrix cores (control points, TPS solve, grid, per-step decoder projections stay fp32)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -54,6 +57,8 @@ def main():
     cpu_sds = [{k: v.clone() for k, v in m.state_dict().items()}
                for m in (model.backbone, model.tpsnet, model.encoder, model.decoder)]
     model.to(dev)
+    if a.bf16:
+        model.backbone.compute_dtype = model.encoder.compute_dtype = model.decoder.compute_dtype = torch.bfloat16
 
     # IC15-shaped synthetic crops, test_pipeline normalisation (crnn_pp_pipeline.py: mean/std of ImageNet)
     n = a.batch
@@ -82,13 +87,31 @@ def main():
         res = tdist.recognize_sharded(decode_local, n, model.label_convertor)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
+    if rank == 0 and a.bf16:
+        # random-init weights decode 40 characters of noise autoregressively: one flipped arg-max rewrites the rest of
+        # the string.  The per-position figure: feed the fp32 model's own tokens (teacher forcing) to the bf16 model and
+        # count the positions whose arg-max is still the fp32 token.
+        k2 = min(64, n)
+        metas = [dict(resize_shape=(32, widths[i], 3), valid_ratio=widths[i] / 128) for i in range(k2)]
+        x = img[:k2].to(dev)
+        with torch.no_grad():
+            model.backbone.compute_dtype = model.encoder.compute_dtype = model.decoder.compute_dtype = None
+            f32 = model.extract_feat(x, test=True)["output"]
+            model.decoder(f32, model.encoder(f32, metas), None, metas, train_mode=False)
+            tok = model.decoder.last_tokens.clone()                                   # (k2, 41): <start>, 40 predictions
+            model.backbone.compute_dtype = model.encoder.compute_dtype = model.decoder.compute_dtype = torch.bfloat16
+            f16 = model.extract_feat(x, test=True)["output"]
+            logits = model.decoder(f16, model.encoder(f16, metas), dict(padded_targets=tok[:, :40]), metas, train_mode=True)
+        agree = (logits.argmax(-1) == tok[:, 1:41].to(logits.device)).float().mean().item()
+        print(f"bf16 vs fp32 (HIP), teacher-forced on {k2} images: {100 * agree:.2f} % of the {k2 * 40} positions keep "
+              f"their arg-max")
     if rank == 0:
         from oracle import tpspp_oracle as TO                  # checker only
         k = min(a.check, n)
         want = TO.recognizer_simple_test(cpu_sds[0], cpu_sds[1], cpu_sds[2], cpu_sds[3], img[:k].numpy(), widths[:k])["text"]
         got = [r["text"] for r in res[:k]]
         acc = metrics.eval_ocr_metric(got, want, all_metrics=True)
-        print(f"ranks {world}, batch {n}: {n / dt:,.0f} images/s end to end (incl. host->device copy and the "
+        print(f"ranks {world}, batch {n}, {'bf16' if a.bf16 else 'fp32'}: {n / dt:,.0f} images/s end to end (incl. host->device copy and the "
               f"all-gather); parity vs CPU oracle on {k} images: word_acc {acc['word_acc']:.4f}, "
               f"1-N.E.D {acc['1-N.E.D']:.4f}")
         print("sample:", got[:2])
