@@ -443,10 +443,13 @@ void launch_wide(const ConvParams& P, hipStream_t st)
 // MFMA operands (both are k-major, so a fragment is two 128-B rows per load instruction; no LDS
 // staging, all loads of a wavefront in flight together), the four partial tiles are summed through
 // LDS and every wavefront finishes a quarter of the tile (bias / activation / residual as above).
-__global__ void __launch_bounds__(kThreads)
+// NW wavefronts split K (4, or 16 for K >= 256: the kernel is one dependent chain per wavefront -- operand rows from
+// L2, then K/NW/2 dependent 64-cycle MFMAs --, so a 4x shorter chain is worth the larger reduction).
+template <int NW>
+__global__ void __launch_bounds__(NW * kWave)
 conv1x1_skinny_f32_kernel(const ConvParams P)
 {
-    __shared__ float sRed[4][16][kWave];
+    __shared__ float sRed[NW][16][kWave];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -455,7 +458,7 @@ conv1x1_skinny_f32_kernel(const ConvParams P)
     const int HoWo = P.Ho * P.Wo;
     const int m0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int K = P.Cin;
-    const int Kw = ((K + 7) / 8) * 2;                  // k values per wavefront (even)
+    const int Kw = ((K + 2 * NW - 1) / (2 * NW)) * 2;  // k values per wavefront (even)
     const int k_lo = wv * Kw;
     const int k_hi = min(K, k_lo + Kw);
     const int pix = m0 + l31, co = co0 + l31;
@@ -487,14 +490,17 @@ conv1x1_skinny_f32_kernel(const ConvParams P)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
     __syncthreads();
-    // wavefront w finishes registers [4w, 4w+4): channels co0 + {0..3} + 8w + 4*half
-    if (!pix_ok) return;
+    // wavefront w < 4 finishes registers [4w, 4w+4): channels co0 + {0..3} + 8w + 4*half
+    if (!pix_ok || wv >= 4) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = 4 * wv + q;
         const int c = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (c < P.Cout) {
             float v = (sRed[0][r][lane] + sRed[1][r][lane]) + (sRed[2][r][lane] + sRed[3][r][lane]);
+#pragma unroll
+            for (int j = 4; j < NW; j += 4)
+                v += (sRed[j][r][lane] + sRed[j + 1][r][lane]) + (sRed[j + 2][r][lane] + sRed[j + 3][r][lane]);
             if (P.bias) v = v + P.bias[c];
             const size_t o = ((size_t)n * P.Cout + c) * HoWo + pix;
             if (P.res_mode == 2) v = v + P.res[o];
@@ -523,12 +529,12 @@ struct LnArgs {
     float eps;
 };
 
-template <bool LN_ON_A>
-__global__ void __launch_bounds__(kThreads)
+template <bool LN_ON_A, int NW>
+__global__ void __launch_bounds__(NW * kWave)
 conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
 {
-    __shared__ float sRed[4][16][kWave];
-    __shared__ float sSum[8][32], sSq[8][32];
+    __shared__ float sRed[NW][16][kWave];
+    __shared__ float sSum[2 * NW][32], sSq[2 * NW][32];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -537,7 +543,7 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
     const int HoWo = P.Ho * P.Wo;
     const int m0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int K = P.Cin;
-    const int Kw = ((K + 7) / 8) * 2;
+    const int Kw = ((K + 2 * NW - 1) / (2 * NW)) * 2;
     const int k_lo = wv * Kw;
     const int k_hi = min(K, k_lo + Kw);
     const int pix = m0 + l31, co = co0 + l31;
@@ -577,12 +583,12 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
     sSum[wv * 2 + half][l31] = s1;
     sSq[wv * 2 + half][l31] = s2;
     __syncthreads();
-    if (!pix_ok) return;
+    if (!pix_ok || wv >= 4) return;
     float mean_l = 0.0f, rstd_l = 0.0f;
     if (!LN_ON_A) {                                        // statistics of this lane's pixel column
         float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { t1 += sSum[j][l31]; t2 += sSq[j][l31]; }
+        for (int j = 0; j < 2 * NW; ++j) { t1 += sSum[j][l31]; t2 += sSq[j][l31]; }
         mean_l = t1 / (float)K;
         rstd_l = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean_l * mean_l, 0.0f) + L.eps);
     }
@@ -596,7 +602,7 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
             if (LN_ON_A) {                                 // statistics belong to the ROW (a column of x)
                 float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { t1 += sSum[j][cl]; t2 += sSq[j][cl]; }
+                for (int j = 0; j < 2 * NW; ++j) { t1 += sSum[j][cl]; t2 += sSq[j][cl]; }
                 mean = t1 / (float)K;
                 rstd = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean * mean, 0.0f) + L.eps);
                 csum = L.colsum[pix];
@@ -604,6 +610,9 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
                 csum = L.colsum[c];
             }
             float val = (sRed[0][r][lane] + sRed[1][r][lane]) + (sRed[2][r][lane] + sRed[3][r][lane]);
+#pragma unroll
+            for (int j = 4; j < NW; j += 4)
+                val += (sRed[j][r][lane] + sRed[j + 1][r][lane]) + (sRed[j + 2][r][lane] + sRed[j + 3][r][lane]);
             val = rstd * (val - mean * csum);
             if (P.bias) val = val + P.bias[LN_ON_A ? pix : c];
             const size_t o = ((size_t)n * P.Cout + c) * HoWo + pix;
@@ -628,7 +637,8 @@ bool skinny_applies(const ConvParams& P, int KH)
 void launch_skinny(const ConvParams& P, hipStream_t st)
 {
     const dim3 grid((unsigned)((P.Ho * P.Wo + 31) / 32), (unsigned)((P.Cout + 31) / 32), (unsigned)P.N);
-    hipLaunchKernelGGL(conv1x1_skinny_f32_kernel, grid, dim3(kThreads), 0, st, P);
+    if (P.Cin >= 256) hipLaunchKernelGGL(conv1x1_skinny_f32_kernel<16>, grid, dim3(16 * kWave), 0, st, P);
+    else              hipLaunchKernelGGL(conv1x1_skinny_f32_kernel<4>, grid, dim3(4 * kWave), 0, st, P);
 }
 
 template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1>
@@ -784,13 +794,15 @@ TPSPP_EXPORT int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, co
         P.src[1] = P.src[0]; P.src[2] = P.src[0];
         const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Cout + 31) / 32), 1);
         TPSPP_REQUIRE(grid.y <= 65535, "tpspp_linear_ln_fwd: too many output features");
-        hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false>), grid, dim3(kThreads), 0, st, P, L);
+        if (K >= 256) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false, 16>), grid, dim3(16 * kWave), 0, st, P, L);
+        else          hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false, 4>), grid, dim3(4 * kWave), 0, st, P, L);
     } else {                               // out (M, Cout): the weight plays the image, x the weights
         P.src[0].p = w_gamma; P.src[0].W = Cout; P.Wi = Cout; P.Wo = Cout; P.Cout = M; P.wt = x;
         P.src[1] = P.src[0]; P.src[2] = P.src[0];
         const dim3 grid((unsigned)((Cout + 31) / 32), (unsigned)((M + 31) / 32), 1);
         TPSPP_REQUIRE(grid.y <= 65535, "tpspp_linear_ln_fwd: too many columns");
-        hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true>), grid, dim3(kThreads), 0, st, P, L);
+        if (K >= 256) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true, 16>), grid, dim3(16 * kWave), 0, st, P, L);
+        else          hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true, 4>), grid, dim3(4 * kWave), 0, st, P, L);
     }
     return tpspp::check_launch("tpspp_linear_ln_fwd");
 }
