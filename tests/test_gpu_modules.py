@@ -85,6 +85,25 @@ def test_tpspp_module_against_reference(cuda, variant, fname):
     assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])
 
 
+def test_classic_module_bf16_localisation(cuda):
+    """TPSPreprocessor with the localisation network's convolutions on the bf16 matrix cores
+    (`LocalizationNetwork.compute_dtype`): control points and the rectified image against the reference's fp32 run
+    (golden G1) at bf16 resolution -- the warp itself stays the fp32 kernel."""
+    G = cases.load("classic_module")
+    m = TPSPreprocessor(num_fiducial=cases.CL_F, img_size=cases.CL_HW,
+                        rectified_img_size=cases.CL_HW, num_img_channel=3).eval()
+    sd = cases.synth_state(m.state_dict(), 1, cases.g1_state_rule, cases.G1_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    m.LocalizationNetwork.compute_dtype = torch.bfloat16
+    img = dev(cases.g1_inputs()["img"], cuda)
+    with torch.no_grad():
+        ctrl = m.LocalizationNetwork(img)
+        out = m(img)
+    assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() <= 5e-3
+    assert np.abs(out.cpu().numpy() - G["out"]).mean() <= 5e-3 * np.abs(G["out"]).max()
+
+
 @pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"), ("ResNet45", "tpspp_module_v1")])
 def test_tpspp_module_bf16(cuda, variant, fname):
     """The bf16 configuration (bf16 inputs -> bf16 MFMA convolutions, fp32 from the control points on) against

@@ -75,6 +75,19 @@ class LocalizationNetwork(nn.Module):
             self._cw_cache = cache = (key, cw)
         return cache[1]
 
+    def _hip_weights_bf16(self):
+        mods = [self.conv[i] for i in (0, 1, 4, 5, 8, 9, 12, 13)]
+        key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        cache = getattr(self, "_cw16_cache", None)
+        if cache is None or cache[0] != key:
+            cw = []
+            for ci, bi in ((0, 1), (4, 5), (8, 9), (12, 13)):
+                bn = self.conv[bi]
+                cw.append(ops.prep_conv_weight_bf16(self.conv[ci].weight, eps=bn.eps,
+                                                    bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var)))
+            self._cw16_cache = cache = (key, cw)
+        return cache[1]
+
     def forward(self, batch_img):
         """fp32 MFMA convolutions with BatchNorm folded in, HIP pooling kernels, the two FCs as 1x1
         convolutions over the batch.  No CPU / library-kernel path."""
@@ -82,6 +95,15 @@ class LocalizationNetwork(nn.Module):
         n = batch_img.size(0)
         cw = self._hip_weights()
         x = batch_img.float().contiguous()
+        if getattr(self, "compute_dtype", None) == torch.bfloat16:
+            # bf16 configuration: the four convolutions on the bf16 matrix cores (fp32 maps in and out: operands are
+            # rounded as they are staged, accumulation / bias / ReLU fp32); pooling and the two FCs stay fp32
+            c16 = self._hip_weights_bf16()
+            for i in range(3):
+                x = ops.maxpool2x2(ops.conv2d_bf16([x], c16[i], 1, True, out_dtype=torch.float32))
+            x = ops.global_avgpool(ops.conv2d_bf16([x], c16[3], 1, True, out_dtype=torch.float32))
+            x = ops.linear(x, cw[4], relu=True)
+            return ops.linear(x, cw[5], relu=False).view(n, self.num_fiducial, 2)
         for i in range(3):
             x = ops.maxpool2x2(ops.conv2d([x], cw[i], 1, True))
         x = ops.global_avgpool(ops.conv2d([x], cw[3], 1, True))
