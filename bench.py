@@ -132,6 +132,11 @@ def extra_measurements(dev):
         t_bwd = timeit(lambda: ops.warp_backward(g0, fgc, grid, cp, at.hat_C, at.P_hat, (16, 64), P_xy=P_xy, score=sc,
                                                  in1=x, g_out1=g1, P_hat_t=P_hat_t), 10, 3)
         del g0, g1, grid, fgc
+        # the same fp32 tensors with the three-term bf16 split in the convolutions ("bf16x3": within the 1e-4 bar,
+        # tests/test_gpu_modules.py::test_tpspp_module_bf16x3_meets_the_fp32_bar)
+        m.compute_dtype = "bf16x3"
+        t_x3 = timeit(lambda: m(x, [o0, o1]), 10, 4)
+        m.compute_dtype = None
         # BASELINE.json configs[2]: the same module at batch 1024 on bf16 activations (bf16 MFMA convolutions;
         # control points, TPS solve, grid and sampling stay fp32)
         n2 = 1024
@@ -153,6 +158,9 @@ def extra_measurements(dev):
                                                   "kernels": "warp_bwd_sample_lds_kernel + warp_bwd_params_kernel<36>"},
             "tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
                                            "gflop_per_image": 0.82},
+            "tpspp_module_batch512_bf16x3": {"images_per_s": n / (t_x3 * 1e-3), "ms_per_batch": t_x3,
+                                             "note": "fp32 tensors, convolution products as hi*hi + hi*lo + lo*hi of bf16 "
+                                                     "halves: within 1e-4 of the reference"},
             "tpspp_module_batch1024_bf16": {"images_per_s": n2 / (t_bf16 * 1e-3), "ms_per_batch": t_bf16,
                                             "gflop_per_image": 0.82,
                                             "note": "BASELINE.json configs[2]: bf16 tensors at the module boundary"},
@@ -191,6 +199,12 @@ def recognizer_measurement(dev, timeit):
         t_dec = timeit(lambda: m.decoder(feat, out_enc, None, None, train_mode=False), 3, 1)
         k = 4
         got = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+        # fp32 tensors, three-term bf16 split in every wide matrix product (within 1e-4: strings must not change)
+        m.backbone.compute_dtype = m.tpsnet.compute_dtype = m.encoder.compute_dtype = m.decoder.compute_dtype = "bf16x3"
+        t_allx3 = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
+        t_featx3 = timeit(lambda: m.extract_feat(img, test=True), 3, 1)
+        gotx3 = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
+        m.tpsnet.compute_dtype = m.encoder.compute_dtype = m.decoder.compute_dtype = None
         # BASELINE.json configs[4]: backbone + TPS++ convolutions on the bf16 matrix cores (head stays fp32)
         m.backbone.compute_dtype = torch.bfloat16
         t_all16 = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
@@ -209,6 +223,8 @@ def recognizer_measurement(dev, timeit):
     return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
             "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
             "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
+            "bf16x3": {"images_per_s": n / (t_allx3 * 1e-3), "ms_per_batch": t_allx3, "ms_backbone_tpspp": t_featx3,
+                       "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(gotx3, want))}/{k}"},
             "bf16_backbone": {"images_per_s": n / (t_all16 * 1e-3), "ms_per_batch": t_all16,
                               "ms_backbone_tpspp": t_feat16,
                               "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(got16, want))}/{k}"},

@@ -299,6 +299,10 @@ int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
  *   residual         (N, Cout, Ho, Wo), fp32 when residual_f32 else bf16, or NULL; res_mode as above
  *   relu             0 none, 1 ReLU, 2 GELU (exact erf form)
  *   out              (N, Cout, Ho, Wo), fp32 when out_f32 else bf16 (round to nearest even)
+ *   split3           "bf16x3": every fp32 operand is split into bf16 halves (hi = bf16(x), lo = bf16(x - hi)) and a
+ *                    product is hi*hi + hi*lo + lo*hi in fp32: ~5e-6 relative error per layer (fp32: 3e-7, bf16:
+ *                    2.5e-3) at three bf16 matrix instructions.  weight_arranged then holds TWO slabs per chunk,
+ *                    [Cout/64][Cin/KC][hi|lo][KH*KW][KC/8][64][8]; fp32 sources are split as they are staged
  * replaces: the call sites listed for tpspp_conv2d_fwd when the module runs in bf16.
  */
 int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* src_dims, int nsrc,
@@ -306,7 +310,7 @@ int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* src_dims, int 
                           const void* residual, int residual_f32,
                           const float* post_scale, const float* post_shift,
                           int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
-                          void* out, int out_f32, int Ho, int Wo, tpspp_stream_t stream);
+                          void* out, int out_f32, int Ho, int Wo, int split3, tpspp_stream_t stream);
 
 /* Channels per K-chunk of the bf16 conv kernel for a 1x1 / 3x3 kernel (layout of weight_arranged). */
 int tpspp_conv_bf16_chunk_channels(int kernel_size);
@@ -402,6 +406,10 @@ int tpspp_resize_normalize_fwd(const unsigned char* src_packed, const long long*
  * classifier stay fp32.
  */
 #define TPSPP_HEAD_BF16 1
+/* The same projections with the "bf16x3" split of tpspp_conv2d_bf16_fwd (fp32 tensors, ~5e-6 per layer): encoder wqkv / fc /
+ * w1 / w2 and the decoder's key projection of the encoder output; their layer_ptrs entries point to hi+lo arranged weights.
+ * Keys / values stay fp32. */
+#define TPSPP_HEAD_BF16X3 2
 
 /* Scratch sizes (bytes) for the two calls below; 0 on bad arguments. */
 size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner);

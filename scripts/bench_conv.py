@@ -49,10 +49,13 @@ for name, cin, h, w, cout, k, st in SHAPES:
     cwb = ops.prep_conv_weight_bf16(wgt, conv_bias=b)
     xb = x.to(torch.bfloat16)
     t_b16 = timeit(lambda: ops.conv2d_bf16([xb], cwb, st, True))
+    cw3 = ops.prep_conv_weight_bf16(wgt, conv_bias=b, x3=True)          # bf16x3 on fp32 tensors
+    t_x3 = timeit(lambda: ops.conv2d_bf16([x], cw3, st, True, out_dtype=torch.float32))
     with torch.no_grad():
         wb, bb = wgt.to(torch.bfloat16), b.to(torch.bfloat16)
         t_tb16 = timeit(lambda: F.relu(F.conv2d(xb, wb, bb, stride=st, padding=(k - 1) // 2)))
     print(f"{name:36s} fp32 ours {t_ours:7.3f} ms {flop / t_ours / 1e9:6.1f} TF | torch {t_torch:7.3f} ms {flop / t_torch / 1e9:6.1f} TF"
+          f" || bf16x3 {t_x3:7.3f} ms {flop / t_x3 / 1e9:6.1f} TF"
           f" || bf16 ours {t_b16:7.3f} ms {flop / t_b16 / 1e9:6.1f} TF | torch {t_tb16:7.3f} ms {flop / t_tb16 / 1e9:6.1f} TF")
     tot_ours += t_ours
     tot_torch += t_torch

@@ -42,3 +42,14 @@ with torch.no_grad():
     t_dec = timeit(lambda: m.decoder(feat, out_enc, None, None, train_mode=False))
 print(f"NRTR+TPS++ batch {N}: simple_test {t_all:.1f} ms = {N / t_all * 1e3:,.0f} img/s | backbone+TPS++ {t_feat:.1f} ms | "
       f"encoder {t_enc:.2f} ms | greedy decoder (40 steps) {t_dec:.1f} ms")
+for tag, bb, hd in (("bf16x3 backbone/TPS++ (fp32 tensors, <= 1e-4)", "bf16x3", None),
+                    ("bf16x3 backbone/TPS++ and head (fp32 tensors, <= 1e-4)", "bf16x3", "bf16x3"),
+                    ("bf16 backbone/TPS++", torch.bfloat16, None),
+                    ("bf16 backbone/TPS++ and head", torch.bfloat16, torch.bfloat16)):
+    m.backbone.compute_dtype = bb
+    m.tpsnet.compute_dtype = bb if bb == "bf16x3" else None
+    m.encoder.compute_dtype = m.decoder.compute_dtype = hd
+    with torch.no_grad():
+        t_all = timeit(lambda: m(img, metas, return_loss=False))
+        t_feat = timeit(lambda: m.extract_feat(img, test=True))
+    print(f"  {tag}: simple_test {t_all:.1f} ms = {N / t_all * 1e3:,.0f} img/s | backbone+TPS++ {t_feat:.1f} ms")

@@ -45,6 +45,13 @@ with torch.no_grad():
     t_warp = timeit(lambda: m.rectify(fg, x, cp, sc))
 print(f"TPS_PP batch {N}: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | regressor {t_reg:.2f} ms "
       f"({0.82 * N / t_reg:.1f} TFLOP/s) | warp {t_warp * 1e3:.0f} us")
+m.compute_dtype = "bf16x3"        # fp32 tensors, three-term bf16 split in the convolutions (within 1e-4 of the reference)
+with torch.no_grad():
+    timeit(lambda: m(x, [o0, o1]), iters=3)
+    t_reg3 = timeit(lambda: m.regress(x, [o0, o1]))
+    t_full3 = timeit(lambda: m(x, [o0, o1]))
+print(f"TPS_PP batch {N} bf16x3: full {t_full3:.2f} ms = {N / t_full3 * 1e3:,.0f} img/s | regressor {t_reg3:.2f} ms")
+m.compute_dtype = None
 p = TPSPreprocessor(20, (32, 100), (32, 100), 3).eval().to(dev)
 img = torch.rand(N, 3, 32, 100, device=dev)
 with torch.no_grad():

@@ -143,3 +143,32 @@ def test_front_bf16_fused_against_cpu_reference(cuda, fg_dtype):
     scale = float(fg.abs().max())
     assert float((got - fg).abs().max()) <= 2.0 ** -7 * scale
     assert float((got - fg).abs().mean()) <= (2e-3 if fg_dtype == "bf16" else 2e-4) * scale
+
+
+@pytest.mark.parametrize("name,srcs,cout,k,stride,relu,res_mode,res_dt,N", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16x3_matches_fp32_reference(cuda, name, srcs, cout, k, stride, relu, res_mode, res_dt, N):
+    """split3 ("bf16x3": hi*hi + hi*lo + lo*hi on fp32 tensors): against float64 PyTorch-CPU on the UNROUNDED fp32
+    operands, to 2e-5 of the tensor's scale (plain bf16 sits at 2.5e-3, the fp32 MFMA kernel at 3e-7)."""
+    xs = [(t(synth.dyadic((N, c, h, w), f"{name}.x{i}", 1)), uh, uw) for i, (c, h, w, uh, uw, _) in enumerate(srcs)]
+    cin = sum(s_[0] for s_ in srcs)
+    w = t(synth.dyadic((cout, cin, k, k), name + ".w", 1, 1.0 / np.sqrt(cin * k * k)))
+    b = t(synth.dyadic((cout,), name + ".b", 1, 0.1))
+
+    def ref_fp(res):
+        xi = [F.interpolate(x.double(), scale_factor=(uh, uw), mode="nearest") if (uh, uw) != (1, 1) else x.double()
+              for x, uh, uw in xs]
+        y = F.conv2d(torch.cat(xi, 1), w.double(), b.double(), stride=stride, padding=(k - 1) // 2)
+        if res_mode == 2:
+            y = y + res.double()
+        if relu:
+            y = F.relu(y)
+        if res_mode == 1:
+            y = y + res.double()
+        return y.float()
+    res = t(synth.dyadic(tuple(ref_fp(torch.zeros(1)).shape if not res_mode else ref_conv(xs, w, b, k, stride, relu, None, 0).shape),
+                         name + ".r", 1)) if res_mode else None
+    ref = ref_fp(res)
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda), x3=True)
+    got = ops.conv2d_bf16([(x.to(cuda), uh, uw) for x, uh, uw in xs], cw, stride, relu,
+                          None if res is None else res.to(cuda), res_mode, out_dtype=torch.float32).cpu()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), name

@@ -234,6 +234,22 @@ def test_recognizer_bf16_backbone_against_reference(cuda):
     assert np.abs(np.array(res16[0]["score"], dtype=np.float32) - G["score0"]).max() <= 2e-2
 
 
+def test_recognizer_bf16x3_against_reference(cuda):
+    """The "bf16x3" configuration end to end (fp32 tensors, three-term bf16 split in the backbone / TPS++ convolutions
+    and the head's wide projections): the north-star's 1e-4 bar against the reference's fp32 run (golden G12)."""
+    G = cases.load("recognizer_e2e")
+    m = build_recognizer(cuda)
+    m.backbone.compute_dtype = m.tpsnet.compute_dtype = m.encoder.compute_dtype = m.decoder.compute_dtype = "bf16x3"
+    img = dev(cases.g12_inputs()["img"], cuda)
+    metas = [dict(resize_shape=(32, w, 3)) for w in cases.G12_WIDTHS]
+    with torch.no_grad():
+        res = m(img, metas, return_loss=False)
+        feat = m.extract_feat(img, test=True)["output"]
+    assert np.abs(feat.cpu().numpy()[:, ::8] - G["feat_sub"]).max() <= TOL
+    assert [r["text"] for r in res] == [str(s) for s in G["text"]]
+    assert np.abs(np.array(res[0]["score"], dtype=np.float32) - G["score0"]).max() <= TOL
+
+
 def test_head_bf16_flag_against_fp32_head(cuda):
     """TPSPP_HEAD_BF16 on the small head (odd sizes, key masks): encoder output and decoder probabilities against
     the fp32 HIP head at bf16 resolution; greedy tokens identical."""

@@ -85,6 +85,28 @@ def test_tpspp_module_against_reference(cuda, variant, fname):
     assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])
 
 
+@pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"), ("ResNet45", "tpspp_module_v1")])
+def test_tpspp_module_bf16x3_meets_the_fp32_bar(cuda, variant, fname):
+    """`compute_dtype = "bf16x3"` (fp32 tensors, three-term bf16 split in the convolutions) against the reference's
+    outputs with the SAME tolerances as the exact-fp32 path (test_tpspp_module_against_reference)."""
+    G = cases.load(fname)
+    m = build_backbone(dict(type="TPS_PP", variant=variant)).eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    m.compute_dtype = "bf16x3"
+    inp = cases.g4_inputs(variant)
+    x, outs = dev(inp["x"], cuda), [dev(o, cuda) for o in inp["outs"]]
+    with torch.no_grad():
+        ctrl, score, _ = m.regress(x, outs)
+        res = m(x, outs)
+    assert res["output"].dtype == torch.float32
+    assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 2e-5
+    assert np.abs(score.cpu().numpy() - G["pc_score"]).max() < 1e-4
+    assert np.abs(res["mp_img"].cpu().numpy() - G["mp_img"]).max() <= TOL
+    assert np.abs(res["output"].cpu().numpy() - G["output"]).max() <= TOL
+
+
 def test_classic_module_bf16_localisation(cuda):
     """TPSPreprocessor with the localisation network's convolutions on the bf16 matrix cores
     (`LocalizationNetwork.compute_dtype`): control points and the rectified image against the reference's fp32 run

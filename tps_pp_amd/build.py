@@ -36,20 +36,42 @@ def _stale():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per .hip file (compiled in parallel, rebuilt only when that file or a header changed), then one link."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libtpspp_hip.so")
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, ".build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(ROOT, "include", "tpspp.h"), os.path.abspath(__file__)]
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+    cflags = [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj, None
+        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return obj, (r.returncode, r.stdout)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(compile_one, sources()))
+    for obj, res in results:
+        if res is not None and res[0] != 0:
+            raise RuntimeError("hipcc failed:\n" + res[1])
+        if verbose and res is not None and res[1].strip():
+            print(res[1])
     tmp = LIB + ".tmp"
-    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC] + sources() + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden"] + [o for o, _ in results] + ["-o", tmp]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout)
-    if verbose and r.stdout.strip():
-        print(r.stdout)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout)
     os.replace(tmp, LIB)
     return LIB
 

@@ -103,7 +103,12 @@ struct BCfg {
     static constexpr int NW = (WSLAB + kThreads - 1) / kThreads;
 };
 
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
+// X3: "bf16x3" -- every fp32 operand is split into two bf16 halves (hi = bf16(x), lo = bf16(x - hi)) and a product
+// is hi*hi + hi*lo + lo*hi, accumulated in fp32: 16-17 mantissa bits per operand (relative error ~5e-6 per layer
+// against 3e-7 for fp32 and 2.5e-3 for plain bf16) at three matrix instructions that are each 16x faster than the
+// fp32 one.  For the fp32 tensors of the parity-bound (1e-4) path: activations stay fp32 in HBM, the split happens
+// in the staging registers; the weight arrives as two arranged slabs per chunk.
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_tiled_bf16_kernel(const BParams P)
 {
@@ -112,8 +117,9 @@ conv_tiled_bf16_kernel(const BParams P)
     constexpr int NPOS = Cfg::NPOS, KG = Cfg::KG, WSLAB = Cfg::WSLAB, NW = Cfg::NW;
     static_assert(NI * TH * TW == BM, "tile must hold 256 pixels");
     static_assert(KC % 16 == 0, "whole MFMA k-steps");
-    __shared__ u32x4 sP[KG * PSN];                     // [k group][position] x 8 bf16
-    __shared__ u32x4 sW[WSLAB];                        // [tap][k group][cout] x 8 bf16
+    constexpr int NS = X3 ? 2 : 1;                     // hi (and lo) images
+    __shared__ u32x4 sP[NS * KG * PSN];                // [hi|lo][k group][position] x 8 bf16
+    __shared__ u32x4 sW[NS * WSLAB];                   // [hi|lo][tap][k group][cout] x 8 bf16
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -163,10 +169,12 @@ conv_tiled_bf16_kernel(const BParams P)
             for (int i = 0; i < 16; ++i) acc[f][h2][i] = 0.0f;
 
     unsigned rp[NPOS][KC / 2];          // packed channel pairs of each position
+    unsigned rpl[X3 ? NPOS : 1][X3 ? KC / 2 : 1];   // their low halves (X3)
     u32x4 rw[NW];
+    u32x4 rwl[X3 ? NW : 1];
     int cbase = 0, s = 0;
     BSrc cur = P.src[0];
-    const u32x4* wbase = P.wt + (size_t)ctile * P.nchunks * WSLAB;
+    const u32x4* wbase = P.wt + (size_t)ctile * P.nchunks * (NS * WSLAB);
 
     auto prefetch = [&](int chunk) {
         const int c0 = chunk * KC;
@@ -193,6 +201,11 @@ conv_tiled_bf16_kernel(const BParams P)
                     const unsigned pk = pack2_bf16(v[2 * c2], v[2 * c2 + 1]);
                     const unsigned m = (2 * c2 + 1 < cleft) ? 0xffffffffu : ((2 * c2 < cleft) ? 0x0000ffffu : 0u);
                     rp[i][c2] = ok ? (pk & m) : 0u;
+                    if constexpr (X3) {
+                        const float h0 = __builtin_bit_cast(float, pk << 16), h1 = __builtin_bit_cast(float, pk & 0xffff0000u);
+                        const unsigned pl = pack2_bf16(v[2 * c2] - h0, v[2 * c2 + 1] - h1);
+                        rpl[i][c2] = ok ? (pl & m) : 0u;
+                    }
                 }
             } else {
                 const unsigned short* sp = reinterpret_cast<const unsigned short*>(cur.p) + chan0;
@@ -204,14 +217,16 @@ conv_tiled_bf16_kernel(const BParams P)
                     const unsigned lo16 = (2 * c2 < cleft) ? (unsigned)v[2 * c2] : 0u;
                     const unsigned hi16 = (2 * c2 + 1 < cleft) ? (unsigned)v[2 * c2 + 1] : 0u;
                     rp[i][c2] = ok ? (lo16 | (hi16 << 16)) : 0u;
+                    if constexpr (X3) rpl[i][c2] = 0u;         // a bf16 tensor has no low half
                 }
             }
         }
-        const u32x4* wp = wbase + (size_t)chunk * WSLAB;
+        const u32x4* wp = wbase + (size_t)chunk * (NS * WSLAB);
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int e = tid + i * kThreads;
             rw[i] = wp[e < WSLAB ? e : 0];
+            if constexpr (X3) rwl[i] = wp[WSLAB + (e < WSLAB ? e : 0)];
         }
     };
     auto commit = [&]() {
@@ -224,13 +239,20 @@ conv_tiled_bf16_kernel(const BParams P)
                     u32x4 v;
                     v[0] = rp[i][4 * g]; v[1] = rp[i][4 * g + 1]; v[2] = rp[i][4 * g + 2]; v[3] = rp[i][4 * g + 3];
                     sP[g * PSN + e] = v;
+                    if constexpr (X3) {
+                        v[0] = rpl[i][4 * g]; v[1] = rpl[i][4 * g + 1]; v[2] = rpl[i][4 * g + 2]; v[3] = rpl[i][4 * g + 3];
+                        sP[KG * PSN + g * PSN + e] = v;
+                    }
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int e = tid + i * kThreads;
-            if (e < WSLAB) sW[e] = rw[i];
+            if (e < WSLAB) {
+                sW[e] = rw[i];
+                if constexpr (X3) sW[WSLAB + e] = rwl[i];
+            }
         }
     };
 
@@ -252,6 +274,20 @@ conv_tiled_bf16_kernel(const BParams P)
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                if constexpr (X3) {
+                    const bf16x8 b0l = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[0] + (2 * ks) * PSN + ky * PW + kx]);
+                    const bf16x8 b1l = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[1] + (2 * ks) * PSN + ky * PW + kx]);
+                    const bf16x8 a0l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + l31]);
+                    const bf16x8 a1l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + 32 + l31]);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0l, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0l, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1l, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1l, acc[1][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1, acc[1][1], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -330,30 +366,30 @@ conv_tiled_bf16_kernel(const BParams P)
     }
 }
 
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3>
 void launch_b(const BParams& P, hipStream_t st)
 {
     const int ctiles = (P.Cout + BN - 1) / BN;
     const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
                     (unsigned)(((P.N + NI - 1) / NI) * ctiles));
-    hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC>), grid, dim3(kThreads), 0, st, P);
+    hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3>), grid, dim3(kThreads), 0, st, P);
 }
 
 constexpr int kKC3 = 16;      // channels per chunk, 3x3 kernels
 constexpr int kKC1 = 32;      // channels per chunk, 1x1 kernels
 
 // picks the tile by output width / height; false when no instantiation fits
-template <int KH, int SH, int SW, int KC>
+template <int KH, int SH, int SW, int KC, bool X3>
 bool launch_by_shape(const BParams& P, hipStream_t st)
 {
-    if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC>(P, st);   // a row of tokens
-    else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC>(P, st);
-    else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC>(P, st);
-    else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC>(P, st);
-    else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC>(P, st);
-    else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC>(P, st);
-    else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 4, KC>(P, st);
-    else                launch_b<KH, SH, SW, 2, 16, 8, KC>(P, st);
+    if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC, X3>(P, st);   // a row of tokens
+    else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC, X3>(P, st);
+    else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC, X3>(P, st);
+    else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC, X3>(P, st);
+    else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC, X3>(P, st);
+    else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC, X3>(P, st);
+    else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 4, KC, X3>(P, st);
+    else                launch_b<KH, SH, SW, 2, 16, 8, KC, X3>(P, st);
     return true;
 }
 
@@ -369,7 +405,7 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
                                        const void* residual, int residual_f32,
                                        const float* post_scale, const float* post_shift,
                                        int res_mode, int relu, int N, int Cout, int KH, int KW, int sh, int sw,
-                                       void* out, int out_f32, int Ho, int Wo, tpspp_stream_t stream)
+                                       void* out, int out_f32, int Ho, int Wo, int split3, tpspp_stream_t stream)
 {
     TPSPP_REQUIRE(src_ptrs && src_dims && weight_arranged && out, "tpspp_conv2d_bf16_fwd: null pointer");
     TPSPP_REQUIRE(nsrc >= 1 && nsrc <= 3, "tpspp_conv2d_bf16_fwd: 1..3 sources");
@@ -414,11 +450,19 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     TPSPP_REQUIRE((long)N * ((Cout + BN - 1) / BN) <= 65535, "tpspp_conv2d_bf16_fwd: grid too large");
     hipStream_t st = tpspp::as_stream(stream);
     bool ok = false;
-    if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1>(P, st);
-    else if (KH == 1 && sh == 2 && sw == 2) ok = launch_by_shape<1, 2, 2, kKC1>(P, st);
-    else if (KH == 3 && sh == 1 && sw == 1) ok = launch_by_shape<3, 1, 1, kKC3>(P, st);
-    else if (KH == 3 && sh == 2 && sw == 2) ok = launch_by_shape<3, 2, 2, kKC3>(P, st);
-    else if (KH == 3 && sh == 2 && sw == 1) ok = launch_by_shape<3, 2, 1, kKC3>(P, st);
+    if (split3) {
+        if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1, true>(P, st);
+        else if (KH == 1 && sh == 2 && sw == 2) ok = launch_by_shape<1, 2, 2, kKC1, true>(P, st);
+        else if (KH == 3 && sh == 1 && sw == 1) ok = launch_by_shape<3, 1, 1, kKC3, true>(P, st);
+        else if (KH == 3 && sh == 2 && sw == 2) ok = launch_by_shape<3, 2, 2, kKC3, true>(P, st);
+        else if (KH == 3 && sh == 2 && sw == 1) ok = launch_by_shape<3, 2, 1, kKC3, true>(P, st);
+    } else {
+        if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1, false>(P, st);
+        else if (KH == 1 && sh == 2 && sw == 2) ok = launch_by_shape<1, 2, 2, kKC1, false>(P, st);
+        else if (KH == 3 && sh == 1 && sw == 1) ok = launch_by_shape<3, 1, 1, kKC3, false>(P, st);
+        else if (KH == 3 && sh == 2 && sw == 2) ok = launch_by_shape<3, 2, 2, kKC3, false>(P, st);
+        else if (KH == 3 && sh == 2 && sw == 1) ok = launch_by_shape<3, 2, 1, kKC3, false>(P, st);
+    }
     TPSPP_REQUIRE(ok, "tpspp_conv2d_bf16_fwd: no kernel for a %dx%d kernel with stride (%d,%d)", KH, KW, sh, sw);
     return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
 }

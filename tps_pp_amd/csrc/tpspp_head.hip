@@ -541,14 +541,15 @@ struct Gemm {
     int rc = 0;
     // the same product on the bf16 matrix cores: W16 = the weight arranged for tpspp_conv2d_bf16_fwd (1x1),
     // X / res fp32 (rounded to bf16 as they are staged), out fp32 or bf16
+    // split3: the "bf16x3" three-term split on the fp32 operands (W16 then holds hi and lo slabs)
     void cm16(const void* W16, const float* bias, const float* X, int K, int Co, int M, void* out, int out_f32, int act,
-              const float* res)
+              const float* res, int split3 = 0)
     {
         if (rc) return;
         const void* src[1] = {X};
         const int dims[6] = {K, 1, M, 1, 1, 1};
         rc = tpspp_conv2d_bf16_fwd(src, dims, 1, W16, bias, res, 1, nullptr, nullptr, res ? 1 : 0, act, 1, Co, 1, 1, 1, 1,
-                                   out, out_f32, 1, M, st);
+                                   out, out_f32, 1, M, split3, st);
     }
     // out (Co, M) = act(W^T X + bias) [+ res]      W (K, Co) k-major, X (K, M) channel-major
     void cm(const float* W, const float* bias, const float* X, int K, int Co, int M, float* out, int act,
@@ -694,7 +695,8 @@ TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, 
                                         const int* valid_len, void* workspace, size_t workspace_bytes,
                                         float* out_cm, float* out_ntc, int flags, tpspp_stream_t stream)
 {
-    const bool b16 = (flags & TPSPP_HEAD_BF16) != 0;
+    const int x3 = (flags & TPSPP_HEAD_BF16X3) ? 1 : 0;
+    const bool b16 = (flags & (TPSPP_HEAD_BF16 | TPSPP_HEAD_BF16X3)) != 0;
     TPSPP_REQUIRE(feat && layer_ptrs && ln_g && ln_b && workspace && (out_cm || out_ntc),
                   "tpspp_nrtr_encoder_fwd: null pointer");
     TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0,
@@ -731,19 +733,19 @@ TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, 
         // x = x + fc(attn(LN1(x)))                                   transformer_layers.py:67-70
         rc = tpspp_layernorm_cm_fwd(x, w[E_LN1G], w[E_LN1B], C, M, 1e-5f, y, stream);
         if (rc) break;
-        if (b16) g.cm16(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 1, 0, nullptr);
+        if (b16) g.cm16(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 1, 0, nullptr, x3);
         else g.cm(w[E_WQKV], w[E_BQKV], y, C, 3 * C, M, qkv, 0, nullptr);
         if (g.rc) break;
         rc = launch_attn_enc(qkv, N, C, T, valid_len, a, st);
         if (rc) break;
-        if (b16) g.cm16(w[E_WFC], w[E_BFC], a, C, C, M, y, 1, 0, x);
+        if (b16) g.cm16(w[E_WFC], w[E_BFC], a, C, C, M, y, 1, 0, x, x3);
         else g.cm(w[E_WFC], w[E_BFC], a, C, C, M, y, 0, x);          // y = x + fc(a)
         // x = y + w2(gelu(w1(LN2(y))))                                transformer_layers.py:72-75
         rc = tpspp_layernorm_cm_fwd(y, w[E_LN2G], w[E_LN2B], C, M, 1e-5f, a, stream);
         if (rc) break;
         if (b16) {
-            g.cm16(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 1, 2, nullptr);
-            g.cm16(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 1, 0, y);
+            g.cm16(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 1, 2, nullptr, x3);
+            g.cm16(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 1, 0, y, x3);
         } else {
             g.cm(w[E_W1], w[E_B1], a, C, d_inner, M, hid, 2, nullptr);
             g.cm(w[E_W2], w[E_B2], hid, d_inner, C, M, x, 0, y);
@@ -768,6 +770,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                                         float* out, int* tokens_out, int flags, tpspp_stream_t stream)
 {
     const bool b16 = (flags & TPSPP_HEAD_BF16) != 0;
+    const bool x3 = !b16 && (flags & TPSPP_HEAD_BF16X3) != 0;
     TPSPP_REQUIRE(enc_cm && layer_ptrs && emb && pos_table && w_cls && cls_colsum && workspace && out,
                   "tpspp_nrtr_decoder_fwd: null pointer");
     TPSPP_REQUIRE(N > 0 && T > 0 && n_layers > 0 && d_inner > 0 && C > 0 && C % kDK == 0 && num_out > 0,
@@ -818,7 +821,8 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
                                0, st, vt, C, MT, reinterpret_cast<unsigned short*>(Vx[l]));
         } else {
-            g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
+            if (x3) g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 1, 0, nullptr, 1);   // fp32 keys, three-term split
+            else g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
             g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);        // (a value bias would be per channel = per column here: not supported)
         }
     }

@@ -121,10 +121,14 @@ def _valid_len(img_metas, n, t, device):
     return torch.tensor([min(t, math.ceil(t * r)) for r in ratios], dtype=torch.int32, device=device)
 
 
-def _arranged16(weight):
-    """nn.Linear weight (out, in) -> bf16, arranged as a 1x1 kernel for tpspp_conv2d_bf16_fwd."""
+def _arranged16(weight, x3=False):
+    """nn.Linear weight (out, in) -> bf16, arranged as a 1x1 kernel for tpspp_conv2d_bf16_fwd (x3: hi + lo slabs)."""
     w = weight.detach().float()
-    return ops.prep_conv_weight_bf16(w.view(w.shape[0], w.shape[1], 1, 1)).arranged
+    return ops.prep_conv_weight_bf16(w.view(w.shape[0], w.shape[1], 1, 1), x3=x3).arranged
+
+
+def _head_flags(compute_dtype):
+    return ops.HEAD_BF16 if compute_dtype == torch.bfloat16 else ops.HEAD_BF16X3 if compute_dtype == "bf16x3" else 0
 
 
 @ENCODERS.register_module()
@@ -147,17 +151,18 @@ class NRTREncoder(nn.Module):
         pass
 
     def _weights(self):
-        b16 = self.compute_dtype == torch.bfloat16
-        key = (_state_key(self), b16)
+        x3 = self.compute_dtype == "bf16x3"
+        b16 = self.compute_dtype == torch.bfloat16 or x3
+        key = (_state_key(self), b16, x3)
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != key:
             ts = []
-            # fp32: k-major (in, out); bf16 (TPSPP_HEAD_BF16): arranged for the bf16 1x1 convolution kernel
-            km = _arranged16 if b16 else ops.kmajor
+            # fp32: k-major (in, out); bf16 / bf16x3 (TPSPP_HEAD_BF16[X3]): arranged for the bf16 1x1 convolution kernel
+            km = (lambda w: _arranged16(w, x3)) if b16 else ops.kmajor
             for lyr in self.layer_stack:
                 a = lyr.attn
                 if b16:
-                    wqkv = _arranged16(torch.cat([a.linear_q.weight, a.linear_k.weight, a.linear_v.weight], dim=0))
+                    wqkv = _arranged16(torch.cat([a.linear_q.weight, a.linear_k.weight, a.linear_v.weight], dim=0), x3)
                 else:
                     wqkv = torch.cat([ops.kmajor(a.linear_q.weight), ops.kmajor(a.linear_k.weight),
                                       ops.kmajor(a.linear_v.weight)], dim=1).contiguous()
@@ -179,7 +184,7 @@ class NRTREncoder(nn.Module):
             raise ValueError(f"NRTREncoder: feature width {c} != d_model {self.d_model}")
         vl = _valid_len(img_metas, n, h * w, feat.device)
         out, out_cm = ops.nrtr_encoder(feat.float(), table, len(self.layer_stack), self.d_inner, g, b, vl, holder=self,
-                                       flags=ops.HEAD_BF16 if self.compute_dtype == torch.bfloat16 else 0)
+                                       flags=_head_flags(self.compute_dtype))
         out._tpspp_cm = out_cm          # lets NRTRDecoder skip the re-layout of its input
         return out
 
@@ -212,12 +217,15 @@ class NRTRDecoder(nn.Module):
         pass
 
     def _weights(self):
+        x3 = self.compute_dtype == "bf16x3"
         b16 = self.compute_dtype == torch.bfloat16
-        key = (_state_key(self), b16)
+        key = (_state_key(self), b16, x3)
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != key:
             ts = []
-            kv = _arranged16 if b16 else ops.kmajor        # the one-off key / value projections of the encoder output
+            # the one-off key / value projections of the encoder output: bf16 both; bf16x3 the keys only
+            kk = (lambda w: _arranged16(w, x3)) if (b16 or x3) else ops.kmajor
+            kv = _arranged16 if b16 else ops.kmajor
             for lyr in self.layer_stack:
                 sa, ea = lyr.self_attn, lyr.enc_attn
                 wqkv = torch.cat([ops.kmajor(sa.linear_q.weight), ops.kmajor(sa.linear_k.weight),
@@ -227,7 +235,7 @@ class NRTRDecoder(nn.Module):
                 q = ops.fold_layernorm(lyr.norm2.weight, lyr.norm2.bias, ops.kmajor(ea.linear_q.weight))
                 w1 = ops.fold_layernorm(lyr.norm3.weight, lyr.norm3.bias, ops.kmajor(lyr.mlp.w_1.weight), lyr.mlp.w_1.bias)
                 ts += [qkv[0], qkv[1], qkv[2], ops.kmajor(sa.fc.weight), None,
-                       q[0], q[1], q[2], kv(ea.linear_k.weight), None, kv(ea.linear_v.weight),
+                       q[0], q[1], q[2], kk(ea.linear_k.weight), None, kv(ea.linear_v.weight),
                        ops.kmajor(ea.fc.weight), None, w1[0], w1[1], w1[2],
                        ops.kmajor(lyr.mlp.w_2.weight), _f32(lyr.mlp.w_2.bias)]
             cls = ops.fold_layernorm(self.layer_norm.weight, self.layer_norm.bias, ops.kmajor(self.classifier.weight),
@@ -250,7 +258,7 @@ class NRTRDecoder(nn.Module):
         seq_len = self.max_seq_len if forced is None else forced.shape[1]
         out, tokens = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, emb, pos, cls,
                                        seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self,
-                                       flags=ops.HEAD_BF16 if self.compute_dtype == torch.bfloat16 else 0)
+                                       flags=_head_flags(self.compute_dtype))
         self.last_tokens = tokens
         return out
 

@@ -358,14 +358,14 @@ class ConvWeightBf16:
     """Device-side weights of one fused bf16 convolution: `arranged` bf16
     [Cout/64][Cin/KC][taps][KC/8][64][8] (include/tpspp.h, tpspp_conv2d_bf16_fwd), fp32 `bias` | None."""
 
-    def __init__(self, arranged, bias, kernel, cin, cout, post_scale=None, post_shift=None):
+    def __init__(self, arranged, bias, kernel, cin, cout, post_scale=None, post_shift=None, x3=False):
         self.arranged, self.bias, self.kernel, self.cin, self.cout = arranged, bias, kernel, cin, cout
-        self.post_scale, self.post_shift = post_scale, post_shift
+        self.post_scale, self.post_shift, self.x3 = post_scale, post_shift, x3
 
 
-def prep_conv_weight_bf16(weight, bn=None, conv_bias=None, eps=1e-5, post_bn=None):
+def prep_conv_weight_bf16(weight, bn=None, conv_bias=None, eps=1e-5, post_bn=None, x3=False):
     """PyTorch conv weight (Cout, Cin, KH, KW) [+ eval-mode BatchNorm folded in fp32, then rounded] ->
-    ConvWeightBf16.  Same folding rules as `prep_conv_weight`."""
+    ConvWeightBf16.  Same folding rules as `prep_conv_weight`.  x3: the "bf16x3" split (hi and lo slabs per chunk)."""
     w = weight.detach().float()
     b = None if conv_bias is None else conv_bias.detach().float()
     if bn is not None:
@@ -379,13 +379,19 @@ def prep_conv_weight_bf16(weight, bn=None, conv_bias=None, eps=1e-5, post_bn=Non
     wp = torch.zeros((ct * 64, nch * kc, kh, kw), device=w.device, dtype=torch.float32)
     wp[:cout, :cin] = w
     # (ctile, co, chunk, kgroup, k8, ky, kx) -> (ctile, chunk, ky, kx, kgroup, co, k8)
-    arranged = wp.view(ct, 64, nch, kc // 8, 8, kh, kw).permute(0, 2, 5, 6, 3, 1, 4).contiguous().to(torch.bfloat16)
+    arranged = wp.view(ct, 64, nch, kc // 8, 8, kh, kw).permute(0, 2, 5, 6, 3, 1, 4).contiguous()
+    if x3:          # [ctile][chunk][hi|lo][tap...]: hi = bf16(w), lo = bf16(w - hi)
+        hi = arranged.to(torch.bfloat16)
+        lo = (arranged - hi.float()).to(torch.bfloat16)
+        arranged = torch.stack([hi, lo], dim=2).contiguous()
+    else:
+        arranged = arranged.to(torch.bfloat16)
     ps = pb = None
     if post_bn is not None:
         gamma, beta, mean, var = (t.detach().float() for t in post_bn)
         ps = (gamma / torch.sqrt(var + eps)).contiguous()
         pb = (beta - mean * ps).contiguous()
-    return ConvWeightBf16(arranged, None if b is None else b.contiguous(), kh, cin, cout, ps, pb)
+    return ConvWeightBf16(arranged, None if b is None else b.contiguous(), kh, cin, cout, ps, pb, x3)
 
 
 def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out_dtype=torch.bfloat16):
@@ -425,7 +431,7 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
                                               len(ts), _ptr(cw.arranged), _ptr(cw.bias), _ptr(residual), res_f32,
                                               _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode), int(relu),
                                               N, Cout, kernel, kernel, sh, sw, _ptr(out),
-                                              int(out_dtype == torch.float32), Ho, Wo, _stream(ts[0]))
+                                              int(out_dtype == torch.float32), Ho, Wo, int(cw.x3), _stream(ts[0]))
     _lib.check(rc, "tpspp_conv2d_bf16_fwd")
     return out
 
@@ -796,6 +802,7 @@ def _workspace(holder, nbytes, device):
 
 
 HEAD_BF16 = 1            # TPSPP_HEAD_BF16
+HEAD_BF16X3 = 2          # TPSPP_HEAD_BF16X3
 
 
 def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, holder=None, want_ntc=True, flags=0):

@@ -63,26 +63,29 @@ class BasicBlock(nn.Module):
             self._cw_cache = cache = (key, cw)
         return cache[1]
 
-    def _weights_bf16(self):
+    def _weights_bf16(self, x3=False):
         mods = [self.conv1, self.bn1, self.conv2, self.bn2] + \
             ([self.downsample[0], self.downsample[1]] if self.downsample is not None else [])
         key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
-        cache = getattr(self, "_cw16_cache", None)
+        name = "_cw16x3_cache" if x3 else "_cw16_cache"
+        cache = getattr(self, name, None)
         if cache is None or cache[0] != key:
             def fold(conv, bn):
-                return ops.prep_conv_weight_bf16(conv.weight, eps=bn.eps,
+                return ops.prep_conv_weight_bf16(conv.weight, eps=bn.eps, x3=x3,
                                                  bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
             cw = [fold(self.conv1, self.bn1), fold(self.conv2, self.bn2),
                   fold(self.downsample[0], self.downsample[1]) if self.downsample is not None else None]
-            self._cw16_cache = cache = (key, cw)
+            cache = (key, cw)
+            setattr(self, name, cache)
         return cache[1]
 
-    def _forward_hip_bf16(self, x, out_dtype=torch.bfloat16):
+    def _forward_hip_bf16(self, x, out_dtype=torch.bfloat16, x3=False):
         """The block on the bf16 matrix cores (BatchNorm folded in fp32, then rounded): activations bf16 in
-        HBM, accumulation / bias / residual add / ReLU in fp32."""
-        c1, c2, cd = self._weights_bf16()
-        out = ops.conv2d_bf16([x], c1, self.conv1.stride, True)
-        residual = x if cd is None else ops.conv2d_bf16([x], cd, self.downsample[0].stride, False)
+        HBM, accumulation / bias / residual add / ReLU in fp32.  x3: fp32 activations, three-term bf16 split."""
+        c1, c2, cd = self._weights_bf16(x3)
+        mid = torch.float32 if x3 else torch.bfloat16
+        out = ops.conv2d_bf16([x], c1, self.conv1.stride, True, out_dtype=mid)
+        residual = x if cd is None else ops.conv2d_bf16([x], cd, self.downsample[0].stride, False, out_dtype=mid)
         return ops.conv2d_bf16([out], c2, self.conv2.stride, True, residual=residual, res_mode=2,
                                out_dtype=out_dtype)
 
@@ -112,7 +115,8 @@ class ResNetABI_v2_large(nn.Module):
         assert out_indices is None or isinstance(out_indices, (list, tuple))
         assert isinstance(last_stage_pool, bool)
         self.init_cfg = init_cfg
-        self.compute_dtype = None          # None: follow the input dtype; torch.bfloat16: bf16 convolutions
+        # None: follow the input dtype; torch.bfloat16: bf16 convolutions; "bf16x3": fp32 tensors, three-term split
+        self.compute_dtype = None
         self.out_indices = out_indices
         self.last_stage_pool = last_stage_pool
         self.block = BasicBlock
@@ -167,18 +171,25 @@ class ResNetABI_v2_large(nn.Module):
             last = getattr(self, self.res_layers[-1])[-1]
             return self._run(x, tpsnet, self._stem_bf16, lambda blk, t: blk._forward_hip_bf16(
                 t, torch.float32 if blk is last else torch.bfloat16), **kwargs)
+        if self.compute_dtype == "bf16x3":
+            # fp32 tensors everywhere, every convolution product the three-term bf16 split (~5e-6 per layer); a
+            # `tpsnet` that should do the same needs its own compute_dtype = "bf16x3"
+            return self._run(x.float(), tpsnet, lambda t: self._stem_bf16(t, True),
+                             lambda blk, t: blk._forward_hip_bf16(t, torch.float32, True), **kwargs)
         return self._run(x, tpsnet, self._stem, lambda blk, t: blk(t), **kwargs)
 
-    def _stem_bf16(self, x):
+    def _stem_bf16(self, x, x3=False):
         mods = [self.conv1, self.bn1]
         key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
-        cache = getattr(self, "_cw16_cache", None)
+        name = "_cw16x3_cache" if x3 else "_cw16_cache"
+        cache = getattr(self, name, None)
         if cache is None or cache[0] != key:
             bn = self.bn1
-            cw = ops.prep_conv_weight_bf16(self.conv1.weight, conv_bias=self.conv1.bias, eps=bn.eps,
+            cw = ops.prep_conv_weight_bf16(self.conv1.weight, conv_bias=self.conv1.bias, eps=bn.eps, x3=x3,
                                            bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
-            self._cw16_cache = cache = (key, cw)
-        return ops.conv2d_bf16([x], cache[1], 1, True)
+            cache = (key, cw)
+            setattr(self, name, cache)
+        return ops.conv2d_bf16([x], cache[1], 1, True, out_dtype=torch.float32 if x3 else torch.bfloat16)
 
     def _run(self, x, tpsnet, stem, apply_block, **kwargs):
         x = stem(x)

@@ -306,7 +306,9 @@ class TPS_PP(nn.Module):
         self.init_cfg = init_cfg
         self.heads = 16
         self.type = variant
-        self.compute_dtype = None          # None: follow the input dtype; torch.bfloat16: bf16 convolutions
+        # None: follow the input dtype (fp32 -> exact fp32 kernels); torch.bfloat16: bf16 convolutions;
+        # "bf16x3": fp32 tensors, three-term bf16 split in the convolutions
+        self.compute_dtype = None
         self.visual_point = visual_point
         self.num_fiducial = point_size[0] * point_size[1]
         self.img_size = img_size
@@ -373,7 +375,7 @@ class TPS_PP(nn.Module):
         return e3, k
 
     # ---- bf16 path (BASELINE.json configs[2]): bf16 MFMA convolutions, tpspp_conv_bf16.hip ------------
-    def _conv_weights_bf16(self):
+    def _conv_weights_bf16(self, x3=False):
         convs = {"down0": self.down0, "down1": self.down1, "down2": self.down2}
         if self.type == "ResNet45v2":
             convs.update(down0_1=self.down0_1, down1_1=self.down1_1, down_feat=self.down_feat)
@@ -382,26 +384,32 @@ class TPS_PP(nn.Module):
             convs[f"dec{i}"] = self.MSFA.conv.k_decoder[i][1]
         key = tuple((n, m.conv.weight._version, m.conv.bias._version, m.conv.weight.data_ptr())
                     for n, m in convs.items())
-        cache = getattr(self, "_cw16_cache", None)
+        name = "_cw16x3_cache" if x3 else "_cw16_cache"
+        cache = getattr(self, name, None)
         if cache is None or cache[0] != key:
-            cw = {n: ops.prep_conv_weight_bf16(m.conv.weight, conv_bias=m.conv.bias) for n, m in convs.items()}
-            self._cw16_cache = cache = (key, cw)
+            cw = {n: ops.prep_conv_weight_bf16(m.conv.weight, conv_bias=m.conv.bias, x3=x3) for n, m in convs.items()}
+            cache = (key, cw)
+            setattr(self, name, cache)
         return cache[1]
 
-    def _regress_hip_bf16(self, batch_img, outs):
+    def _regress_hip_bf16(self, batch_img, outs, x3=False):
         """The regressor with every convolution on the bf16 matrix cores.  Activations between convolutions
         are bf16 in HBM; the three tensors that feed fp32 arithmetic -- `en_feat` (CBAM, control points:
         amplified ~223x by the TPS solve), `de_feat` (DGAB, score) and `feat_grid` (sampled by the warp) --
         leave their convolution in fp32 (fp32 accumulators, never rounded).  Inputs may be bf16 or fp32."""
-        cw = self._conv_weights_bf16()
-        bf, f32 = torch.bfloat16, torch.float32
-        c16 = ops.conv2d_bf16
+        cw = self._conv_weights_bf16(x3)
+        f32 = torch.float32
+        # x3 ("bf16x3", `compute_dtype = "bf16x3"`): every tensor stays fp32 in HBM and every product is the
+        # three-term bf16 split (~5e-6 per layer): the convolutions of the parity-bound (1e-4) path at a third of
+        # the fp32 matrix time.  DGAB / score / control points then run on their exact fp32 kernels.
+        bf = f32 if x3 else torch.bfloat16
+        c16 = (lambda *a, **k: ops.conv2d_bf16(*a, **{"out_dtype": f32, **k})) if x3 else ops.conv2d_bf16
         x, o0, o1 = batch_img, outs[0], outs[1]
         if self.type == "ResNet45v2":
             # feat_grid is sampled by the warp: bf16 when the module boundary is bf16 (the warp then moves half
             # the bytes and rounds once at its store), fp32 when the caller's tensors are fp32
             fg_dtype = bf if x.dtype == bf else f32
-            if ops.front_bf16_applicable(o0, o1, x):
+            if not x3 and ops.front_bf16_applicable(o0, o1, x):
                 # the four pointwise convolutions fused, register-chained (tpspp_front_bf16.hip)
                 fkey = tuple((t.data_ptr(), t._version) for mdl in (self.down0, self.down1, self.down2, self.down_feat)
                              for t in mdl.parameters())
@@ -428,7 +436,7 @@ class TPS_PP(nn.Module):
         k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
         k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
         de_feat = c16([k], cw["dec3"], 1, out_dtype=f32)
-        control_point, atten_score = self._tpe_hip(e3, de_feat, bf16=True)
+        control_point, atten_score = self._tpe_hip(e3, de_feat, bf16=not x3)
         return control_point, atten_score, feat_grid
 
     def grid(self, a1, a2, a3):
@@ -448,6 +456,8 @@ class TPS_PP(nn.Module):
         ops.require_gpu(batch_img, "TPS_PP")
         if self._bf16(batch_img):
             return self._regress_hip_bf16(batch_img, outs)
+        if self.compute_dtype == "bf16x3":
+            return self._regress_hip_bf16(batch_img.float(), [o.float() for o in outs], x3=True)
         return self._regress_hip(batch_img, outs)
 
     def _bf16(self, batch_img):
