@@ -201,13 +201,15 @@ int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1_w, const flo
  *   fc1_slab  [4 blocks][4][2][64][8] = W1[64 b + m][16 j + perm[8 h + e]];
  *   fc2_slab  [4 blocks][4][2][64][8] = W2[m][64 b + 16 j + perm[8 h + e]];  perm as in tpspp_front_bf16_fwd;
  *   scratch   (N,C,16,64) bf16;  everything else as tpspp_dgab_fwd.
+ *   split3: the three-term "bf16x3" split (see tpspp_conv2d_bf16_fwd): scratch is then fp32 and every slab holds its hi
+ *   and lo halves back to back ([..][hi|lo][4 k-steps][2][64][8]); results within ~1e-5 of tpspp_dgab_fwd.
  * replaces: backbones/tps_pp/DGAB.py:25-77
  */
 int tpspp_dgab_bf16_fwd(const float* x, const float* y, const float* ln1_w, const float* ln1_b,
                         const float* mlp_w_t, const float* mlp_h_t, const void* proj_slab,
                         const float* proj_b, const float* ln2_w, const float* ln2_b,
                         const void* fc1_slab, const float* fc1_b, const void* fc2_slab,
-                        const float* fc2_b, void* scratch, float* out, int N, int C,
+                        const float* fc2_b, void* scratch, float* out, int N, int C, int split3,
                         tpspp_stream_t stream);
 
 /*

@@ -32,6 +32,11 @@ x = torch.rand(N, 64, 16, 64, device=dev)
 o0 = torch.rand(N, 32, 32, 128, device=dev)
 o1 = torch.rand(N, 32, 32, 128, device=dev)
 with torch.no_grad():
+    if len(sys.argv) > 2 and sys.argv[2] == "x3only":
+        m.compute_dtype = "bf16x3"
+        t3 = timeit(lambda: m(x, [o0, o1]), iters=20)
+        print(f"TPS_PP batch {N} bf16x3: full {t3:.2f} ms = {N / t3 * 1e3:,.0f} img/s")
+        sys.exit(0)
     if ONLY16:
         xb, o0b, o1b = x.to(torch.bfloat16), o0.to(torch.bfloat16), o1.to(torch.bfloat16)
         t16 = timeit(lambda: m(xb, [o0b, o1b]), iters=20)

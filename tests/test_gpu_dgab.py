@@ -54,6 +54,23 @@ def test_dgab_bf16_matches_bf16_oracle(cuda):
     assert e32.max().item() <= 2e-2 * scale and e32.mean().item() <= 2e-3 * scale, (e32.max().item(), e32.mean().item())
 
 
+def test_dgab_bf16x3_matches_fp32_oracle(cuda):
+    """split3 of tpspp_dgab_bf16_fwd (three-term bf16 split on fp32 operands): the fp32 oracle's tolerance."""
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N = 5
+    from tps_pp_amd import synth
+    x = torch.from_numpy(synth.dyadic((N, 64, 16, 64), "dgabx3.x"))
+    en = torch.from_numpy(synth.dyadic((N, 64, 2, 16), "dgabx3.en"))
+    with torch.no_grad():
+        ref = TO.dgab(dict(m.state_dict()), "TPE.atten.0", x, en.flatten(2).transpose(1, 2))
+    m.to(cuda)
+    got = ops.dgab_bf16(x.to(cuda), en.to(cuda).view(N, 64, 32), ops.DgabWeightsBf16(m.TPE.atten[0], x3=True)).cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4, f"max abs err {err:.3e}"
+
+
 def test_score_matches_oracle(cuda):
     from tps_pp_amd import synth
     m = TPS_PP().eval()

@@ -298,7 +298,7 @@ dgab_chain_kernel(const ChainParams P)
 // LDS holds the bf16 weight slabs: 72 KB, two workgroups per CU.
 struct ChainBParams {
     const float* x;              // (rows, 64) fp32 residual input
-    const unsigned short* a;     // (rows, 64) bf16 gated map
+    const void* a;               // (rows, 64) gated map: bf16, or fp32 for the three-term split (X3)
     const u32x4* wp_s;           // [4 k-steps][2][64 out][8]            proj, natural k order
     const u32x4* w1_s;           // [4 blocks][4][2][64 hidden][8]       fc1, chain k order
     const u32x4* w2_s;           // [4 blocks][4][2][64 out][8]          fc2, chain k order (hidden units of the block)
@@ -338,6 +338,49 @@ __device__ __forceinline__ void gemm64b(const u32x4* __restrict__ slab, const u3
     }
 }
 
+// three-term split ("bf16x3", tpspp_conv_bf16.hip): acc += hi*hi + hi*lo + lo*hi; slab holds hi at [0, 512) and lo at [512, 1024)
+__device__ __forceinline__ void gemm64b3(const u32x4* __restrict__ slab, const u32x4 (&in)[4], const u32x4 (&inl)[4], int half,
+                                         int l31, f32x16 (&acc)[2])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, slab[(2 * j + half) * 64 + l31]);
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, slab[(2 * j + half) * 64 + 32 + l31]);
+        const bf16x8 a0l = __builtin_bit_cast(bf16x8, slab[512 + (2 * j + half) * 64 + l31]);
+        const bf16x8 a1l = __builtin_bit_cast(bf16x8, slab[512 + (2 * j + half) * 64 + 32 + l31]);
+        const bf16x8 bb = __builtin_bit_cast(bf16x8, in[j]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, inl[j]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bl, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bl, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bb, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bb, acc[1], 0, 0, 0);
+    }
+}
+
+// hi / lo halves of a pair: hi = bf16(v), lo = bf16(v - hi)
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo)
+{
+    hi = pack_bf16(v0, v1);
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16(v0 - h0, v1 - h1);
+}
+
+__device__ __forceinline__ void to_operands3(const float (&v)[32], u32x4 (&out)[4], u32x4 (&outl)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned h, l;
+            split2(v[16 * t + 4 * g], v[16 * t + 4 * g + 1], h, l);
+            out[2 * t + (g >> 1)][2 * (g & 1)] = h; outl[2 * t + (g >> 1)][2 * (g & 1)] = l;
+            split2(v[16 * t + 4 * g + 2], v[16 * t + 4 * g + 3], h, l);
+            out[2 * t + (g >> 1)][2 * (g & 1) + 1] = h; outl[2 * t + (g >> 1)][2 * (g & 1) + 1] = l;
+        }
+}
+
 // 32 fp32 values in the C/D pattern (index 16t + 4g + e <-> feature 32t + 8g + 4h + e) -> chain-ordered operands
 __device__ __forceinline__ void to_operands(const float (&v)[32], u32x4 (&out)[4])
 {
@@ -350,17 +393,21 @@ __device__ __forceinline__ void to_operands(const float (&v)[32], u32x4 (&out)[4
         }
 }
 
-__global__ void __launch_bounds__(256, 2)
+// X3: fp32 gated map and the three-term bf16 split of every product (slabs hold hi and lo: [layer][hi|lo][512]);
+// the parity-bound (1e-4) configuration.  Weights then take 144 KB of LDS: one workgroup per CU.
+template <bool X3>
+__global__ void __launch_bounds__(256, X3 ? 1 : 2)
 dgab_chain_bf16_kernel(const ChainBParams P)
 {
+    constexpr int SL = X3 ? 1024 : 512;                  // 16-B units per 64x64 slab (hi [+ lo])
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    u32x4* sWp = reinterpret_cast<u32x4*>(smem);        // 512
-    u32x4* sW1 = sWp + 512;                              // 4 x 512
-    u32x4* sW2 = sW1 + 4 * 512;                          // 4 x 512
-    float* sB = reinterpret_cast<float*>(sW2 + 4 * 512); // bp (64) | b1 (256) | b2 (64)
+    u32x4* sWp = reinterpret_cast<u32x4*>(smem);
+    u32x4* sW1 = sWp + SL;                               // 4 slabs
+    u32x4* sW2 = sW1 + 4 * SL;                           // 4 slabs
+    float* sB = reinterpret_cast<float*>(sW2 + 4 * SL);  // bp (64) | b1 (256) | b2 (64)
     const int tid = threadIdx.x;
-    for (int i = tid; i < 512; i += 256) sWp[i] = P.wp_s[i];
-    for (int i = tid; i < 4 * 512; i += 256) { sW1[i] = P.w1_s[i]; sW2[i] = P.w2_s[i]; }
+    for (int i = tid; i < SL; i += 256) sWp[i] = P.wp_s[i];
+    for (int i = tid; i < 4 * SL; i += 256) { sW1[i] = P.w1_s[i]; sW2[i] = P.w2_s[i]; }
     for (int i = tid; i < 64; i += 256) { sB[i] = P.bp[i]; sB[64 + HID + i] = P.b2[i]; }
     for (int i = tid; i < HID; i += 256) sB[64 + i] = P.b1[i];
     __syncthreads();
@@ -373,10 +420,22 @@ dgab_chain_bf16_kernel(const ChainBParams P)
     for (int tile = blockIdx.x; tile < P.tiles; tile += gridDim.x) {
         const size_t row = (size_t)tile * 128 + wv * 32 + l31;
         const float* xr = P.x + row * W;
-        // the gated map is already the operand: 8 consecutive bf16 per k-step
-        u32x4 ab[4];
+        // bf16 gated map: already the operand, 8 consecutive bf16 per k-step; fp32 (X3): split while loading
+        u32x4 ab[4], abl[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ab[j] = *reinterpret_cast<const u32x4*>(P.a + row * W + 16 * j + 8 * half);
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (X3) {
+                const float* ap = reinterpret_cast<const float*>(P.a) + row * W + 16 * j + 8 * half;
+                const float4 v0 = *reinterpret_cast<const float4*>(ap), v1 = *reinterpret_cast<const float4*>(ap + 4);
+                unsigned h[4], l[4];
+                split2(v0.x, v0.y, h[0], l[0]); split2(v0.z, v0.w, h[1], l[1]);
+                split2(v1.x, v1.y, h[2], l[2]); split2(v1.z, v1.w, h[3], l[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ab[j][e] = h[e]; abl[j][e] = l[e]; }
+            } else {
+                ab[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(P.a) + row * W + 16 * j + 8 * half);
+            }
+        }
         float x1[32];
 #pragma unroll
         for (int g8 = 0; g8 < 8; ++g8) {                 // g8 = 4t + g
@@ -388,7 +447,8 @@ dgab_chain_bf16_kernel(const ChainBParams P)
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-        gemm64b(sWp, ab, half, l31, acc);
+        if constexpr (X3) gemm64b3(sWp, ab, abl, half, l31, acc);
+        else gemm64b(sWp, ab, half, l31, acc);
         // ---- x1 = x + proj(A) ----
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -404,7 +464,7 @@ dgab_chain_bf16_kernel(const ChainBParams P)
 #pragma unroll
         for (int i = 0; i < 32; ++i) { const float d = x1[i] - mean; q += d * d; }
         const float rstd = 1.0f / sqrtf(plane_sum(q) * (1.0f / (H * W)) + kEps);
-        u32x4 xb[4];
+        u32x4 xb[4], xbl[4];
         {
             float xn[32];
 #pragma unroll
@@ -417,7 +477,8 @@ dgab_chain_bf16_kernel(const ChainBParams P)
                 xn[4 * g8 + 2] = (x1[4 * g8 + 2] - mean) * rstd * gg.z + bb.z;
                 xn[4 * g8 + 3] = (x1[4 * g8 + 3] - mean) * rstd * gg.w + bb.w;
             }
-            to_operands(xn, xb);
+            if constexpr (X3) to_operands3(xn, xb, xbl);
+            else to_operands(xn, xb);
         }
         // ---- out = x1 + fc2(gelu(fc1(xn))): hidden units in 4 blocks of 64, never leaving registers ----
         f32x16 o[2];
@@ -432,16 +493,22 @@ dgab_chain_bf16_kernel(const ChainBParams P)
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) hh[t][i] = 0.0f;
-            gemm64b(sW1 + hb * 512, xb, half, l31, hh);
+            if constexpr (X3) gemm64b3(sW1 + hb * SL, xb, xbl, half, l31, hh);
+            else gemm64b(sW1 + hb * SL, xb, half, l31, hh);
             float hid[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 const int f = 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3) + 4 * half;
                 hid[i] = gelu_as(hh[i >> 4][i & 15] + sB[64 + hb * 64 + f]);
             }
-            u32x4 hb4[4];
-            to_operands(hid, hb4);
-            gemm64b(sW2 + hb * 512, hb4, half, l31, o);
+            u32x4 hb4[4], hb4l[4];
+            if constexpr (X3) {
+                to_operands3(hid, hb4, hb4l);
+                gemm64b3(sW2 + hb * SL, hb4, hb4l, half, l31, o);
+            } else {
+                to_operands(hid, hb4);
+                gemm64b(sW2 + hb * SL, hb4, half, l31, o);
+            }
         }
         float* orow = P.out + row * W;
 #pragma unroll
@@ -499,7 +566,7 @@ TPSPP_EXPORT int tpspp_dgab_bf16_fwd(const float* x, const float* y, const float
                                      const float* mlp_w_t, const float* mlp_h_t, const void* proj_slab,
                                      const float* proj_b, const float* ln2_w, const float* ln2_b,
                                      const void* fc1_slab, const float* fc1_b, const void* fc2_slab,
-                                     const float* fc2_b, void* scratch, float* out, int N, int C,
+                                     const float* fc2_b, void* scratch, float* out, int N, int C, int split3,
                                      tpspp_stream_t stream)
 {
     TPSPP_REQUIRE(x && y && ln1_w && ln1_b && mlp_w_t && mlp_h_t && proj_slab && proj_b && ln2_w && ln2_b &&
@@ -511,24 +578,32 @@ TPSPP_EXPORT int tpspp_dgab_bf16_fwd(const float* x, const float* y, const float
     GateParams G;
     G.x = x; G.y = y; G.g1 = ln1_w; G.b1 = ln1_b; G.mw_t = mlp_w_t; G.mh_t = mlp_h_t; G.a = scratch;
     G.planes = planes;
-    hipLaunchKernelGGL(dgab_gate_kernel<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
+    if (split3) hipLaunchKernelGGL(dgab_gate_kernel<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
+    else hipLaunchKernelGGL(dgab_gate_kernel<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, st, G);
     int rc = tpspp::check_launch("tpspp_dgab_bf16_fwd(gate)");
     if (rc) return rc;
     ChainBParams Q;
-    Q.x = x; Q.a = static_cast<const unsigned short*>(scratch);
+    Q.x = x; Q.a = scratch;
     Q.wp_s = static_cast<const u32x4*>(proj_slab); Q.w1_s = static_cast<const u32x4*>(fc1_slab);
     Q.w2_s = static_cast<const u32x4*>(fc2_slab);
     Q.bp = proj_b; Q.b1 = fc1_b; Q.b2 = fc2_b; Q.g2 = ln2_w; Q.be2 = ln2_b; Q.out = out;
     Q.tiles = planes / 8;
-    const size_t lds = (size_t)(9 * 512) * 16 + (size_t)(64 + HID + 64) * sizeof(float);
+    const size_t lds = (size_t)(9 * (split3 ? 1024 : 512)) * 16 + (size_t)(64 + HID + 64) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_bf16_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_bf16_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_bf16_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
         attr_done = true;
     }
-    const int grid = Q.tiles < 512 ? Q.tiles : 512;                 // persistent: two workgroups per CU
-    hipLaunchKernelGGL(dgab_chain_bf16_kernel, dim3((unsigned)grid), dim3(256), lds, st, Q);
+    if (split3) {
+        const int grid = Q.tiles < 256 ? Q.tiles : 256;             // persistent: one workgroup per CU
+        hipLaunchKernelGGL(dgab_chain_bf16_kernel<true>, dim3((unsigned)grid), dim3(256), lds, st, Q);
+    } else {
+        const int grid = Q.tiles < 512 ? Q.tiles : 512;             // persistent: two workgroups per CU
+        hipLaunchKernelGGL(dgab_chain_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), lds, st, Q);
+    }
     return tpspp::check_launch("tpspp_dgab_bf16_fwd(chain)");
 }

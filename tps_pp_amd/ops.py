@@ -484,29 +484,35 @@ def dgab(x, y, dw):
 _PERM16 = [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]
 
 
-def _bf16_slab(w, chain):
+def _bf16_slab(w, chain, x3=False):
     """(out 64, K) fp32 -> [K/16][2][64][8] bf16 A-operand slab of v_mfma_f32_32x32x16_bf16; `chain`: k-slots in the
-    order in which the previous layer's result registers come back as operands (include/tpspp.h)."""
+    order in which the previous layer's result registers come back as operands (include/tpspp.h).  x3: the hi and lo
+    halves of the three-term split, stacked [hi|lo][K/16][2][64][8]."""
     cout, cin = w.shape
     idx = torch.arange(cin, device=w.device).view(cin // 16, 16)
     if chain:
         idx = idx[:, torch.tensor(_PERM16, device=w.device)]
-    return w[:, idx.reshape(-1)].view(cout, cin // 16, 2, 8).permute(1, 2, 0, 3).contiguous().to(torch.bfloat16)
+    a = w[:, idx.reshape(-1)].view(cout, cin // 16, 2, 8).permute(1, 2, 0, 3).contiguous()
+    if not x3:
+        return a.to(torch.bfloat16)
+    hi = a.to(torch.bfloat16)
+    return torch.stack([hi, (a - hi.float()).to(torch.bfloat16)]).contiguous()
 
 
 class DgabWeightsBf16:
-    def __init__(self, blk):
-        """blk: the DGAB module.  Slabs for tpspp_dgab_bf16_fwd."""
+    def __init__(self, blk, x3=False):
+        """blk: the DGAB module.  Slabs for tpspp_dgab_bf16_fwd (x3: hi + lo halves, split3)."""
+        self.x3 = x3
         f = lambda t: t.detach().float().contiguous()          # noqa: E731
         self.ln1_w, self.ln1_b = f(blk.norm1.weight), f(blk.norm1.bias)
         self.ln2_w, self.ln2_b = f(blk.norm2.weight), f(blk.norm2.bias)
         self.mw_t = f(blk.attn.mlp_w[0].weight.t())
         self.mh_t = f(blk.attn.mlp_h[0].weight.t())
-        self.proj_slab = _bf16_slab(f(blk.attn.proj.weight), False)
+        self.proj_slab = _bf16_slab(f(blk.attn.proj.weight), False, x3)
         self.proj_b = f(blk.attn.proj.bias)
         w1, w2 = f(blk.mlp.fc1.weight), f(blk.mlp.fc2.weight)
-        self.fc1_slab = torch.stack([_bf16_slab(w1[hb * 64:(hb + 1) * 64], True) for hb in range(4)]).contiguous()
-        self.fc2_slab = torch.stack([_bf16_slab(w2[:, hb * 64:(hb + 1) * 64], True) for hb in range(4)]).contiguous()
+        self.fc1_slab = torch.stack([_bf16_slab(w1[hb * 64:(hb + 1) * 64], True, x3) for hb in range(4)]).contiguous()
+        self.fc2_slab = torch.stack([_bf16_slab(w2[:, hb * 64:(hb + 1) * 64], True, x3) for hb in range(4)]).contiguous()
         self.fc1_b, self.fc2_b = f(blk.mlp.fc1.bias), f(blk.mlp.fc2.bias)
 
 
@@ -517,12 +523,12 @@ def dgab_bf16(x, y, dw):
     if (H, W) != (16, 64) or tuple(y.shape) != (N, C, 32):
         raise ValueError("dgab_bf16: needs x (N, C, 16, 64) and y (N, C, 32)")
     out = torch.empty_like(x)
-    scratch = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    scratch = torch.empty(x.shape, device=x.device, dtype=torch.float32 if dw.x3 else torch.bfloat16)
     with torch.cuda.device(x.device):
         rc = _lib.lib().tpspp_dgab_bf16_fwd(_ptr(x), _ptr(y), _ptr(dw.ln1_w), _ptr(dw.ln1_b), _ptr(dw.mw_t),
                                             _ptr(dw.mh_t), _ptr(dw.proj_slab), _ptr(dw.proj_b), _ptr(dw.ln2_w),
                                             _ptr(dw.ln2_b), _ptr(dw.fc1_slab), _ptr(dw.fc1_b), _ptr(dw.fc2_slab),
-                                            _ptr(dw.fc2_b), _ptr(scratch), _ptr(out), N, C, _stream(x))
+                                            _ptr(dw.fc2_b), _ptr(scratch), _ptr(out), N, C, int(dw.x3), _stream(x))
     _lib.check(rc, "tpspp_dgab_bf16_fwd")
     return out
 

@@ -436,7 +436,7 @@ class TPS_PP(nn.Module):
         k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
         k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
         de_feat = c16([k], cw["dec3"], 1, out_dtype=f32)
-        control_point, atten_score = self._tpe_hip(e3, de_feat, bf16=not x3)
+        control_point, atten_score = self._tpe_hip(e3, de_feat, bf16=True, x3=x3)
         return control_point, atten_score, feat_grid
 
     def grid(self, a1, a2, a3):
@@ -512,7 +512,7 @@ class TPS_PP(nn.Module):
         control_point, atten_score = self._tpe_hip(en_feat, de_feat)
         return control_point, atten_score, feat_grid
 
-    def _tpe_hip(self, en_feat, de_feat, bf16=False):
+    def _tpe_hip(self, en_feat, de_feat, bf16=False, x3=False):
         """Transformation_Parameter_Estimation.forward (`tps_pp.py:315-325`) with the DGAB block on the
         fused kernels (tpspp_dgab.hip), the per-point FC stacks on tpspp_points.hip and the score on
         tpspp_score.hip: no library kernel is left on the GPU path of the regressor."""
@@ -526,8 +526,8 @@ class TPS_PP(nn.Module):
         n = en_feat.size(0)
         if bf16:          # the three Linear layers of the DGAB chain on the bf16 matrix cores
             c16 = getattr(self, "_dgab16_cache", None)
-            if c16 is None or c16[0] != key:
-                self._dgab16_cache = c16 = (key, ops.DgabWeightsBf16(blk))
+            if c16 is None or c16[0] != (key, x3):
+                self._dgab16_cache = c16 = ((key, x3), ops.DgabWeightsBf16(blk, x3))
             de = ops.dgab_bf16(de_feat, en_feat.reshape(n, en_feat.size(1), -1), c16[1])
         else:
             de = ops.dgab(de_feat, en_feat.reshape(n, en_feat.size(1), -1), cache[1])
