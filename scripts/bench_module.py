@@ -63,12 +63,13 @@ with torch.no_grad():
     t_full = timeit(lambda: p(img))
     t_loc = timeit(lambda: p.LocalizationNetwork(img))
 print(f"TPSPreprocessor batch {N}: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | localisation net {t_loc:.2f} ms")
-p.LocalizationNetwork.compute_dtype = torch.bfloat16
-with torch.no_grad():
-    t_full = timeit(lambda: p(img))
-    t_loc = timeit(lambda: p.LocalizationNetwork(img))
-print(f"TPSPreprocessor batch {N}, bf16 localisation convolutions: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | "
-      f"localisation net {t_loc:.2f} ms")
+for mode, tag in (("bf16x3", "bf16x3 (<= 1e-4)"), (torch.bfloat16, "bf16")):
+    p.LocalizationNetwork.compute_dtype = mode
+    with torch.no_grad():
+        t_full = timeit(lambda: p(img))
+        t_loc = timeit(lambda: p.LocalizationNetwork(img))
+    print(f"TPSPreprocessor batch {N}, {tag} localisation convolutions: full {t_full:.2f} ms = {N / t_full * 1e3:,.0f} img/s | "
+          f"localisation net {t_loc:.2f} ms")
 
 
 # bf16 configuration (BASELINE.json configs[2]): bf16 tensors at the module boundary, bf16 MFMA convolutions

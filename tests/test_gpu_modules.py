@@ -124,6 +124,13 @@ def test_classic_module_bf16_localisation(cuda):
         out = m(img)
     assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() <= 5e-3
     assert np.abs(out.cpu().numpy() - G["out"]).mean() <= 5e-3 * np.abs(G["out"]).max()
+    # "bf16x3": the three-term split keeps the exact path's tolerances (test_classic_module_against_reference)
+    m.LocalizationNetwork.compute_dtype = "bf16x3"
+    with torch.no_grad():
+        ctrl = m.LocalizationNetwork(img)
+        out = m(img)
+    assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 1e-5
+    assert np.abs(out.cpu().numpy() - G["out"]).max() <= TOL
 
 
 @pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"), ("ResNet45", "tpspp_module_v1")])

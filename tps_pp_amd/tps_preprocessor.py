@@ -75,15 +75,15 @@ class LocalizationNetwork(nn.Module):
             self._cw_cache = cache = (key, cw)
         return cache[1]
 
-    def _hip_weights_bf16(self):
+    def _hip_weights_bf16(self, x3=False):
         mods = [self.conv[i] for i in (0, 1, 4, 5, 8, 9, 12, 13)]
-        key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
+        key = (tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers())), x3)
         cache = getattr(self, "_cw16_cache", None)
         if cache is None or cache[0] != key:
             cw = []
             for ci, bi in ((0, 1), (4, 5), (8, 9), (12, 13)):
                 bn = self.conv[bi]
-                cw.append(ops.prep_conv_weight_bf16(self.conv[ci].weight, eps=bn.eps,
+                cw.append(ops.prep_conv_weight_bf16(self.conv[ci].weight, eps=bn.eps, x3=x3,
                                                     bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var)))
             self._cw16_cache = cache = (key, cw)
         return cache[1]
@@ -95,10 +95,12 @@ class LocalizationNetwork(nn.Module):
         n = batch_img.size(0)
         cw = self._hip_weights()
         x = batch_img.float().contiguous()
-        if getattr(self, "compute_dtype", None) == torch.bfloat16:
+        mode = getattr(self, "compute_dtype", None)
+        if mode == torch.bfloat16 or mode == "bf16x3":
             # bf16 configuration: the four convolutions on the bf16 matrix cores (fp32 maps in and out: operands are
-            # rounded as they are staged, accumulation / bias / ReLU fp32); pooling and the two FCs stay fp32
-            c16 = self._hip_weights_bf16()
+            # rounded as they are staged, accumulation / bias / ReLU fp32); pooling and the two FCs stay fp32.
+            # "bf16x3": the three-term split of the fp32 operands instead of a plain rounding (within the 1e-4 bar).
+            c16 = self._hip_weights_bf16(mode == "bf16x3")
             for i in range(3):
                 x = ops.maxpool2x2(ops.conv2d_bf16([x], c16[i], 1, True, out_dtype=torch.float32))
             x = ops.global_avgpool(ops.conv2d_bf16([x], c16[3], 1, True, out_dtype=torch.float32))
