@@ -57,6 +57,34 @@ def test_config2_regressor_and_warp_batch_1024(cuda):
     assert np.abs(small["mp_img"][:2].cpu().numpy() - o["mp_img"]).max() <= TOL
 
 
+def test_config2_bf16x3_regressor_and_warp_batch_1024(cuda):
+    """configs[2] geometry at batch 1024 with `compute_dtype = "bf16x3"` (fp32 tensors, three-term bf16 split): rows of
+    the full batch equal the small batch bit for bit, the small batch meets the exact path's 1e-4 against the fp32 CPU
+    oracle, and the full batch stays within 1e-4 of the exact-fp32 HIP kernels on every image."""
+    from tps_pp_amd import TPS_PP
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    cpu_sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.to(cuda)
+    n = 1024
+    inp = cases.g4_inputs("ResNet45v2")
+    x = tile_batch(inp["x"], n)
+    outs = [tile_batch(o, n) for o in inp["outs"]]
+    pick = [0, 1, 513, 1023]
+    with torch.no_grad():
+        exact = m(dev(x, cuda), [dev(o, cuda) for o in outs])
+        m.compute_dtype = "bf16x3"
+        full = m(dev(x, cuda), [dev(o, cuda) for o in outs])
+        small = m(dev(x[pick], cuda), [dev(o[pick], cuda) for o in outs])
+    for k in ("output", "mp_img", "pc_score"):
+        assert torch.equal(full[k][pick], small[k]), k
+        assert (full[k] - exact[k]).abs().max().item() <= TOL, k
+    o = TO.tpspp_forward(cpu_sd, x[pick[:2]], [o_[pick[:2]] for o_ in outs], "ResNet45v2")
+    assert np.abs(small["output"][:2].cpu().numpy() - o["output"]).max() <= TOL
+    assert np.abs(small["mp_img"][:2].cpu().numpy() - o["mp_img"]).max() <= TOL
+
+
 def test_config2_bf16_regressor_and_warp_batch_1024(cuda):
     """BASELINE.json configs[2] as named: batch 1024, bf16.  Rows of the full batch equal the same images run
     as a small batch bit for bit; the small batch is checked against the CPU oracle that rounds to bfloat16
