@@ -31,6 +31,12 @@ python3 scripts/bench_conv.py > $OUT/conv_bf16.log 2>&1
 # 4. MFMA-busy counters (own pass) for the regressor kernels + the calibration kernel (pure MFMA)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc -o module -- \
     python3 scripts/bench_module.py > $OUT/mfma_module.log 2>&1
+for mode in bf16only x3only; do
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc_$mode -o module -- \
+      python3 scripts/bench_module.py 512 $mode > $OUT/mfma_module_$mode.log 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_x3 -o module_x3 -- \
+    python3 scripts/bench_module.py 512 x3only > $OUT/module_x3.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_cal -o cal -- \
     ./scripts/ubench/mfma_bench > $OUT/mfma_cal.log 2>&1
 ls -R $OUT | head -60

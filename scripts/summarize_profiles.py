@@ -57,9 +57,11 @@ def mfma_summary():
         rows.append((sum(b), k, len(b), sum(b) / sum(a) / per_active))
     rows.sort(reverse=True)
     with open(os.path.join(DST, f"{TAG}_mfma_util.md"), "w") as f:
-        f.write(f"""# {TAG}: fp32 matrix-pipe utilisation of the TPS++ regressor kernels (MI355X, 1 GPU)
+        f.write(f"""# {TAG}: matrix-pipe utilisation of the TPS++ regressor kernels (MI355X, 1 GPU)
 
-`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 scripts/bench_module.py` (batch 512, own pass).
+`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 scripts/bench_module.py` (batch 512, own pass; the
+script runs the exact-fp32, the "bf16x3" (`..., true>` instantiations) and the bf16 configuration one after the other,
+so the first table holds the kernels of all three; per-configuration passes follow).
 
 Calibration (`scripts/ubench/mfma_bench.hip`: every SIMD issues only `v_mfma_f32_32x32x2_f32`):
 {tf[-1].strip() if tf else ""}
@@ -72,6 +74,22 @@ GRBM_GUI_ACTIVE summed over the 8 XCDs); utilisation below = the same ratio of a
         for _, k, n, u in rows:
             f.write(f"| `{k[:100]}` | {n} | {100 * u:.1f} % |\n")
         f.write("\n(counter collection serialises dispatches and slows kernels slightly; un-profiled rates are in DESIGN.md section 4b)\n")
+        # the bf16 and "bf16x3" configurations of the same module: the pipe-busy ratio does not depend on the operand type
+        for mode, title in (("bf16only", "bf16 configuration (`bench_module.py 512 bf16only`)"),
+                            ("x3only", '"bf16x3" configuration (`bench_module.py 512 x3only`): fp32 tensors, three bf16 MFMAs per product')):
+            pth = os.path.join(SRC, f"mfma_pmc_{mode}", "module_counter_collection.csv")
+            if not os.path.exists(pth):
+                continue
+            rows2 = []
+            for k, v in load(pth).items():
+                b, a = v.get("SQ_VALU_MFMA_BUSY_CYCLES"), v.get("GRBM_GUI_ACTIVE")
+                if not b or not a or sum(b) == 0:
+                    continue
+                rows2.append((sum(b), k, len(b), sum(b) / sum(a) / per_active))
+            rows2.sort(reverse=True)
+            f.write(f"\n## {title}\n\n| kernel | dispatches | MFMA pipe busy |\n|---|---|---|\n")
+            for _, k, n, u in rows2:
+                f.write(f"| `{k[:100]}` | {n} | {100 * u:.1f} % |\n")
 
 
 def main():
@@ -130,7 +148,7 @@ Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / 
 """)
     # kernel stats of the wider rows (whole TPS++ module, whole recogniser, warp backward)
     for w, name in (("module", "module"), ("head", "recognizer"), ("backward", "warp_backward"),
-                    ("module_bf16", "module_bf16")):
+                    ("module_bf16", "module_bf16"), ("module_x3", "module_bf16x3")):
         src = os.path.join(SRC, f"trace_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(src):
             rows = sorted(csv.DictReader(open(src)), key=lambda r: -float(r["TotalDurationNs"]))
