@@ -279,13 +279,15 @@ int tpspp_conv_chunk_channels(int kernel_size);
  *   wg       [12][2][64][8] with value Wg[cout][16 j + perm[8 h + e]], perm = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15}
  *            (the order in which the matrix core's result registers come back as the next operand);
  *   b0 / b1 / b2 / bg (64) fp32.  Needs H even and W a multiple of 32.
+ *   split3: the three-term "bf16x3" split on fp32 tensors -- inputs and all four outputs fp32, every slab holds its hi
+ *   and lo halves ([hi|lo][k-steps][2][64][8]), feat0 / feat1 / feat2 are chained without an intermediate rounding.
  * replaces: backbones/tps_pp/tps_pp.py:560-562,581-585
  */
 int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
                          const void* w0, const float* b0, const void* w1, const float* b1,
                          const void* w2, const float* b2, const void* wg, const float* bg,
                          void* feat0, void* feat1, void* feat2, void* feat_grid, int feat_grid_f32,
-                         int N, int H, int W, tpspp_stream_t stream);
+                         int N, int H, int W, int split3, tpspp_stream_t stream);
 
 /*
  * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32

@@ -172,3 +172,29 @@ def test_conv_bf16x3_matches_fp32_reference(cuda, name, srcs, cout, k, stride, r
     got = ops.conv2d_bf16([(x.to(cuda), uh, uw) for x, uh, uw in xs], cw, stride, relu,
                           None if res is None else res.to(cuda), res_mode, out_dtype=torch.float32).cpu()
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), name
+
+
+def test_front_bf16x3_fused_against_fp32_reference(cuda):
+    """split3 of tpspp_front_bf16_fwd (fp32 tensors, three-term bf16 split, feat0 / feat1 / feat2 chained without an
+    intermediate rounding) against float64 PyTorch-CPU on the unrounded operands: 2e-5 of each tensor's scale."""
+    from tps_pp_amd import TPS_PP
+    import cases
+    m = TPS_PP().eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    N, H, W = 3, 6, 96
+    o0 = t(synth.dyadic((N, 32, H, W), "fx.o0", 1))
+    o1 = t(synth.dyadic((N, 32, H, W), "fx.o1", 1))
+    x = t(synth.dyadic((N, 64, H // 2, W // 2), "fx.x", 1))
+
+    def cm(mod, v):
+        return F.relu(F.conv2d(v.double(), mod.conv.weight.detach().double(), mod.conv.bias.detach().double()))
+    f0, f1, f2 = cm(m.down0, o0), cm(m.down1, o1), cm(m.down2, x)
+    fg = cm(m.down_feat, torch.cat((f0, f1, F.interpolate(f2, scale_factor=2, mode="nearest")), 1))
+    m.to(cuda)
+    fw = ops.FrontWeightsBf16(m, x3=True)
+    got = ops.front_bf16(o0.to(cuda), o1.to(cuda), x.to(cuda), fw)
+    for g_, r_, name in zip(got, (f0, f1, f2, fg), ("feat0", "feat1", "feat2", "feat_grid")):
+        assert g_.dtype == torch.float32
+        err = float((g_.cpu().double() - r_).abs().max())
+        assert err <= 2e-5 * float(r_.abs().max()), (name, err)

@@ -597,40 +597,36 @@ def front(o0, o1, x, fw):
 
 
 class FrontWeightsBf16:
-    def __init__(self, m):
-        """m: TPS_PP (ResNet45v2 wiring).  Slabs for tpspp_front_bf16_fwd (include/tpspp.h)."""
-        dev = m.down0.conv.weight.device
-        perm16 = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=dev)
-
-        def slab(w, chain):
-            cout, cin = w.shape
-            idx = torch.arange(cin, device=dev).view(cin // 16, 16)
-            if chain:
-                idx = idx[:, perm16]
-            # [k-step][half][cout][8]: value W[cout][idx[j][8 h + e]]
-            return w[:, idx.reshape(-1)].view(cout, cin // 16, 2, 8).permute(1, 2, 0, 3).contiguous().to(torch.bfloat16)
+    def __init__(self, m, x3=False):
+        """m: TPS_PP (ResNet45v2 wiring).  Slabs for tpspp_front_bf16_fwd (include/tpspp.h); x3: hi + lo halves."""
         f = lambda t: t.detach().float().contiguous()          # noqa: E731
-        self.w0 = slab(f(m.down0.conv.weight).view(64, 32), False)
-        self.w1 = slab(f(m.down1.conv.weight).view(64, 32), False)
-        self.w2 = slab(f(m.down2.conv.weight).view(64, 64), False)
-        self.wg = slab(f(m.down_feat.conv.weight).view(64, 192), True)
+        self.x3 = x3
+        self.w0 = _bf16_slab(f(m.down0.conv.weight).view(64, 32), False, x3)
+        self.w1 = _bf16_slab(f(m.down1.conv.weight).view(64, 32), False, x3)
+        self.w2 = _bf16_slab(f(m.down2.conv.weight).view(64, 64), False, x3)
+        self.wg = _bf16_slab(f(m.down_feat.conv.weight).view(64, 192), True, x3)
         self.b0, self.b1, self.b2, self.bg = (f(c.conv.bias) for c in (m.down0, m.down1, m.down2, m.down_feat))
 
 
-def front_bf16_applicable(o0, o1, x):
-    return all(t.dtype == torch.bfloat16 for t in (o0, o1, x)) and o0.shape[2] % 2 == 0 and o0.shape[3] % 32 == 0
+def front_bf16_applicable(o0, o1, x, x3=False):
+    dt = torch.float32 if x3 else torch.bfloat16
+    return all(t.dtype == dt for t in (o0, o1, x)) and o0.shape[2] % 2 == 0 and o0.shape[3] % 32 == 0
 
 
 def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16):
-    """`front` on the bf16 matrix cores: bf16 in, bf16 feat0 / feat1 / feat2, feat_grid bf16 or fp32."""
+    """`front` on the bf16 matrix cores: bf16 in, bf16 feat0 / feat1 / feat2, feat_grid bf16 or fp32; with x3 weights
+    (`FrontWeightsBf16(m, x3=True)`) fp32 in and out, three-term split."""
     o0, o1, x = _chk16("outs[0]", o0, 4), _chk16("outs[1]", o1, 4), _chk16("x", x, 4)
     N, c0, H, W = o0.shape
     if c0 != 32 or tuple(o1.shape) != (N, 32, H, W) or tuple(x.shape) != (N, 64, H // 2, W // 2):
         raise ValueError("front_bf16: needs outs (N,32,H,W) x2 and x (N,64,H/2,W/2)")
-    if not front_bf16_applicable(o0, o1, x):
-        raise ValueError("front_bf16: needs bfloat16 inputs, an even height and a width that is a multiple of 32")
+    if not front_bf16_applicable(o0, o1, x, fw.x3):
+        raise ValueError("front_bf16: needs bfloat16 inputs (float32 with x3 weights), an even height and a width that "
+                         "is a multiple of 32")
     dev = o0.device
-    bf = torch.bfloat16
+    bf = torch.float32 if fw.x3 else torch.bfloat16
+    if fw.x3:
+        feat_grid_dtype = torch.float32
     feat0 = torch.empty((N, 64, H, W), device=dev, dtype=bf)
     feat1 = torch.empty_like(feat0)
     feat_grid = torch.empty((N, 64, H, W), device=dev, dtype=feat_grid_dtype)
@@ -639,7 +635,7 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16):
         rc = _lib.lib().tpspp_front_bf16_fwd(_ptr(o0), _ptr(o1), _ptr(x), _ptr(fw.w0), _ptr(fw.b0), _ptr(fw.w1),
                                              _ptr(fw.b1), _ptr(fw.w2), _ptr(fw.b2), _ptr(fw.wg), _ptr(fw.bg),
                                              _ptr(feat0), _ptr(feat1), _ptr(feat2), _ptr(feat_grid),
-                                             int(feat_grid_dtype == torch.float32), N, H, W, _stream(o0))
+                                             int(feat_grid_dtype == torch.float32), N, H, W, int(fw.x3), _stream(o0))
     _lib.check(rc, "tpspp_front_bf16_fwd")
     return feat0, feat1, feat2, feat_grid
 

@@ -409,13 +409,13 @@ class TPS_PP(nn.Module):
             # feat_grid is sampled by the warp: bf16 when the module boundary is bf16 (the warp then moves half
             # the bytes and rounds once at its store), fp32 when the caller's tensors are fp32
             fg_dtype = bf if x.dtype == bf else f32
-            if not x3 and ops.front_bf16_applicable(o0, o1, x):
+            if ops.front_bf16_applicable(o0, o1, x, x3):
                 # the four pointwise convolutions fused, register-chained (tpspp_front_bf16.hip)
-                fkey = tuple((t.data_ptr(), t._version) for mdl in (self.down0, self.down1, self.down2, self.down_feat)
-                             for t in mdl.parameters())
+                fkey = (tuple((t.data_ptr(), t._version) for mdl in (self.down0, self.down1, self.down2, self.down_feat)
+                              for t in mdl.parameters()), x3)
                 fc = getattr(self, "_front16_cache", None)
                 if fc is None or fc[0] != fkey:
-                    self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self))
+                    self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self, x3))
                 feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype)
             else:
                 feat0 = c16([o0], cw["down0"], 1)
