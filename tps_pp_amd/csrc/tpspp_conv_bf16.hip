@@ -27,373 +27,7 @@
 // backbones/tps_pp/tps_pp.py:126-131,149-154,156-169,538-552,560-562; backbones/resnet_v2_large.py:131-135;
 // layers/conv_layer.py:12-33 -- when the module runs in bf16.
 // Bound: operand delivery (LDS bandwidth) below the bf16 MFMA peak (2.5 PFLOP/s); 1x1 layers HBM.
-#include "tpspp_common.h"
-
-namespace {
-
-constexpr int kWave = 64;
-constexpr int kThreads = 256;
-constexpr int BM = 256;       // output pixels per workgroup
-constexpr int BN = 64;        // output channels per workgroup
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct BSrc {
-    const void* p;
-    int C, H, W;              // stored size
-    int lh, lw;               // log2 of the nearest upsampling factors
-    int f32;                  // element type: 1 fp32, 0 bf16
-};
-
-struct BParams {
-    BSrc src[3];
-    int nsrc;
-    const u32x4* wt;          // [ctile][chunk][tap][k group][64][8] bf16, 16-B units
-    const float* bias;        // (Cout) fp32 or null
-    const void* res;          // (N, Cout, Ho, Wo) or null
-    const float* post_scale;
-    const float* post_shift;
-    void* out;
-    int res_f32, out_f32;
-    int N, Cin, Cout, Hi, Wi, Ho, Wo, ph, pw;
-    int relu, res_mode;
-    int nchunks;
-};
-
-__device__ __forceinline__ unsigned f32_to_bf16_bits(float f)
-{
-    // round to nearest even (inputs are finite activations)
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-// v_cvt_pk_bf16_f32: two fp32 -> packed bf16, round to nearest even
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi)
-{
-    f32x2 v; v[0] = lo; v[1] = hi;
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h)
-{
-    return __builtin_bit_cast(float, (unsigned)h << 16);
-}
-
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC>
-struct BCfg {
-    static constexpr int KW = KH;
-    static constexpr int TAPS = KH * KW;
-    // a 1x1 kernel stages exactly the pixels it reads (one patch position per output pixel, input step =
-    // stride); a 3x3 kernel stages the dense patch (input step 1, output pixels `stride` positions apart)
-    static constexpr int OSH = KH == 1 ? 1 : SH, OSW = KH == 1 ? 1 : SW;   // patch positions per output step
-    static constexpr int ISH = KH == 1 ? SH : 1, ISW = KH == 1 ? SW : 1;   // input pixels per patch position
-    static constexpr int PH = (TH - 1) * OSH + KH;
-    static constexpr int PW = (TW - 1) * OSW + KW;
-    static constexpr int PS = PH * PW;                 // positions per image
-    static constexpr int PSN = NI * PS;                // positions per tile
-    static constexpr int NPOS = (PSN + kThreads - 1) / kThreads;
-    static constexpr int KG = KC / 8;                  // channel groups of 8
-    static constexpr int WSLAB = TAPS * KG * BN;       // 16-B units of a chunk's weight slab
-    static constexpr int NW = (WSLAB + kThreads - 1) / kThreads;
-};
-
-// X3: "bf16x3" -- every fp32 operand is split into two bf16 halves (hi = bf16(x), lo = bf16(x - hi)) and a product
-// is hi*hi + hi*lo + lo*hi, accumulated in fp32: 16-17 mantissa bits per operand (relative error ~5e-6 per layer
-// against 3e-7 for fp32 and 2.5e-3 for plain bf16) at three matrix instructions that are each 16x faster than the
-// fp32 one.  For the fp32 tensors of the parity-bound (1e-4) path: activations stay fp32 in HBM, the split happens
-// in the staging registers; the weight arrives as two arranged slabs per chunk.
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false>
-__global__ void __launch_bounds__(kThreads, 2)
-conv_tiled_bf16_kernel(const BParams P)
-{
-    using Cfg = BCfg<KH, SH, SW, TH, TW, NI, KC>;
-    constexpr int KW = Cfg::KW, TAPS = Cfg::TAPS, PW = Cfg::PW, PS = Cfg::PS, PSN = Cfg::PSN;
-    constexpr int NPOS = Cfg::NPOS, KG = Cfg::KG, WSLAB = Cfg::WSLAB, NW = Cfg::NW;
-    static_assert(NI * TH * TW == BM, "tile must hold 256 pixels");
-    static_assert(KC % 16 == 0, "whole MFMA k-steps");
-    constexpr int NS = X3 ? 2 : 1;                     // hi (and lo) images
-    __shared__ u32x4 sP[NS * KG * PSN];                // [hi|lo][k group][position] x 8 bf16
-    __shared__ u32x4 sW[NS * WSLAB];                   // [hi|lo][tap][k group][cout] x 8 bf16
-
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wv = tid / kWave;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int ctiles = (P.Cout + BN - 1) / BN;
-    const int ngrp = blockIdx.z / ctiles;
-    const int ctile = blockIdx.z - ngrp * ctiles;
-    const int n0 = ngrp * NI;
-    const int co_base = ctile * BN;
-    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
-    const int iy_base = oy0 * SH - P.ph, ix_base = ox0 * SW - P.pw;
-    const int HoWo = P.Ho * P.Wo;
-
-    // the two 32-pixel fragments of this wavefront: tile-linear pixel -> (image, row, column)
-    int fimg[2], fty[2], ftx[2], fpos[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int tp = (wv * 2 + f) * 32 + l31;
-        fimg[f] = tp / (TH * TW);
-        const int tpi = tp - fimg[f] * (TH * TW);
-        fty[f] = tpi / TW;
-        ftx[f] = tpi - fty[f] * TW;
-        fpos[f] = half * PSN + fimg[f] * PS + fty[f] * Cfg::OSH * PW + ftx[f] * Cfg::OSW;
-    }
-
-    // staging: this thread's patch positions (fixed over the chunks): logical input coordinates, or -1
-    int piy[NPOS], pix[NPOS], pim[NPOS];
-#pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-        const int e = tid + i * kThreads;
-        const int im = e / PS, e1 = e - im * PS;
-        const int py = e1 / PW, px = e1 - py * PW;
-        const int iy = iy_base + py * Cfg::ISH, ix = ix_base + px * Cfg::ISW;
-        const bool ok = e < PSN && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
-        piy[i] = ok ? iy : -1;
-        pix[i] = ix;
-        pim[i] = im;
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[f][h2][i] = 0.0f;
-
-    unsigned rp[NPOS][KC / 2];          // packed channel pairs of each position
-    unsigned rpl[X3 ? NPOS : 1][X3 ? KC / 2 : 1];   // their low halves (X3)
-    u32x4 rw[NW];
-    u32x4 rwl[X3 ? NW : 1];
-    int cbase = 0, s = 0;
-    BSrc cur = P.src[0];
-    const u32x4* wbase = P.wt + (size_t)ctile * P.nchunks * (NS * WSLAB);
-
-    auto prefetch = [&](int chunk) {
-        const int c0 = chunk * KC;
-        while (c0 >= cbase + cur.C) { cbase += cur.C; ++s; cur = P.src[s]; }
-        const int plane = cur.H * cur.W;
-        const int cleft = min(KC, cur.C - (c0 - cbase));           // channels of this chunk that exist
-        const size_t img_stride = (size_t)cur.C * plane;
-        const size_t chan0 = (size_t)n0 * img_stride + (size_t)(c0 - cbase) * plane;   // uniform
-        // every load is unconditional (a predicate per load would put each one in its own basic block and
-        // serialise them behind s_waitcnt): channels beyond the source's last one re-read that last channel
-        // and are zeroed by a select, padding positions read the chunk's first element.  Addresses are
-        // wave-uniform channel base + one 32-bit lane offset per position (no 64-bit vector arithmetic).
-#pragma unroll
-        for (int i = 0; i < NPOS; ++i) {
-            const bool ok = piy[i] >= 0;
-            const unsigned lo = ok ? (unsigned)(pim[i] * (int)img_stride + (piy[i] >> cur.lh) * cur.W + (pix[i] >> cur.lw)) : 0u;
-            if (cur.f32) {
-                const float* sp = reinterpret_cast<const float*>(cur.p) + chan0;
-                float v[KC];
-#pragma unroll
-                for (int c = 0; c < KC; ++c) v[c] = (sp + (size_t)min(c, cleft - 1) * plane)[lo];
-#pragma unroll
-                for (int c2 = 0; c2 < KC / 2; ++c2) {
-                    const unsigned pk = pack2_bf16(v[2 * c2], v[2 * c2 + 1]);
-                    const unsigned m = (2 * c2 + 1 < cleft) ? 0xffffffffu : ((2 * c2 < cleft) ? 0x0000ffffu : 0u);
-                    rp[i][c2] = ok ? (pk & m) : 0u;
-                    if constexpr (X3) {
-                        const float h0 = __builtin_bit_cast(float, pk << 16), h1 = __builtin_bit_cast(float, pk & 0xffff0000u);
-                        const unsigned pl = pack2_bf16(v[2 * c2] - h0, v[2 * c2 + 1] - h1);
-                        rpl[i][c2] = ok ? (pl & m) : 0u;
-                    }
-                }
-            } else {
-                const unsigned short* sp = reinterpret_cast<const unsigned short*>(cur.p) + chan0;
-                unsigned short v[KC];
-#pragma unroll
-                for (int c = 0; c < KC; ++c) v[c] = (sp + (size_t)min(c, cleft - 1) * plane)[lo];
-#pragma unroll
-                for (int c2 = 0; c2 < KC / 2; ++c2) {
-                    const unsigned lo16 = (2 * c2 < cleft) ? (unsigned)v[2 * c2] : 0u;
-                    const unsigned hi16 = (2 * c2 + 1 < cleft) ? (unsigned)v[2 * c2 + 1] : 0u;
-                    rp[i][c2] = ok ? (lo16 | (hi16 << 16)) : 0u;
-                    if constexpr (X3) rpl[i][c2] = 0u;         // a bf16 tensor has no low half
-                }
-            }
-        }
-        const u32x4* wp = wbase + (size_t)chunk * (NS * WSLAB);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int e = tid + i * kThreads;
-            rw[i] = wp[e < WSLAB ? e : 0];
-            if constexpr (X3) rwl[i] = wp[WSLAB + (e < WSLAB ? e : 0)];
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < NPOS; ++i) {
-            const int e = tid + i * kThreads;
-            if (e < PSN) {
-#pragma unroll
-                for (int g = 0; g < KG; ++g) {
-                    u32x4 v;
-                    v[0] = rp[i][4 * g]; v[1] = rp[i][4 * g + 1]; v[2] = rp[i][4 * g + 2]; v[3] = rp[i][4 * g + 3];
-                    sP[g * PSN + e] = v;
-                    if constexpr (X3) {
-                        v[0] = rpl[i][4 * g]; v[1] = rpl[i][4 * g + 1]; v[2] = rpl[i][4 * g + 2]; v[3] = rpl[i][4 * g + 3];
-                        sP[KG * PSN + g * PSN + e] = v;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int e = tid + i * kThreads;
-            if (e < WSLAB) {
-                sW[e] = rw[i];
-                if constexpr (X3) sW[WSLAB + e] = rwl[i];
-            }
-        }
-    };
-
-    prefetch(0);
-    for (int chunk = 0; chunk < P.nchunks; ++chunk) {
-        commit();
-        __syncthreads();
-        if (chunk + 1 < P.nchunks) prefetch(chunk + 1);       // in flight during the MFMA phase
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KW, kx = tap - ky * KW;
-#pragma unroll
-            for (int ks = 0; ks < KC / 16; ++ks) {
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, sP[fpos[0] + (2 * ks) * PSN + ky * PW + kx]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, sP[fpos[1] + (2 * ks) * PSN + ky * PW + kx]);
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + l31]);
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + 32 + l31]);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-                if constexpr (X3) {
-                    const bf16x8 b0l = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[0] + (2 * ks) * PSN + ky * PW + kx]);
-                    const bf16x8 b1l = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[1] + (2 * ks) * PSN + ky * PW + kx]);
-                    const bf16x8 a0l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + l31]);
-                    const bf16x8 a1l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + 32 + l31]);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0l, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0l, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1l, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1l, acc[1][1], 0, 0, 0);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1, acc[1][1], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias, residual, ReLU, affine; half-wavefronts store rows of 32 consecutive pixels ----
-    // For a 1x1 layer with 32 input channels the epilogue IS the kernel (8 MFMAs against 64 outputs per lane),
-    // so it is kept off the vector ALU: addresses are a wave-uniform base (image group, channel tile, channel:
-    // scalar arithmetic) plus ONE 32-bit lane offset per fragment, the bias arrives as eight float4 per lane,
-    // bf16 pairs are rounded by v_cvt_pk_bf16_f32 and stored from the two halves of one register.
-    const bool full_c = co_base + BN <= P.Cout;                  // uniform
-    float bq[2][4][4];
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = co_base + 32 * h2 + 8 * g + 4 * half;
-            if (P.bias && full_c) {
-                const float4 b4 = *reinterpret_cast<const float4*>(P.bias + co);
-                bq[h2][g][0] = b4.x; bq[h2][g][1] = b4.y; bq[h2][g][2] = b4.z; bq[h2][g][3] = b4.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bq[h2][g][e] = (P.bias && co + e < P.Cout) ? P.bias[co + e] : 0.0f;
-            }
-        }
-    const size_t ubase = ((size_t)n0 * P.Cout + co_base) * HoWo;  // uniform: first image / channel of the tile
-    // (GELU goes through the general path: with erff inlined into the common one the compiler no longer keeps that
-    //  path branch-free and every convolution pays for it -- measured: 1x1 32->64 0.11 -> 0.21 ms)
-    const bool simple = P.res_mode == 0 && P.post_scale == nullptr && P.relu != 2;
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
-        const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
-        const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                const int cu = 32 * h2 + 8 * g;                   // + 4*half (in `lo`) + e
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[f][h2][4 * g + e] + bq[h2][g][e];
-                    if (!simple) {
-                        const size_t o = ubase + (size_t)(cu + e) * HoWo + lo;
-                        const int co = co_base + cu + 4 * half + e;
-                        float rv = 0.0f;
-                        if (P.res_mode && valid && co < P.Cout)
-                            rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
-                                           : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
-                        if (P.res_mode == 2) v[e] = v[e] + rv;
-                        if (P.relu == 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                        else if (P.relu == 2) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-                        if (P.res_mode == 1) v[e] = v[e] + rv;
-                        if (P.post_scale && co < P.Cout) v[e] = v[e] * P.post_scale[co] + P.post_shift[co];
-                    } else if (P.relu == 1) {
-                        v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                    }
-                }
-                const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
-                if (P.out_f32) {
-                    float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (valid && (full_c || co4 + e < P.Cout)) (ob + (size_t)e * HoWo)[lo] = v[e];
-                } else {
-                    unsigned short* ob = reinterpret_cast<unsigned short*>(P.out) + ubase + (size_t)cu * HoWo;
-                    const unsigned p01 = pack2_bf16(v[0], v[1]), p23 = pack2_bf16(v[2], v[3]);
-                    if (valid && (full_c || co4 < P.Cout)) ob[lo] = (unsigned short)(p01 & 0xffffu);
-                    if (valid && (full_c || co4 + 1 < P.Cout)) (ob + (size_t)HoWo)[lo] = (unsigned short)(p01 >> 16);
-                    if (valid && (full_c || co4 + 2 < P.Cout)) (ob + (size_t)2 * HoWo)[lo] = (unsigned short)(p23 & 0xffffu);
-                    if (valid && (full_c || co4 + 3 < P.Cout)) (ob + (size_t)3 * HoWo)[lo] = (unsigned short)(p23 >> 16);
-                }
-            }
-        }
-    }
-}
-
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3>
-void launch_b(const BParams& P, hipStream_t st)
-{
-    const int ctiles = (P.Cout + BN - 1) / BN;
-    const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
-                    (unsigned)(((P.N + NI - 1) / NI) * ctiles));
-    hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3>), grid, dim3(kThreads), 0, st, P);
-}
-
-constexpr int kKC3 = 16;      // channels per chunk, 3x3 kernels
-constexpr int kKC1 = 32;      // channels per chunk, 1x1 kernels
-
-// picks the tile by output width / height; false when no instantiation fits
-template <int KH, int SH, int SW, int KC, bool X3>
-bool launch_by_shape(const BParams& P, hipStream_t st)
-{
-    if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC, X3>(P, st);   // a row of tokens
-    else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC, X3>(P, st);
-    else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC, X3>(P, st);
-    else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC, X3>(P, st);
-    else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC, X3>(P, st);
-    else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC, X3>(P, st);
-    else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 4, KC, X3>(P, st);
-    else                launch_b<KH, SH, SW, 2, 16, 8, KC, X3>(P, st);
-    return true;
-}
-
-}  // namespace
+#include "tpspp_conv_bf16_impl.h"
 
 TPSPP_EXPORT int tpspp_conv_bf16_chunk_channels(int kernel_size)
 {
@@ -451,11 +85,7 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     hipStream_t st = tpspp::as_stream(stream);
     bool ok = false;
     if (split3) {
-        if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1, true>(P, st);
-        else if (KH == 1 && sh == 2 && sw == 2) ok = launch_by_shape<1, 2, 2, kKC1, true>(P, st);
-        else if (KH == 3 && sh == 1 && sw == 1) ok = launch_by_shape<3, 1, 1, kKC3, true>(P, st);
-        else if (KH == 3 && sh == 2 && sw == 2) ok = launch_by_shape<3, 2, 2, kKC3, true>(P, st);
-        else if (KH == 3 && sh == 2 && sw == 1) ok = launch_by_shape<3, 2, 1, kKC3, true>(P, st);
+        ok = tpspp::conv_bf16x3_launch(P, KH, sh, sw, st);
     } else {
         if (KH == 1 && sh == 1 && sw == 1)      ok = launch_by_shape<1, 1, 1, kKC1, false>(P, st);
         else if (KH == 1 && sh == 2 && sw == 2) ok = launch_by_shape<1, 2, 2, kKC1, false>(P, st);
