@@ -9,6 +9,7 @@ the two facts the oracle's arithmetic rests on:
   * F.grid_sample on the CPU == oracle weight_form 2,
 both bit for bit, and refuses to write fixtures if either fails.
 """
+import json
 import os
 import sys
 
