@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--bf16", action="store_true",
                     help="BASELINE.json configs[4]: backbone / TPS++ convolutions and the head's wide projections on the "
                          "bf16 matrix cores (control points, TPS solve, grid, per-step decoder projections stay fp32)")
+    ap.add_argument("--x3", action="store_true",
+                    help='"bf16x3": fp32 tensors, three-term bf16 split in the convolutions and wide projections '
+                         "(within the 1e-4 bar: strings must equal the CPU oracle's)")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -59,6 +62,9 @@ def main():
     model.to(dev)
     if a.bf16:
         model.backbone.compute_dtype = model.encoder.compute_dtype = model.decoder.compute_dtype = torch.bfloat16
+    elif a.x3:
+        model.backbone.compute_dtype = model.tpsnet.compute_dtype = "bf16x3"
+        model.encoder.compute_dtype = model.decoder.compute_dtype = "bf16x3"
 
     # IC15-shaped synthetic crops, test_pipeline normalisation (crnn_pp_pipeline.py: mean/std of ImageNet)
     n = a.batch
@@ -111,7 +117,7 @@ def main():
         want = TO.recognizer_simple_test(cpu_sds[0], cpu_sds[1], cpu_sds[2], cpu_sds[3], img[:k].numpy(), widths[:k])["text"]
         got = [r["text"] for r in res[:k]]
         acc = metrics.eval_ocr_metric(got, want, all_metrics=True)
-        print(f"ranks {world}, batch {n}, {'bf16' if a.bf16 else 'fp32'}: {n / dt:,.0f} images/s end to end (incl. host->device copy and the "
+        print(f"ranks {world}, batch {n}, {'bf16' if a.bf16 else 'bf16x3' if a.x3 else 'fp32'}: {n / dt:,.0f} images/s end to end (incl. host->device copy and the "
               f"all-gather); parity vs CPU oracle on {k} images: word_acc {acc['word_acc']:.4f}, "
               f"1-N.E.D {acc['1-N.E.D']:.4f}")
         print("sample:", got[:2])
