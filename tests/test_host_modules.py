@@ -249,3 +249,22 @@ def test_ocr_metric_matches_the_reference():
     full = metrics.eval_ocr_metric(["abc", "Abd"], ["abc", "abd"], all_metrics=True)
     assert full["word_acc"] == 0.5 and full["word_acc_ignore_case"] == 1.0 and full["1-N.E.D"] == 1.0
     assert metrics.levenshtein("kitten", "sitting") == 3 and metrics.levenshtein("", "abc") == 3
+
+
+def test_recognizer_set_compute_dtype_switches_every_stage():
+    import tps_pp_amd as P
+    m = P.build_detector(dict(
+        type="NRTR", backbone=dict(type="ResNetABI_v2_large", arch_settings=[1, 1, 1, 1, 1], strides=[2, 1, 2, 1, 2]),
+        tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder", n_layers=1),
+        decoder=dict(type="NRTRDecoder", n_layers=1), loss=dict(type="TFLoss"),
+        label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True), max_seq_len=40))
+    m.set_compute_dtype("bf16x3")
+    assert m.backbone.compute_dtype == m.tpsnet.compute_dtype == m.encoder.compute_dtype == m.decoder.compute_dtype == "bf16x3"
+    m.set_compute_dtype(torch.bfloat16)
+    assert m.backbone.compute_dtype == torch.bfloat16 and m.tpsnet.compute_dtype is None
+    assert m.encoder.compute_dtype == torch.bfloat16 and m.decoder.compute_dtype == torch.bfloat16
+    m.set_compute_dtype(None)
+    assert m.backbone.compute_dtype is None and m.encoder.compute_dtype is None
+    import pytest
+    with pytest.raises(ValueError):
+        m.set_compute_dtype(torch.float16)

@@ -423,6 +423,23 @@ class EncodeDecodeRecognizer(nn.Module):
         self.loss_cfg = None if loss is None else dict(loss, ignore_index=self.label_convertor.padding_idx)
         self.train_cfg, self.test_cfg, self.max_seq_len = train_cfg, test_cfg, max_seq_len
 
+    def set_compute_dtype(self, mode):
+        """One switch for the precision of the wide matrix products of every stage (not in the reference: its modules
+        are fp32).  None: the exact fp32 kernels; "bf16x3": fp32 tensors, three-term bf16 split (still within the
+        1e-4 bar); torch.bfloat16: bf16 operands / feature maps / encoder keys and values (control points, TPS solve,
+        grid, LayerNorms, softmaxes and the decoder's per-step projections stay fp32 in every mode)."""
+        if mode not in (None, "bf16x3", torch.bfloat16):
+            raise ValueError('set_compute_dtype: None, "bf16x3" or torch.bfloat16')
+        self.backbone.compute_dtype = mode
+        if self.tpsnet is not None:          # on bf16 activations TPS_PP follows its input; "bf16x3" must be told
+            self.tpsnet.compute_dtype = mode if mode == "bf16x3" else None
+        for m in (self.encoder, self.decoder):
+            if m is not None and hasattr(m, "compute_dtype"):
+                m.compute_dtype = mode
+        if self.preprocessor is not None and hasattr(self.preprocessor, "LocalizationNetwork"):
+            self.preprocessor.LocalizationNetwork.compute_dtype = mode
+        return self
+
     def extract_feat(self, img, test=False, **kwargs):
         if self.preprocessor is not None:
             img = self.preprocessor(img)
