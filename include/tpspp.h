@@ -240,6 +240,17 @@ int tpspp_score_fwd(const float* de_feat, const float* w1_slab, const float* b1,
                     tpspp_stream_t stream);
 
 /*
+ * tpspp_score_fwd with the three-term "bf16x3" split (see tpspp_conv2d_bf16_fwd) in its three matrix products: fp32
+ * tensors in and out, ~5e-6 of scale before the tanh.
+ *   w1_slab [hi|lo][4 k-steps][2][32 out][8] bf16 = W1[out][16 j + 8 h + e];
+ *   w2_slab [hi|lo][2 k-steps][2][128 out][8]     = W2[out][16 j + perm[8 h + e]]  (perm as in tpspp_front_bf16_fwd)
+ * replaces: backbones/tps_pp/tps_pp.py:293-312
+ */
+int tpspp_score_x3_fwd(const float* de_feat, const void* w1_slab, const float* b1,
+                       const void* w2_slab, const float* b2, const float* p, float scale,
+                       float* score_t, int N, int n, tpspp_stream_t stream);
+
+/*
  * CBAM(64, ratio 16) on the (N, 64, 2, 16) bottleneck map: mlp0_w (4,64), mlp2_w (64,4) = the
  * bias-free shared 1x1 MLP; sp_w (1,2,3,3), sp_b (1) = the spatial-attention conv.
  * replaces: backbones/tps_pp/tps_pp.py:27-82 as called at :163

@@ -86,6 +86,16 @@ def test_score_matches_oracle(cuda):
     got = ops.score(de.to(cuda), p1.to(cuda).contiguous(), ops.ScoreWeights(m.TPE.feat_linear), m.TPE.scale)
     assert got.shape == ref.shape
     assert (got.cpu() - ref).abs().max().item() <= 2e-5
+    # the three-term bf16 split of the same three products (tpspp_score_x3_fwd): the exact kernel's tolerance
+    got3 = ops.score(de.to(cuda), p1.to(cuda).contiguous(), ops.ScoreWeights(m.TPE.feat_linear), m.TPE.scale, x3=True)
+    assert (got3.cpu() - ref).abs().max().item() <= 2e-5
+    # ragged pixel count (partial last workgroup)
+    de2 = de[:, :, :5, :50].contiguous()
+    with torch.no_grad():
+        ref2 = m.cpu().TPE.get_score(en, de2)
+    m.to(cuda)
+    got2 = ops.score(de2.to(cuda), p1.to(cuda).contiguous(), ops.ScoreWeights(m.TPE.feat_linear), m.TPE.scale, x3=True)
+    assert (got2.cpu() - ref2).abs().max().item() <= 2e-5
 
 
 def test_cbam_and_point_stages_match_pytorch_cpu(cuda):

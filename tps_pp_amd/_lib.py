@@ -29,6 +29,7 @@ _SIGNATURES = {
     "tpspp_dgab_fwd": ([_f] * 16 + [_i, _i, _f], _i),
     "tpspp_dgab_bf16_fwd": ([_f] * 16 + [_i, _i, _i, _f], _i),
     "tpspp_score_fwd": ([_f, _f, _f, _f, _f, _f, ctypes.c_float, _f, _i, _i, _f], _i),
+    "tpspp_score_x3_fwd": ([_f, _f, _f, _f, _f, _f, ctypes.c_float, _f, _i, _i, _f], _i),
     "tpspp_front_fwd": ([_f] * 15 + [_i, _i, _i, _f], _i),
     "tpspp_front_bf16_fwd": ([_f] * 15 + [_i, _i, _i, _i, _i, _f], _i),
     "tpspp_cbam_fwd": ([_f, _f, _f, _f, _f, _f, _i, _f], _i),

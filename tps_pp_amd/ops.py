@@ -544,11 +544,14 @@ class ScoreWeights:
         self.w2_slab = l2.weight.detach().float()[:, perm16].t().contiguous()   # [32 slots][128]
         self.b1 = l1.bias.detach().float().contiguous()
         self.b2 = l2.bias.detach().float().contiguous()
+        # hi / lo slabs of the three-term split (tpspp_score_x3_fwd)
+        self.w1_x3 = _bf16_slab(l1.weight.detach().float(), False, True)
+        self.w2_x3 = _bf16_slab(l2.weight.detach().float(), True, True)
 
 
-def score(de_feat, p, sw, scale):
+def score(de_feat, p, sw, scale, x3=False):
     """get_score (tps_pp.py:303-312) fused: de_feat (N, 64, H, W), p (N, 32, 128) -> (N, H*W, 32) as
-    the transposed VIEW of an (N, 32, H*W) buffer."""
+    the transposed VIEW of an (N, 32, H*W) buffer.  x3: the three-term bf16 split in the three products."""
     de_feat, p = _chk("de_feat", de_feat, 4), _chk("p", p, 3)
     N, C, H, W = de_feat.shape
     if C != 64 or tuple(p.shape) != (N, 32, 128):
@@ -556,8 +559,12 @@ def score(de_feat, p, sw, scale):
     n = H * W
     out = torch.empty((N, 32, n), device=de_feat.device, dtype=torch.float32)
     with torch.cuda.device(de_feat.device):
-        rc = _lib.lib().tpspp_score_fwd(_ptr(de_feat), _ptr(sw.w1_slab), _ptr(sw.b1), _ptr(sw.w2_slab),
-                                        _ptr(sw.b2), _ptr(p), float(scale), _ptr(out), N, n, _stream(de_feat))
+        if x3:
+            rc = _lib.lib().tpspp_score_x3_fwd(_ptr(de_feat), _ptr(sw.w1_x3), _ptr(sw.b1), _ptr(sw.w2_x3),
+                                               _ptr(sw.b2), _ptr(p), float(scale), _ptr(out), N, n, _stream(de_feat))
+        else:
+            rc = _lib.lib().tpspp_score_fwd(_ptr(de_feat), _ptr(sw.w1_slab), _ptr(sw.b1), _ptr(sw.w2_slab),
+                                            _ptr(sw.b2), _ptr(p), float(scale), _ptr(out), N, n, _stream(de_feat))
     _lib.check(rc, "tpspp_score_fwd")
     return out.transpose(1, 2)
 

@@ -534,7 +534,8 @@ class TPS_PP(nn.Module):
         control_point, p1 = ops.tpe_points(en_feat, T)
         if T.without_as:
             return control_point, torch.zeros((n, de.shape[2] * de.shape[3], T.num_fiducial), device=de.device)
-        return control_point, ops.score(de, p1, cache[2], T.scale)
+        # (in the bf16 and bf16x3 configurations the score's three products take the three-term split as well: ~5e-6)
+        return control_point, ops.score(de, p1, cache[2], T.scale, x3=bf16)
 
     def rectify(self, feat_grid, batch_img, control_point, atten_score, want_grid=False):
         """The transformation stage alone (`tps_pp.py:597-615`): one fused HIP kernel."""
