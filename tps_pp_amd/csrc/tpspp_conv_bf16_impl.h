@@ -39,7 +39,7 @@ using tpspp::BParams;
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;
-constexpr int BM = 256;       // output pixels per workgroup
+constexpr int BM = 256;       // output pixels per workgroup (NF = 2 fragments per wavefront; 128 with NF = 1)
 constexpr int BN = 64;        // output channels per workgroup
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -93,14 +93,18 @@ struct BCfg {
 // against 3e-7 for fp32 and 2.5e-3 for plain bf16) at three matrix instructions that are each 16x faster than the
 // fp32 one.  For the fp32 tensors of the parity-bound (1e-4) path: activations stay fp32 in HBM, the split happens
 // in the staging registers; the weight arrives as two arranged slabs per chunk.
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false>
+// NF: 32-pixel fragments per wavefront.  2 (a 256-pixel workgroup tile: one LDS fragment read per MFMA) is the default;
+// 1 (128 pixels) halves the patch and the accumulators: more, lighter workgroups for the layers whose patch is large
+// against their work (stride 2: the patch holds 4x the output positions) or whose maps are so small that 256-pixel tiles
+// leave CUs idle -- those kernels wait on memory, not on the matrix pipe.
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false, int NF = 2>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_tiled_bf16_kernel(const BParams P)
 {
     using Cfg = BCfg<KH, SH, SW, TH, TW, NI, KC>;
     constexpr int KW = Cfg::KW, TAPS = Cfg::TAPS, PW = Cfg::PW, PS = Cfg::PS, PSN = Cfg::PSN;
     constexpr int NPOS = Cfg::NPOS, KG = Cfg::KG, WSLAB = Cfg::WSLAB, NW = Cfg::NW;
-    static_assert(NI * TH * TW == BM, "tile must hold 256 pixels");
+    static_assert(NI * TH * TW == 128 * NF, "tile must hold 128 * NF pixels");
     static_assert(KC % 16 == 0, "whole MFMA k-steps");
     constexpr int NS = X3 ? 2 : 1;                     // hi (and lo) images
     __shared__ u32x4 sP[NS * KG * PSN];                // [hi|lo][k group][position] x 8 bf16
@@ -120,10 +124,10 @@ conv_tiled_bf16_kernel(const BParams P)
     const int HoWo = P.Ho * P.Wo;
 
     // the two 32-pixel fragments of this wavefront: tile-linear pixel -> (image, row, column)
-    int fimg[2], fty[2], ftx[2], fpos[2];
+    int fimg[NF], fty[NF], ftx[NF], fpos[NF];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int tp = (wv * 2 + f) * 32 + l31;
+    for (int f = 0; f < NF; ++f) {
+        const int tp = (wv * NF + f) * 32 + l31;
         fimg[f] = tp / (TH * TW);
         const int tpi = tp - fimg[f] * (TH * TW);
         fty[f] = tpi / TW;
@@ -145,9 +149,9 @@ conv_tiled_bf16_kernel(const BParams P)
         pim[i] = im;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[NF][2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -251,27 +255,25 @@ conv_tiled_bf16_kernel(const BParams P)
             const int ky = tap / KW, kx = tap - ky * KW;
 #pragma unroll
             for (int ks = 0; ks < KC / 16; ++ks) {
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, sP[fpos[0] + (2 * ks) * PSN + ky * PW + kx]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, sP[fpos[1] + (2 * ks) * PSN + ky * PW + kx]);
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + l31]);
                 const bf16x8 a1 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + 32 + l31]);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+                bf16x8 a0l, a1l;
                 if constexpr (X3) {
-                    const bf16x8 b0l = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[0] + (2 * ks) * PSN + ky * PW + kx]);
-                    const bf16x8 b1l = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[1] + (2 * ks) * PSN + ky * PW + kx]);
-                    const bf16x8 a0l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + l31]);
-                    const bf16x8 a1l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + 32 + l31]);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0l, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0l, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1l, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1l, acc[1][1], 0, 0, 0);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1, acc[1][1], 0, 0, 0);
+                    a0l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + l31]);
+                    a1l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + 32 + l31]);
+                }
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, sP[fpos[f] + (2 * ks) * PSN + ky * PW + kx]);
+                    acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[f][0], 0, 0, 0);
+                    acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[f][1], 0, 0, 0);
+                    if constexpr (X3) {
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[f] + (2 * ks) * PSN + ky * PW + kx]);
+                        acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bl, acc[f][0], 0, 0, 0);
+                        acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bl, acc[f][1], 0, 0, 0);
+                        acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh, acc[f][0], 0, 0, 0);
+                        acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh, acc[f][1], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -303,7 +305,7 @@ conv_tiled_bf16_kernel(const BParams P)
     //  path branch-free and every convolution pays for it -- measured: 1x1 32->64 0.11 -> 0.21 ms)
     const bool simple = P.res_mode == 0 && P.post_scale == nullptr && P.relu != 2;
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < NF; ++f) {
         const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
         const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
         const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
@@ -351,13 +353,13 @@ conv_tiled_bf16_kernel(const BParams P)
     }
 }
 
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3>
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3, int NF = 2>
 void launch_b(const BParams& P, hipStream_t st)
 {
     const int ctiles = (P.Cout + BN - 1) / BN;
     const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
                     (unsigned)(((P.N + NI - 1) / NI) * ctiles));
-    hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3>), grid, dim3(kThreads), 0, st, P);
+    hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3, NF>), grid, dim3(kThreads), 0, st, P);
 }
 
 constexpr int kKC3 = 16;      // channels per chunk, 3x3 kernels
@@ -367,15 +369,27 @@ constexpr int kKC1 = 32;      // channels per chunk, 1x1 kernels
 template <int KH, int SH, int SW, int KC, bool X3>
 bool launch_by_shape(const BParams& P, hipStream_t st)
 {
-    if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC, X3>(P, st);   // a row of tokens
-    else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC, X3>(P, st);
-    else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC, X3>(P, st);
-    else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC, X3>(P, st);
-    else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC, X3>(P, st);
-    else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC, X3>(P, st);
-    else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 4, KC, X3>(P, st);
-    else                launch_b<KH, SH, SW, 2, 16, 8, KC, X3>(P, st);
-    return true;
+    if constexpr (KH == 3 && SH == 2) {
+        // stride 2: the patch holds 4x the output positions -- 128-pixel tiles (half the LDS and registers, twice the
+        // workgroups); the same for the maps of at most 8 rows of 16, where 256-pixel tiles start too few workgroups
+        if (P.Wo > 64)      launch_b<KH, SH, SW, 1, 128, 1, KC, X3, 1>(P, st);
+        else if (P.Wo > 32) launch_b<KH, SH, SW, 2, 64, 1, KC, X3, 1>(P, st);
+        else if (P.Wo > 16) launch_b<KH, SH, SW, 4, 32, 1, KC, X3, 1>(P, st);
+        else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 1, KC, X3, 1>(P, st);
+        else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 2, KC, X3, 1>(P, st);
+        else                launch_b<KH, SH, SW, 2, 16, 4, KC, X3, 1>(P, st);
+        return true;
+    } else {
+        if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC, X3>(P, st);   // a row of tokens
+        else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC, X3>(P, st);
+        else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC, X3>(P, st);
+        else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC, X3>(P, st);
+        else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC, X3>(P, st);
+        else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC, X3>(P, st);
+        else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 2, KC, X3, 1>(P, st);          // 128-pixel tiles: 2 images
+        else                launch_b<KH, SH, SW, 2, 16, 4, KC, X3, 1>(P, st);          //                  4 images
+        return true;
+    }
 }
 
 }  // namespace
