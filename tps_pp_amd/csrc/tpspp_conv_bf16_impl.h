@@ -379,11 +379,24 @@ bool launch_by_shape(const BParams& P, hipStream_t st)
         else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 2, KC, X3, 1>(P, st);
         else                launch_b<KH, SH, SW, 2, 16, 4, KC, X3, 1>(P, st);
         return true;
+    } else if constexpr (KH == 3 && X3) {
+        // three-term split, stride 1: 128-pixel tiles as well (two 256-pixel workgroups would need 2 x 62 KB of LDS)
+        if (P.Wo > 64)      launch_b<KH, SH, SW, 1, 128, 1, KC, X3, 1>(P, st);
+        else if (P.Wo > 32) launch_b<KH, SH, SW, 2, 64, 1, KC, X3, 1>(P, st);
+        else if (P.Wo > 16) launch_b<KH, SH, SW, 4, 32, 1, KC, X3, 1>(P, st);
+        else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 1, KC, X3, 1>(P, st);
+        else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 2, KC, X3, 1>(P, st);
+        else                launch_b<KH, SH, SW, 2, 16, 4, KC, X3, 1>(P, st);
+        return true;
     } else {
         if (P.Ho == 1 && P.Wo > 128) launch_b<KH, SH, SW, 1, 256, 1, KC, X3>(P, st);   // a row of tokens
         else if (P.Wo > 64) launch_b<KH, SH, SW, 2, 128, 1, KC, X3>(P, st);
         else if (P.Wo > 32) launch_b<KH, SH, SW, 4, 64, 1, KC, X3>(P, st);
-        else if (P.Wo > 16) launch_b<KH, SH, SW, 8, 32, 1, KC, X3>(P, st);
+        else if (P.Wo > 16) {
+            // 3x3 on 32-wide maps (backbone layer 3-4): 128-pixel tiles measured 3 % faster (64-wide maps: neutral)
+            if constexpr (KH == 3) launch_b<KH, SH, SW, 4, 32, 1, KC, X3, 1>(P, st);
+            else launch_b<KH, SH, SW, 8, 32, 1, KC, X3>(P, st);
+        }
         else if (P.Ho > 8)  launch_b<KH, SH, SW, 16, 16, 1, KC, X3>(P, st);
         else if (P.Ho > 4)  launch_b<KH, SH, SW, 8, 16, 2, KC, X3>(P, st);
         else if (P.Ho > 2)  launch_b<KH, SH, SW, 4, 16, 2, KC, X3, 1>(P, st);          // 128-pixel tiles: 2 images
