@@ -94,6 +94,18 @@ def test_conv_bf16_matches_cpu_reference(cuda, name, srcs, cout, k, stride, relu
         assert float((got == rb(ref)).float().mean()) > 0.98, name
 
 
+def test_conv_bf16_empty_batch_and_single_image(cuda):
+    w = t(synth.dyadic((64, 32, 3, 3), "eb.w", 1, 0.1))
+    for x3 in (False, True):
+        cw = ops.prep_conv_weight_bf16(w.to(cuda), x3=x3)
+        e = ops.conv2d_bf16([torch.zeros((0, 32, 8, 8), device=cuda)], cw, 1, True)
+        assert tuple(e.shape) == (0, 64, 8, 8)
+        x = t(synth.dyadic((1, 32, 5, 7), "eb.x", 1))
+        got = ops.conv2d_bf16([x.to(cuda)], cw, 2, False, out_dtype=torch.float32).cpu()
+        ref = F.conv2d((x if x3 else rb(x)).double(), (w if x3 else rb(w)).double(), stride=2, padding=1).float()
+        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 def test_conv_bf16_argument_errors(cuda):
     from tps_pp_amd import _lib
     w = torch.zeros((64, 32, 3, 3), device=cuda)

@@ -106,3 +106,21 @@ def test_gpu_preprocessor_feeds_the_recogniser(cuda):
     assert [r["text"] for r in a] == [r["text"] for r in b]
     with pytest.raises(ValueError):
         OCRBatchPreprocessor(ResizeOCR(32, min_width=32, max_width=None), NormalizeOCR(MEAN, STD), cuda)(imgs)
+
+
+@pytest.mark.gpu
+def test_gpu_preprocessor_gray_and_upscaled_images(cuda):
+    """One-channel crops, crops smaller than the target (up-scaling in both directions) and a single-row crop."""
+    g = np.random.default_rng(11)
+    imgs = [g.integers(0, 256, (h, w, 1), dtype=np.uint8) for h, w in [(8, 20), (3, 5), (1, 9), (40, 300), (32, 128), (64, 256)]]
+    pre = OCRBatchPreprocessor(ResizeOCR(32, min_width=32, max_width=128, keep_aspect_ratio=True, img_pad_value=3),
+                               NormalizeOCR([0.5], [0.25]), cuda)
+    out, metas = pre(imgs)
+    ref, plans = RO.preprocess_batch(imgs, 32, 32, 128, True, 3, [0.5], [0.25])
+    assert tuple(out.shape) == (6, 1, 32, 128)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert [m["valid_ratio"] for m in metas] == [p["valid_ratio"] for p in plans]
+    with pytest.raises(TypeError):
+        pre([np.zeros((4, 4, 1), dtype=np.float32)])
+    with pytest.raises(ValueError):
+        pre([])

@@ -328,6 +328,8 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
         raise ValueError("conv2d: res_mode without residual")
     if out is None:
         out = torch.empty((N, Cout, Ho, Wo), device=ts[0].device, dtype=torch.float32)
+    if N == 0:          # an empty batch has no device pointer to hand over
+        return out
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     dim_arr = (ctypes.c_int * len(dims))(*dims)
     with torch.cuda.device(ts[0].device):
@@ -424,6 +426,8 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("conv2d_bf16: out_dtype must be float32 or bfloat16")
     out = torch.empty((N, Cout, Ho, Wo), device=ts[0].device, dtype=out_dtype)
+    if N == 0:          # an empty batch has no device pointer to hand over
+        return out
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     dim_arr = (ctypes.c_int * len(dims))(*dims)
     with torch.cuda.device(ts[0].device):
