@@ -268,3 +268,31 @@ def test_recognizer_set_compute_dtype_switches_every_stage():
     import pytest
     with pytest.raises(ValueError):
         m.set_compute_dtype(torch.float16)
+
+
+def test_attn_convertor_tensor2idx_scan_matches_the_reference_loop():
+    """`tensor2idx` does the reference's per-character scan (convertors/attn.py:124-137: skip <PAD>, stop at the first
+    <EOS>) as array operations; here against the literal loop."""
+    import tps_pp_amd as P
+    c = P.AttnConvertor(dict_type="DICT90", with_unknown=True)
+    g = torch.Generator().manual_seed(0)
+    out = torch.rand((41, 40, 93), generator=g)
+    for i in range(41):
+        for j in torch.randint(0, 40, (3,), generator=g).tolist():
+            out[i, j, c.end_idx if (i + j) % 2 else c.padding_idx] = 2.0
+    out[0, :, c.end_idx] = 0.0                                  # a row without <EOS>
+    max_value, max_idx = torch.max(out, -1)
+    want_i, want_s = [], []
+    for row_idx, row_val in zip(max_idx.tolist(), max_value.tolist()):
+        si, ss = [], []
+        for ci, cs in zip(row_idx, row_val):
+            if ci == c.padding_idx:
+                continue
+            if ci == c.end_idx:
+                break
+            si.append(ci)
+            ss.append(cs)
+        want_i.append(si)
+        want_s.append(ss)
+    got_i, got_s = c.tensor2idx(out)
+    assert got_i == want_i and got_s == want_s

@@ -375,21 +375,22 @@ class AttnConvertor(BaseConvertor):
         return {"targets": tensors, "padded_targets": torch.stack(padded_targets, 0).long()}
 
     def tensor2idx(self, outputs, img_metas=None):
-        # one device->host copy for the batch instead of the reference's two per image
+        # one device->host copy for the batch instead of the reference's two per image, and the per-character scan
+        # (skip <PAD>, stop at the first <EOS>: attn.py:124-137) as array operations per batch
         max_value, max_idx = torch.max(outputs, -1)
-        max_idx, max_value = max_idx.cpu().numpy().tolist(), max_value.cpu().numpy().tolist()
-        indexes, scores = [], []
-        for row_idx, row_val in zip(max_idx, max_value):
-            str_index, str_score = [], []
-            for char_index, char_score in zip(row_idx, row_val):
-                if char_index == self.padding_idx:
-                    continue
-                if char_index == self.end_idx:
-                    break
-                str_index.append(char_index)
-                str_score.append(char_score)
-            indexes.append(str_index)
-            scores.append(str_score)
+        both = torch.stack([max_idx.to(torch.float64), max_value.to(torch.float64)]).cpu().numpy()
+        idx, val = both[0].astype(np.int64), both[1]
+        n, L = idx.shape
+        is_end = idx == self.end_idx
+        first_end = np.where(is_end.any(1), is_end.argmax(1), L)
+        keep = (np.arange(L)[None, :] < first_end[:, None]) & (idx != self.padding_idx)
+        counts = keep.sum(1)
+        flat_i, flat_v = idx[keep].tolist(), val[keep].tolist()
+        indexes, scores, o = [], [], 0
+        for c in counts.tolist():
+            indexes.append(flat_i[o:o + c])
+            scores.append(flat_v[o:o + c])
+            o += c
         return indexes, scores
 
 
