@@ -10,7 +10,15 @@ grid_sample HIP kernel on a batch of 512 synthetic 3x32x100 fp32 images, 20 fidu
 points = fiducial lattice + 0.05 * noise.  Inputs are resident in HBM before the timed region; the
 steps rotate over enough distinct input/output buffers (> 256 MB) that the Infinity Cache cannot
 hold the working set.  Weak scaling: every rank rectifies its own 512-image batches, there is no
-data-path collective (images are independent).
+data-path collective (images are independent).  `value` and `ms_per_step` come from HIP events on the
+launch stream over exactly K steps (max over ranks); the host wall clock around the same K steps
+(barrier + synchronize on both sides) is reported beside it as `wall_ms_per_step`.
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself (torch.distributed.run as a
+child process; the parent never touches a GPU) and passes rank 0's JSON line through.  At N > 1 the line
+also carries `extra.recognizer_sharded`: the whole recogniser on 256 images per rank with the one collective
+of the inference path, the RCCL all-gather of the decoder scores, inside the timed region
+(tools/test.py:202-207).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- algorithmic HBM bytes per launch / average launch duration (HIP events on the
@@ -21,6 +29,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,29 +50,51 @@ HBM_PEAK_GBS = 8000.0                                               # MI355X_MIC
 CACHE_BYTES = 256 << 20
 
 
+TRAFFIC_FILE = "profiles/pmc_traffic.json"
+
+
 def load_traffic():
-    """HBM bytes per launch from the PMC passes, if a summary was committed (profiles/)."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    """HBM bytes per launch from the PMC passes, if a summary was committed (profiles/): (bytes, kernel it was
+    measured on).  Not measured in this run: PMC collection needs its own rocprofv3 passes."""
     try:
-        return json.load(open(p)).get("hbm_bytes_per_launch")
+        d = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        return d.get("hbm_bytes_per_launch"), d.get("kernel")
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(img, ctrl, inv, p_hat, budget_s=12.0):
-    """The CPU oracle on the host cores, same workload, bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(img, ctrl, inv, p_hat, budget_s=10.0):
+    """The CPU oracle on the host cores, same workload, bounded sample: all threads and one thread
+    (SURVEY.md section 8d), plus the reference's own composition on PyTorch's CPU kernels."""
     from oracle import tps_oracle as O
     O.build()
     threads = O.max_threads()
-    O.warp(img, ctrl, inv, p_hat, (H, W))                           # warm-up (page faults, OpenMP)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        O.warp(img, ctrl, inv, p_hat, (H, W))
-        reps += 1
-        if time.perf_counter() - t0 >= budget_s or reps >= 2000:
-            break
-    dt = time.perf_counter() - t0
+
+    def sample(nthreads, budget):
+        O.set_threads(nthreads)
+        O.warp(img, ctrl, inv, p_hat, (H, W))                       # warm-up (page faults, OpenMP)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            O.warp(img, ctrl, inv, p_hat, (H, W))
+            reps += 1
+            if time.perf_counter() - t0 >= budget or reps >= 2000:
+                break
+        return reps, time.perf_counter() - t0
+
+    reps1, dt1 = sample(1, 5.0)
+    reps, dt = sample(threads, budget_s)
+    O.set_threads(threads)
     # the same arithmetic as the reference composes it, on PyTorch's CPU kernels (torch.bmm x2 +
     # F.grid_sample; tps_preprocessor.py:71-83,270-282), all host threads, ~6 s sample
     import torch.nn.functional as Fn
@@ -83,8 +115,11 @@ def cpu_baseline(img, ctrl, inv, p_hat, budget_s=12.0):
             treps += 1
         tdt = time.perf_counter() - t1
     return {"value": reps * BATCH / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": f"{reps} batches of {BATCH} images (3x32x100, F=20) in {dt:.1f} s, "
                       f"oracle/tps_oracle.c with {threads} OpenMP threads",
+            "one_thread": {"value": reps1 * BATCH / dt1, "unit": "images/s", "cores": 1,
+                           "sample": f"{reps1} batches of {BATCH} in {dt1:.1f} s, same code, 1 thread"},
             "pytorch_cpu_composition": {"value": treps * BATCH / tdt, "unit": "images/s",
                                         "threads": torch.get_num_threads(),
                                         "sample": f"{treps} batches of {BATCH} in {tdt:.1f} s: torch.bmm x2 + "
@@ -177,11 +212,7 @@ def recognizer_measurement(dev, timeit):
     import tps_pp_amd as P
     from oracle import tpspp_oracle as TO
     torch.manual_seed(11)
-    m = P.build_detector(dict(
-        type="NRTR", backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=[2, 1, 2, 1, 2]),
-        tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder"),
-        decoder=dict(type="NRTRDecoder"), loss=dict(type="TFLoss"),
-        label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True), max_seq_len=40)).eval()
+    m = P.build_detector(NRTR_TPSPP_MODEL).eval()
     with torch.no_grad():      # spread the classifier so that the random-init arg-max is far from ties
         m.decoder.classifier.weight.mul_(8.0)
     sds = [{k: v.clone() for k, v in mod.state_dict().items()} for mod in (m.backbone, m.tpsnet, m.encoder, m.decoder)]
@@ -235,6 +266,100 @@ def recognizer_measurement(dev, timeit):
             "data": "synthetic images, random-init weights"}
 
 
+def _free_port():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as children (torch.distributed.run)
+    and pass their output through.  This process never initialises a GPU and never exec()s."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(a, world, rank):
+    """CPU stand-in for the launch path (tests/test_bench_launch.py): the same process-group set-up, barrier,
+    all-gather of per-rank rows and max-over-ranks reduction, on gloo, without a GPU and without the kernels."""
+    from tps_pp_amd import dist as tdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = torch.full((3, 40, 93), float(rank))
+    t0 = time.perf_counter()
+    got = tdist.all_gather_rows(rows, 3 * world) if world > 1 else rows
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = all(float(got[3 * r, 0, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "gathered_rows": int(got.shape[0]), "gather_ok": bool(ok)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def recognizer_sharded(dev, world, rank, per_rank=256):
+    """N > 1: the whole recogniser (NRTR + TPS++, the model dict of configs/textrecog/nrtr/nrtr_tps++.py:26-42) on
+    `per_rank` 3x32x128 images per rank; the decoder scores (per_rank, 40, 92) fp32 of every rank are all-gathered
+    over RCCL inside the timed region and every rank converts the full tensor to strings (tools/test.py:202-207)."""
+    import tps_pp_amd as P
+    from tps_pp_amd import dist as tdist
+    torch.manual_seed(11)                                            # identical replicated weights on every rank
+    m = P.build_detector(NRTR_TPSPP_MODEL).eval().to(dev)
+    n_total = per_rank * world
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    img = torch.rand((per_rank, 3, 32, 128), generator=g, device=dev) * 2 - 1
+    metas = [dict(resize_shape=(32, 128, 3)) for _ in range(per_rank)]
+
+    def decode_local(lo, hi):
+        feat = m.extract_feat(img, test=True)["output"]
+        return m.decoder(feat, m.encoder(feat, metas), None, metas, train_mode=False)
+
+    def once():
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        res = tdist.recognize_sharded(decode_local, n_total, m.label_convertor)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        return time.perf_counter() - t0, res
+
+    with torch.no_grad():
+        once()
+        times = []
+        for _ in range(3):
+            dt, res = once()
+            times.append(dt)
+    tt = torch.tensor([min(times)], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    payload = per_rank * 40 * 92 * 4
+    return {"images_per_s": n_total / float(tt[0]), "ms_per_batch": float(tt[0]) * 1e3, "images_per_rank": per_rank,
+            "strings_returned": len(res), "collective": "all_gather_into_tensor of (images_per_rank, 40, 92) fp32 scores",
+            "all_gather_bytes_per_rank": payload, "backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
+            "data": "synthetic images, random-init weights (replicated)"}
+
+
+# the model dict of configs/textrecog/nrtr/nrtr_tps++.py:26-42 (values typed here; dictionary file replaced by DICT90)
+NRTR_TPSPP_MODEL = dict(
+    type="NRTR",
+    backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=[2, 1, 2, 1, 2]),
+    tpsnet=dict(type="TPS_PP"),
+    encoder=dict(type="NRTREncoder"),
+    decoder=dict(type="NRTRDecoder"),
+    loss=dict(type="TFLoss"),
+    label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True),
+    max_seq_len=40)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,14 +367,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--precondition-ms", type=float, default=800.0,
+                    help="device copies over the bench buffers before the warm-up steps: the chip leaves its idle "
+                         "clocks only after some hundred ms of activity (not steps of the workload; 0 disables)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo check of the launch path, no GPU work")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
+    if a.dry_run:
+        raise SystemExit(dry_run(a, world, rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
@@ -263,6 +395,7 @@ def main():
                           num_img_channel=C).eval().to(dev)
     gg = mod.GridGenerator
     p_hat_t, flags = gg.prepared_table()
+    pair_kernel = bool(flags & ops.TABLE_PACKED) and bool(flags & ops.TABLE_MIRROR4)
 
     # ---- synthetic inputs, resident in HBM; buffer 0 is the exactly reproducible one ----
     per_set = 2 * BATCH * C * H * W * 4
@@ -291,6 +424,16 @@ def main():
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
+
+    # ---- not steps: keep the device busy with plain copies until its clocks have left the idle state ----
+    if a.precondition_ms > 0:
+        t_end = time.perf_counter() + a.precondition_ms * 1e-3
+        j = 0
+        while time.perf_counter() < t_end:
+            for _ in range(64):
+                outs[j % nbuf].copy_(imgs[j % nbuf])
+                j += 1
+            torch.cuda.synchronize(dev)
 
     for i in range(a.warmup):
         step(i)
@@ -337,17 +480,23 @@ def main():
         torch.cuda.synchronize(dev)
         copy_us = c0.elapsed_time(c1) * 1e3 / 500
 
+    sharded = recognizer_sharded(dev, world, rank) if (world > 1 and not a.no_extras) else None
+
     if rank == 0:
         launch_us = ev_ms * 1e3 / a.steps
         achieved = BYTES_PER_IMG * BATCH / (launch_us * 1e-6) / 1e9
+        traffic, traffic_kernel = load_traffic()
+        kernel = "tps_warp_pair_kernel<20,3,32,100,32,100,false,false>" if pair_kernel else \
+            "tps_warp_lds_mirror_kernel<20,3,32,100,false>"
         rec = {
             "metric": "rectified images/sec (3x32x100)",
-            "value": world * BATCH * a.steps / dt,
+            "value": world * BATCH * a.steps / (ev_ms * 1e-3),
             "unit": "images/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": dt * 1e3 / a.steps,
+            "ms_per_step": ev_ms / a.steps,
+            "wall_ms_per_step": dt * 1e3 / a.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -357,11 +506,18 @@ def main():
                                    "grid_sample HIP kernel, batch 512 per GPU, 3x32x100 fp32, "
                                    "20 fiducials, inputs resident in HBM",
                        "batch_per_gpu": BATCH, "rotating_buffer_sets": int(nbuf),
-                       "working_set_MB": round(nbuf * per_set / 1e6, 1)},
+                       "working_set_MB": round(nbuf * per_set / 1e6, 1),
+                       "timing": "HIP events on the launch stream around exactly `steps` launches, max over ranks "
+                                 "(`value`, `ms_per_step`); `wall_ms_per_step` = host clock around the same launches "
+                                 "incl. the final synchronize",
+                       "preconditioning": f"{a.precondition_ms:.0f} ms of plain device copies over the bench buffers "
+                                          "before the warm-up steps (clock ramp; not steps)"},
             "max_abs_err_vs_oracle": max_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
-                         "kernel": "tps_warp_lds_mirror_kernel<20,3,32,100,false>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": f"{TRAFFIC_FILE} (rocprofv3 --pmc passes of this command, measured on "
+                                           f"{traffic_kernel}; not re-measured in this run)" if traffic else None,
+                         "kernel": kernel,
                          "launch_us": launch_us,
                          "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH,
                          "plain_copy_of_the_image_bytes": {
@@ -372,6 +528,8 @@ def main():
         }
         if world == 1 and not a.no_extras:
             rec["extra"] = extra_measurements(dev)
+        if sharded is not None:
+            rec["extra"] = {"recognizer_sharded": sharded}
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(img0, ctrl0, gg.inv_delta_C.cpu().numpy(),
                                                gg.P_hat.cpu().numpy())

@@ -90,7 +90,22 @@ int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, int cols, flo
  */
 int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, int Wo, int F);
 
+/*
+ * The prepared form of a mirror-symmetric classic table that the image-pair kernel reads: the (F+3, n) transposed
+ * table of tpspp_transpose_p_hat followed by a packed copy in that kernel's thread order (a thread's F+3 values as
+ * 16-byte pieces, [wavefront][(F+3+3)/4][lane][4]; thread -> pixel: a half-wavefront owns 4 columns x 8 rows of the
+ * left half of the upper half-image).  tpspp_prepared_table_floats: buffer size in floats, 0 when the geometry has
+ * no prepared form (needs Ho % 16 == 0, Wo % 4 == 0).  One-off preparation, like the transposition.  Pass the buffer
+ * as p_hat_t together with TPSPP_TABLE_PACKED (and TPSPP_TABLE_MIRROR4 once the symmetry has been verified).
+ * replaces nothing in the reference (its table is a module buffer, tps_preprocessor.py:187-188); see tpspp_warp_fwd.
+ */
+size_t tpspp_prepared_table_floats(int Ho, int Wo, int F);
+int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo, int F, float* prepared,
+                               tpspp_stream_t stream);
+
 #define TPSPP_TABLE_MIRROR4 1      /* table_flags bit: symmetry verified by the caller */
+#define TPSPP_TABLE_PACKED 8       /* table_flags bit: p_hat_t is a tpspp_prepare_mirror_table buffer (the packed copy
+                                      follows the transposed table).  Never changes results. */
 #define TPSPP_SCORE_TRANSPOSED 2   /* table_flags bit: `score` is laid out (N, F, n) instead of the
                                       reference's (N, n, F): lanes that own consecutive pixels then read
                                       it coalesced.  Same values, same results. */
@@ -107,8 +122,8 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
  *   ctrl (N,F,2); score (N,Ho*Wo,F) or NULL; inv_delta_c (F+3,F+3); p_hat / p_hat_ld / p_xy as in
  *   tpspp_build_grid; p_hat_t_or_null = tpspp_transpose_p_hat(p_hat) (same values, enables the
  *   coalesced / LDS-staged fast kernels; NULL selects the generic kernel -- identical results);
- *   table_flags: OR of TPSPP_TABLE_MIRROR4 (only meaningful with p_hat_t), TPSPP_SCORE_TRANSPOSED
- *   (neither changes results) and TPSPP_IO_BF16 (bf16 images in and out);
+ *   table_flags: OR of TPSPP_TABLE_MIRROR4, TPSPP_TABLE_PACKED (only meaningful with p_hat_t),
+ *   TPSPP_SCORE_TRANSPOSED (none of them changes results) and TPSPP_IO_BF16 (bf16 images in and out);
  *   grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
  * replaces: GridGenerator.build_P_prime + F.grid_sample   tps_preprocessor.py:71-83
  *           Attention_Enhanced_TPS.build_P_prime + 2x F.grid_sample   tps_pp.py:597-615
@@ -338,15 +353,17 @@ int tpspp_conv_set_tuning(int force_generic);
  * it): images per workgroup and threads per workgroup of the gather kernel (0 = heuristic), and
  * kernel choice: 0 = automatic, 1 = force the gather kernel, 2 = require the LDS-staged kernel
  * (TPSPP_EINVAL if the shape does not qualify), 3 = as 2 but ignore TPSPP_TABLE_MIRROR4,
- * 4 = require the plane-streaming kernel; bands = workgroups per image pair in the LDS-staged
- * kernel (0 = heuristic).
+ * 4 = require the plane-streaming kernel, 5 = require the image-pair kernel (classic 32x100 geometry with a
+ * tpspp_prepare_mirror_table buffer); bands = workgroups per image pair in the LDS-staged kernel (0 = heuristic).
  */
 int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);
 
 /*
  * Diagnostics: when device_buf is non-NULL the LDS-staged kernel writes 8 int64 shader-clock stamps
  * per workgroup (start, T ready, grid expanded, images in LDS, stores retired, DMA issued, DMA
- * landed, unused) into device_buf[workgroup * 8 + i].  NULL (default) disables it.
+ * landed, unused) into device_buf[workgroup * 8 + i]; the image-pair kernel writes ticks since kernel entry
+ * of (T ready, tap descriptors done, image A landed, A staged, image B landed, B staged, stores retired) and
+ * the 100 MHz wall clock at entry.  NULL (default) disables it.
  */
 int tpspp_warp_set_trace(long long* device_buf);
 

@@ -174,15 +174,26 @@ def test_head_batch_against_oracle(cuda):
     assert idx == o["indexes"] and conv.idx2str(idx) == o["text"]
 
 
+# The model dict of configs/textrecog/nrtr/nrtr_tps++.py:26-42, values typed here (its `label_convertor` comes from
+# _base_ with a dictionary file: DICT90 + <UKN> is the same 93-class table).  No `variant` for TPS_PP: the recogniser
+# picks the wiring that fits its backbone's strides, so the config runs unchanged.
+NRTR_TPSPP_CONFIG_MODEL = dict(
+    type="NRTR",
+    backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=[2, 1, 2, 1, 2]),
+    tpsnet=dict(type="TPS_PP"),
+    encoder=dict(type="NRTREncoder"),
+    decoder=dict(type="NRTRDecoder"),
+    loss=dict(type="TFLoss"),
+    label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True),
+    max_seq_len=40)
+
+
 def build_recognizer(cuda):
-    """configs/textrecog/nrtr/nrtr_tps++.py:23-42 (TPS_PP in the geometry that config's strides need)."""
+    """configs/textrecog/nrtr/nrtr_tps++.py:26-42, exactly as written there."""
     import tps_pp_amd as P
-    m = P.build_detector(dict(
-        type="NRTR",
-        backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=cases.G12_STRIDES),
-        tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder"),
-        decoder=dict(type="NRTRDecoder"), loss=dict(type="TFLoss"),
-        label_convertor=dict(type="AttnConvertor", dict_type="DICT90", with_unknown=True), max_seq_len=40)).eval()
+    assert NRTR_TPSPP_CONFIG_MODEL["backbone"]["strides"] == list(cases.G12_STRIDES)
+    m = P.build_detector(NRTR_TPSPP_CONFIG_MODEL).eval()
+    assert m.tpsnet.type == "ResNet45" and not m.tpsnet.variant_explicit
     for mod, seed, rule, keep in ((m.backbone, 7, cases.backbone_state_rule, ()),
                                   (m.tpsnet, 4, cases.tpspp_state_rule, cases.TPSPP_KEEP),
                                   (m.encoder, 9, cases.head_state_rule, cases.HD_KEEP),

@@ -79,9 +79,10 @@ def test_tpspp_module_against_reference(cuda, variant, fname):
     assert set(res) == {"output", "logits", "mp_img", "pc_score"} and res["logits"] is None
     assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 2e-5
     assert np.abs(score.cpu().numpy() - G["pc_score"]).max() < 1e-4
-    # whole forward, regressor on the GPU: image-like inputs, north-star tolerance
-    assert np.abs(res["mp_img"].cpu().numpy() - G["mp_img"]).max() <= 5 * TOL
-    assert np.abs(res["output"].cpu().numpy() - G["output"]).max() <= 5 * TOL
+    # whole forward, regressor on the GPU (exact-fp32 kernels): image-like inputs, the north-star's 1e-4
+    e_mp = np.abs(res["mp_img"].cpu().numpy() - G["mp_img"]).max()
+    e_out = np.abs(res["output"].cpu().numpy() - G["output"]).max()
+    assert e_mp <= TOL and e_out <= TOL, (e_mp, e_out)
     assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])
 
 
@@ -184,9 +185,14 @@ def test_backbone_stem_and_tps_call_site(cuda):
     with torch.no_grad():
         res = m(dev(cases.g7_inputs()["img"], cuda), Spy())
     assert set(res) == {"output", "img_ref"} and res["output"].shape == torch.Size([cases.G7_N, 512, 4, 16])
-    assert np.abs(got["x"].cpu().numpy() - G["x"]).max() <= 2e-4
-    assert np.abs(got["outs"][0].cpu().numpy()[:, ::4] - G["outs0_sub"]).max() <= 2e-4
-    assert np.abs(got["outs"][1].cpu().numpy()[:, ::4] - G["outs1_sub"]).max() <= 2e-4
+    # 1e-4 of each map's scale (max |reference value|, never below 1): the stage outputs of 3 + 4 residual blocks with
+    # hash-generated weights are not O(1) like an image
+    for name, a, b in (("x", got["x"].cpu().numpy(), G["x"]),
+                       ("outs[0]", got["outs"][0].cpu().numpy()[:, ::4], G["outs0_sub"]),
+                       ("outs[1]", got["outs"][1].cpu().numpy()[:, ::4], G["outs1_sub"])):
+        scale = max(1.0, float(np.abs(b).max()))
+        err = float(np.abs(a - b).max())
+        assert err <= 1e-4 * scale, f"{name}: max |err| {err:.3e} against scale {scale:.3f}"
     # end to end with the real rectifier in the loop
     tps = build_backbone(dict(type="TPS_PP")).eval().to(cuda)
     with torch.no_grad():

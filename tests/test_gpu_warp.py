@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import cases
-from tps_pp_amd import ops, synth
+from tps_pp_amd import _lib, ops, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -45,19 +45,68 @@ def test_classic_warp_matches_reference_golden(cuda):
     P_hat_t = ops.transpose_p_hat(P_hat)
     assert torch.equal(P_hat_t, P_hat.t().contiguous())
     assert ops.table_mirror_symmetry(K["classic_P_hat"], cases.CL_HW, cases.CL_F) == 1
+    P_prep, packed = ops.prepare_mirror_table(P_hat, cases.CL_HW)
+    assert packed == ops.TABLE_PACKED and torch.equal(P_prep, P_hat_t)
     try:
-        # 1 = gather, 3 = LDS-staged kernel, 2 = LDS-staged kernel on the mirror-symmetric table
-        for kernel, bands in ((1, 0), (3, 1), (3, 2), (3, 3), (2, 1), (2, 2), (2, 3)):
+        # 1 = gather, 3 = LDS-staged kernel, 2 = LDS-staged kernel on the mirror-symmetric table,
+        # 5 = image-pair kernel (prepared table), 0 = whatever the library picks for a prepared table
+        for kernel, bands in ((1, 0), (3, 1), (3, 2), (3, 3), (2, 1), (2, 2), (2, 3), (5, 0), (0, 0)):
             ops.set_warp_tuning(0, 0, kernel, bands)
+            tab, flags = (P_prep, ops.TABLE_MIRROR4 | packed) if kernel in (5, 0) else (P_hat_t, ops.TABLE_MIRROR4)
             for key_in, key_out in (("img", "out"), ("img_smooth", "out_smooth")):
                 out, _, grid, idx = ops.warp(dev(inp[key_in], cuda), dev(inp["ctrl"], cuda), inv,
                                              P_hat, cases.CL_HW, want_grid=True, want_idx=True,
-                                             P_hat_t=P_hat_t, table_flags=ops.TABLE_MIRROR4)
+                                             P_hat_t=tab, table_flags=flags)
                 assert_biteq(grid, G["grid"], f"kernel {kernel}: grid vs reference bmm")
                 assert np.abs(out.cpu().numpy() - G[key_out]).max() <= TOL
                 assert_biteq(out, G[key_out], f"kernel {kernel}: warped {key_in} vs reference")
+                # the same call without the optional outputs takes another instantiation of the kernels
+                out2, _, _, _ = ops.warp(dev(inp[key_in], cuda), dev(inp["ctrl"], cuda), inv, P_hat, cases.CL_HW,
+                                         P_hat_t=tab, table_flags=flags)
+                assert_biteq(out2, G[key_out], f"kernel {kernel}: warped {key_in}, no grid / idx outputs")
     finally:
         ops.set_warp_tuning(0, 0, 0)
+
+
+def test_packed_table_contract(cuda):
+    """TABLE_PACKED is a promise about the memory behind P_hat_t: the binding refuses anything but the view that
+    prepare_mirror_table returned; a geometry without a prepared form falls back to the plain transposition."""
+    K = cases.load("constants")
+    P_hat = dev(K["classic_P_hat"], cuda)
+    inv = dev(K["classic_inv_delta_C"], cuda)
+    inp = cases.g2_inputs()
+    with pytest.raises(ValueError):
+        ops.warp(dev(inp["img"], cuda), dev(inp["ctrl"], cuda), inv, P_hat, cases.CL_HW,
+                 P_hat_t=ops.transpose_p_hat(P_hat), table_flags=ops.TABLE_MIRROR4 | ops.TABLE_PACKED)
+    with pytest.raises(ValueError):
+        ops.warp(dev(inp["img"], cuda), dev(inp["ctrl"], cuda), inv, P_hat, cases.CL_HW, table_flags=ops.TABLE_PACKED)
+    odd = torch.zeros((31 * 99, 23), device=cuda)
+    t, flags = ops.prepare_mirror_table(odd, (31, 99))
+    assert flags == 0 and tuple(t.shape) == (23, 31 * 99)
+    # the packed copy itself: thread t of the image-pair kernel = (r, c) of a 4-column x 8-row block per half-wavefront
+    P_prep, packed = ops.prepare_mirror_table(P_hat, cases.CL_HW)
+    tail = P_prep._base[23 * 3200:].cpu().numpy().reshape(13, 6, 64, 4)
+    ref = np.zeros((13, 6, 64, 4), np.float32)
+    ph = K["classic_P_hat"]
+    for t_ in range(832):
+        hw, l5 = t_ >> 5, t_ & 31
+        rg, cg = divmod(hw, 13)
+        r, c = rg * 8 + (l5 >> 2), cg * 4 + (l5 & 3)
+        row = np.zeros(24, np.float32)
+        row[:23] = ph[r * 100 + c]
+        ref[t_ // 64, :, t_ % 64, :] = row.reshape(6, 4)
+    assert (bits(tail) == bits(ref)).all()
+    # shape / device / dtype of caller-supplied outputs are checked before any pointer reaches a kernel
+    img, ctrl = dev(inp["img"], cuda), dev(inp["ctrl"], cuda)
+    for bad in (torch.empty((img.shape[0], 3, 32, 99), device=cuda), torch.empty(img.shape, device=cuda, dtype=torch.bfloat16),
+                torch.empty(img.shape), torch.empty((img.shape[0] - 1, 3, 32, 100), device=cuda)):
+        with pytest.raises((ValueError, TypeError, _lib.TpsppError)):
+            ops.warp(img, ctrl, inv, P_hat, cases.CL_HW, out0=bad)
+        with pytest.raises((ValueError, TypeError, _lib.TpsppError)):
+            ops.WarpPlan(img, ctrl, inv, P_hat, cases.CL_HW, bad)
+    with pytest.raises(ValueError):
+        ops.WarpPlan(img, ctrl, inv, P_hat[:, :20].contiguous(), cases.CL_HW, torch.empty_like(img),
+                     P_xy=torch.zeros((5, 2), device=cuda))       # P_xy must be (n, 2)
 
 
 def test_unfused_pieces_match_reference_golden(cuda):
@@ -152,9 +201,12 @@ def test_classic_warp_vs_oracle(cuda, oracle, N, C, H, W, Ho, Wo, F, perturb):
     P_hat = dev(Kc["P_hat"], cuda)
     sym = ops.table_mirror_symmetry(Kc["P_hat"], (Ho, Wo), F)
     assert sym == (1 if (Ho % 2 == 0 and Wo % 2 == 0 and F % 2 == 0) else 0)
-    # generic path / coalesced + LDS paths / mirror-symmetric-table path
+    # generic path / coalesced + LDS paths / mirror-symmetric-table path / prepared table (image-pair kernel
+    # where the geometry has one: odd batches end in a group with a single image)
+    prep, packed = ops.prepare_mirror_table(P_hat, (Ho, Wo))
     for P_hat_t, flags in ((None, 0), (ops.transpose_p_hat(P_hat), 0),
-                           (ops.transpose_p_hat(P_hat), ops.TABLE_MIRROR4 * sym)):
+                           (ops.transpose_p_hat(P_hat), ops.TABLE_MIRROR4 * sym),
+                           (prep, ops.TABLE_MIRROR4 * sym | packed)):
         out, _, grid, idx = ops.warp(dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda),
                                      P_hat, (Ho, Wo), want_grid=True, want_idx=True,
                                      P_hat_t=P_hat_t, table_flags=flags)
@@ -253,10 +305,29 @@ def test_full_size_batch512_properties(cuda, oracle):
     sel = np.array([0, 1, 63, 64, 255, 256, 300, 511])
     ref = oracle.warp(x[sel], ctrl[sel], Kc["inv_delta_C"], Kc["P_hat"], (32, 100))["out0"]
     assert_biteq(ox[sel], ref, "batch-512 sample vs oracle")
+    # the image-pair kernel (prepared table) at batch 512, with specials in the image: -0.0, +-inf, nan and denormals
+    # must come out exactly as the LDS-staged kernel's (out-of-image taps read as zero, never as 0 * value)
+    prep, packed = ops.prepare_mirror_table(P_hat, (32, 100))
+    xs = x.copy()
+    xs.reshape(-1)[::997] = -0.0
+    xs.reshape(-1)[5::4099] = np.inf
+    xs.reshape(-1)[7::5003] = np.nan
+    xs.reshape(-1)[11::3001] = 1e-42
+    wide = ident + 0.8 * synth.dyadic((N, 20, 2), "f.wide")       # grids that leave the image: clamped taps
+    for c_, x_ in ((ctrl, x), (wide, xs)):
+        a = ops.warp(dev(x_, cuda), dev(c_, cuda), inv, P_hat, (32, 100), P_hat_t=P_hat_t,
+                     table_flags=ops.TABLE_MIRROR4, want_grid=True, want_idx=True)
+        b = ops.warp(dev(x_, cuda), dev(c_, cuda), inv, P_hat, (32, 100), P_hat_t=prep,
+                     table_flags=ops.TABLE_MIRROR4 | packed, want_grid=True, want_idx=True)
+        c = ops.warp(dev(x_, cuda), dev(c_, cuda), inv, P_hat, (32, 100), P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+        for k_, what in ((0, "warped"), (2, "grid"), (3, "corner indices")):
+            assert (a[k_].cpu().numpy().view(np.uint32) == b[k_].cpu().numpy().view(np.uint32)).all(), \
+                f"image-pair kernel vs LDS-staged kernel at batch 512: {what}"
+        assert (a[0].cpu().numpy().view(np.uint32) == c[0].cpu().numpy().view(np.uint32)).all()
     # the pre-marshalled call bench.py times (ops.WarpPlan) is the same launch
     out_p = torch.empty((N, 3, 32, 100), device=cuda)
-    plan = ops.WarpPlan(dev(x, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100), out_p, P_hat_t=P_hat_t,
-                        table_flags=ops.TABLE_MIRROR4)
+    plan = ops.WarpPlan(dev(x, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100), out_p, P_hat_t=prep,
+                        table_flags=ops.TABLE_MIRROR4 | packed)
     plan.run()
     plan.run()
     assert_biteq(out_p, ox, "WarpPlan vs ops.warp")

@@ -103,13 +103,45 @@ def test_no_cpu_fallback_and_forward_only():
         ResNetABI_v2_large().eval()(torch.zeros(1, 3, 32, 128))
 
 
-def test_variant_geometry_is_checked_with_a_useful_message():
-    m = TPS_PP()
+def test_variant_is_picked_by_geometry_checkpoint_or_backbone_strides():
+    """configs/textrecog/nrtr/nrtr_tps++.py:34-38: `tpsnet=dict(type='TPS_PP')` next to backbone strides [2,1,2,1,2] --
+    the geometry the reference's hard-coded wiring cannot take."""
+    v2_maps = [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 32, 128)]
+    v1_maps = [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 16, 64)]
+    x = torch.zeros(1, 64, 16, 64)
+    # an explicit choice is never overridden: the other geometry is an error that names the way out
+    m = TPS_PP(variant="ResNet45v2")
     with torch.no_grad(), pytest.raises(ValueError, match="variant='ResNet45'"):
-        m(torch.zeros(1, 64, 16, 64), [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 16, 64)])
+        m(x, v1_maps)
     v1 = TPS_PP(variant="ResNet45")
     assert "down0_1.conv.weight" not in v1.state_dict()
     assert tuple(v1.down0.conv.weight.shape) == (64, 32, 3, 3)
+    with torch.no_grad(), pytest.raises(ValueError, match="ResNet45v2"):
+        v1(x, v2_maps)
+    # default: the reference's hard-coded wiring, switched by the first forward with the other geometry ...
+    auto = TPS_PP()
+    assert auto.type == "ResNet45v2" and not auto.variant_explicit
+    with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):      # (then the CPU tensor is refused)
+        auto(x, v1_maps)
+    assert auto.type == "ResNet45" and list(auto.state_dict()) == list(v1.state_dict())
+    # ... by the checkpoint that is loaded (down0.conv.weight is 1x1 in one wiring, 3x3 in the other) ...
+    fresh = TPS_PP()
+    fresh.load_state_dict(v1.state_dict())
+    assert fresh.type == "ResNet45" and torch.equal(fresh.down0.conv.weight, v1.down0.conv.weight)
+    with torch.no_grad(), pytest.raises(ValueError, match="set_variant"):      # a loaded module is not re-wired silently
+        fresh(x, v2_maps)
+    back = TPS_PP()
+    back.load_state_dict(TPS_PP(variant="ResNet45v2").state_dict())
+    assert back.type == "ResNet45v2"
+    with pytest.raises(ValueError, match="checkpoint holds"):
+        TPS_PP(variant="ResNet45v2").load_state_dict(v1.state_dict())
+    # ... and by the recogniser that owns it, from its backbone's strides
+    assert TPS_PP.variant_for_strides([2, 1, 2, 1, 2]) == "ResNet45"
+    assert TPS_PP.variant_for_strides([1, 2, 2, 1, 2]) == "ResNet45v2"
+    assert TPS_PP.variant_for_strides([2, 2, 1]) is None
+    # the 60-entry state_dict order of the reference survives a round trip through the other wiring
+    rt = TPS_PP().set_variant("ResNet45", explicit=False).set_variant("ResNet45v2", explicit=False)
+    assert list(rt.state_dict()) == list(TPS_PP().state_dict())
 
 
 def test_register_into_a_mmocr_like_builder(monkeypatch):
@@ -188,9 +220,16 @@ def test_head_state_dict_layout_and_registries():
     m = P.build_detector(dict(type="NRTR",
                               backbone=dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3],
                                             strides=[2, 1, 2, 1, 2]),
-                              tpsnet=dict(type="TPS_PP", variant="ResNet45"), encoder=dict(type="NRTREncoder"),
+                              tpsnet=dict(type="TPS_PP"), encoder=dict(type="NRTREncoder"),
                               decoder=dict(type="NRTRDecoder"), loss=dict(type="TFLoss"),
                               label_convertor=label_convertor, max_seq_len=40))
+    assert m.tpsnet.type == "ResNet45" and not m.tpsnet.variant_explicit      # from the backbone's strides [2,1,...]
+    m_v2 = P.build_detector(dict(type="NRTR", backbone=dict(type="ResNetABI_v2_large", arch_settings=[1, 1, 1, 1, 1],
+                                                            strides=[1, 2, 2, 1, 2]),
+                                 tpsnet=dict(type="TPS_PP"), encoder=dict(type="NRTREncoder", n_layers=1),
+                                 decoder=dict(type="NRTRDecoder", n_layers=1), loss=dict(type="TFLoss"),
+                                 label_convertor=label_convertor, max_seq_len=40))
+    assert m_v2.tpsnet.type == "ResNet45v2"
     assert (m.decoder.start_idx, m.decoder.padding_idx, m.decoder.max_seq_len) == (91, 92, 40)
     assert m.decoder.classifier.out_features == 92 and m.decoder.trg_word_emb.num_embeddings == 93
     with pytest.raises(Exception, match="GPU"):

@@ -21,6 +21,8 @@ _SIGNATURES = {
     "tpspp_grid_sample": ([_f, _f, _i, _i, _i, _i, _i, _i, _f, _f, _f], _i),
     "tpspp_transpose_p_hat": ([_f, _i, _i, _i, _f, _f], _i),
     "tpspp_table_mirror_symmetry": ([_f, _i, _i, _i, _i], _i),
+    "tpspp_prepared_table_floats": ([_i, _i, _i], ctypes.c_size_t),
+    "tpspp_prepare_mirror_table": ([_f, _i, _i, _i, _i, _f, _f], _i),
     "tpspp_warp_fwd": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i,
                         _f, _f, _f, _f, _f], _i),
     "tpspp_conv2d_fwd": ([_f, _f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f], _i),

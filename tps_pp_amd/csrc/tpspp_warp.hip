@@ -22,6 +22,7 @@
 #include "tpspp_common.h"
 #include "tpspp_warp_dev.h"
 #include "tpspp_warp_stream.h"
+#include "tpspp_warp_pair.h"
 
 #include <cstring>
 
@@ -769,7 +770,7 @@ void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStre
 TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice,
                                        int bands)
 {
-    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 4, "kernel_choice must be 0..4");
+    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 5, "kernel_choice must be 0..5");
     TPSPP_REQUIRE(bands >= 0 && bands <= 8, "bands must be in [0, 8]");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
@@ -867,6 +868,31 @@ TPSPP_EXPORT int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, 
     return tpspp::check_launch("tpspp_transpose_p_hat");
 }
 
+TPSPP_EXPORT size_t tpspp_prepared_table_floats(int Ho, int Wo, int F)
+{
+    if (Ho <= 0 || Wo <= 0 || F <= 0 || F + 3 > kMaxK || Wo % 4 != 0 || Ho % 16 != 0) return 0;
+    const int K = F + 3, KG = (K + 3) / 4;
+    const int PW = ((Wo / 2) + 3) & ~3, nthr = (Ho / 2) * PW, NW = (nthr + kWave - 1) / kWave;
+    return (size_t)K * Ho * Wo + (size_t)NW * KG * kWave * 4;
+}
+
+TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo, int F,
+                                            float* prepared, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(p_hat && prepared, "tpspp_prepare_mirror_table: null pointer");
+    TPSPP_REQUIRE(tpspp_prepared_table_floats(Ho, Wo, F) != 0,
+                  "tpspp_prepare_mirror_table: needs Ho %% 16 == 0, Wo %% 4 == 0, 0 < F <= %d", kMaxK - 3);
+    TPSPP_REQUIRE(p_hat_ld >= F + 3, "tpspp_prepare_mirror_table: p_hat_ld too small (classic layout: F + 3 columns)");
+    const int K = F + 3, KG = (K + 3) / 4, n = Ho * Wo;
+    const int rc = tpspp_transpose_p_hat(p_hat, p_hat_ld, n, K, prepared, stream);
+    if (rc != TPSPP_OK) return rc;
+    const int PW = ((Wo / 2) + 3) & ~3, nthr = (Ho / 2) * PW, NW = (nthr + kWave - 1) / kWave;
+    const int total = NW * KG * kWave * 4;
+    hipLaunchKernelGGL(tpspp_pair::pack_mirror_table_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, PW / 4, nthr, K, prepared + (size_t)K * n);
+    return tpspp::check_launch("tpspp_prepare_mirror_table");
+}
+
 namespace {
 
 template <int F, int C, int HC, int WC>
@@ -934,6 +960,33 @@ bool launch_lds(const LdsParams& P, int ppt, int threads, size_t lds, hipStream_
 }
 
 
+template <int C>
+void launch_pair(const float* in, const float* ctrl, const float* inv_delta_c, const float* packed, int N,
+                 float* out, float* grid, int32_t* idx, hipStream_t st)
+{
+    using namespace tpspp_pair;
+    PairParams P;
+    P.in = in; P.ctrl = ctrl; P.inv_delta_c = inv_delta_c; P.packed = packed; P.N = N;
+    P.out = out; P.grid = grid; P.idx = idx; P.trace = g_trace;
+    const size_t lds = pair_lds_bytes<20, C, 32, 100, 32, 100>(&P.zero_off, &P.out_off);
+    const dim3 grid_dim((unsigned)((N + 1) / 2)), block((PairGeo<32, 100>::NW + kPairLoaders) * kWave);
+    auto go = [&](auto kern) {
+        // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and device
+        static bool attr_done[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+            attr_done[dev] = true;
+        }
+        hipLaunchKernelGGL(kern, grid_dim, block, lds, st, P);
+    };
+    if (g_trace) go(tps_warp_pair_kernel<20, C, 32, 100, 32, 100, false, true>);
+    else if (grid || idx) go(tps_warp_pair_kernel<20, C, 32, 100, 32, 100, true, false>);
+    else go(tps_warp_pair_kernel<20, C, 32, 100, 32, 100, false, false>);
+}
+
 }  // namespace
 
 TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
@@ -968,6 +1021,22 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: TPSPP_IO_BF16 needs a shape the plane-streaming kernel "
                                "takes (F = 20 or 32, <= 1024 output pixels, planes that fit the LDS ring)");
         return tpspp::launch_stream_kernel(A, g_trace, st);
+    }
+
+    // ---- image-pair kernel: the reference's own geometry, mirror-symmetric table, packed copy available ----
+    {
+        const bool pair_ok = (table_flags & TPSPP_TABLE_MIRROR4) && (table_flags & TPSPP_TABLE_PACKED) && p_hat_t &&
+                             !in1 && !score && !p_xy && F == 20 && (C0 == 1 || C0 == 3) && H0 == 32 && W0 == 100 &&
+                             Ho == 32 && Wo == 100 && (reinterpret_cast<uintptr_t>(in0) % 16 == 0) &&
+                             (reinterpret_cast<uintptr_t>(out0) % 16 == 0);
+        if (g_tune_kernel == 5 && !pair_ok)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the image-pair kernel");
+        if (pair_ok && (g_tune_kernel == 0 || g_tune_kernel == 5)) {
+            const float* packed = p_hat_t + (size_t)(F + 3) * Ho * Wo;      // second part of the prepared table
+            if (C0 == 1) launch_pair<1>(in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st);
+            else         launch_pair<3>(in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st);
+            return tpspp::check_launch("tpspp_warp_fwd(pair)");
+        }
     }
 
     // ---- LDS-staged kernel: single small input, classic layout, transposed table available ----

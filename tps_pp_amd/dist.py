@@ -48,13 +48,15 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None):
     if send.shape[0] != cap:
         pad = torch.zeros((cap - send.shape[0],) + tail, dtype=local.dtype, device=local.device)
         send = torch.cat([send, pad], dim=0)
-    recv = torch.empty((world * cap,) + tail, dtype=local.dtype, device=local.device)
-    try:
-        dist.all_gather_into_tensor(recv, send, group=group)
-    except (RuntimeError, NotImplementedError):          # gloo builds without the fused form
+    # the code path is chosen up front from the backend: a collective that fails on one rank (comm abort, timeout, size
+    # mismatch) must propagate, not be followed by a different collective on a desynchronised communicator
+    if str(dist.get_backend(group)).lower() == "gloo":   # CPU tests; gloo builds may lack the fused form
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send, group=group)
         recv = torch.cat(parts, dim=0)
+    else:                                                # RCCL: one large message per link
+        recv = torch.empty((world * cap,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
     if n_total == world * cap:
         return recv
     pieces = []

@@ -412,6 +412,13 @@ class EncodeDecodeRecognizer(nn.Module):
         assert backbone is not None
         self.backbone = build_backbone(backbone)
         self.tpsnet = build_backbone(tpsnet) if tpsnet is not None else None
+        # configs/textrecog/nrtr/nrtr_tps++.py:34-38 builds `tpsnet=dict(type='TPS_PP')` next to backbone strides
+        # [2,1,2,1,2]; the reference's hard-coded wiring cannot take that geometry.  A TPS_PP
+        # whose wiring was not chosen explicitly follows the strides of the backbone that will call it.
+        if self.tpsnet is not None and hasattr(self.tpsnet, "variant_for_strides") and not self.tpsnet.variant_explicit:
+            want = self.tpsnet.variant_for_strides(getattr(self.backbone, "strides", None) or [])
+            if want is not None:
+                self.tpsnet.set_variant(want, explicit=False)
         self.kd_loss = kd_loss
         self.encoder = build_encoder(encoder) if encoder is not None else None
         if decoder is not None:

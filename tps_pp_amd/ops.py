@@ -107,6 +107,50 @@ def transpose_p_hat(P_hat):
 TABLE_MIRROR4 = 1
 SCORE_TRANSPOSED = 2
 IO_BF16 = 4              # TPSPP_IO_BF16: in0 / in1 / out0 / out1 are bfloat16
+TABLE_PACKED = 8         # TPSPP_TABLE_PACKED: P_hat_t is the head of a prepare_mirror_table() buffer
+
+
+def prepare_mirror_table(P_hat, out_hw):
+    """One-off preparation of a classic-layout table for the image-pair kernel (`tpspp_prepare_mirror_table`):
+    returns `(P_hat_t, flags)` where `P_hat_t` is the usual (F+3, n) transposed table -- a view of the head of a
+    larger buffer whose tail is the packed copy -- and `flags` is `TABLE_PACKED`; for a geometry without a
+    prepared form: `(transpose_p_hat(P_hat), 0)`.  OR `TABLE_MIRROR4` in once the symmetry has been verified."""
+    P_hat = _chk("P_hat", P_hat, 2)
+    n, cols = P_hat.shape
+    Ho, Wo = int(out_hw[0]), int(out_hw[1])
+    if n != Ho * Wo:
+        raise ValueError("prepare_mirror_table: P_hat must have Ho * Wo rows")
+    total = int(_lib.lib().tpspp_prepared_table_floats(Ho, Wo, cols - 3)) if cols > 3 else 0
+    if total == 0:
+        return transpose_p_hat(P_hat), 0
+    buf = torch.empty((total,), device=P_hat.device, dtype=torch.float32)
+    with torch.cuda.device(P_hat.device):
+        rc = _lib.lib().tpspp_prepare_mirror_table(_ptr(P_hat), cols, Ho, Wo, cols - 3, _ptr(buf), _stream(P_hat))
+    _lib.check(rc, "tpspp_prepare_mirror_table")
+    return buf[:cols * n].view(cols, n), TABLE_PACKED
+
+
+def _chk_table(who, P_hat, P_hat_t, n, out_hw, table_flags):
+    """P_hat_t must be P_hat transposed; with TABLE_PACKED it must be the head of a prepare_mirror_table buffer
+    (the kernel reads the packed copy behind it: anything else would be an out-of-bounds read)."""
+    P_hat_t = _chk("P_hat_t", P_hat_t, 2)
+    if tuple(P_hat_t.shape) != (P_hat.shape[1], n) or P_hat_t.device != P_hat.device:
+        raise ValueError(f"{who}: P_hat_t must be P_hat transposed, on the same device")
+    if int(table_flags) & TABLE_PACKED:
+        need = int(_lib.lib().tpspp_prepared_table_floats(int(out_hw[0]), int(out_hw[1]), P_hat.shape[1] - 3))
+        base = P_hat_t._base
+        if need == 0 or base is None or base.numel() < need or base.data_ptr() != P_hat_t.data_ptr():
+            raise ValueError(f"{who}: TABLE_PACKED needs the P_hat_t that prepare_mirror_table() returned")
+    return P_hat_t
+
+
+def _chk_out(who, name, o, shape, dtype, device):
+    """Caller-supplied output buffers reach the kernels as raw pointers: everything is checked here."""
+    if not isinstance(o, torch.Tensor) or tuple(o.shape) != tuple(shape) or o.dtype != dtype \
+            or o.device != device or not o.is_contiguous():
+        got = (tuple(o.shape), o.dtype, str(o.device)) if isinstance(o, torch.Tensor) else type(o)
+        raise ValueError(f"{who}: {name} must be a contiguous {dtype} tensor of shape {tuple(shape)} on {device}, got {got}")
+    return o
 
 
 def table_mirror_symmetry(P_hat_host, out_hw, F):
@@ -166,9 +210,9 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
         else:
             score = _chk("score", score, 3)
     if P_hat_t is not None:
-        P_hat_t = _chk("P_hat_t", P_hat_t, 2)
-        if tuple(P_hat_t.shape) != (P_hat.shape[1], n):
-            raise ValueError("warp: P_hat_t must be P_hat transposed")
+        P_hat_t = _chk_table("warp", P_hat, P_hat_t, n, (Ho, Wo), table_flags)
+    elif int(table_flags) & TABLE_PACKED:
+        raise ValueError("warp: TABLE_PACKED without P_hat_t")
     C1 = H1 = W1 = 0
     if in1 is not None:
         in1 = _chk16("in1", in1, 4) if io16 else _chk("in1", in1, 4)
@@ -180,9 +224,16 @@ def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
         out0 = torch.empty((N, C0, Ho, Wo), device=dev, dtype=io_dtype)
     if in1 is not None and out1 is None:
         out1 = torch.empty((N, C1, Ho, Wo), device=dev, dtype=io_dtype)
-    for o in (out0, out1):
-        if o is not None and (o.dtype != io_dtype or not o.is_contiguous()):
-            raise TypeError("warp: out0 / out1 must be contiguous and of the inputs' dtype")
+    _chk_out("warp", "out0", out0, (N, C0, Ho, Wo), io_dtype, dev)
+    if in1 is not None:
+        if in1.device != dev:
+            raise ValueError("warp: in1 must be on in0's device")
+        _chk_out("warp", "out1", out1, (N, C1, Ho, Wo), io_dtype, dev)
+    elif out1 is not None:
+        raise ValueError("warp: out1 given without in1")
+    for nm, t in (("ctrl", ctrl), ("inv_delta_C", inv_delta_C), ("P_hat", P_hat), ("P_xy", P_xy), ("score", score)):
+        if t is not None and t.device != dev:
+            raise ValueError(f"warp: {nm} must be on in0's device")
     grid = torch.empty((N, n, 2), device=dev, dtype=torch.float32) if want_grid else None
     idx = torch.empty((N, n, 2), device=dev, dtype=torch.int32) if want_idx else None
     with torch.cuda.device(dev):
@@ -216,6 +267,8 @@ class WarpPlan:
             raise ValueError("WarpPlan: ctrl must be (N, F, 2), inv_delta_C (F+3, F+3)")
         if P_xy is not None:
             P_xy = _chk("P_xy", P_xy, 2)
+            if tuple(P_xy.shape) != (n, 2):
+                raise ValueError("WarpPlan: P_xy must be (n, 2)")
         if tuple(P_hat.shape) != (n, F if P_xy is not None else F + 3):
             raise ValueError(f"WarpPlan: P_hat has shape {tuple(P_hat.shape)}")
         if score is not None:
@@ -227,18 +280,23 @@ class WarpPlan:
             else:
                 score = _chk("score", score, 3)
         if P_hat_t is not None:
-            P_hat_t = _chk("P_hat_t", P_hat_t, 2)
-            if tuple(P_hat_t.shape) != (P_hat.shape[1], n):
-                raise ValueError("WarpPlan: P_hat_t must be P_hat transposed")
+            P_hat_t = _chk_table("WarpPlan", P_hat, P_hat_t, n, (Ho, Wo), table_flags)
+        elif int(table_flags) & TABLE_PACKED:
+            raise ValueError("WarpPlan: TABLE_PACKED without P_hat_t")
+        dev = in0.device
         C1 = H1 = W1 = 0
         if in1 is not None:
             in1 = _chk("in1", in1, 4)
             _, C1, H1, W1 = in1.shape
-            if in1.shape[0] != N or out1 is None or tuple(out1.shape) != (N, C1, Ho, Wo) or not out1.is_contiguous():
-                raise ValueError("WarpPlan: in1 needs a contiguous out1 (N, C1, Ho, Wo)")
-        if tuple(out0.shape) != (N, C0, Ho, Wo) or out0.dtype != torch.float32 or not out0.is_contiguous() \
-                or out0.device != in0.device:
-            raise ValueError("WarpPlan: out0 must be a contiguous float32 (N, C0, Ho, Wo) tensor on in0's device")
+            if in1.shape[0] != N or in1.device != dev:
+                raise ValueError("WarpPlan: in1 must have in0's batch size and device")
+            _chk_out("WarpPlan", "out1", out1, (N, C1, Ho, Wo), torch.float32, dev)
+        elif out1 is not None:
+            raise ValueError("WarpPlan: out1 given without in1")
+        _chk_out("WarpPlan", "out0", out0, (N, C0, Ho, Wo), torch.float32, dev)
+        for nm, t in (("ctrl", ctrl), ("inv_delta_C", inv_delta_C), ("P_hat", P_hat), ("P_xy", P_xy), ("score", score)):
+            if t is not None and t.device != dev:
+                raise ValueError(f"WarpPlan: {nm} must be on in0's device")
         self._keep = (in0, in1, ctrl, score, inv_delta_C, P_hat, P_xy, P_hat_t, out0, out1)
         vp, ci = ctypes.c_void_p, ctypes.c_int
         self._args = (vp(_ptr(in0)), ci(C0), ci(H0), ci(W0), vp(_ptr(in1)), ci(C1), ci(H1), ci(W1), vp(_ptr(ctrl)),
@@ -722,7 +780,8 @@ def linear(x, cw, relu=False):
 
 
 def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
-    """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel (error if not applicable);
+    """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel, 3 the same without the mirror trick, 4 plane-streaming
+    kernel, 5 image-pair kernel (2..5: error if not applicable);
     bands: workgroups per image pair in the LDS-staged kernel (0 = heuristic)."""
     _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group),
                                                 int(kernel_choice), int(bands)),

@@ -115,6 +115,7 @@ class ResNetABI_v2_large(nn.Module):
         assert out_indices is None or isinstance(out_indices, (list, tuple))
         assert isinstance(last_stage_pool, bool)
         self.init_cfg = init_cfg
+        self.strides = list(strides)       # read by EncodeDecodeRecognizer to pick the TPS_PP wiring that fits
         # None: follow the input dtype; torch.bfloat16: bf16 convolutions; "bf16x3": fp32 tensors, three-term split
         self.compute_dtype = None
         self.out_indices = out_indices

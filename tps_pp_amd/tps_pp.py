@@ -7,13 +7,15 @@ contract `forward(batch_img, outs) -> dict(output, logits=None, mp_img, pc_score
 the 60-entry `state_dict` (58 parameters + buffers `atten_tps.hat_C`, `atten_tps.P_hat`), so
 released checkpoints load unchanged.
 
-Division of labour in this round:
+Every stage of `forward` in eval mode runs on the hand-written HIP kernels of libtpspp_hip.so:
   * the transformation stage -- `Attention_Enhanced_TPS.build_P_prime` + both `F.grid_sample` calls
-    (`:597-615`) -- is ONE hand-written HIP kernel (T in LDS, grid in registers, arithmetic identical
-    to the reference's CPU run);
-  * the control-point regressor (MSFA / TPE / DGAB, `:84-325`) still runs on PyTorch-ROCm library
-    kernels; its MFMA replacement is the next row of the build plan.
-No CPU fallback: CPU tensors raise.
+    (`:597-615`) -- is ONE kernel (T in LDS, grid in registers, arithmetic identical to the reference's
+    CPU run);
+  * the control-point regressor (MSFA / TPE / DGAB, `:84-325`): MFMA convolutions with everything around
+    them fused, the DGAB chain, the score and the per-point FC stacks.
+In training mode (`module.train()`) the transformation stage still runs on the HIP kernels in both
+directions while the regressor is the plain PyTorch composition of the same layers, so that autograd
+reaches its parameters (logged once).  No CPU fallback: CPU tensors raise.
 """
 import numpy as np
 import torch
@@ -290,21 +292,29 @@ class TPS_PP(nn.Module):
 
     Args (as the reference): img_size, rectified_img_size (tuples), num_img_channel, point_size,
         p_stride, visual_point, init_cfg.
-    Extra: variant -- 'ResNet45v2' (default; the wiring the reference hard-codes at :522: both
-        `outs` at 2x the resolution of `batch_img`) or 'ResNet45' (the reference's other branch,
-        :549-552,574-579: `outs[0]` at 2x, `outs[1]` at 1x -- the geometry the shipped config's
-        backbone strides [2,1,2,1,2] actually produce).
+    Extra: variant -- the reference has two wirings and hard-codes the one its shipped config cannot run
+        (SURVEY.md section 0, fact 4): 'ResNet45v2' (:522: both `outs` at 2x the resolution of `batch_img`) and
+        'ResNet45' (:549-552,574-579: `outs[0]` at 2x, `outs[1]` at 1x -- the geometry the backbone strides
+        [2,1,2,1,2] of configs/textrecog/nrtr/nrtr_tps++.py produce).  None (default) = pick by geometry: the
+        module is built with the reference's hard-coded wiring and re-wires itself
+          * when the recogniser that owns it knows its backbone's strides (`EncodeDecodeRecognizer.__init__`),
+          * when a checkpoint is loaded (`down0.conv.weight` is (64,32,1,1) in one wiring, (64,32,3,3) in the other),
+          * at the first forward whose feature maps have the other geometry, if nothing was loaded yet;
+        an explicit value is never overridden.
     """
 
     def __init__(self, img_size=(16, 64), rectified_img_size=(16, 64), num_img_channel=64,
                  point_size=(2, 16), p_stride=2, visual_point=False, init_cfg=None,
-                 variant="ResNet45v2"):
+                 variant=None):
         super().__init__()
         assert isinstance(img_size, tuple)
         assert isinstance(rectified_img_size, tuple)
-        assert variant in ("ResNet45v2", "ResNet45")
+        assert variant in (None, "ResNet45v2", "ResNet45")
         self.init_cfg = init_cfg
         self.heads = 16
+        self.variant_explicit = variant is not None
+        self._weights_loaded = False
+        variant = variant or "ResNet45v2"                     # the reference's hard-coded choice (:522)
         self.type = variant
         # None: follow the input dtype (fp32 -> exact fp32 kernels); torch.bfloat16: bf16 convolutions;
         # "bf16x3": fp32 tensors, three-term bf16 split in the convolutions (DESIGN.md section 4e)
@@ -322,19 +332,66 @@ class TPS_PP(nn.Module):
         # (the reference passes point_channel / img_channel swapped, :240 vs :534; both are 64)
         self.TPE = Transformation_Parameter_Estimation(self.point_channel, self.img_channel,
                                                        num_img_channel, point_size, img_size)
-        if variant == "ResNet45v2":
-            self.down0 = ConvModule(32, ic, 1)
-            self.down1 = ConvModule(32, ic, 1)
-            self.down2 = ConvModule(64, ic, 1)
-            self.down0_1 = ConvModule(ic, ic, 3, stride=2, padding=1)
-            self.down1_1 = ConvModule(ic, ic, 3, stride=2, padding=1)
-            self.up_sample = nn.Upsample(scale_factor=2, mode="nearest")
-            self.down_feat = ConvModule(3 * ic, ic, 1)
-        else:
-            self.down0 = ConvModule(32, ic, 3, stride=2, padding=1)
-            self.down1 = ConvModule(32, ic, 1)
-            self.down2 = ConvModule(64, ic, 1)
+        self.down1 = ConvModule(32, ic, 1)
+        self.down2 = ConvModule(64, ic, 1)
+        self._wire(variant)
         self.atten_tps = Attention_Enhanced_TPS(rectified_img_size, point_size)
+        self._register_load_state_dict_pre_hook(self._variant_from_state_dict)
+
+    def _wire(self, variant):
+        """The layers that differ between the two wirings (`tps_pp.py:537-552`); registration order as the reference."""
+        ic = self.img_channel
+        ref = self.down1.conv.weight
+        for name in ("down0", "down0_1", "down1_1", "up_sample", "down_feat"):
+            if name in self._modules:
+                del self._modules[name]
+        if variant == "ResNet45v2":
+            new = dict(down0=ConvModule(32, ic, 1), down0_1=ConvModule(ic, ic, 3, stride=2, padding=1),
+                       down1_1=ConvModule(ic, ic, 3, stride=2, padding=1),
+                       up_sample=nn.Upsample(scale_factor=2, mode="nearest"), down_feat=ConvModule(3 * ic, ic, 1))
+        else:
+            new = dict(down0=ConvModule(32, ic, 3, stride=2, padding=1))
+        for name, mod in new.items():
+            setattr(self, name, mod.to(device=ref.device, dtype=ref.dtype))
+        # keep the reference's module order (state_dict order): down0, down1, down2, down0_1, down1_1, up_sample, down_feat
+        order = ["down0", "down1", "down2", "down0_1", "down1_1", "up_sample", "down_feat"]
+        head = [k for k in self._modules if k not in order]        # MSFA, TPE (registered before), atten_tps (after)
+        rest = [k for k in order if k in self._modules]
+        tail = [k for k in head if k == "atten_tps"]
+        head = [k for k in head if k != "atten_tps"]
+        for k in head + rest + tail:
+            self._modules[k] = self._modules.pop(k)           # re-insert: dicts keep insertion order
+        self.type = variant
+        for c in ("_cw_cache", "_cw16_cache", "_front_cache", "_front16_cache"):
+            if hasattr(self, c):
+                delattr(self, c)
+
+    def set_variant(self, variant, explicit=True):
+        """Switch the wiring ('ResNet45v2' / 'ResNet45'); the layers the two do not share are re-created with a fresh
+        default initialisation (load a checkpoint afterwards)."""
+        assert variant in ("ResNet45v2", "ResNet45")
+        if variant != self.type:
+            self._wire(variant)
+        self.variant_explicit = self.variant_explicit or explicit
+        return self
+
+    @staticmethod
+    def variant_for_strides(strides):
+        """The wiring whose feature-map geometry the backbone's first two stage strides produce
+        (`resnet_v2_large.py:183-191`: outs[0] = stage-0 input, outs[1] = stage-1 input, x = stage-1 output)."""
+        s = [v if isinstance(v, int) else v[0] for v in list(strides)[:2]]
+        return {(1, 2): "ResNet45v2", (2, 1): "ResNet45"}.get(tuple(s))
+
+    def _variant_from_state_dict(self, state_dict, prefix, *args):
+        w = state_dict.get(prefix + "down0.conv.weight")
+        if w is not None and w.dim() == 4:
+            want = "ResNet45" if tuple(w.shape[-2:]) == (3, 3) else "ResNet45v2"
+            if want != self.type:
+                if self.variant_explicit:
+                    raise ValueError(f"TPS_PP(variant={self.type!r}): the checkpoint holds the {want!r} wiring "
+                                     f"(down0.conv.weight {tuple(w.shape)})")
+                self._wire(want)
+            self._weights_loaded = True
 
     def init_weights(self):
         pass
@@ -445,20 +502,35 @@ class TPS_PP(nn.Module):
     def regress(self, batch_img, outs):
         """Control points, attention score and the feature map to rectify (`tps_pp.py:572-594`).
         Hand-written kernels only; CPU tensors raise (no fallback)."""
-        h, w = batch_img.shape[-2:]
-        if self.type == "ResNet45v2":
-            if tuple(outs[1].shape[-2:]) != (2 * h, 2 * w) or tuple(outs[0].shape[-2:]) != (2 * h, 2 * w):
-                raise ValueError(
-                    f"TPS_PP(variant='ResNet45v2') needs outs[0], outs[1] at {(2 * h, 2 * w)}, got "
-                    f"{tuple(outs[0].shape[-2:])}, {tuple(outs[1].shape[-2:])}: backbone strides "
-                    "[2,1,2,1,2] (configs/textrecog/nrtr/nrtr_tps++.py) produce the 'ResNet45' "
-                    "geometry -- build with variant='ResNet45' (the reference itself fails here)")
+        self._check_geometry(batch_img, outs)
         ops.require_gpu(batch_img, "TPS_PP")
         if self._bf16(batch_img):
             return self._regress_hip_bf16(batch_img, outs)
         if self.compute_dtype == "bf16x3":
             return self._regress_hip_bf16(batch_img.float(), [o.float() for o in outs], x3=True)
         return self._regress_hip(batch_img, outs)
+
+    def _check_geometry(self, batch_img, outs):
+        """Pick the wiring by the feature maps' geometry when it was not chosen explicitly and no checkpoint has been
+        loaded; otherwise fail with a message that names the way out."""
+        h, w = batch_img.shape[-2:]
+        g0, g1 = tuple(outs[0].shape[-2:]), tuple(outs[1].shape[-2:])
+        want = "ResNet45v2" if (g0, g1) == ((2 * h, 2 * w), (2 * h, 2 * w)) else \
+               "ResNet45" if (g0, g1) == ((2 * h, 2 * w), (h, w)) else None
+        if want == self.type:
+            return
+        if want is not None and not self.variant_explicit and not self._weights_loaded:
+            import logging
+            logging.getLogger("tps_pp_amd").warning(
+                "TPS_PP: feature maps %s / %s for a %s input: switching to the %r wiring (freshly initialised layers)",
+                g0, g1, (h, w), want)
+            self._wire(want)
+            return
+        raise ValueError(
+            f"TPS_PP(variant={self.type!r}) got outs[0], outs[1] at {g0}, {g1} for a {(h, w)} input: 'ResNet45v2' needs "
+            f"both at {(2 * h, 2 * w)}, 'ResNet45' needs {(2 * h, 2 * w)} and {(h, w)} (backbone strides [2,1,2,1,2] of "
+            "configs/textrecog/nrtr/nrtr_tps++.py produce the latter; the reference itself fails here) -- build with "
+            "variant='ResNet45' / call set_variant(), or leave variant unset before loading the checkpoint")
 
     def _bf16(self, batch_img):
         """bf16 compute when the caller hands over bf16 activations or sets `compute_dtype`.  The module's
@@ -563,9 +635,18 @@ class TPS_PP(nn.Module):
     def forward(self, batch_img, outs, **kwargs):
         """batch_img (N,64,16,64), outs = [stage-0 input, stage-1 input] ->
         dict(output, logits=None, mp_img, pc_score)."""
-        if torch.is_grad_enabled() and (batch_img.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
-            return self._forward_autograd(batch_img, outs)
+        if self.training:
+            # training graph; eval mode ALWAYS takes the HIP kernels (wrap the call in torch.no_grad() as the reference's
+            # test loops do: the kernels record no autograd graph)
+            if not getattr(self, "_logged_autograd", False):
+                import logging
+                logging.getLogger("tps_pp_amd").warning(
+                    "TPS_PP.train(): control-point regressor as a PyTorch composition (library kernels, fp32) so that "
+                    "autograd reaches its parameters; warp forward / backward on the HIP kernels. Call .eval() for the "
+                    "all-HIP inference path.")
+                self._logged_autograd = True
+            self._check_geometry(batch_img, outs)
+            return self._forward_autograd(batch_img.float(), [o.float() for o in outs])
         control_point, atten_score, feat_grid = self.regress(batch_img, outs)
         # (the score stays the transposed view of its (N, F, n) buffer: ops.warp reads it in place)
         if batch_img.dtype == torch.bfloat16:

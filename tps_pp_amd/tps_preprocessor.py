@@ -136,16 +136,19 @@ class GridGenerator(nn.Module):
 
     def prepared_table(self):
         """(P_hat_t, table_flags) for the current P_hat buffer: the transposed copy the coalesced
-        kernels read, and whether the table has the reference's mirror symmetry (checked bitwise,
-        once per buffer version; a checkpoint that loads a different table simply gets 0)."""
+        kernels read (with the packed copy of the image-pair kernel behind it when the geometry has one:
+        `ops.prepare_mirror_table`), and whether the table has the reference's mirror symmetry (checked
+        bitwise, once per buffer version; a checkpoint that loads a different table simply gets 0)."""
         p = self.P_hat
         key = (p.data_ptr(), p._version, str(p.device))
         if self._prep is None or self._prep[0] != key:
-            flags = 0
-            if ops.table_mirror_symmetry(p, (self.rectified_img_height, self.rectified_img_width),
-                                         self.num_fiducial):
+            hw = (self.rectified_img_height, self.rectified_img_width)
+            if ops.table_mirror_symmetry(p, hw, self.num_fiducial):
+                P_hat_t, flags = ops.prepare_mirror_table(p, hw)
                 flags |= ops.TABLE_MIRROR4
-            self._prep = (key, ops.transpose_p_hat(p), flags)
+            else:
+                P_hat_t, flags = ops.transpose_p_hat(p), 0
+            self._prep = (key, P_hat_t, flags)
         return self._prep[1], self._prep[2]
 
     def build_P_prime(self, batch_C_prime, device="cuda"):
@@ -195,14 +198,20 @@ class TPSPreprocessor(BasePreprocessor):
 
     def forward(self, batch_img):
         """(N, C, H, W) -> (N, C, H_r, W_r)."""
-        if torch.is_grad_enabled() and (batch_img.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
+        if self.training:
             # training graph (SURVEY.md section 8f row F2): HIP warp forward + backward; the localisation
-            # network is the plain PyTorch composition so that autograd reaches its parameters
+            # network is the plain PyTorch composition (fp32) so that autograd reaches its parameters.
+            # Eval mode ALWAYS takes the HIP kernels, like the other stages of a recogniser.
             ops.require_gpu(batch_img, "TPSPreprocessor")
+            if not getattr(self, "_logged_autograd", False):
+                import logging
+                logging.getLogger("tps_pp_amd").warning(
+                    "TPSPreprocessor.train(): localisation network as a PyTorch composition (library kernels, fp32); "
+                    "warp forward / backward on the HIP kernels. Call .eval() for the all-HIP inference path.")
+                self._logged_autograd = True
             gg = self.GridGenerator
             P_hat_t, flags = gg.prepared_table()
-            ctrl = self.LocalizationNetwork._forward_torch(batch_img)
+            ctrl = self.LocalizationNetwork._forward_torch(batch_img.float())
             return ops.warp_autograd(batch_img.float(), ctrl.float(), gg.inv_delta_C, gg.P_hat,
                                      self.rectified_img_size, P_hat_t=P_hat_t, table_flags=flags)
         batch_C_prime = self.LocalizationNetwork(batch_img)
