@@ -367,7 +367,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--precondition-ms", type=float, default=800.0,
+    ap.add_argument("--precondition-ms", type=float, default=300.0,
                     help="device copies over the bench buffers before the warm-up steps: the chip leaves its idle "
                          "clocks only after some hundred ms of activity (not steps of the workload; 0 disables)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo check of the launch path, no GPU work")

@@ -336,6 +336,44 @@ static void launch_m14(const Bufs& B, int set, float* out, float* grid, int32_t*
     else go(tps_warp_m14_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, false, AWAIT, KB>);
 }
 
+template <int NLOAD, int STORE, int LDNT, int AWAIT, int KB>
+static void launch_m15(const Bufs& B, int set, float* out, float* grid, int32_t* idx, long long* trace, hipStream_t st)
+{
+    M3Params P;
+    P.in = B.in[set]; P.ctrl = B.ctrl[set]; P.inv_delta_c = B.inv; P.p_hat_t = B.p_hat_pk2;
+    P.N = N; P.n = n; P.Ho = H; P.Wo = W;
+    P.out = out; P.grid = grid; P.idx = idx; P.trace = trace; P.trace2 = B.trace2;
+    const size_t lds = m5_lds_bytes(F, C, H, W, H, W, &P.zero_off, &P.out_off);
+    const int threads = (13 + NLOAD) * 64;
+    auto go = [&](auto kern) {
+        static bool done = false;
+        if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+        hipLaunchKernelGGL(kern, dim3((N + 1) / 2), dim3(threads), lds, st, P);
+    };
+    if (trace) go(tps_warp_m15_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, true, AWAIT, KB>);
+    else if (grid || idx) go(tps_warp_m15_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, true, false, AWAIT, KB>);
+    else go(tps_warp_m15_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, false, AWAIT, KB>);
+}
+
+template <int NLOAD, int STORE, int LDNT, int AWAIT, int KB, int BMODE>
+static void launch_m16(const Bufs& B, int set, float* out, float* grid, int32_t* idx, long long* trace, hipStream_t st)
+{
+    M3Params P;
+    P.in = B.in[set]; P.ctrl = B.ctrl[set]; P.inv_delta_c = B.inv; P.p_hat_t = B.p_hat_pk2;
+    P.N = N; P.n = n; P.Ho = H; P.Wo = W;
+    P.out = out; P.grid = grid; P.idx = idx; P.trace = trace; P.trace2 = B.trace2;
+    const size_t lds = m5_lds_bytes(F, C, H, W, H, W, &P.zero_off, &P.out_off);
+    const int threads = (13 + NLOAD) * 64;
+    auto go = [&](auto kern) {
+        static bool done = false;
+        if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+        hipLaunchKernelGGL(kern, dim3((N + 1) / 2), dim3(threads), lds, st, P);
+    };
+    if (trace) go(tps_warp_m16_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, true, AWAIT, KB, BMODE>);
+    else if (grid || idx) go(tps_warp_m16_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, true, false, AWAIT, KB, BMODE>);
+    else go(tps_warp_m16_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, false, AWAIT, KB, BMODE>);
+}
+
 template <int NLOAD, int STORE, int LDNT, int AWAIT>
 static void launch_m12(const Bufs& B, int set, float* out, float* grid, int32_t* idx, long long* trace, hipStream_t st)
 {
@@ -457,6 +495,14 @@ struct Variant { std::string name; std::function<void(const Bufs&, int, float*, 
     Variant{ "m14 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT " await=" #AWAIT " kb=" #KB, \
       [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
           launch_m14<NLOAD, STORE, LDNT, AWAIT, KB>(B, s, o, g, ix, tr, st); } }
+#define M15VAR(NLOAD, STORE, LDNT, AWAIT, KB) \
+    Variant{ "m15 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT " await=" #AWAIT " kb=" #KB, \
+      [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
+          launch_m15<NLOAD, STORE, LDNT, AWAIT, KB>(B, s, o, g, ix, tr, st); } }
+#define M16VAR(NLOAD, STORE, LDNT, AWAIT, KB, BMODE) \
+    Variant{ "m16 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT " await=" #AWAIT " kb=" #KB " bmode=" #BMODE, \
+      [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
+          launch_m16<NLOAD, STORE, LDNT, AWAIT, KB, BMODE>(B, s, o, g, ix, tr, st); } }
 #define M5VAR(NLOAD, STORE, LDNT) \
     Variant{ "m5 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT, \
       [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
@@ -729,16 +775,31 @@ int main(int argc, char** argv)
         trace_report(B, 256);
     }
 
+    // the library's image-pair kernel through the C ABI (prepared table)
+    float* prepared = nullptr;
+    {
+        auto prep_floats = (size_t (*)(int, int, int))dlsym(lib, "tpspp_prepared_table_floats");
+        auto prep = (int (*)(const float*, int, int, int, int, float*, void*))dlsym(lib, "tpspp_prepare_mirror_table");
+        if (prep_floats && prep) {
+            CK(hipMalloc(&prepared, prep_floats(H, W, F) * 4));
+            if (prep(B.p_hat, K, H, W, F, prepared, nullptr)) { printf("prepare failed\n"); return 1; }
+            CK(hipDeviceSynchronize());
+        }
+    }
+    Variant libpair{"lib pair kernel (tpspp_warp_fwd, prepared table)",
+        [&, warp_fwd, prepared](const Bufs& Bf, int s, float* o, float* g, int32_t* ix, long long*, hipStream_t) {
+            warp_fwd(Bf.in[s], C, H, W, nullptr, 0, 0, 0, Bf.ctrl[s], nullptr, Bf.inv, Bf.p_hat, K, nullptr, prepared, 1 | 8, N, F, H, W, o, nullptr, g, ix, nullptr); }};
     std::vector<Variant> vars = {
-        M13VAR(3, 1, 1, 2, 2), M14VAR(3, 1, 1, 2, 2), M14VAR(3, 1, 1, 0, 0), M14VAR(3, 2, 1, 2, 2), M14VAR(3, 1, 1, 6, 4),
+        M15VAR(3, 1, 1, 6, 4), M16VAR(3, 1, 1, 6, 4, 0), M16VAR(3, 1, 1, 6, 4, 1), M16VAR(3, 1, 1, 6, 4, 2), M16VAR(3, 1, 1, 0, 0, 1),
     };
+    if (prepared) vars.push_back(libpair);
     std::vector<float> hout((size_t)N * C * n), hgrid((size_t)N * n * 2); std::vector<int32_t> hidx((size_t)N * n * 2);
     for (auto& v : vars) {
         if (*only && v.name.find(only) == std::string::npos) continue;
         printf("-- %s\n", v.name.c_str()); fflush(stdout);
         // correctness: set 0 plain, set 1 with grid + idx
         bool ok = true; size_t bad = 0;
-        const bool is_m = v.name[0] == 'm' && v.name[1] == ' ';
+        const bool is_m = (v.name[0] == 'm' && v.name[1] == ' ');
         const bool dbg = v.name[0] == 'm' && v.name[1] != '3' && v.name[1] != '4' && v.name[1] != '5' && v.name[1] != '6' && v.name[1] != '7' && v.name[1] != '8' && v.name[1] != '9' && v.name[1] != '1' && v.name.find("dbg=0") == std::string::npos && v.name.find("dbg=4") == std::string::npos && v.name.find("dbg=8") == std::string::npos && v.name.find("dbg=16") == std::string::npos && v.name.find("dbg=24") == std::string::npos;
         for (int s = 0; s < 2 && !dbg; ++s) {
             CK(hipMemset(B.out[s], 0xff, img_bytes));
@@ -762,7 +823,8 @@ int main(int argc, char** argv)
         report(nm, us);
         if (!ok) printf("   %zu differing output words\n", bad);
         CK(hipMemset(B.trace, 0, 4096 * 128));
-        if (v.name.compare(0, 2, "m3") == 0 || v.name.compare(0, 2, "m4") == 0 || v.name.compare(0, 2, "m5") == 0 || v.name.compare(0, 2, "m6") == 0 || v.name.compare(0, 2, "m7") == 0 || v.name.compare(0, 2, "m8") == 0 || v.name.compare(0, 2, "m9") == 0 || v.name.compare(0, 3, "m10") == 0 || v.name.compare(0, 3, "m11") == 0 || v.name.compare(0, 3, "m12") == 0 || v.name.compare(0, 3, "m13") == 0 || v.name.compare(0, 3, "m14") == 0) {
+        if (v.name.compare(0, 3, "lib") == 0) continue;
+        if (v.name.compare(0, 2, "m3") == 0 || v.name.compare(0, 2, "m4") == 0 || v.name.compare(0, 2, "m5") == 0 || v.name.compare(0, 2, "m6") == 0 || v.name.compare(0, 2, "m7") == 0 || v.name.compare(0, 2, "m8") == 0 || v.name.compare(0, 2, "m9") == 0 || v.name.compare(0, 3, "m10") == 0 || v.name.compare(0, 3, "m11") == 0 || v.name.compare(0, 3, "m12") == 0 || v.name.compare(0, 3, "m13") == 0 || v.name.compare(0, 3, "m14") == 0 || v.name.compare(0, 3, "m15") == 0 || v.name.compare(0, 3, "m16") == 0) {
             const int L = 4;
             for (int l = 0; l < 20; ++l) v.run(B, l % SETS, B.out[l % SETS], nullptr, nullptr, nullptr, 0);
             for (int l = 0; l < L; ++l) v.run(B, (l + 3) % SETS, B.out[(l + 3) % SETS], nullptr, nullptr, B.trace + (size_t)l * 256 * 16, 0);

@@ -253,8 +253,8 @@ tps_warp_pair_kernel(const PairParams P)
     constexpr unsigned row_bytes = n * 4u;
     constexpr int out16 = (C * n) >> 2;                      // 16-byte pieces of one output image
     constexpr int nct = NW * kWave;
-    // Tap descriptors (4 LDS byte addresses + 4 weights per mirror pixel) are pure VALU work: image A's are built
-    // while A is still in flight, image B's between the issue of A's tap reads and their use.
+    // Tap descriptors (4 LDS byte addresses + 4 weights per mirror pixel) of both images are pure VALU work, done
+    // while image A is still in flight (the wavefront would idle otherwise).
     typedef __attribute__((address_space(3))) const float lds_cfloat;
     const unsigned img_lds = (unsigned)(size_t)sImg, zero_lds = (unsigned)(size_t)sZero;
     unsigned ta[2][4][4];
@@ -290,7 +290,8 @@ tps_warp_pair_kernel(const PairParams P)
             for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(ta[im][m][q]), "+v"(tw[im][m][q]));
     };
     describe(std::integral_constant<int, 0>{});
-    PAIR_STAMP(1);                                           // grid + image A's tap descriptors done
+    describe(std::integral_constant<int, 1>{});
+    PAIR_STAMP(1);                                           // grid + tap descriptors done
 
     constexpr int NOUT = (out16 + nct - 1) / nct;            // 16-byte output pieces per thread and image
     v4f ostage[NOUT];                                        // image A's pieces between their LDS read and their store
@@ -314,10 +315,13 @@ tps_warp_pair_kernel(const PairParams P)
             for (int ch = 0; ch < C; ++ch)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) tv[m][ch][q] = *((lds_cfloat*)(size_t)(ta[im][m][q]) + ch * HW);
-        __builtin_amdgcn_sched_barrier(0);
-        if (im == 0) describe(std::integral_constant<int, 1>{});   // overlaps the LDS service time of A's tap reads
-        else store_image(b0);   // image A's store issue (back-pressured by HBM) overlaps it for image B
-        __builtin_amdgcn_sched_barrier(0);
+        if (im == 1) {
+            // image A's output pieces leave while the LDS serves image B's tap reads: their issue is back-pressured
+            // by HBM and would otherwise sit on the critical path between the two images
+            __builtin_amdgcn_sched_barrier(0);
+            store_image(b0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float res[4][C];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
