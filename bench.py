@@ -251,18 +251,24 @@ def recognizer_measurement(dev, timeit):
         m.encoder.compute_dtype = m.decoder.compute_dtype = None
         m.backbone.compute_dtype = None
     want = TO.recognizer_simple_test(sds[0], sds[1], sds[2], sds[3], img[:k].cpu().numpy(), [128] * k)["text"]
+    # configs[4]: decisions of the reduced-precision configurations against the exact-fp32 kernels, 256 images
+    from tps_pp_amd import metrics
+    agree16 = metrics.precision_agreement(m, img[:256], metas[:256], torch.bfloat16)
+    agreex3 = metrics.precision_agreement(m, img[:256], metas[:256], "bf16x3")
     return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
             "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
             "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
             "bf16x3": {"images_per_s": n / (t_allx3 * 1e-3), "ms_per_batch": t_allx3, "ms_backbone_tpspp": t_featx3,
-                       "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(gotx3, want))}/{k}"},
+                       "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(gotx3, want))}/{k}",
+                       "agreement_with_fp32_kernels_256_images": agreex3},
             "bf16_backbone": {"images_per_s": n / (t_all16 * 1e-3), "ms_per_batch": t_all16,
                               "ms_backbone_tpspp": t_feat16,
                               "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(got16, want))}/{k}"},
             "bf16_backbone_and_head": {"images_per_s": n / (t_all16h * 1e-3), "ms_per_batch": t_all16h,
                                        "ms_encoder": t_enc16, "ms_greedy_decoder_40_steps": t_dec16,
                                        "strings_equal_to_fp32_cpu_oracle":
-                                           f"{sum(a == b for a, b in zip(got16h, want))}/{k}"},
+                                           f"{sum(a == b for a, b in zip(got16h, want))}/{k}",
+                                       "agreement_with_fp32_kernels_256_images": agree16},
             "data": "synthetic images, random-init weights"}
 
 

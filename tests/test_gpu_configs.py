@@ -172,3 +172,26 @@ def test_config3_and_4_bf16_256_per_gpu(cuda):
     err = np.abs(feat_small[:2].cpu().numpy() - ref)
     assert err.max() <= 0.05 * np.abs(ref).max() and err.mean() <= 0.005 * np.abs(ref).max()
     assert [r["text"] for r in res_small[:2]] == o["text"]
+
+
+@pytest.mark.parametrize("mode,tf_min,word_min,char_min", [(torch.bfloat16, 0.98, 0.55, 0.85), ("bf16x3", 0.9995, 0.97, 0.99)])
+def test_config4_reduced_precision_agreement_on_256_distinct_images(cuda, mode, tf_min, word_min, char_min):
+    """BASELINE.json configs[4], "word-accuracy parity check", on 256 DISTINCT synthetic crops with random-init weights
+    (classifier spread x8 as in bench.py): decisions of the bf16 / bf16x3 configurations against the exact-fp32 kernels
+    of the same model -- which other tests hold to 1e-4 / identical strings against the reference and the CPU oracle.
+    Thresholds: measured 0.993 / 0.75 / 0.96 (bf16) and 1.0 / 1.0 / 1.0 (bf16x3) in round 1; random-init
+    decoding is the worst case for word agreement (40 characters of noise, one flipped near-tie rewrites the tail)."""
+    from tps_pp_amd import metrics
+    m = build_recognizer(cuda)
+    with torch.no_grad():
+        m.decoder.classifier.weight.mul_(8.0)
+    n = 256
+    img = dev(synth.smooth_image((n, 3, 32, 128), "cfg4.agree", 5), cuda)
+    metas = [dict(resize_shape=(32, 128 if i % 3 else 96, 3)) for i in range(n)]
+    r = metrics.precision_agreement(m, img, metas, mode)
+    print("precision_agreement", mode, r)
+    assert r["images"] == n and r["positions"] >= n
+    assert r["teacher_forced_self_check_fp32"] >= 0.9999          # forced decoding == greedy decoding in fp32
+    assert r["teacher_forced_argmax_agreement"] >= tf_min, r
+    assert r["greedy_word_agreement"] >= word_min, r
+    assert r["greedy_char_agreement"] >= char_min, r

@@ -3,7 +3,10 @@
 CPU part: the host logic and the normalisation against the reference's own known answers
 (tests/test_dataset/test_ocr_transforms.py:13-57 of the reference) -- for the oracle and for the mirror;
 GPU part: the kernel bit for bit against the oracle on ragged batches.  The interpolation arithmetic itself is
-"parity unpinned" (OpenCV is not installed here): see oracle/resize_oracle.py."""
+"parity unpinned" against a real cv2 (OpenCV is not installed here: see oracle/resize_oracle.py); what stands in for
+it are (i) expected arrays for tiny cases derived step by step from OpenCV's published 8-bit INTER_LINEAR arithmetic
+(HAND_CASES below, tables in the comments) and (ii) properties any correct resize has.  Until a fixture produced by
+cv2 itself exists the row stays "partial"."""
 import math
 
 import numpy as np
@@ -65,6 +68,86 @@ def test_oracle_bilinear_properties():
     half = RO.imresize_bilinear_u8(big, (57, 23))                                          # exact 2x2 shrink: area mean
     s = big.astype(np.int32)
     assert np.array_equal(half, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2))
+
+
+# ---- expected outputs derived by hand from cv::resize(INTER_LINEAR) on uint8 (modules/imgproc/src/resize.cpp) -------------
+# For a destination index d:  f = float((d + 0.5) * scale - 0.5) with scale = 1 / (dst / src) in double;  s = floor(f);
+# w = f - s;  in x only: s < 0 -> (s, w) = (0, 0);  s >= src - 1 -> (s, w) = (src - 1, 0);  11-bit coefficients
+# a0 = saturate_cast<short>((1 - w) * 2048), a1 = saturate_cast<short>(w * 2048) (round to nearest even).  Horizontal pass
+# (HResizeLinear) in int32:  S[y][d] = img[y][s] * a0 + img[y][s + 1] * a1.  Vertical pass (VResizeLinear, rows clamped to
+# [0, H - 1], weights b0 / b1 kept):  out = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+# An exact 2 x 2 shrink takes INTER_AREA instead: (a + b + c + d + 2) >> 2.
+HAND_CASES = {
+    # 3 -> 5 columns: scale 0.6; f = -0.2, 0.4, 1.0, 1.6, 2.2 -> (s, a0, a1) = (0,2048,0) (0,1229,819) (1,2048,0) (1,819,1229)
+    # (2,2048,0); rows unchanged (b = 2048, 0).  e.g. d = 1, row 0: S = 10*1229 + 20*819 = 28670; 28670 >> 4 = 1791;
+    # (2048*1791) >> 16 = 55; (55 + 2) >> 2 = 14.   d = 3: S = 20*819 + 40*1229 = 65540 -> 4096 -> 128 -> 130 >> 2 = 32.
+    "A: 2x3 -> 2x5": ([[10, 20, 40], [255, 0, 128]], (5, 2), [[10, 14, 20, 32, 40], [255, 153, 0, 77, 128]]),
+    # 2 -> 3 rows: scale 2/3; f = -1/6, 1/2, 7/6 -> rows (0,0) (0,1) (1,1) with (b0, b1) = (341,1707) (1024,1024) (1707,341);
+    # x unchanged.  Row 1: (100 + 0) / 2 = 50;  S = 50*2048 and 255*2048: ((1024*6400) >> 16) + ((1024*32640) >> 16) = 100 + 510
+    # -> (610 + 2) >> 2 = 153.
+    "B: 2x2 -> 3x2": ([[100, 50], [0, 255]], (2, 3), [[100, 50], [50, 153], [0, 255]]),
+    # 4 -> 3 in both directions: scale 4/3; f = 1/6, 3/2, 17/6 -> (s, a0, a1) = (0,1707,341) (1,1024,1024) (2,341,1707).
+    # Top-left: S0 = 0*1707 + 64*341 = 21824 -> 1364; S1 = 16*1707 + 80*341 = 54592 -> 3412;
+    # ((1707*1364) >> 16) + ((341*3412) >> 16) = 35 + 17 = 52 -> 54 >> 2 = 13.
+    "C: 4x4 -> 3x3": ([[0, 64, 128, 255], [16, 80, 144, 240], [32, 96, 160, 224], [48, 112, 176, 208]], (3, 3),
+                      [[13, 99, 232], [35, 120, 219], [56, 141, 204]]),
+    # 2 -> 7 columns (f = -0.357.. -0.071.. 0.214 0.5 0.786 1.071 1.357: the ends clamp) and 3 -> 4 rows
+    # (f = -0.125 0.625 1.375 2.125: (b0, b1) = (256,1792) (768,1280) (1280,768) (1792,256), rows (0,0) (0,1) (1,2) (2,2)).
+    "E: 3x2 -> 4x7": ([[0, 255], [255, 0], [7, 9]], (7, 4),
+                      [[0, 0, 55, 127, 200, 255, 255], [159, 159, 145, 127, 109, 96, 96], [162, 162, 128, 83, 37, 3, 3],
+                       [7, 7, 7, 8, 8, 9, 9]]),
+    # exact 2 x 2 shrink -> INTER_AREA: (1+3+9+11+2) >> 2 = 6, (5+7+13+15+2) >> 2 = 10, (250+251+254+255+2) >> 2 = 253
+    "D: 2x6 -> 1x3 (area)": ([[1, 3, 5, 7, 250, 251], [9, 11, 13, 15, 254, 255]], (3, 1), [[6, 10, 253]]),
+}
+
+
+def test_hand_derived_opencv_vectors_pin_the_oracle():
+    for name, (src, size, want) in HAND_CASES.items():
+        img = np.array(src, dtype=np.uint8)[:, :, None]
+        got = RO.imresize_bilinear_u8(img, size)[:, :, 0]
+        assert np.array_equal(got, np.array(want, dtype=np.uint8)), (name, got.tolist())
+        rgb = np.repeat(img, 3, axis=2)                        # the channels are independent
+        assert np.array_equal(RO.imresize_bilinear_u8(rgb, size), np.repeat(np.array(want, np.uint8)[:, :, None], 3, 2))
+
+
+def test_oracle_resize_properties():
+    """What any correct INTER_LINEAR resize does, whatever its fixed-point details."""
+    ramp = np.tile(np.arange(0, 250, 5, dtype=np.uint8)[None, :, None], (6, 1, 1))            # 6 x 50, monotone in x
+    for size in ((128, 32), (37, 6), (50, 19), (200, 3)):
+        r = RO.imresize_bilinear_u8(ramp, size)[:, :, 0].astype(np.int32)
+        assert (np.diff(r, axis=1) >= 0).all(), f"monotone ramp, size {size}"
+        # (two truncating products in the vertical pass: rows of a column-only pattern may differ by one level)
+        assert np.abs(r - r[:1]).max() <= 1, "rows of a column-only pattern stay equal up to one level"
+        assert r.min() >= 0 and r.max() <= 245
+    for v in (0, 1, 127, 254, 255):
+        c = np.full((5, 9, 2), v, dtype=np.uint8)
+        for size in ((9, 5), (31, 17), (4, 2), (18, 10)):
+            assert (RO.imresize_bilinear_u8(c, size) == v).all(), (v, size)
+    # ResizeOCR pads on the right with img_pad_value, never on the left, and only beyond the resized width
+    img = np.full((16, 40, 1), 200, dtype=np.uint8)
+    out, plan = RO.resize_ocr(img, 32, min_width=32, max_width=128, keep_aspect_ratio=True, img_pad_value=9)
+    assert plan["resize_w"] == 80 and out.shape == (32, 128, 1)
+    assert (out[:, :80] == 200).all() and (out[:, 80:] == 9).all()
+
+
+@pytest.mark.gpu
+def test_gpu_kernel_reproduces_the_hand_derived_vectors(cuda):
+    for name, (src, size, want) in HAND_CASES.items():
+        img = np.array(src, dtype=np.uint8)[:, :, None]
+        w, h = size
+        pre = OCRBatchPreprocessor(ResizeOCR(h, min_width=w, max_width=w, keep_aspect_ratio=False), NormalizeOCR([0.0], [1.0]), cuda)
+        out, _ = pre([img])
+        ref = RO.to_tensor_normalize(np.array(want, dtype=np.uint8)[:, :, None], [0.0], [1.0])
+        assert np.array_equal(out.cpu().numpy()[0].view(np.uint32), ref.view(np.uint32)), name
+    # properties on the device: constants, identity at scale 1, monotone ramps
+    c = np.full((5, 9, 1), 131, dtype=np.uint8)
+    pre = OCRBatchPreprocessor(ResizeOCR(32, min_width=128, max_width=128, keep_aspect_ratio=False), NormalizeOCR([0.0], [1.0]), cuda)
+    assert (pre([c])[0].cpu().numpy() == np.float32(131) / np.float32(255)).all()
+    ramp = np.tile(np.arange(0, 250, 5, dtype=np.uint8)[None, :, None], (6, 1, 1))
+    r = pre([ramp])[0].cpu().numpy()[0, 0]
+    assert (np.diff(r, axis=1) >= 0).all() and np.abs(r - r[:1]).max() <= np.float32(1.001 / 255)
+    same = np.random.default_rng(3).integers(0, 256, (32, 128, 1), dtype=np.uint8)
+    assert np.array_equal(pre([same])[0].cpu().numpy()[0, 0], same[:, :, 0].astype(np.float32) / np.float32(255))
 
 
 def ragged_images(n, seed):

@@ -39,6 +39,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """One object per .hip file (compiled in parallel, rebuilt only when that file or a header changed), then one link."""
     if not force and not _stale():
         return LIB
+    # several ranks / pytest workers may call build() at once: one builds, the others wait and re-check
+    import fcntl
+    os.makedirs(os.path.join(CSRC, ".build"), exist_ok=True)
+    with open(os.path.join(CSRC, ".build", "lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libtpspp_hip.so")
@@ -67,7 +81,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + res[1])
         if verbose and res is not None and res[1].strip():
             print(res[1])
-    tmp = LIB + ".tmp"
+    tmp = LIB + f".tmp{os.getpid()}"
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden"] + [o for o, _ in results] + ["-o", tmp]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -20,6 +20,18 @@ int check_launch(const char* what);
 
 inline hipStream_t as_stream(tpspp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-device one-off set-up (hipFuncSetAttribute for > 64 KB of dynamic LDS is a per-device property of a kernel):
+//     static bool done[tpspp::kMaxDevices] = {};  if (tpspp::first_use_on_device(done)) { ... }
+constexpr int kMaxDevices = 64;
+inline bool first_use_on_device(bool (&done)[kMaxDevices])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return true;   // unknown device: always set up
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 }  // namespace tpspp
 
 #define TPSPP_REQUIRE(cond, ...)                                   \

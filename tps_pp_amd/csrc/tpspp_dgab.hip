@@ -550,12 +550,11 @@ TPSPP_EXPORT int tpspp_dgab_fwd(const float* x, const float* y, const float* ln1
     Q.bp = proj_b; Q.b1 = fc1_b; Q.b2 = fc2_b; Q.g2 = ln2_w; Q.be2 = ln2_b; Q.out = out;
     Q.tiles = planes / 8;                                           // 8 planes = 128 rows per tile
     const size_t lds = (size_t)(64 * 64 + 2 * 4 * 64 * 64 + 64 + HID + 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
     }
     const int grid = Q.tiles < 256 ? Q.tiles : 256;                 // persistent: one workgroup per CU
     hipLaunchKernelGGL(dgab_chain_kernel, dim3((unsigned)grid), dim3(256), lds, st, Q);
@@ -589,14 +588,13 @@ TPSPP_EXPORT int tpspp_dgab_bf16_fwd(const float* x, const float* y, const float
     Q.bp = proj_b; Q.b1 = fc1_b; Q.b2 = fc2_b; Q.g2 = ln2_w; Q.be2 = ln2_b; Q.out = out;
     Q.tiles = planes / 8;
     const size_t lds = (size_t)(9 * (split3 ? 1024 : 512)) * 16 + (size_t)(64 + HID + 64) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_bf16_kernel<false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dgab_chain_bf16_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
     }
     if (split3) {
         const int grid = Q.tiles < 256 ? Q.tiles : 256;             // persistent: one workgroup per CU

@@ -181,12 +181,11 @@ TPSPP_EXPORT int tpspp_front_fwd(const float* outs0, const float* outs1, const f
     P.b0 = b0; P.b1 = b1; P.b2 = b2; P.bg = bg;
     P.feat0 = feat0; P.feat1 = feat1; P.feat2 = feat2; P.feat_grid = feat_grid; P.H = H; P.W = W;
     const size_t lds = (size_t)(2 * 32 * 64 + 64 * 64 + 3 * 64 * 64 + 256) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
     }
     const int tiles = (H * W + kFrontTile - 1) / kFrontTile;
     // a few tiles per workgroup so the 81 KB of weight slabs are staged once per several tiles

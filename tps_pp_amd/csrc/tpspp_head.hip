@@ -650,12 +650,11 @@ static int launch_attn_enc(const float* qkv, int N, int C, int T, const int* val
     const int H = C / kDK;
     const size_t M = (size_t)N * T;
     const size_t lds = (size_t)2 * T * kKRow * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_enc_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
     }
     if (T <= 128) {                                          // matrix-core kernel: a wavefront per 32 queries
         const int nj = (T + 31) / 32;

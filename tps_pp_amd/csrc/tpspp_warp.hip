@@ -900,8 +900,8 @@ bool launch_lds_geo(const LdsParams& P, int ppt, int threads, size_t lds, hipStr
 {
     const dim3 grid((unsigned)(((P.N + 1) / 2) * P.bands)), block(threads);
     // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 1, HC, WC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 2, HC, WC>),
@@ -911,7 +911,6 @@ bool launch_lds_geo(const LdsParams& P, int ppt, int threads, size_t lds, hipStr
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_kernel<F, C, 4, HC, WC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
     }
     switch (ppt) {
     case 1: hipLaunchKernelGGL((tps_warp_lds_kernel<F, C, 1, HC, WC>), grid, block, lds, st, P); return true;
@@ -925,12 +924,11 @@ bool launch_lds_geo(const LdsParams& P, int ppt, int threads, size_t lds, hipStr
 template <int F, int C, int HC, int WC, bool AUX>
 void launch_lds_mirror_aux(const LdsParams& P, int threads, size_t lds, hipStream_t st)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_lds_mirror_kernel<F, C, HC, WC, AUX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
-        attr_done = true;
     }
     const dim3 grid((unsigned)(((P.N + 1) / 2) * P.bands)), block(threads);
     hipLaunchKernelGGL((tps_warp_lds_mirror_kernel<F, C, HC, WC, AUX>), grid, block, lds, st, P);
@@ -972,13 +970,10 @@ void launch_pair(const float* in, const float* ctrl, const float* inv_delta_c, c
     const dim3 grid_dim((unsigned)((N + 1) / 2)), block((PairGeo<32, 100>::NW + kPairLoaders) * kWave);
     auto go = [&](auto kern) {
         // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and device
-        static bool attr_done[64] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !attr_done[dev]) {
+        static bool attr_done[tpspp::kMaxDevices] = {};
+        if (tpspp::first_use_on_device(attr_done)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
-            attr_done[dev] = true;
         }
         hipLaunchKernelGGL(kern, grid_dim, block, lds, st, P);
     };

@@ -310,12 +310,11 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
         G = G < 1 ? 1 : (G > most ? most : G);
         const size_t accb = (size_t)cpt0 * plane0 > (size_t)cpt1 * plane1 ? (size_t)cpt0 * plane0 : (size_t)cpt1 * plane1;
         const size_t lds = gg_bytes + accb;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static bool attr_done[tpspp::kMaxDevices] = {};
+        if (tpspp::first_use_on_device(attr_done)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_bwd_sample_lds_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipGetLastError();
-            attr_done = true;
         }
         hipLaunchKernelGGL(warp_bwd_sample_lds_kernel, dim3((unsigned)(G * P.nin), (unsigned)N), dim3(1024), lds, st, P,
                            G, cpt0, cpt1, g_grid_ws);

@@ -373,13 +373,12 @@ void launch_ppt(const StreamParams& P, int ppt, size_t lds, hipStream_t st)
     const dim3 grid((unsigned)P.N), block(kThreads);
 #define TPSPP_LAUNCH(PP)                                                                            \
     {                                                                                               \
-        static bool attr_done = false;                                                              \
-        if (!attr_done) {                                                                           \
+        static bool attr_done[tpspp::kMaxDevices] = {};                                                              \
+        if (tpspp::first_use_on_device(attr_done)) {                                                                           \
             (void)hipFuncSetAttribute(                                                              \
                 reinterpret_cast<const void*>(&tps_warp_stream_kernel<F, PXY, SCORE, PP, B16>),          \
                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                            \
             (void)hipGetLastError();                                                                \
-            attr_done = true;                                                                       \
         }                                                                                           \
         hipLaunchKernelGGL((tps_warp_stream_kernel<F, PXY, SCORE, PP, B16>), grid, block, lds, st, P);   \
     }

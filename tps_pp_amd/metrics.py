@@ -64,3 +64,52 @@ def eval_ocr_metric(pred_texts, gt_texts, all_metrics=False):
                     "char_precision": m["true_positive_char_num"] / (eps + m["pred_char_num"]),
                     "1-N.E.D": 1.0 - m["ned"]})
     return {k: float("{:.4f}".format(v)) for k, v in out.items()}
+
+
+def precision_agreement(model, img, img_metas, mode):
+    """How far a reduced-precision configuration of a recogniser (`mode`: torch.bfloat16 or "bf16x3", see
+    `EncodeDecodeRecognizer.set_compute_dtype`) moves its decisions away from the exact-fp32 kernels of the SAME model on
+    the same images (BASELINE.json configs[4], "word-accuracy parity check"):
+      * teacher forcing: the reduced-precision model is fed the fp32 run's greedy tokens; fraction of positions (up to and
+        including the fp32 run's <EOS>) whose arg-max is the fp32 one -- every position is an independent decision;
+      * greedy: word agreement (identical strings) and character agreement (difflib matching blocks over the fp32
+        strings' characters) -- on random-init weights one flipped near-tie rewrites the rest of a string.
+    Returns a dict of floats; `model` is left in the exact-fp32 configuration."""
+    import torch
+    conv, dec = model.label_convertor, model.decoder
+    metas = [dict(m) for m in img_metas]
+    for m in metas:
+        m.setdefault("valid_ratio", 1.0 * m["resize_shape"][1] / img.size(-1))
+
+    def run(forced=None):
+        feat = model.extract_feat(img, test=True)
+        feat = feat["output"] if isinstance(feat, dict) else feat
+        out_enc = model.encoder(feat, metas)
+        if forced is None:
+            return dec(feat, out_enc, None, metas, train_mode=False)
+        return dec(feat, out_enc, dict(padded_targets=forced), metas, train_mode=True)
+
+    with torch.no_grad():
+        model.set_compute_dtype(None)
+        ref = run()                                                   # (N, L, num_classes - 1) softmax scores
+        ref_tok = ref.argmax(-1)                                      # (N, L)
+        ref_txt = conv.idx2str(conv.tensor2idx(ref)[0])
+        n, L = ref_tok.shape
+        start = torch.full((n, 1), dec.start_idx, dtype=ref_tok.dtype, device=ref_tok.device)
+        forced = torch.cat([start, ref_tok[:, :L - 1]], dim=1)        # position t sees <BOS>, tok_0 .. tok_{t-1}
+        self_tf = run(forced).argmax(-1)                              # sanity: the fp32 kernels reproduce themselves
+        model.set_compute_dtype(mode)
+        low_tf = run(forced).argmax(-1)
+        low = run()
+        low_txt = conv.idx2str(conv.tensor2idx(low)[0])
+        model.set_compute_dtype(None)
+    is_end = ref_tok == conv.end_idx
+    first_end = torch.where(is_end.any(1), is_end.float().argmax(1), torch.full((n,), L - 1, device=ref_tok.device))
+    valid = torch.arange(L, device=ref_tok.device)[None, :] <= first_end[:, None]
+    m = count_matches(low_txt, ref_txt)
+    return {"images": n, "positions": int(valid.sum()),
+            "teacher_forced_argmax_agreement": float((low_tf == ref_tok)[valid].float().mean()),
+            "teacher_forced_self_check_fp32": float((self_tf == ref_tok)[valid].float().mean()),
+            "greedy_word_agreement": sum(a == b for a, b in zip(low_txt, ref_txt)) / max(1, n),
+            "greedy_char_agreement": m["true_positive_char_num"] / max(1, m["gt_char_num"]),
+            "mean_fp32_string_length": sum(len(t) for t in ref_txt) / max(1, n)}

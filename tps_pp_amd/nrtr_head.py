@@ -377,7 +377,7 @@ class AttnConvertor(BaseConvertor):
     def tensor2idx(self, outputs, img_metas=None):
         # one device->host copy for the batch instead of the reference's two per image, and the per-character scan
         # (skip <PAD>, stop at the first <EOS>: attn.py:124-137) as array operations per batch
-        max_value, max_idx = torch.max(outputs, -1)
+        max_value, max_idx = torch.max(outputs.detach(), -1)       # (the reference detaches as well: attn.py:129-130)
         both = torch.stack([max_idx.to(torch.float64), max_value.to(torch.float64)]).cpu().numpy()
         idx, val = both[0].astype(np.int64), both[1]
         n, L = idx.shape

@@ -305,9 +305,17 @@ class WarpPlan:
                       vp(_ptr(out1)), vp(0), vp(0), vp(_stream(in0)))
         self._fn = _lib.lib().tpspp_warp_fwd
         self.out0, self.out1 = out0, out1
+        self._dev = in0.device
 
-    def run(self):
-        rc = self._fn(*self._args)
+    def run(self, stream=None):
+        """One launch on the stream that was current when the plan was built; pass `stream` (a torch.cuda.Stream)
+        to launch on another one (the caller orders the buffers' producers / consumers on it)."""
+        if stream is not None:
+            import ctypes
+            args = self._args[:-1] + (ctypes.c_void_p(stream.cuda_stream),)
+            rc = self._fn(*args)
+        else:
+            rc = self._fn(*self._args)
         if rc != 0:
             _lib.check(rc, "tpspp_warp_fwd")
         return self.out0, self.out1
@@ -352,6 +360,22 @@ def prep_conv_weight(weight, bn=None, conv_bias=None, eps=1e-5, src_channels=Non
     return ConvWeight(wt, tiled, None if b is None else b.contiguous(), kh, ps, pb)
 
 
+def _chk_conv_sources(who, ts, dims, stride_of_dims):
+    """Every source reaches the kernel as a raw pointer with only its (C, H, W, uh, uw): batch size, device and the
+    shared logical size (H*uh, W*uw) are checked here."""
+    N, dev = ts[0].shape[0], ts[0].device
+    Hi, Wi = ts[0].shape[2] * dims[3], ts[0].shape[3] * dims[4]
+    for i, t in enumerate(ts):
+        d = dims[stride_of_dims * i: stride_of_dims * (i + 1)]
+        if t.shape[0] != N or t.device != dev:
+            raise ValueError(f"{who}: source {i} must have the first source's batch size and device")
+        if d[3] < 1 or d[4] < 1 or (t.shape[2] * d[3], t.shape[3] * d[4]) != (Hi, Wi):
+            raise ValueError(f"{who}: source {i} does not have the shared logical size {(Hi, Wi)}")
+    if not 1 <= len(ts) <= 3:
+        raise ValueError(f"{who}: 1..3 sources")
+    return N, dev, Hi, Wi
+
+
 def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=None):
     """Fused conv on the fp32 matrix cores (`tpspp_conv2d_fwd`).
 
@@ -366,8 +390,7 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
         t = _chk("conv source", t, 4)
         ts.append(t)
         dims += [t.shape[1], t.shape[2], t.shape[3], int(uh), int(uw)]
-    N = ts[0].shape[0]
-    Hi, Wi = ts[0].shape[2] * dims[3], ts[0].shape[3] * dims[4]
+    N, dev, Hi, Wi = _chk_conv_sources("conv2d", ts, dims, 5)
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     pad = (kernel - 1) // 2
     Ho = (Hi + 2 * pad - kernel) // sh + 1
@@ -380,12 +403,14 @@ def conv2d(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out=No
         bias = _chk("bias", bias, 1)
     if residual is not None:
         residual = _chk("residual", residual, 4)
-        if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2):
-            raise ValueError("conv2d: residual shape / res_mode")
+        if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2) or residual.device != dev:
+            raise ValueError("conv2d: residual shape / device / res_mode")
     elif res_mode != 0:
         raise ValueError("conv2d: res_mode without residual")
     if out is None:
-        out = torch.empty((N, Cout, Ho, Wo), device=ts[0].device, dtype=torch.float32)
+        out = torch.empty((N, Cout, Ho, Wo), device=dev, dtype=torch.float32)
+    else:
+        _chk_out("conv2d", "out", out, (N, Cout, Ho, Wo), torch.float32, dev)
     if N == 0:          # an empty batch has no device pointer to hand over
         return out
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -464,10 +489,9 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
         t = _chk16("conv source", t, 4)
         ts.append(t)
         dims += [t.shape[1], t.shape[2], t.shape[3], int(uh), int(uw), int(t.dtype == torch.float32)]
-    N = ts[0].shape[0]
+    N, dev, Hi, Wi = _chk_conv_sources("conv2d_bf16", ts, dims, 6)
     if sum(t.shape[1] for t in ts) != cw.cin:
         raise ValueError("conv2d_bf16: source channels != Cin of the weight")
-    Hi, Wi = ts[0].shape[2] * dims[3], ts[0].shape[3] * dims[4]
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     kernel, Cout = cw.kernel, cw.cout
     pad = (kernel - 1) // 2
@@ -476,8 +500,8 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
     res_f32 = 0
     if residual is not None:
         residual = _chk16("residual", residual, 4)
-        if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2):
-            raise ValueError("conv2d_bf16: residual shape / res_mode")
+        if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2) or residual.device != dev:
+            raise ValueError("conv2d_bf16: residual shape / device / res_mode")
         res_f32 = int(residual.dtype == torch.float32)
     elif res_mode != 0:
         raise ValueError("conv2d_bf16: res_mode without residual")
@@ -866,10 +890,17 @@ class PtrTable:
 
 
 def _workspace(holder, nbytes, device):
-    ws = getattr(holder, "_tpspp_ws", None)
-    if ws is None or ws.numel() < nbytes or ws.device != device:
+    """Scratch of the encoder / decoder, cached on the module per (device, stream): two calls on different HIP streams
+    must not share a buffer (they could overlap on the GPU)."""
+    key = (str(device), _stream(torch.empty(0, device=device)))
+    cache = getattr(holder, "_tpspp_ws", None)
+    if not isinstance(cache, dict):
+        cache = {}
+        holder._tpspp_ws = cache
+    ws = cache.get(key)
+    if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
-        holder._tpspp_ws = ws
+        cache[key] = ws
     return ws
 
 
