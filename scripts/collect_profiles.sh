@@ -19,6 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -o copy -- \
       ./scripts/ubench/copy_bench > $OUT/copy_pmc_$c.log 2>&1
 done
+[ "${ONLY_BENCH:-0}" = "1" ] && { ls -R $OUT | head -30; tail -2 $OUT/bench_trace.log; exit 0; }
 # 3. kernel traces of the wider rows: whole TPS++ module, whole recogniser (F1), warp backward (F2)
 for w in module head backward; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o $w -- \

@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "tps_warp_lds_mirror_kernel"
+KERNEL = os.environ.get("TPSPP_PROFILE_KERNEL", "tps_warp_pair_kernel")
 COPY_BYTES = 512 * 3 * 32 * 100 * 4          # scripts/ubench/copy_bench.hip: bytes read = bytes written
 ALGO_BYTES = 512 * 76960
 
@@ -94,8 +94,15 @@ GRBM_GUI_ACTIVE summed over the 8 XCDs); utilisation below = the same ratio of a
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"),
-                os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
+    # rocprofv3's own summary, kernel names cut to 200 characters (PyTorch's RNG kernels have 5-KB names)
+    with open(os.path.join(SRC, "trace", "bench_kernel_stats.csv")) as fin, \
+            open(os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"), "w", newline="") as fout:
+        rd = csv.reader(fin)
+        wr = csv.writer(fout, quoting=csv.QUOTE_NONNUMERIC)
+        for i, row in enumerate(rd):
+            if i and len(row[0]) > 200:
+                row[0] = row[0][:200] + "..."
+            wr.writerow(row if i == 0 else [row[0]] + [float(x) if "." in x else int(x) for x in row[1:]])
     stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_stats.csv")))}
     krow = next(v for k, v in stats.items() if KERNEL in k)
     bench_line = [l for l in open(os.path.join(SRC, "bench_trace.log")) if l.startswith("{")][-1]
