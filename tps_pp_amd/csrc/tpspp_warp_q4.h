@@ -3812,6 +3812,352 @@ tps_warp_m15_kernel(const M3Params P)
 #undef M15_STAMP
 }
 
+template <int F, int C, int HC, int WC, int OH, int OW, int NLOAD, int STORE, int LDNT, bool AUX, bool TRACE, int AWAIT, int KB>
+__global__ void __launch_bounds__(1024)
+tps_warp_m17_kernel(const M3Params P)
+{
+    constexpr int K = F + 3;
+    constexpr int H = HC, W = WC;
+    constexpr int halfW = OW / 2, PW = (halfW + 3) & ~3, nthr = (OH / 2) * PW;
+    constexpr int NW = (nthr + kWave - 1) / kWave;
+    constexpr int n = OH * OW;
+    static_assert(NW + NLOAD <= 16, "too many wavefronts");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* sT = reinterpret_cast<float4*>(smem);          // K x (TxA, TyA, TxB, TyB)
+    float* sInv = smem + 4 * K;                            // 2 x K*K (one copy per solving wavefront)
+    float* sFlag = sInv + 2 * ((K * K + 3) & ~3);          // [0] T rows published, [1] loaders done with A, [2] with B
+    float* sImg = sFlag + 4;
+    float* sZero = sImg + P.zero_off;
+    float* sOut = sImg + P.out_off;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int b0 = blockIdx.x * 2;
+    const bool hasB = (b0 + 1) < P.N;
+    constexpr int HW = H * W;
+    constexpr int img_elems = C * HW;
+
+    unsigned ts[10];
+#define M17_STAMP(i) do { if (TRACE) ts[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+    long long wall0 = 0;
+    if (TRACE) { wall0 = (long long)wall_clock64(); }
+    M17_STAMP(0);
+    // the T-solve inputs are requested before anything else on this CU (wavefront g -> image b0 + g; lane i keeps
+    // control point i); the loaders are held at the entry barrier until these requests are on their way
+    constexpr int KK = K * K;
+    constexpr int NINV = (KK + kWave - 1) / kWave;
+    float invv[NINV];
+    float cx = 0.0f, cy = 0.0f;
+    if (wv < 2) {
+        if (lane < F) {
+            const int b = (wv == 1 && hasB) ? b0 + 1 : b0;
+            const float2 cc = reinterpret_cast<const float2*>(P.ctrl + (size_t)b * F * 2)[lane];
+            cx = cc.x; cy = cc.y;
+        }
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            invv[i] = P.inv_delta_c[e < KK ? e : KK - 1];
+        }
+    }
+    if (tid < 3) reinterpret_cast<int*>(sFlag)[tid] = 0;
+    lds_only_barrier();
+
+    if (wv >= NW) {
+        // ================= loader wavefronts =================
+        const int lw = wv - NW;
+        const int total_bytes = (hasB ? 2 : 1) * img_elems * 4;
+        const int pieces = (total_bytes + 1023) >> 10;
+        const int piecesA = (img_elems * 4 + 1023) >> 10;   // pieces that hold bytes of image A
+        const char* src = reinterpret_cast<const char*>(P.in + (size_t)b0 * img_elems);
+        auto dma = [&](int piece) {
+            int off = piece * 1024 + lane * 16;
+            if (off >= total_bytes) off = 0;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + off),
+                (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sImg) + piece * 1024),
+                16, 0, LDNT ? 2 : 0);
+        };
+        auto now = [&]() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return (unsigned)t; };
+        unsigned t_l0 = 0, t_ia = 0, t_ib = 0, t_a = 0, t_b = 0;
+        // flag operands live in registers BEFORE the first DMA: a VGPR written after it had been an operand of an
+        // LDS-DMA instruction makes the compiler wait for vmcnt(0) first -- which would turn "A has landed" into
+        // "everything has landed"
+        unsigned fa = (unsigned)(size_t)(sFlag + 1), fb = (unsigned)(size_t)(sFlag + 2);
+        int one = 1;
+        asm volatile("" : "+v"(fa), "+v"(fb), "+v"(one));
+        if (TRACE) t_l0 = now();
+        // Image A first.  Image B's requests start when at most AWAIT of this loader's requests for A are still
+        // outstanding (HBM does not serve requests in arrival order: with B's queued behind them A would land together
+        // with B), KB of them are issued, then A is complete once at most KB requests remain (vmcnt retires in order):
+        // flag A is raised before the bulk of B's requests -- which take ~1 us to issue against HBM back-pressure.
+        int piece = lw;
+        for (; piece < piecesA; piece += NLOAD) dma(piece);
+        if (TRACE) t_ia = now();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AWAIT) : "memory");
+#pragma unroll
+        for (int i = 0; i < KB; ++i) { if (piece < pieces) dma(piece); piece += NLOAD; }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KB) : "memory");
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(fa), "v"(one) : "memory");
+        if (TRACE) t_a = now();
+        for (; piece < pieces; piece += NLOAD) dma(piece);
+        if (TRACE) t_ib = now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (TRACE) {
+            t_b = now();
+            if (lw == 0 && lane == 0 && P.trace) {
+                long long* t = P.trace + (size_t)blockIdx.x * 16;
+                // relative to this loader's first stamp after the entry barrier; slot 11 = that stamp relative to the kernel-entry stamp
+                t[11] = (long long)(t_l0 - ts[0]); t[14] = (long long)(t_a - ts[0]); t[15] = (long long)(t_b - ts[0]);
+                P.trace2[(size_t)blockIdx.x * 2] = (long long)(t_ia - ts[0]); P.trace2[(size_t)blockIdx.x * 2 + 1] = (long long)(t_ib - ts[0]);
+            }
+        }
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(fb), "v"(one) : "memory");
+        return;
+    }
+
+    // ================= compute wavefronts =================
+    const bool live = tid < nthr;
+    // Thread -> pixel: a half-wavefront (the 32 lanes one ds_read_b32 cycle serves) owns a block of 4 columns x 8 rows.
+    // With a row pitch of W = 100 floats (bank shift 4 per row) such a block touches 32 different LDS banks wherever
+    // the warp is locally a translation; 32 consecutive pixels of a row pair would collide where they wrap into the
+    // next row (a third of all LDS cycles were bank conflicts with the row-major mapping).
+    static_assert(PW % 4 == 0 && (OH / 2) % 8 == 0, "block mapping needs whole 4 x 8 blocks");
+    const int qp = live ? tid : nthr - 1;
+    const int hw = qp >> 5, l5 = qp & 31;
+    constexpr int CG = PW / 4;                               // column groups
+    const int rg = hw / CG, cg = hw - rg * CG;
+    const int r = rg * 8 + (l5 >> 2), c = cg * 4 + (l5 & 3);
+    const bool xdup = (c & ~3) + 4 > halfW;
+    unsigned poff[4];                                        // byte offsets of the 4 pixels in a plane
+    poff[0] = 4u * (unsigned)(r * OW + c);
+    poff[1] = 4u * (unsigned)(r * OW + (OW - 1 - c));
+    poff[2] = 4u * (unsigned)((OH - 1 - r) * OW + c);
+    poff[3] = 4u * (unsigned)((OH - 1 - r) * OW + (OW - 1 - c));
+
+    // packed table: [wavefront][K/4 groups][lane] x 16 bytes = this thread's K values (padded to a multiple of 4)
+    // as KG coalesced 16-byte loads (P.p_hat_t points at the packed copy)
+    constexpr int KG = (K + 3) / 4;
+    float v[KG * 4];
+    {
+        const v4f* pk = reinterpret_cast<const v4f*>(P.p_hat_t) + (size_t)wv * KG * kWave + lane;
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            v4f x = {0.1f, 0.2f, 0.3f, 0.4f};
+            if (AWAIT != 100) x = pk[j * kWave];
+            else asm volatile("" : "+v"(x));
+            v[4 * j] = x[0]; v[4 * j + 1] = x[1]; v[4 * j + 2] = x[2]; v[4 * j + 3] = x[3];
+        }
+    }
+    if (tid < C) sZero[tid * HW] = 0.0f;
+    M17_STAMP(1);                                             // loads issued
+    if (wv < 2) {
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            if (e < KK) sInv[wv * ((KK + 3) & ~3) + e] = invv[i];     // a private copy per solving wavefront
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes visible to own reads
+        const float* hrow = sInv + wv * ((KK + 3) & ~3) + (lane < K ? lane : K - 1) * K;
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float hv = hrow[q];
+            ax = fmaf(hv, readlane_f(cx, q), ax);
+            ay = fmaf(hv, readlane_f(cy, q), ay);
+        }
+        if (lane < K) {
+            float* dst = reinterpret_cast<float*>(sT + lane) + 2 * wv;
+            dst[0] = ax; dst[1] = ay;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) bump_flag(sFlag + 0);
+    }
+    wait_flag(sFlag + 0, 2);
+    M17_STAMP(3);                                             // T ready
+
+    float gx[4][2], gy[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gx[m][0] = gx[m][1] = gy[m][0] = gy[m][1] = 0.0f;
+    static_for<K>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const float4 t = sT[q];
+        float val[4];
+        if constexpr (q == 0) {
+            val[0] = val[1] = val[2] = val[3] = v[0];
+        } else if constexpr (q == 1) {
+            val[0] = v[1]; val[1] = -v[1]; val[2] = v[1]; val[3] = -v[1];
+        } else if constexpr (q == 2) {
+            val[0] = v[2]; val[1] = v[2]; val[2] = -v[2]; val[3] = -v[2];
+        } else {
+            constexpr int k = q - 3;
+            val[0] = v[3 + k];
+            val[1] = v[3 + perm_x<F>(k)];
+            val[2] = v[3 + perm_y<F>(k)];
+            val[3] = v[3 + perm_x<F>(perm_y<F>(k))];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            gx[m][0] = fmaf(val[m], t.x, gx[m][0]);
+            gy[m][0] = fmaf(val[m], t.y, gy[m][0]);
+            gx[m][1] = fmaf(val[m], t.z, gx[m][1]);
+            gy[m][1] = fmaf(val[m], t.w, gy[m][1]);
+        }
+    });
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(gx[m][0]), "+v"(gy[m][0]), "+v"(gx[m][1]), "+v"(gy[m][1]));
+    constexpr unsigned row_bytes = n * 4u;
+    constexpr int out16 = (C * n) >> 2;                      // 16-byte pieces of one output image
+    constexpr int nct = NW * kWave;
+    // Tap descriptors (4 LDS byte addresses + 4 weights per mirror pixel) are pure VALU work: image A's are built
+    // while A is still in flight, image B's between the issue of A's tap reads and their use.
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    const unsigned img_lds = (unsigned)(size_t)sImg, zero_lds = (unsigned)(size_t)sZero;
+    unsigned ta[2][4][4];
+    float tw[2][4][4];
+    auto describe = [&](auto imc) {
+        constexpr int im = decltype(imc)::value;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const Taps t = make_taps(gx[m][im], gy[m][im], H, W);
+            if constexpr (AUX) {
+                const int b = b0 + im;
+                const bool st = live && !((m & 1) && xdup) && (im == 0 || hasB);
+                if (P.grid && st)
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid) + (size_t)b * 2 * row_bytes + 2u * poff[m]) =
+                        make_float2(gx[m][im], gy[m][im]);
+                if (P.idx && st)
+                    *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx) + (size_t)b * 2 * row_bytes + 2u * poff[m]) =
+                        make_int2(t.x0, t.y0);
+            }
+            const unsigned base = img_lds + (unsigned)(im * img_elems * 4);
+            const bool inxy = t.inx && t.iny;
+            ta[im][m][0] = base + 4u * (unsigned)t.o00;
+            ta[im][m][1] = t.inx ? ta[im][m][0] + 4u : zero_lds;
+            ta[im][m][2] = t.iny ? base + 4u * (unsigned)t.o10 : zero_lds;
+            ta[im][m][3] = inxy ? base + 4u * (unsigned)t.o10 + 4u : zero_lds;
+            tw[im][m][0] = t.nw; tw[im][m][1] = t.ne; tw[im][m][2] = t.sw; tw[im][m][3] = t.se;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(ta[im][m][q]), "+v"(tw[im][m][q]));
+    };
+    describe(std::integral_constant<int, 0>{});
+    describe(std::integral_constant<int, 1>{});              // both before image A lands: the wavefront would idle otherwise
+    M17_STAMP(4);                                             // grid + tap descriptors done
+
+    constexpr int NOUT = (out16 + nct - 1) / nct;            // 16-byte output pieces per thread and image
+    v4f ostage[NOUT];                                        // image A's pieces between their LDS read and their store
+    // Staging layout [mirror][channel][thread]: a wavefront's 64 results of one (mirror, channel) are 256 contiguous
+    // bytes, written with ds_write_addtid_b32 (address = M0 + offset + 4 * lane: 2 LDS cycles instead of 4).  The
+    // 16-byte output piece e = (channel, row, group of 4 columns) is then 4 consecutive threads of one block:
+    // (row, 4 g .. 4 g + 3) for the left half-row and the middle group, the x-mirror's threads in reverse order otherwise.
+    static_assert(nthr == nct, "thread-ordered staging needs whole wavefronts");
+    unsigned oaddr[NOUT];
+    bool orev[NOUT];
+#pragma unroll
+    for (int i = 0; i < NOUT; ++i) {
+        constexpr int G = OW / 4, CGc = PW / 4;
+        const int e0 = tid + i * nct, e = e0 < out16 ? e0 : out16 - 1;
+        const int ch = e / (OH * G), rem = e - ch * (OH * G), row = rem / G, g = rem - row * G;
+        const bool xm = g >= CGc, ym = row >= OH / 2;
+        const int rr = ym ? OH - 1 - row : row, c4 = xm ? 4 * (G - 1 - g) : 4 * g;
+        const int t = ((rr >> 3) * CGc + (c4 >> 2)) * 32 + (rr & 7) * 4;
+        oaddr[i] = (unsigned)(size_t)sOut + 4u * (unsigned)(((2 * (int)ym + (int)xm) * C + ch) * nct + t);
+        orev[i] = xm;
+    }
+    const unsigned m0_stage = (unsigned)(size_t)sOut + (unsigned)wv * 256u;
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+        if (im == 1 && !hasB) {
+            // no image B: image A's pieces leave now
+            gchar* ob = (gchar*)(P.out) + (size_t)b0 * C * row_bytes;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) { const int e = tid + i * nct; if (e < out16) store16<STORE>(ob, 16u * (unsigned)e, ostage[i]); }
+            break;
+        }
+        wait_flag(sFlag + 1 + im, NLOAD);                    // image `im` has landed
+        M17_STAMP(5 + 2 * im);
+        const int b = b0 + im;
+        float tv[4][C][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tv[m][ch][q] = *((lds_cfloat*)(ta[im][m][q]) + ch * HW);
+        if (im == 1) {
+            // image A's output pieces (read from the staging buffer before this point) are stored while the LDS
+            // serves image B's tap reads: the store issue (back-pressured by HBM) is off the critical path
+            __builtin_amdgcn_sched_barrier(0);
+            gchar* ob = (gchar*)(P.out) + (size_t)b0 * C * row_bytes;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) { const int e = tid + i * nct; if (e < out16) store16<STORE>(ob, 16u * (unsigned)e, ostage[i]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float res[4][C];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                float acc = tv[m][ch][0] * tw[im][m][0];
+                acc = fmaf(tv[m][ch][1], tw[im][m][1], acc);
+                acc = fmaf(tv[m][ch][2], tw[im][m][2], acc);
+                acc = fmaf(tv[m][ch][3], tw[im][m][3], acc);
+                res[m][ch] = acc;
+            }
+        if (im == 1) lds_only_barrier();                     // everybody has read image A out of the staging buffer
+        static_assert(C == 3, "the staging block below is written out for 3 channels");
+        asm volatile("s_mov_b32 m0, %12\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:%13\n\tds_write_addtid_b32 %1 offset:%14\n\tds_write_addtid_b32 %2 offset:%15\n\t"
+                     "ds_write_addtid_b32 %3 offset:%16\n\tds_write_addtid_b32 %4 offset:%17\n\tds_write_addtid_b32 %5 offset:%18\n\t"
+                     "ds_write_addtid_b32 %6 offset:%19\n\tds_write_addtid_b32 %7 offset:%20\n\tds_write_addtid_b32 %8 offset:%21\n\t"
+                     "ds_write_addtid_b32 %9 offset:%22\n\tds_write_addtid_b32 %10 offset:%23\n\tds_write_addtid_b32 %11 offset:%24"
+                     ::"v"(res[0][0]), "v"(res[0][1]), "v"(res[0][2]), "v"(res[1][0]), "v"(res[1][1]), "v"(res[1][2]),
+                       "v"(res[2][0]), "v"(res[2][1]), "v"(res[2][2]), "v"(res[3][0]), "v"(res[3][1]), "v"(res[3][2]),
+                       "s"(m0_stage),
+                       "n"(0 * nct * 4), "n"(1 * nct * 4), "n"(2 * nct * 4), "n"(3 * nct * 4), "n"(4 * nct * 4), "n"(5 * nct * 4),
+                       "n"(6 * nct * 4), "n"(7 * nct * 4), "n"(8 * nct * 4), "n"(9 * nct * 4), "n"(10 * nct * 4), "n"(11 * nct * 4)
+                     : "memory");
+        lds_only_barrier();                                  // results of image `im` staged
+        M17_STAMP(6 + 2 * im);
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+            typedef __attribute__((address_space(3))) const v4f lds_cv4;
+            const v4f x = *((lds_cv4*)(size_t)oaddr[i]);
+            v4f y;
+            y[0] = orev[i] ? x[3] : x[0]; y[1] = orev[i] ? x[2] : x[1]; y[2] = orev[i] ? x[1] : x[2]; y[3] = orev[i] ? x[0] : x[3];
+            ostage[i] = y;
+        }
+        if (im == 1) {
+            gchar* ob = (gchar*)(P.out) + (size_t)b * C * row_bytes;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) { const int e = tid + i * nct; if (e < out16) store16<STORE>(ob, 16u * (unsigned)e, ostage[i]); }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) asm volatile("" : "+v"(ostage[i]));
+        }
+    }
+    if (TRACE && wv == 0) {
+        M17_STAMP(9);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tend = (unsigned)__builtin_amdgcn_s_memtime();
+        const long long wall1 = (long long)wall_clock64();
+        if (lane == 0 && P.trace) {
+            long long* t = P.trace + (size_t)blockIdx.x * 16;
+            ts[2] = ts[1];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) t[i] = (long long)(ts[i] - ts[0]);
+            t[10] = (long long)(tend - ts[0]);
+            t[12] = wall0; t[13] = wall1;
+        }
+    }
+#undef M17_STAMP
+}
+
 template <int F, int C, int HC, int WC, int OH, int OW, int NLOAD, int STORE, int LDNT, bool AUX, bool TRACE, int AWAIT, int KB, int BMODE>
 __global__ void __launch_bounds__(1024)
 tps_warp_m16_kernel(const M3Params P)
