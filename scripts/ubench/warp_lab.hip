@@ -1,8 +1,8 @@
 // Kernel lab for the classic warp (BASELINE configs[1]: 512 x 3x32x100 fp32, F = 20).
 // Times every variant of the q4 kernel over rotating buffers with HIP events, checks each one bit for
 // bit against the library's production path (tpspp_warp_fwd), prints per-workgroup phase stamps.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I tps_pp_amd/csrc -I include \
-//         scripts/ubench/warp_lab.hip -o scripts/ubench/warp_lab -ldl
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -I tps_pp_amd/csrc -I include \
+//         -I scripts/ubench scripts/ubench/warp_lab.hip -o scripts/ubench/warp_lab -ldl
 //   scripts/ubench/warp_lab scripts/ubench/warp_lab_consts.bin tps_pp_amd/libtpspp_hip.so
 // (consts file: scripts/ubench/make_lab_consts.py)
 #include <hip/hip_runtime.h>
@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "tpspp_warp_q4.h"
+#include "warp_lab_kernels.h"
 
 using namespace tpspp_q4;
 
@@ -374,6 +374,25 @@ static void launch_m17(const Bufs& B, int set, float* out, float* grid, int32_t*
     else go(tps_warp_m17_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, false, AWAIT, KB>);
 }
 
+template <int NLOAD, int STORE, int LDNT, int AWAIT, int KB>
+static void launch_m18(const Bufs& B, int set, float* out, float* grid, int32_t* idx, long long* trace, hipStream_t st)
+{
+    M3Params P;
+    P.in = B.in[set]; P.ctrl = B.ctrl[set]; P.inv_delta_c = B.inv; P.p_hat_t = B.p_hat_pk2;
+    P.N = N; P.n = n; P.Ho = H; P.Wo = W;
+    P.out = out; P.grid = grid; P.idx = idx; P.trace = trace; P.trace2 = B.trace2;
+    const size_t lds = m5_lds_bytes(F, C, H, W, H, W, &P.zero_off, &P.out_off);
+    const int threads = (13 + NLOAD) * 64;
+    auto go = [&](auto kern) {
+        static bool done = false;
+        if (!done) { CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); done = true; }
+        hipLaunchKernelGGL(kern, dim3((N + 1) / 2), dim3(threads), lds, st, P);
+    };
+    if (trace) go(tps_warp_m18_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, true, AWAIT, KB>);
+    else if (grid || idx) go(tps_warp_m18_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, true, false, AWAIT, KB>);
+    else go(tps_warp_m18_kernel<F, C, H, W, H, W, NLOAD, STORE, LDNT, false, false, AWAIT, KB>);
+}
+
 template <int NLOAD, int STORE, int LDNT, int AWAIT, int KB, int BMODE>
 static void launch_m16(const Bufs& B, int set, float* out, float* grid, int32_t* idx, long long* trace, hipStream_t st)
 {
@@ -526,6 +545,10 @@ struct Variant { std::string name; std::function<void(const Bufs&, int, float*, 
     Variant{ "m17 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT " await=" #AWAIT " kb=" #KB, \
       [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
           launch_m17<NLOAD, STORE, LDNT, AWAIT, KB>(B, s, o, g, ix, tr, st); } }
+#define M18VAR(NLOAD, STORE, LDNT, AWAIT, KB) \
+    Variant{ "m18 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT " await=" #AWAIT " kb=" #KB, \
+      [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
+          launch_m18<NLOAD, STORE, LDNT, AWAIT, KB>(B, s, o, g, ix, tr, st); } }
 #define M5VAR(NLOAD, STORE, LDNT) \
     Variant{ "m5 nload=" #NLOAD " store=" #STORE " ldnt=" #LDNT, \
       [](const Bufs& B, int s, float* o, float* g, int32_t* ix, long long* tr, hipStream_t st) { \
@@ -813,7 +836,7 @@ int main(int argc, char** argv)
         [&, warp_fwd, prepared](const Bufs& Bf, int s, float* o, float* g, int32_t* ix, long long*, hipStream_t) {
             warp_fwd(Bf.in[s], C, H, W, nullptr, 0, 0, 0, Bf.ctrl[s], nullptr, Bf.inv, Bf.p_hat, K, nullptr, prepared, 1 | 8, N, F, H, W, o, nullptr, g, ix, nullptr); }};
     std::vector<Variant> vars = {
-        M15VAR(3, 1, 1, 6, 4), M17VAR(3, 1, 1, 6, 4), M17VAR(3, 1, 1, 2, 2),
+        M15VAR(3, 1, 1, 6, 4), M18VAR(3, 1, 1, 6, 4), M18VAR(3, 1, 1, 6, 2), M18VAR(3, 0, 1, 6, 4),
     };
     if (prepared) vars.push_back(libpair);
     std::vector<float> hout((size_t)N * C * n), hgrid((size_t)N * n * 2); std::vector<int32_t> hidx((size_t)N * n * 2);
@@ -847,7 +870,7 @@ int main(int argc, char** argv)
         if (!ok) printf("   %zu differing output words\n", bad);
         CK(hipMemset(B.trace, 0, 4096 * 128));
         if (v.name.compare(0, 3, "lib") == 0) continue;
-        if (v.name.compare(0, 2, "m3") == 0 || v.name.compare(0, 2, "m4") == 0 || v.name.compare(0, 2, "m5") == 0 || v.name.compare(0, 2, "m6") == 0 || v.name.compare(0, 2, "m7") == 0 || v.name.compare(0, 2, "m8") == 0 || v.name.compare(0, 2, "m9") == 0 || v.name.compare(0, 3, "m10") == 0 || v.name.compare(0, 3, "m11") == 0 || v.name.compare(0, 3, "m12") == 0 || v.name.compare(0, 3, "m13") == 0 || v.name.compare(0, 3, "m14") == 0 || v.name.compare(0, 3, "m15") == 0 || v.name.compare(0, 3, "m16") == 0 || v.name.compare(0, 3, "m17") == 0) {
+        if (v.name.compare(0, 2, "m3") == 0 || v.name.compare(0, 2, "m4") == 0 || v.name.compare(0, 2, "m5") == 0 || v.name.compare(0, 2, "m6") == 0 || v.name.compare(0, 2, "m7") == 0 || v.name.compare(0, 2, "m8") == 0 || v.name.compare(0, 2, "m9") == 0 || v.name.compare(0, 3, "m10") == 0 || v.name.compare(0, 3, "m11") == 0 || v.name.compare(0, 3, "m12") == 0 || v.name.compare(0, 3, "m13") == 0 || v.name.compare(0, 3, "m14") == 0 || v.name.compare(0, 3, "m15") == 0 || v.name.compare(0, 3, "m16") == 0 || v.name.compare(0, 3, "m17") == 0 || v.name.compare(0, 3, "m18") == 0) {
             const int L = 4;
             for (int l = 0; l < 20; ++l) v.run(B, l % SETS, B.out[l % SETS], nullptr, nullptr, nullptr, 0);
             for (int l = 0; l < L; ++l) v.run(B, (l + 3) % SETS, B.out[(l + 3) % SETS], nullptr, nullptr, B.trace + (size_t)l * 256 * 16, 0);

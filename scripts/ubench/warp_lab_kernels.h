@@ -1,4 +1,24 @@
-// Classic-geometry warp, "q4" kernel: the LDS-staged mirror kernel re-cut for few, fat wavefronts.
+// KERNEL LAB, not product code: the variants of the classic-geometry warp that were measured on the way to
+// tps_pp_amd/csrc/tpspp_warp_pair.h (round 2).  Built only by scripts/ubench/warp_lab.hip; every variant is checked bit for
+// bit against the library and timed interleaved with the others.  Kept as the record behind DESIGN.md section 4:
+//   q4   thread = 4 consecutive pixels x 4 mirrors, 7 fat wavefronts         16 us   (VALU phases need >= 3 wavefronts / SIMD)
+//   m    the round-1 mapping with knobs (store policy, nt DMA, loader count, debug switches: no stores / no DMA)
+//   m2   16-byte stores of quad-transposed (DPP) registers                    partial lines: write-through at 4 TB/s
+//   m3   image A / B pipeline through barriers, LDS-staged flat output copy  10.2 us (flag A was raised late: vmcnt(0))
+//   m4   dedicated T-solver wavefront, unthrottled loaders                    13.7 us (control points behind the DMA flood)
+//   m5   control points before the entry barrier, LDS flags                   10.5 us
+//   m7   packed table (6 x 16-byte loads per thread)                          10.4 us
+//   m8/m9 tap descriptors as 32-bit LDS addresses, hoisted; B held back behind A
+//   m10  4 x 8 pixel blocks per half-wavefront (bank conflicts 33 % -> 14 %); flag raised before B's bulk   9.7 us
+//   m11  every wavefront issues image A's DMA (inline asm)                    no gain: HBM-bound
+//   m12  table loads deferred until T is known                                no gain: same L2 time, later
+//   m13/m14 flag A before the bulk of B's requests; A's stores behind B's tap reads          9.6 us
+//   m15  both descriptor sets before image A lands  = the production kernel   9.5 us (8.9 - 9.8 by box)
+//   m16  image B through registers + ds_write_b128                            11.0 us
+//   m17  ds_write_addtid_b32 staging in thread order                          +0.35 us
+//   m18  plane-granular pipeline (6 units per pair)                           10.3 us (a barrier and 16 reads in flight per unit)
+//
+// (first variant) Classic-geometry warp, "q4" kernel: the LDS-staged mirror kernel re-cut for few, fat wavefronts.
 //
 // Replaces (same arithmetic, bit for bit): preprocessor/tps_preprocessor.py:71-83, 270-282
 // (GridGenerator.build_P_prime + F.grid_sample) for a mirror-symmetric RBF table.
@@ -3810,6 +3830,335 @@ tps_warp_m15_kernel(const M3Params P)
         }
     }
 #undef M15_STAMP
+}
+
+template <int F, int C, int HC, int WC, int OH, int OW, int NLOAD, int STORE, int LDNT, bool AUX, bool TRACE, int AWAIT, int KB>
+__global__ void __launch_bounds__(1024)
+tps_warp_m18_kernel(const M3Params P)
+{
+    constexpr int K = F + 3;
+    constexpr int H = HC, W = WC;
+    constexpr int halfW = OW / 2, PW = (halfW + 3) & ~3, nthr = (OH / 2) * PW;
+    constexpr int NW = (nthr + kWave - 1) / kWave;
+    constexpr int n = OH * OW;
+    static_assert(NW + NLOAD <= 16, "too many wavefronts");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float4* sT = reinterpret_cast<float4*>(smem);          // K x (TxA, TyA, TxB, TyB)
+    float* sInv = smem + 4 * K;                            // 2 x K*K (one copy per solving wavefront)
+    float* sFlag = sInv + 2 * ((K * K + 3) & ~3);          // [0] T rows published, [1 + q] loaders done with plane q of the pair
+    float* sImg = sFlag + 8;
+    float* sZero = sImg + P.zero_off;
+    float* sOut = sImg + P.out_off;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int b0 = blockIdx.x * 2;
+    const bool hasB = (b0 + 1) < P.N;
+    constexpr int HW = H * W;
+    constexpr int img_elems = C * HW;
+
+    unsigned ts[10];
+#define M18_STAMP(i) do { if (TRACE) ts[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+    long long wall0 = 0;
+    if (TRACE) { wall0 = (long long)wall_clock64(); }
+    M18_STAMP(0);
+    // the T-solve inputs are requested before anything else on this CU (wavefront g -> image b0 + g; lane i keeps
+    // control point i); the loaders are held at the entry barrier until these requests are on their way
+    constexpr int KK = K * K;
+    constexpr int NINV = (KK + kWave - 1) / kWave;
+    float invv[NINV];
+    float cx = 0.0f, cy = 0.0f;
+    if (wv < 2) {
+        if (lane < F) {
+            const int b = (wv == 1 && hasB) ? b0 + 1 : b0;
+            const float2 cc = reinterpret_cast<const float2*>(P.ctrl + (size_t)b * F * 2)[lane];
+            cx = cc.x; cy = cc.y;
+        }
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            invv[i] = P.inv_delta_c[e < KK ? e : KK - 1];
+        }
+    }
+    if (tid < 8) reinterpret_cast<int*>(sFlag)[tid] = 0;
+    lds_only_barrier();
+
+    if (wv >= NW) {
+        // ================= loader wavefronts =================
+        const int lw = wv - NW;
+        const int total_bytes = (hasB ? 2 : 1) * img_elems * 4;
+        const int pieces = (total_bytes + 1023) >> 10;
+        const int piecesA = (img_elems * 4 + 1023) >> 10;   // pieces that hold bytes of image A
+        const char* src = reinterpret_cast<const char*>(P.in + (size_t)b0 * img_elems);
+        auto dma = [&](int piece) {
+            int off = piece * 1024 + lane * 16;
+            if (off >= total_bytes) off = 0;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + off),
+                (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(sImg) + piece * 1024),
+                16, 0, LDNT ? 2 : 0);
+        };
+        auto now = [&]() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return (unsigned)t; };
+        // flag operands live in registers BEFORE the first DMA: a VGPR written after it had been an operand of an
+        // LDS-DMA instruction makes the compiler wait for vmcnt(0) first -- which would turn "A has landed" into
+        // "everything has landed"
+        unsigned fq = (unsigned)(size_t)(sFlag + 1);     // flag operands in registers BEFORE the first DMA (see m13)
+        int one = 1;
+        asm volatile("" : "+v"(fq), "+v"(one));
+        // wait until at most n of this wavefront's requests are outstanding (vmcnt retires in order; literal operands)
+        auto wait_le = [&](int n) {
+            switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+        auto raise = [&](int q) {      // flag word 1 + q: the plane index goes into the instruction's offset field
+            if (lane == 0) {
+                switch (q) {
+                case 0: asm volatile("ds_add_u32 %0, %1 offset:0" ::"v"(fq), "v"(one) : "memory"); break;
+                case 1: asm volatile("ds_add_u32 %0, %1 offset:4" ::"v"(fq), "v"(one) : "memory"); break;
+                case 2: asm volatile("ds_add_u32 %0, %1 offset:8" ::"v"(fq), "v"(one) : "memory"); break;
+                case 3: asm volatile("ds_add_u32 %0, %1 offset:12" ::"v"(fq), "v"(one) : "memory"); break;
+                case 4: asm volatile("ds_add_u32 %0, %1 offset:16" ::"v"(fq), "v"(one) : "memory"); break;
+                default: asm volatile("ds_add_u32 %0, %1 offset:20" ::"v"(fq), "v"(one) : "memory"); break;
+                }
+            }
+        };
+        // pieces of this loader with index <= x
+        auto upto = [&](int x) { return x >= lw ? (x - lw) / NLOAD + 1 : 0; };
+        constexpr int plane_bytes = HW * 4;
+        auto last_piece = [&](int q) { return ((q + 1) * plane_bytes + 1023) / 1024 - 1; };   // plane q complete when pieces <= this landed
+        const int nA = upto(piecesA - 1);
+        int piece = lw;
+        for (; piece < piecesA; piece += NLOAD) dma(piece);
+        int issuedB = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            if (q == C - 1) {
+                // the last plane of image A: let the first KB requests of image B go out first (cf. m13)
+#pragma unroll
+                for (int i2 = 0; i2 < KB; ++i2) { if (piece < pieces) { dma(piece); ++issuedB; } piece += NLOAD; }
+            }
+            wait_le(nA - upto(last_piece(q)) + issuedB);
+            raise(q);
+        }
+        for (; piece < pieces; piece += NLOAD) { dma(piece); ++issuedB; }
+        const int firstB = upto(piecesA - 1);     // pieces before image B's first own piece
+#pragma unroll
+        for (int q = C; q < 2 * C; ++q) {
+            const int doneB = upto(last_piece(q) < pieces ? last_piece(q) : pieces - 1) - firstB;   // of this loader's B pieces
+            wait_le(issuedB - (doneB > 0 ? doneB : 0));
+            raise(q);
+        }
+        return;
+    }
+
+    // ================= compute wavefronts =================
+    const bool live = tid < nthr;
+    // Thread -> pixel: a half-wavefront (the 32 lanes one ds_read_b32 cycle serves) owns a block of 4 columns x 8 rows.
+    // With a row pitch of W = 100 floats (bank shift 4 per row) such a block touches 32 different LDS banks wherever
+    // the warp is locally a translation; 32 consecutive pixels of a row pair would collide where they wrap into the
+    // next row (a third of all LDS cycles were bank conflicts with the row-major mapping).
+    static_assert(PW % 4 == 0 && (OH / 2) % 8 == 0, "block mapping needs whole 4 x 8 blocks");
+    const int qp = live ? tid : nthr - 1;
+    const int hw = qp >> 5, l5 = qp & 31;
+    constexpr int CG = PW / 4;                               // column groups
+    const int rg = hw / CG, cg = hw - rg * CG;
+    const int r = rg * 8 + (l5 >> 2), c = cg * 4 + (l5 & 3);
+    const bool xdup = (c & ~3) + 4 > halfW;
+    unsigned poff[4];                                        // byte offsets of the 4 pixels in a plane
+    poff[0] = 4u * (unsigned)(r * OW + c);
+    poff[1] = 4u * (unsigned)(r * OW + (OW - 1 - c));
+    poff[2] = 4u * (unsigned)((OH - 1 - r) * OW + c);
+    poff[3] = 4u * (unsigned)((OH - 1 - r) * OW + (OW - 1 - c));
+
+    // packed table: [wavefront][K/4 groups][lane] x 16 bytes = this thread's K values (padded to a multiple of 4)
+    // as KG coalesced 16-byte loads (P.p_hat_t points at the packed copy)
+    constexpr int KG = (K + 3) / 4;
+    float v[KG * 4];
+    {
+        const v4f* pk = reinterpret_cast<const v4f*>(P.p_hat_t) + (size_t)wv * KG * kWave + lane;
+#pragma unroll
+        for (int j = 0; j < KG; ++j) {
+            v4f x = {0.1f, 0.2f, 0.3f, 0.4f};
+            if (AWAIT != 100) x = pk[j * kWave];
+            else asm volatile("" : "+v"(x));
+            v[4 * j] = x[0]; v[4 * j + 1] = x[1]; v[4 * j + 2] = x[2]; v[4 * j + 3] = x[3];
+        }
+    }
+    if (tid < C) sZero[tid * HW] = 0.0f;
+    M18_STAMP(1);                                             // loads issued
+    if (wv < 2) {
+#pragma unroll
+        for (int i = 0; i < NINV; ++i) {
+            const int e = lane + i * kWave;
+            if (e < KK) sInv[wv * ((KK + 3) & ~3) + e] = invv[i];     // a private copy per solving wavefront
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes visible to own reads
+        const float* hrow = sInv + wv * ((KK + 3) & ~3) + (lane < K ? lane : K - 1) * K;
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const float hv = hrow[q];
+            ax = fmaf(hv, readlane_f(cx, q), ax);
+            ay = fmaf(hv, readlane_f(cy, q), ay);
+        }
+        if (lane < K) {
+            float* dst = reinterpret_cast<float*>(sT + lane) + 2 * wv;
+            dst[0] = ax; dst[1] = ay;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) bump_flag(sFlag + 0);
+    }
+    wait_flag(sFlag + 0, 2);
+    M18_STAMP(3);                                             // T ready
+
+    float gx[4][2], gy[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) gx[m][0] = gx[m][1] = gy[m][0] = gy[m][1] = 0.0f;
+    // one k-step of the 8 chains of image `im` (4 mirror pixels x (x, y)); table values from registers
+    auto chain_step = [&](auto qc, auto imc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int im = decltype(imc)::value;
+        const float2 t = reinterpret_cast<const float2*>(sT + q)[im];
+        float val[4];
+        if constexpr (q == 0) {
+            val[0] = val[1] = val[2] = val[3] = v[0];
+        } else if constexpr (q == 1) {
+            val[0] = v[1]; val[1] = -v[1]; val[2] = v[1]; val[3] = -v[1];
+        } else if constexpr (q == 2) {
+            val[0] = v[2]; val[1] = v[2]; val[2] = -v[2]; val[3] = -v[2];
+        } else {
+            constexpr int k = q - 3;
+            val[0] = v[3 + k];
+            val[1] = v[3 + perm_x<F>(k)];
+            val[2] = v[3 + perm_y<F>(k)];
+            val[3] = v[3 + perm_x<F>(perm_y<F>(k))];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            gx[m][im] = fmaf(val[m], t.x, gx[m][im]);
+            gy[m][im] = fmaf(val[m], t.y, gy[m][im]);
+        }
+    };
+    static_for<K>([&](auto qc) { chain_step(qc, std::integral_constant<int, 0>{}); });
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asm volatile("" : "+v"(gx[m][0]), "+v"(gy[m][0]));
+    constexpr unsigned row_bytes = n * 4u;
+    constexpr int out16 = n >> 2;                            // 16-byte pieces of one output PLANE
+    constexpr int nct = NW * kWave;
+    static_assert(out16 <= nct, "one 16-byte piece per thread and plane");
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    const unsigned img_lds = (unsigned)(size_t)sImg, zero_lds = (unsigned)(size_t)sZero;
+    unsigned ta[2][4][4];
+    float tw[2][4][4];
+    auto describe = [&](auto imc) {
+        constexpr int im = decltype(imc)::value;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const Taps t = make_taps(gx[m][im], gy[m][im], H, W);
+            if constexpr (AUX) {
+                const int b = b0 + im;
+                const bool st = live && !((m & 1) && xdup) && (im == 0 || hasB);
+                if (P.grid && st)
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid) + (size_t)b * 2 * row_bytes + 2u * poff[m]) =
+                        make_float2(gx[m][im], gy[m][im]);
+                if (P.idx && st)
+                    *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx) + (size_t)b * 2 * row_bytes + 2u * poff[m]) =
+                        make_int2(t.x0, t.y0);
+            }
+            const unsigned base = img_lds + (unsigned)(im * img_elems * 4);
+            const bool inxy = t.inx && t.iny;
+            ta[im][m][0] = base + 4u * (unsigned)t.o00;
+            ta[im][m][1] = t.inx ? ta[im][m][0] + 4u : zero_lds;
+            ta[im][m][2] = t.iny ? base + 4u * (unsigned)t.o10 : zero_lds;
+            ta[im][m][3] = inxy ? base + 4u * (unsigned)t.o10 + 4u : zero_lds;
+            tw[im][m][0] = t.nw; tw[im][m][1] = t.ne; tw[im][m][2] = t.sw; tw[im][m][3] = t.se;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(ta[im][m][q]), "+v"(tw[im][m][q]));
+    };
+    describe(std::integral_constant<int, 0>{});
+    M18_STAMP(4);                                            // image A: grid + tap descriptors done
+
+    // ---- plane pipeline: unit = one channel plane of one image (its taps need that plane only) -------------------
+    // plane q = (image q / C, channel q % C) is sampled as soon as the loaders have raised flag q; image B's grid chains
+    // (pure VALU) are slotted in behind the tap reads of image A's planes, whose phases are LDS-bound.
+    v4f opiece = {0, 0, 0, 0};                               // the 16-byte piece this thread copies out, one plane behind
+    auto store_piece = [&](int q) {
+        if (tid < out16) store16<STORE>((gchar*)(P.out) + ((size_t)b0 * C + q) * row_bytes, 16u * (unsigned)tid, opiece);
+    };
+    constexpr int KPART = (K + C - 1) / C;                   // image B's k-steps per plane of image A
+    static_for<2 * C>([&](auto qcst) {
+        constexpr int q = decltype(qcst)::value;
+        constexpr int im = q / C, ch = q % C;
+        if (im == 1 && !hasB) return;
+        if constexpr (q == C) describe(std::integral_constant<int, 1>{});
+        wait_flag(sFlag + 1 + q, NLOAD);
+        if constexpr (q == 0) M18_STAMP(5);
+        if constexpr (q == C) M18_STAMP(7);
+        float tv[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) tv[m][t4] = *((lds_cfloat*)(size_t)(ta[im][m][t4]) + ch * HW);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (q > 0) store_piece(q - 1);             // the previous plane's output leaves behind these reads
+        if constexpr (im == 0) {                             // a third of image B's chains
+            static_for<KPART>([&](auto jc) {
+                constexpr int kq = ch * KPART + decltype(jc)::value;
+                if constexpr (kq < K) chain_step(std::integral_constant<int, kq>{}, std::integral_constant<int, 1>{});
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float* stage = sOut + (q & 1) * n;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float acc = tv[m][0] * tw[im][m][0];
+            acc = fmaf(tv[m][1], tw[im][m][1], acc);
+            acc = fmaf(tv[m][2], tw[im][m][2], acc);
+            acc = fmaf(tv[m][3], tw[im][m][3], acc);
+            if (live) *reinterpret_cast<float*>(reinterpret_cast<char*>(stage) + poff[m]) = acc;
+        }
+        lds_only_barrier();                                  // plane q staged (double-buffered: one barrier per plane)
+        if constexpr (q == C - 1) M18_STAMP(6);
+        if constexpr (q == 2 * C - 1) M18_STAMP(8);
+        if (tid < out16) opiece = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(stage) + 16 * tid);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(opiece));
+    });
+    store_piece(hasB ? 2 * C - 1 : C - 1);
+    if (TRACE && wv == 0) {
+        M18_STAMP(9);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tend = (unsigned)__builtin_amdgcn_s_memtime();
+        const long long wall1 = (long long)wall_clock64();
+        if (lane == 0 && P.trace) {
+            long long* t = P.trace + (size_t)blockIdx.x * 16;
+            ts[2] = ts[1];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) t[i] = (long long)(ts[i] - ts[0]);
+            t[10] = (long long)(tend - ts[0]);
+            t[12] = wall0; t[13] = wall1;
+        }
+    }
+#undef M18_STAMP
 }
 
 template <int F, int C, int HC, int WC, int OH, int OW, int NLOAD, int STORE, int LDNT, bool AUX, bool TRACE, int AWAIT, int KB>
