@@ -195,3 +195,41 @@ def test_config4_reduced_precision_agreement_on_256_distinct_images(cuda, mode, 
     assert r["teacher_forced_argmax_agreement"] >= tf_min, r
     assert r["greedy_word_agreement"] >= word_min, r
     assert r["greedy_char_agreement"] >= char_min, r
+
+
+def test_sharded_recogniser_through_rccl_world_size_1(cuda):
+    """configs[3] / [4] path of `bench.py --gpus N` (extra.recognizer_sharded) and tests/tools/eval_e2e.py on the one GPU of
+    this box: a real RCCL ("nccl") process group of size 1, the decoder scores gathered with all_gather_into_tensor on
+    device tensors, strings converted from the gathered tensor -- equal to the un-sharded recogniser's.  (World size 2 is
+    covered on CPU with gloo: tests/test_dist_gloo.py, tests/test_bench_launch.py.)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from tps_pp_amd import dist as tdist
+    m = build_recognizer(cuda)
+    n = 8
+    img = dev(synth.smooth_image((n, 3, 32, 128), "cfg.shard", 9), cuda)
+    metas = [dict(resize_shape=(32, 128, 3)) for _ in range(n)]
+    with torch.no_grad():
+        want = [r["text"] for r in m(img, [dict(mm) for mm in metas], return_loss=False)]
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda)
+    try:
+        for mm in metas:
+            mm["valid_ratio"] = 1.0
+
+        def decode_local(lo, hi):
+            feat = m.extract_feat(img[lo:hi], test=True)["output"]
+            return m.decoder(feat, m.encoder(feat, metas[lo:hi]), None, metas[lo:hi], train_mode=False)
+        with torch.no_grad():
+            res = tdist.recognize_sharded(decode_local, n, m.label_convertor)
+            rows = tdist.all_gather_rows(torch.arange(6, dtype=torch.float32, device=cuda).reshape(3, 2), 3)
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        assert [r["text"] for r in res] == want
+        assert rows.is_cuda and torch.equal(rows.cpu(), torch.arange(6, dtype=torch.float32).reshape(3, 2))
+    finally:
+        dist.destroy_process_group()
