@@ -377,6 +377,9 @@ def main():
                     help="device copies over the bench buffers before the warm-up steps: the chip leaves its idle "
                          "clocks only after some hundred ms of activity (not steps of the workload; 0 disables)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo check of the launch path, no GPU work")
+    ap.add_argument("--sharded-extra", action="store_true",
+                    help="run extra.recognizer_sharded at N = 1 as well (a 1-rank RCCL group): exercises the N > 1 code path "
+                         "on a single-GPU box")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -486,8 +489,17 @@ def main():
         torch.cuda.synchronize(dev)
         copy_us = c0.elapsed_time(c1) * 1e3 / 500
 
-    sharded = recognizer_sharded(dev, world, rank) if (world > 1 and not a.no_extras) else None
+    sharded = None
+    if world > 1 and not a.no_extras:
+        sharded = recognizer_sharded(dev, world, rank)
+    elif a.sharded_extra:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        sharded = recognizer_sharded(dev, 1, 0)
+        dist.destroy_process_group()
 
+    rec = None
     if rank == 0:
         launch_us = ev_ms * 1e3 / a.steps
         achieved = BYTES_PER_IMG * BATCH / (launch_us * 1e-6) / 1e9
@@ -535,13 +547,22 @@ def main():
         if world == 1 and not a.no_extras:
             rec["extra"] = extra_measurements(dev)
         if sharded is not None:
-            rec["extra"] = {"recognizer_sharded": sharded}
+            rec.setdefault("extra", {})["recognizer_sharded"] = sharded
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(img0, ctrl0, gg.inv_delta_C.cpu().numpy(),
                                                gg.P_hat.cpu().numpy())
-        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which a pipe buffers until exit: flush it first so that the
+        # JSON line is the last line of stdout
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
