@@ -37,6 +37,10 @@ with torch.no_grad():
         t3 = timeit(lambda: m(x, [o0, o1]), iters=20)
         print(f"TPS_PP batch {N} bf16x3: full {t3:.2f} ms = {N / t3 * 1e3:,.0f} img/s")
         sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "fp32only":
+        t1 = timeit(lambda: m(x, [o0, o1]), iters=20)
+        print(f"TPS_PP batch {N} fp32: full {t1:.2f} ms = {N / t1 * 1e3:,.0f} img/s")
+        sys.exit(0)
     if ONLY16:
         xb, o0b, o1b = x.to(torch.bfloat16), o0.to(torch.bfloat16), o1.to(torch.bfloat16)
         t16 = timeit(lambda: m(xb, [o0b, o1b]), iters=20)

@@ -11,14 +11,14 @@
 //
 // A wavefront owns 32 consecutive full-resolution pixels of a row; a lane is (pixel l31, k-half h).  The B
 // operand of a 32x32x16 step is 8 consecutive k per lane: for the three small GEMMs those are 8 input channels
-// of the lane's pixel (coalesced 2-B row loads, packed in pairs).  Their results come back in the C/D layout --
+// of the lane's pixel (read out of the wavefront's LDS tile, see "data movement").  Their results come back in the C/D layout --
 // lane (pixel, h) holds output channels 8g + 4h + {0..3} -- and two consecutive groups g are exactly the 8 values
 // the lane must supply as B operand of one k-step of the 192-deep GEMM, provided its weight slab is permuted on
 // the host to that k-slot order (slot 8h+e of a 16-channel group = channel [0,1,2,3,8,9,10,11,4,5,6,7,12,..,15][8h+e]).
 // So feat0 / feat1 / feat2 are rounded to bf16 once (the same rounding their stores to HBM use: the unfused
 // composition computes feat_grid from exactly these values), packed with v_cvt_pk_bf16_f32 and fed straight
-// back; no LDS, no barrier.  Weight fragments are 16-B reads of host-arranged [k-step][h][64 cout][8 k] slabs
-// (44 KB in all: L1 / L2 resident).
+// back; activations cross no barrier.  Weight fragments are 16-B LDS reads of host-arranged
+// [k-step][h][64 cout][8 k] slabs (40 KB in all, loaded once per persistent workgroup).
 //
 // Reference: TPS_PP.forward / TPS_PP.grid, mmocr/models/textrecog/backbones/tps_pp/tps_pp.py:560-562,580-585.
 // Bound: HBM (2.4 MB per image at 17 kMAC per pixel).
@@ -55,23 +55,94 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// Loads the B operand of NK k-steps: channels 16j + 8h + e of one pixel.  `base` is wave-uniform (first channel
-// plane of the image, at the wavefront's row segment), `lo` the lane's 32-bit element offset (pixel + 8h planes):
-// every load is  scalar base + one shared VGPR offset, and a channel pair lands in the two halves of one
-// register (d16 / d16_hi loads): no 64-bit vector addresses, no packing instructions.
-template <int NK>
-__device__ __forceinline__ void load_b(const unsigned short* __restrict__ base, unsigned lo, int plane, u32x4 (&b)[NK])
+// ---- data movement -------------------------------------------------------------------------------------------------
+// A lane's MFMA operands are 2-byte elements of 16 (32) different channel planes, and its results are 2-byte elements
+// of 64 planes.  Moved as such -- 64 loads and 128 stores of 64 B per half-wavefront and segment, or the same number
+// of 2-byte LDS accesses behind wide loads and stores -- the kernel sits at 3.2 TB/s whatever the memory does (it
+// takes 353 us with every load and store removed).  gfx950 has the instruction for this: ds_read_b64_tr_b16 hands
+// lane (l & 15) of a 16-lane group column l & 15 of a [4 rows][16 columns] block of 16-bit elements whose rows the
+// lanes point at (scripts/ubench/tr_probe.hip).  So
+//   * inputs arrive in 16-byte pieces (8 pixels of a channel) and are laid down as they come, [channel][32 pixels];
+//     a transposing read of 4 channel rows gives a lane 4 consecutive k of ITS pixel: 2 reads per k-step instead of 8
+//     (the half-resolution input is doubled along x on its way into the tile, so it reads the same way);
+//   * results are written [pixel][64 channels] (8 bytes per lane and group: 4 consecutive channels), and the
+//     transposing read of 4 pixel rows gives a lane 4 consecutive pixels of one channel: 2 reads per 16-byte piece
+//     of the NCHW output rows.
+// 84 LDS and 20 global instructions per lane and segment instead of 312 + 20 (or 192 global ones).  Every wavefront
+// owns its 8 KB tile: no barrier, a wavefront's LDS operations execute in order.  Pitches: 64 B for the input rows
+// (4 rows -> 4 disjoint 8-bank ranges of the 64 banks), 152 B for the output rows (writes: 16 lanes x 8 B on 32
+// distinct banks; reads: rows at 0 / 38 / 12 / 50 dwords mod 64).
+constexpr int kTileBytes = 8192;            // inputs: outs0 [32][32] | outs1 [32][32] | x doubled [64][32]; then the outputs
+constexpr int kOutPitch = 76;               // 16-bit elements per pixel row of the output tile
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x2 read_tr(const unsigned short* p)
+{
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+
+// one input tile of 2 KB in global memory: 128 pieces of 16 bytes, two per lane; a channel's row segment holds
+// 1 << QB pieces.  The pieces of the NEXT segment are fetched into registers while this one is computed.
+// The loads are inline asm so that their completion is waited for by COUNT (wait_fetched): the compiler's own
+// wait would be vmcnt(0) at the top of the next segment, which also drains that segment's 12-14 stores -- their
+// write acknowledgements, not the loads, are then what a wavefront spends its time on (measured: 373 us with the
+// drain; 196 us without the stores, 285 us without the loads).  vmcnt retires loads and stores in issue order.
+template <int QB>
+__device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ src, int plane, int lane, u32x4 (&r)[2])
 {
 #pragma unroll
-    for (int j = 0; j < NK; ++j)
+    for (int i = 0; i < 2; ++i) {
+        const int p = lane + 64 * i;
+        const unsigned short* g = src + (size_t)(p >> QB) * plane + (p & ((1 << QB) - 1)) * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(g) : "memory");
+    }
+}
+
+// all but the youngest NSTORES vector-memory operations of this wavefront have completed: the six fetches issued before
+// them have landed.  The registers are operands so that their uses stay behind the wait.
+template <int NSTORES>
+__device__ __forceinline__ void wait_fetched(u32x4 (&a)[2], u32x4 (&b)[2], u32x4 (&c)[2])
+{
+    asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(c[0]), "+v"(c[1]) : "n"(NSTORES) : "memory");
+}
+
+__device__ __forceinline__ void put_tile(unsigned short* lds, const u32x4 (&r)[2], int lane)
+{
+    reinterpret_cast<u32x4*>(lds)[lane] = r[0];
+    reinterpret_cast<u32x4*>(lds)[lane + 64] = r[1];
+}
+
+// the half-resolution tile, every pixel twice: piece p (channel p >> 1, pixels 8 (p & 1) ..) -> 32 bytes of row p >> 1
+__device__ __forceinline__ void put_tile_doubled(unsigned short* lds, const u32x4 (&r)[2], int lane)
+{
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned short* p0 = base + (size_t)(16 * j + 2 * q) * plane;      // uniform
-            u16x2 v;
-            v[0] = p0[lo];
-            v[1] = p0[(size_t)plane + lo];
-            b[j][q] = __builtin_bit_cast(unsigned, v);
+    for (int i = 0; i < 2; ++i) {
+        u32x4 lo, hi;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            lo[2 * d] = __builtin_amdgcn_perm(r[i][d], r[i][d], 0x01000100u);
+            lo[2 * d + 1] = __builtin_amdgcn_perm(r[i][d], r[i][d], 0x03020302u);
+            hi[2 * d] = __builtin_amdgcn_perm(r[i][2 + d], r[i][2 + d], 0x01000100u);
+            hi[2 * d + 1] = __builtin_amdgcn_perm(r[i][2 + d], r[i][2 + d], 0x03020302u);
         }
+        const int p = lane + 64 * i;
+        reinterpret_cast<u32x4*>(lds)[2 * p] = lo;
+        reinterpret_cast<u32x4*>(lds)[2 * p + 1] = hi;
+    }
+}
+
+// B operand of NK k-steps out of an input tile [channel][32 pixels]: channels 16j + 8h + e of the lane's pixel.
+// `lb`: the lane's element offset ((a >> 2) + 8 half) * 32 + 16 * pixel-block + 4 (a & 3), a = lane & 15.
+template <int NK>
+__device__ __forceinline__ void load_b(const unsigned short* tile, int lb, u32x4 (&b)[NK])
+{
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const u32x2 k0 = read_tr(tile + lb + (16 * j) * 32), k1 = read_tr(tile + lb + (16 * j + 4) * 32);
+        b[j][0] = k0[0]; b[j][1] = k0[1]; b[j][2] = k1[0]; b[j][3] = k1[1];
+    }
 }
 
 // out[t] = slab^T in  over NK k-steps, both 32-channel tiles
@@ -89,12 +160,10 @@ __device__ __forceinline__ void gemm(const u32x4* __restrict__ slab, const u32x4
     }
 }
 
-// bias + ReLU + one rounding to bf16; returns the 64 features as chain-ordered B fragments (4 k-steps) and
-// stores them (NCHW, 64-B row segments per half-wavefront) when `st` is set.  `dst` is wave-uniform, `so` the
-// lane's element offset (pixel + 4h planes).
+// bias + ReLU + one rounding to bf16; returns the 64 features as chain-ordered B fragments (4 k-steps) and, when
+// `st`, writes them into row `px` of the wavefront's output tile [pixel][64 channels]
 __device__ __forceinline__ void finish(const f32x16 (&acc)[2], const float* __restrict__ bias, int half,
-                                       unsigned short* __restrict__ dst, unsigned so, int plane, bool st,
-                                       u32x4* __restrict__ out)
+                                       unsigned short* tile, int px, bool st, u32x4* __restrict__ out)
 {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -106,81 +175,175 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[2], const float* __re
                 const float s = acc[t][4 * g + e] + bias[32 * t + 8 * g + 4 * half + e];
                 v[e] = s > 0.0f ? s : 0.0f;
             }
-            const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
+            u32x2 pk;
+            pk[0] = pack_bf16(v[0], v[1]); pk[1] = pack_bf16(v[2], v[3]);
             // group g of tile t is k-step 2t + g/2, slots 4(g&1) .. 4(g&1)+3
-            out[2 * t + (g >> 1)][2 * (g & 1)] = p01;
-            out[2 * t + (g >> 1)][2 * (g & 1) + 1] = p23;
-            if (st) {
-                unsigned short* d = dst + (size_t)(32 * t + 8 * g) * plane;          // uniform
-                d[so] = (unsigned short)(p01 & 0xffffu);
-                d[(size_t)plane + so] = (unsigned short)(p01 >> 16);
-                d[(size_t)2 * plane + so] = (unsigned short)(p23 & 0xffffu);
-                d[(size_t)3 * plane + so] = (unsigned short)(p23 >> 16);
-            }
+            out[2 * t + (g >> 1)][2 * (g & 1)] = pk[0];
+            out[2 * t + (g >> 1)][2 * (g & 1) + 1] = pk[1];
+            if (st) *reinterpret_cast<u32x2*>(tile + px * kOutPitch + 32 * t + 8 * g + 4 * half) = pk;
         }
     }
 }
 
-__global__ void __launch_bounds__(256)
+// the output tile [NPX pixels][64 channels] -> 16-byte pieces (8 pixels) of the 64 channel planes
+template <int NPX>
+__device__ __forceinline__ void flush_tile(const unsigned short* tile, char* __restrict__ dst, size_t plane_bytes, int lane)
+{
+    asm volatile("" ::: "memory");                     // the writes above are not reordered behind these reads
+    constexpr int NI = NPX / 8;                        // pieces per lane: 64 channels x NPX/8 pieces / 64 lanes
+    const int a = lane & 15, g4 = lane >> 4;
+    u32x4 v[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        // NPX = 32: the four groups take the four pixel blocks of channels 16 i ..; NPX = 16: two blocks x two channel sets
+        const int q = NPX == 32 ? g4 : (g4 & 1);
+        const int ch0 = NPX == 32 ? 16 * i : 32 * i + 16 * (g4 >> 1);
+        const unsigned short* p = tile + (8 * q + (a >> 2)) * kOutPitch + ch0 + 4 * (a & 3);
+        const u32x2 lo = read_tr(p), hi = read_tr(p + 4 * kOutPitch);
+        v[i][0] = lo[0]; v[i][1] = lo[1]; v[i][2] = hi[0]; v[i][3] = hi[1];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int q = NPX == 32 ? g4 : (g4 & 1);
+        const int ch0 = NPX == 32 ? 16 * i : 32 * i + 16 * (g4 >> 1);
+        *reinterpret_cast<u32x4*>(dst + (size_t)(ch0 + a) * plane_bytes + q * 16) = v[i];
+    }
+    asm volatile("" ::: "memory");
+}
+
+// Persistent workgroups of NW wavefronts, one workgroup per CU: the 40 KB of weight slabs are read into LDS once --
+// from global memory they cycle through a 32 KB L1 that keeps none of them, 2.7 GB of L2 traffic per 512 images,
+// more than the tensors themselves -- and every wavefront walks its own row segments.
+constexpr int kSlabUnits = (2 + 2 + 4 + 12) * 128;      // 16-byte units: w0 | w1 | w2 | wg
+constexpr int kSlabBytes = kSlabUnits * 16 + 4 * 64 * 4;  // + the four bias vectors
+
+template <bool FG32, int NW>
+__global__ void __launch_bounds__(NW * 64)
 front_bf16_kernel(const FrontBParams P)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* sW = reinterpret_cast<u32x4*>(smem);
+    float* sBias = reinterpret_cast<float*>(smem + kSlabUnits * 16);
+    for (int i = threadIdx.x; i < kSlabUnits; i += NW * 64) {
+        const u32x4* src = i < 256 ? P.w0 + i : i < 512 ? P.w1 + (i - 256) : i < 1024 ? P.w2 + (i - 512) : P.wg + (i - 1024);
+        sW[i] = *src;
+    }
+    for (int i = threadIdx.x; i < 256; i += NW * 64)
+        sBias[i] = (i < 64 ? P.b0 : i < 128 ? P.b1 : i < 192 ? P.b2 : P.bg)[i & 63];
+    __syncthreads();
+
     const int lane = threadIdx.x & (kWave - 1);
     const int half = lane >> 5, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int segs_per_row = P.W >> 5;
-    const long seg = (long)blockIdx.x * 4 + wv;                       // 32-pixel row segment (wave-uniform)
     const long nseg = (long)P.N * P.H * segs_per_row;
-    if (seg >= nseg) return;
-    const int sx = (int)(seg % segs_per_row);
-    const long row = seg / segs_per_row;
-    const int y = (int)(row % P.H);
-    const int n = (int)(row / P.H);
     const int plane = P.H * P.W, W2 = P.W >> 1, plane2 = (P.H >> 1) * W2;
-    const size_t seg0 = (size_t)y * P.W + sx * 32;                    // first pixel of the segment (uniform)
-    const size_t seg2 = (size_t)(y >> 1) * W2 + sx * 16;
-    const int xx = sx * 32 + l31;
+    const size_t pb = (size_t)plane * 2;
+    unsigned short* t0 = reinterpret_cast<unsigned short*>(smem + kSlabBytes + (size_t)wv * kTileBytes);
+    unsigned short* t1 = t0 + 1024;
+    unsigned short* t2 = t1 + 1024;
+    unsigned short* to = t0;                                          // the output tile takes the inputs' place
+    const int lb = (((lane & 15) >> 2) + 8 * half) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
-    // the half-resolution input first (its 32 loads stay in flight across the two small GEMMs)
-    u32x4 in2[4];
-    load_b<4>(P.x + (size_t)n * 64 * plane2 + seg2, (unsigned)((l31 >> 1) + 8 * half * plane2), plane2, in2);
-    u32x4 in0[2], in1[2];
-    const unsigned lo = (unsigned)(l31 + 8 * half * plane);
-    load_b<2>(P.o0 + (size_t)n * 32 * plane + seg0, lo, plane, in0);
-    load_b<2>(P.o1 + (size_t)n * 32 * plane + seg0, lo, plane, in1);
-
-    u32x4 f[12];                                   // [feat0 | feat1 | feat2] as B fragments of the 192-deep GEMM
-    f32x16 acc[2];
-    auto zero = [&]() {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    u32x4 pf0[2], pf1[2], pf2[2];
+    auto fetch = [&](long sg) {
+        const int fx = (int)(sg % segs_per_row);
+        const long frow = sg / segs_per_row;
+        const int fy = (int)(frow % P.H);
+        const size_t fn = (size_t)(frow / P.H);
+        fetch_tile<2>(P.o0 + fn * 32 * plane + (size_t)fy * P.W + fx * 32, plane, lane, pf0);
+        fetch_tile<2>(P.o1 + fn * 32 * plane + (size_t)fy * P.W + fx * 32, plane, lane, pf1);
+        fetch_tile<1>(P.x + fn * 64 * plane2 + (size_t)(fy >> 1) * W2 + fx * 16, plane2, lane, pf2);
     };
-    const size_t obase = (size_t)n * 64 * plane + seg0;               // uniform
-    const unsigned so = (unsigned)(l31 + 4 * half * plane);
-    zero();
-    gemm<2>(P.w0, in0, half, l31, acc);
-    finish(acc, P.b0, half, P.feat0 + obase, so, plane, true, f);
-    zero();
-    gemm<2>(P.w1, in1, half, l31, acc);
-    finish(acc, P.b1, half, P.feat1 + obase, so, plane, true, f + 4);
-    zero();
-    gemm<4>(P.w2, in2, half, l31, acc);
-    // one lane of every 2x2 block writes the half-resolution pixel
-    finish(acc, P.b2, half, P.feat2 + (size_t)n * 64 * plane2 + seg2, (unsigned)((l31 >> 1) + 4 * half * plane2),
-           plane2, ((y | xx) & 1) == 0, f + 8);
-    zero();
-    gemm<12>(P.wg, f, half, l31, acc);
+    const long step = (long)gridDim.x * NW;
+    const long first = (long)blockIdx.x * NW + wv;
+    if (first < nseg) { fetch(first); wait_fetched<0>(pf0, pf1, pf2); }
+    for (long seg = first; seg < nseg; seg += step) {
+        const int sx = (int)(seg % segs_per_row);
+        const long row = seg / segs_per_row;
+        const int y = (int)(row % P.H);
+        const int n = (int)(row / P.H);
+        const size_t seg0 = (size_t)y * P.W + sx * 32;                // first pixel of the segment (uniform)
+        const size_t seg2 = (size_t)(y >> 1) * W2 + sx * 16;
+        // the slabs do not change from segment to segment; the optimiser must not see that (it would hoist 160
+        // registers' worth of LDS reads out of this loop and spill them)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const u32x4* w0 = sW + opaque;
+        const u32x4* w1 = w0 + 256;
+        const u32x4* w2 = w0 + 512;
+        const u32x4* wg = w0 + 1024;
+        const float* bias = sBias + opaque;
+
+        put_tile(t0, pf0, lane);
+        put_tile(t1, pf1, lane);
+        put_tile_doubled(t2, pf2, lane);
+        asm volatile("" ::: "memory");
+        const bool more = seg + step < nseg;                          // uniform
+        if (more) fetch(seg + step);                                  // in flight under this segment's arithmetic
+        u32x4 in0[2], in1[2], in2[4];
+        load_b<2>(t0, lb, in0);
+        load_b<2>(t1, lb, in1);
+        load_b<4>(t2, lb, in2);
+        asm volatile("" ::: "memory");                                // ... before the first output overwrites them
+
+        u32x4 f[12];                               // [feat0 | feat1 | feat2] as B fragments of the 192-deep GEMM
+        f32x16 acc[2];
+        auto zero = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cu = 32 * t + (r & 3) + 8 * (r >> 2);           // + 4*half: in the lane offset
-            float v = acc[t][r] + P.bg[cu + 4 * half];
-            v = v > 0.0f ? v : 0.0f;
-            if (P.fg_f32) (reinterpret_cast<float*>(P.feat_grid) + obase + (size_t)cu * plane)[so] = v;
-            else (reinterpret_cast<unsigned short*>(P.feat_grid) + obase + (size_t)cu * plane)[so] =
-                (unsigned short)(pack_bf16(v, 0.0f) & 0xffffu);
+                for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        };
+        const size_t obase = (size_t)n * 64 * plane + seg0;           // uniform
+        zero();
+        gemm<2>(w0, in0, half, l31, acc);
+        finish(acc, bias, half, to, l31, true, f);
+        flush_tile<32>(to, reinterpret_cast<char*>(P.feat0 + obase), pb, lane);
+        zero();
+        gemm<2>(w1, in1, half, l31, acc);
+        finish(acc, bias + 64, half, to, l31, true, f + 4);
+        flush_tile<32>(to, reinterpret_cast<char*>(P.feat1 + obase), pb, lane);
+        zero();
+        gemm<4>(w2, in2, half, l31, acc);
+        // one lane of every 2x2 block holds the half-resolution pixel: even rows write it, from the even-pixel lanes
+        const bool row2 = (y & 1) == 0;                               // uniform
+        finish(acc, bias + 128, half, to, l31 >> 1, row2 && (l31 & 1) == 0, f + 8);
+        if (row2) flush_tile<16>(to, reinterpret_cast<char*>(P.feat2 + (size_t)n * 64 * plane2 + seg2), (size_t)plane2 * 2, lane);
+        zero();
+        gemm<12>(wg, f, half, l31, acc);
+        if constexpr (FG32) {
+            // fp32 feat_grid: [channel][32 pixels] fp32, 4-byte writes (consecutive lanes, consecutive banks), 16-byte reads
+            float* tf = reinterpret_cast<float*>(to);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = acc[t][r] + bias[192 + c];
+                    tf[c * 32 + l31] = v > 0.0f ? v : 0.0f;
+                }
+            asm volatile("" ::: "memory");
+            u32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const u32x4*>(tf)[lane + 64 * i];
+            float* gdst = reinterpret_cast<float*>(P.feat_grid) + obase;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = lane + 64 * i;
+                *reinterpret_cast<u32x4*>(gdst + (size_t)(p >> 3) * plane + (p & 7) * 4) = v[i];
+            }
+            asm volatile("" ::: "memory");
+        } else {
+            u32x4 unused[4];
+            finish(acc, bias + 192, half, to, l31, true, unused);
+            flush_tile<32>(to, reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(P.feat_grid) + obase), pb, lane);
+        }
+        // stores issued since the fetch: feat0 4, feat1 4, feat2 2 (even rows), feat_grid 4 (bf16) or 8 (fp32)
+        if (more) {
+            constexpr int NS = FG32 ? 16 : 12;
+            if (row2) wait_fetched<NS + 2>(pf0, pf1, pf2);
+            else wait_fetched<NS>(pf0, pf1, pf2);
         }
     }
 }
@@ -377,6 +540,28 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
     P.feat0 = static_cast<unsigned short*>(feat0); P.feat1 = static_cast<unsigned short*>(feat1);
     P.feat2 = static_cast<unsigned short*>(feat2); P.feat_grid = feat_grid; P.fg_f32 = feat_grid_f32 ? 1 : 0;
     P.N = N; P.H = H; P.W = W;
-    hipLaunchKernelGGL(front_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, tpspp::as_stream(stream), P);
+    TPSPP_REQUIRE(((reinterpret_cast<size_t>(outs0) | reinterpret_cast<size_t>(outs1) | reinterpret_cast<size_t>(x) |
+                    reinterpret_cast<size_t>(feat0) | reinterpret_cast<size_t>(feat1) | reinterpret_cast<size_t>(feat2) |
+                    reinterpret_cast<size_t>(feat_grid)) & 15) == 0, "tpspp_front_bf16_fwd: tensors must be 16-byte aligned");
+    // One workgroup per CU.  bf16 feat_grid: 4 wavefronts = one 128-pixel row per workgroup at a time; measured (same box,
+    // interleaved with the previous kernel at 380 us): 3 / 4 / 5 / 6 / 8 wavefronts 373 / 308 / 420 / 383 / 375 us, two
+    // workgroups of 4 per CU 371 us, non-temporal stores 369 us, consecutive rows per workgroup 351 us.
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<true, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<false, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    const int nw = P.fg_f32 ? 8 : 4;
+    const long wgs = (nseg + nw - 1) / nw;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    if (P.fg_f32)
+        hipLaunchKernelGGL((front_bf16_kernel<true, 8>), dim3(grid), dim3(8 * 64), kSlabBytes + 8 * kTileBytes,
+                           tpspp::as_stream(stream), P);
+    else
+        hipLaunchKernelGGL((front_bf16_kernel<false, 4>), dim3(grid), dim3(4 * 64), kSlabBytes + 4 * kTileBytes,
+                           tpspp::as_stream(stream), P);
     return tpspp::check_launch("tpspp_front_bf16_fwd");
 }
