@@ -5,6 +5,8 @@
 #include "tpspp_common.h"
 
 typedef unsigned int tpspp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tpspp_u32x2 __attribute__((ext_vector_type(2)));
+typedef short tpspp_s16x4 __attribute__((ext_vector_type(4)));
 
 namespace tpspp {          // shared by the two translation units: external linkage
 
@@ -97,7 +99,14 @@ struct BCfg {
 // 1 (128 pixels) halves the patch and the accumulators: more, lighter workgroups for the layers whose patch is large
 // against their work (stride 2: the patch holds 4x the output positions) or whose maps are so small that 256-pixel tiles
 // leave CUs idle -- those kernels wait on memory, not on the matrix pipe.
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false, int NF = 2>
+// WIDE (3x3, bf16 sources at full resolution, rows of whole 16-byte pieces): the patch is not gathered element by
+// element (KC 2-byte loads and KC/2 packing instructions per position -- the instruction stream, not the memory,
+// is what that staging is bound by: removing its loads takes 28 us off a 75 us layer that moves 30 us' worth of
+// bytes) but arrives as 16-byte pieces of the NCHW rows, laid down as they come ([channel][image][row][aligned
+// pixels]), and is brought into the channel-innermost patch image by ds_read_b64_tr_b16: a 16-lane group points at
+// 4 channel rows x 16 pixels and each lane receives 4 consecutive channels of its pixel.  Per chunk and thread: 4-6
+// loads of 16 bytes + ~4 x (2 transposing reads + 1 16-byte write) instead of 32 loads + 32 packs.
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false, int NF = 2, bool WIDE = false>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_tiled_bf16_kernel(const BParams P)
 {
@@ -106,9 +115,26 @@ conv_tiled_bf16_kernel(const BParams P)
     constexpr int NPOS = Cfg::NPOS, KG = Cfg::KG, WSLAB = Cfg::WSLAB, NW = Cfg::NW;
     static_assert(NI * TH * TW == 128 * NF, "tile must hold 128 * NF pixels");
     static_assert(KC % 16 == 0, "whole MFMA k-steps");
+    static_assert(!WIDE || (KH == 3 && !X3), "wide staging: 3x3 kernels on bf16 tensors");
     constexpr int NS = X3 ? 2 : 1;                     // hi (and lo) images
-    __shared__ u32x4 sP[NS * KG * PSN];                // [hi|lo][k group][position] x 8 bf16
-    __shared__ u32x4 sW[NS * WSLAB];                   // [hi|lo][tap][k group][cout] x 8 bf16
+    // one block: the patch [hi|lo][k group][position] x 8 bf16, the weight slab [hi|lo][tap][k group][cout] x 8 bf16,
+    // the raw tile of the wide staging; after the last chunk the same bytes stage the output tile of the wide epilogue
+    // wide staging: the aligned patch rows start XOFF pixels left of the patch (tile origins are multiples of 16
+    // pixels and the padding is 1, so that start is a multiple of 8) and are PWA pixels long
+    constexpr int XOFF = 7;
+    constexpr int PWA = ((XOFF + PW + 15) / 16) * 16;
+    constexpr int RP = PWA / 8;                        // 16-byte pieces per row
+    constexpr int PH_ = Cfg::PH;
+    constexpr int NPIECE = KC * NI * PH_ * RP;
+    constexpr int NPL = (NPIECE + kThreads - 1) / kThreads;
+    constexpr int CHROW = NI * PH_ * PWA;              // 16-bit elements per channel of the raw tile
+    constexpr int kOutPitch = 76;                      // 16-bit elements per pixel row of a wavefront's output tile
+    constexpr int LDS16 = NS * KG * PSN + NS * WSLAB + (WIDE ? NPIECE : 0);
+    constexpr int OUT16 = (kThreads / kWave) * 32 * kOutPitch * 2 / 16;
+    __shared__ u32x4 sAll[LDS16 > OUT16 ? LDS16 : OUT16];
+    u32x4* const sP = sAll;
+    u32x4* const sW = sAll + NS * KG * PSN;
+    u32x4* const sR = sW + NS * WSLAB;
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -149,6 +175,23 @@ conv_tiled_bf16_kernel(const BParams P)
         pim[i] = im;
     }
 
+    // wide staging: this thread's pieces (fixed over the chunks): channel inside the chunk, image, element offset of
+    // the piece inside a channel plane (or -1: outside the image)
+    int qc[WIDE ? NPL : 1], qim[WIDE ? NPL : 1], qpix[WIDE ? NPL : 1];
+    if constexpr (WIDE) {
+        const int ax0 = ix_base - XOFF;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int e = tid + i * kThreads;
+            const int c = e / (NI * PH_ * RP), r1 = e - c * (NI * PH_ * RP);
+            const int im = r1 / (PH_ * RP), r2 = r1 - im * (PH_ * RP);
+            const int py = r2 / RP, rp_ = r2 - py * RP;
+            const int iy = iy_base + py, ixa = ax0 + rp_ * 8;
+            const bool ok = e < NPIECE && iy >= 0 && iy < P.Hi && ixa >= 0 && ixa < P.Wi && (n0 + im) < P.N;
+            qc[i] = c; qim[i] = im; qpix[i] = ok ? iy * P.Wi + ixa : -1;
+        }
+    }
+
     f32x16 acc[NF][2];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
@@ -157,8 +200,9 @@ conv_tiled_bf16_kernel(const BParams P)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[f][h2][i] = 0.0f;
 
-    unsigned rp[NPOS][KC / 2];          // packed channel pairs of each position
+    unsigned rp[WIDE ? 1 : NPOS][WIDE ? 1 : KC / 2];          // packed channel pairs of each position
     unsigned rpl[X3 ? NPOS : 1][X3 ? KC / 2 : 1];   // their low halves (X3)
+    u32x4 rq[WIDE ? NPL : 1];                        // wide staging: this thread's pieces
     u32x4 rw[NW];
     u32x4 rwl[X3 ? NW : 1];
     int cbase = 0, s = 0;
@@ -172,6 +216,17 @@ conv_tiled_bf16_kernel(const BParams P)
         const int cleft = min(KC, cur.C - (c0 - cbase));           // channels of this chunk that exist
         const size_t img_stride = (size_t)cur.C * plane;
         const size_t chan0 = (size_t)n0 * img_stride + (size_t)(c0 - cbase) * plane;   // uniform
+        if constexpr (WIDE) {
+            const unsigned short* sp = reinterpret_cast<const unsigned short*>(cur.p) + chan0;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const bool ok = qpix[i] >= 0 && qc[i] < cleft;
+                const unsigned lo = ok ? (unsigned)(qim[i] * (int)img_stride + qc[i] * plane + qpix[i]) : 0u;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(sp + lo);          // unconditional, as below
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                rq[i] = ok ? v : z;
+            }
+        } else
         // every load is unconditional (a predicate per load would put each one in its own basic block and
         // serialise them behind s_waitcnt): channels beyond the source's last one re-read that last channel
         // and are zeroed by a select, padding positions read the chunk's first element.  Addresses are
@@ -219,6 +274,13 @@ conv_tiled_bf16_kernel(const BParams P)
         }
     };
     auto commit = [&]() {
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int e = tid + i * kThreads;
+                if (e < NPIECE) sR[e] = rq[i];
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
             const int e = tid + i * kThreads;
@@ -250,6 +312,29 @@ conv_tiled_bf16_kernel(const BParams P)
         commit();
         __syncthreads();
         if (chunk + 1 < P.nchunks) prefetch(chunk + 1);       // in flight during the MFMA phase
+        if constexpr (WIDE) {
+            // raw tile -> channel-innermost patch: a 16-lane group takes (k group, image, row, 16 aligned pixels)
+            constexpr int NBLK = PWA / 16, T16 = KG * NI * PH_ * NBLK;
+            const unsigned short* R = reinterpret_cast<const unsigned short*>(sR);
+            const int a = tid & 15;
+            for (int t = tid >> 4; t < T16; t += kThreads / 16) {
+                const int g = t / (NI * PH_ * NBLK), r1 = t - g * (NI * PH_ * NBLK);
+                const int im = r1 / (PH_ * NBLK), r2 = r1 - im * (PH_ * NBLK);
+                const int py = r2 / NBLK, blk = r2 - py * NBLK;
+                const unsigned short* p0 = R + (8 * g + (a >> 2)) * CHROW + (im * PH_ + py) * PWA + blk * 16 + 4 * (a & 3);
+                const tpspp_u32x2 k0 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) tpspp_s16x4*)p0));
+                const tpspp_u32x2 k1 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) tpspp_s16x4*)(p0 + 4 * CHROW)));
+                const int px = blk * 16 + a - XOFF;
+                if (px >= 0 && px < PW) {
+                    u32x4 v;
+                    v[0] = k0[0]; v[1] = k0[1]; v[2] = k1[0]; v[3] = k1[1];
+                    sP[g * PSN + im * PS + py * PW + px] = v;
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KW, kx = tap - ky * KW;
@@ -304,6 +389,13 @@ conv_tiled_bf16_kernel(const BParams P)
     // (GELU goes through the general path: with erff inlined into the common one the compiler no longer keeps that
     //  path branch-free and every convolution pays for it -- measured: 1x1 32->64 0.11 -> 0.21 ms)
     const bool simple = P.res_mode == 0 && P.post_scale == nullptr && P.relu != 2;
+    // wide epilogue (bf16 output, whole tile inside the tensor, rows of whole 16-byte pieces): results go through the
+    // wavefront's [pixel][64 channels] LDS tile (8 bytes per lane and channel quad) and leave as 16-byte pieces of the
+    // NCHW rows, brought into pixel order by transposing reads -- 4 stores per lane and fragment instead of 64 (which
+    // were 36 % of a 3x3 64->64 layer's time)
+    const bool wide_out = !P.out_f32 && full_c && (P.Wo & 7) == 0 && (TW & 7) == 0 && oy0 + TH <= P.Ho && ox0 + TW <= P.Wo &&
+                          n0 + NI <= P.N && (reinterpret_cast<size_t>(P.out) & 15) == 0;       // uniform
+    unsigned short* const otile = reinterpret_cast<unsigned short*>(sAll) + wv * (32 * kOutPitch);
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
@@ -343,6 +435,11 @@ conv_tiled_bf16_kernel(const BParams P)
                 } else {
                     unsigned short* ob = reinterpret_cast<unsigned short*>(P.out) + ubase + (size_t)cu * HoWo;
                     const unsigned p01 = pack2_bf16(v[0], v[1]), p23 = pack2_bf16(v[2], v[3]);
+                    if (wide_out) {
+                        tpspp_u32x2 pk; pk[0] = p01; pk[1] = p23;
+                        *reinterpret_cast<tpspp_u32x2*>(otile + l31 * kOutPitch + cu + 4 * half) = pk;
+                        continue;
+                    }
                     if (valid && (full_c || co4 < P.Cout)) ob[lo] = (unsigned short)(p01 & 0xffffu);
                     if (valid && (full_c || co4 + 1 < P.Cout)) (ob + (size_t)HoWo)[lo] = (unsigned short)(p01 >> 16);
                     if (valid && (full_c || co4 + 2 < P.Cout)) (ob + (size_t)2 * HoWo)[lo] = (unsigned short)(p23 & 0xffffu);
@@ -350,7 +447,39 @@ conv_tiled_bf16_kernel(const BParams P)
                 }
             }
         }
+        if (wide_out) {
+            asm volatile("" ::: "memory");
+            const int a = lane & 15, q = lane >> 4;
+            const int tp = (wv * NF + f) * 32 + 8 * q;               // first pixel of this lane's pieces (tile-linear)
+            const int pim_ = tp / (TH * TW), tpi = tp - pim_ * (TH * TW);
+            const int pty = tpi / TW, ptx = tpi - pty * TW;
+            unsigned short* orow = reinterpret_cast<unsigned short*>(P.out) + ubase +
+                                   ((size_t)pim_ * P.Cout) * HoWo + (size_t)(oy0 + pty) * P.Wo + (ox0 + ptx);
+            u32x4 pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned short* pp = otile + (8 * q + (a >> 2)) * kOutPitch + 16 * i + 4 * (a & 3);
+                const tpspp_u32x2 lo2 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) tpspp_s16x4*)pp));
+                const tpspp_u32x2 hi2 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) tpspp_s16x4*)(pp + 4 * kOutPitch)));
+                pv[i][0] = lo2[0]; pv[i][1] = lo2[1]; pv[i][2] = hi2[0]; pv[i][3] = hi2[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(16 * i + a) * HoWo) = pv[i];
+            asm volatile("" ::: "memory");
+        }
     }
+}
+
+// wide staging applies: every source bf16 at full resolution, rows made of whole, aligned 16-byte pieces
+inline bool wide_staging_applies(const BParams& P)
+{
+    for (int i = 0; i < P.nsrc; ++i) {
+        const BSrc& s = P.src[i];
+        if (s.f32 || s.lh || s.lw || (s.W & 7) || (reinterpret_cast<size_t>(s.p) & 15)) return false;
+    }
+    return true;
 }
 
 template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3, int NF = 2>
@@ -359,6 +488,14 @@ void launch_b(const BParams& P, hipStream_t st)
     const int ctiles = (P.Cout + BN - 1) / BN;
     const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
                     (unsigned)(((P.N + NI - 1) / NI) * ctiles));
+    // (stride 2: the dense patch is 4x the output, the raw tile and its transposition cost more than the gather saves:
+    //  127 -> 154 us on the 32x128 -> 16x64 layers)
+    if constexpr (KH == 3 && SH == 1 && SW == 1 && !X3 && (TW % 16) == 0) {
+        if (wide_staging_applies(P)) {
+            hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3, NF, true>), grid, dim3(kThreads), 0, st, P);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3, NF>), grid, dim3(kThreads), 0, st, P);
 }
 
