@@ -10,35 +10,35 @@ OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 STEPS=${STEPS:-400}
 # 1. kernel trace + stats of the bench command
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
     python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline --no-extras > $OUT/bench_trace.log 2>&1
 # 2. PMC passes (own runs, nothing but --pmc)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- \
+  timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- \
       python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_pmc_$c.log 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -o copy -- \
+  timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -o copy -- \
       ./scripts/ubench/copy_bench > $OUT/copy_pmc_$c.log 2>&1
 done
 [ "${ONLY_BENCH:-0}" = "1" ] && { ls -R $OUT | head -30; tail -2 $OUT/bench_trace.log; exit 0; }
 # 3. kernel traces of the wider rows: whole TPS++ module, whole recogniser (F1), warp backward (F2)
 for w in module head backward; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o $w -- \
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -o $w -- \
       python3 scripts/bench_$w.py > $OUT/$w.log 2>&1
 done
 # 3b. the bf16 configuration: TPS_PP on bf16 tensors (BASELINE.json configs[2]) and the bf16 conv kernel beside MIOpen
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_bf16 -o module_bf16 -- \
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_bf16 -o module_bf16 -- \
     python3 scripts/bench_module.py 512 bf16only > $OUT/module_bf16.log 2>&1
-python3 scripts/bench_conv.py > $OUT/conv_bf16.log 2>&1
+timeout 300 python3 scripts/bench_conv.py > $OUT/conv_bf16.log 2>&1
 # 4. MFMA-busy counters (own pass) for the regressor kernels + the calibration kernel (pure MFMA)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc -o module -- \
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc -o module -- \
     python3 scripts/bench_module.py > $OUT/mfma_module.log 2>&1
 for mode in bf16only x3only; do
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc_$mode -o module -- \
+  timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc_$mode -o module -- \
       python3 scripts/bench_module.py 512 $mode > $OUT/mfma_module_$mode.log 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_x3 -o module_x3 -- \
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_x3 -o module_x3 -- \
     python3 scripts/bench_module.py 512 x3only > $OUT/module_x3.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_cal -o cal -- \
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_cal -o cal -- \
     ./scripts/ubench/mfma_bench > $OUT/mfma_cal.log 2>&1
 ls -R $OUT | head -60
 tail -2 $OUT/bench_trace.log

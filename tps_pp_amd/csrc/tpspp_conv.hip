@@ -23,6 +23,7 @@
 // backbones/resnet_v2_large.py:131-135 and layers/conv_layer.py:12-33 (BatchNorm folded on the host).
 // Bound: MFMA (fp32 matrix rate = 157 TFLOP/s peak).
 #include "tpspp_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -291,42 +292,50 @@ conv_tiled_f32_kernel(const ConvParams P)
     const bool simple = P.res_mode == 0 && P.post_scale == nullptr && P.relu != 2;
     const unsigned lo = valid ? (unsigned)((timg * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
     float* obase = P.out + ((size_t)n0 * P.Cout + co_base) * HoWo;     // uniform
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cu = 32 * h2 + 8 * g;                       // + 4*half (in `lo`) + e
-            const int co4 = co_base + cu + 4 * half;
-            float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (P.bias) {
-                if (full_c) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(P.bias + co4);
-                    b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) b[e] = co4 + e < P.Cout ? P.bias[co4 + e] : 0.0f;
+    // two loops, not one test inside the unrolled loop: the general form (residual, inlined erff, affine) would otherwise
+    // sit 32 times between the few instructions of the plain bias + ReLU layers (tpspp_conv_bf16_impl.h has the numbers)
+    const bool relu1 = P.relu == 1;
+    auto epilogue = [&](auto simple_c) {
+        constexpr bool SIMPLE = decltype(simple_c)::value;
+    #pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+    #pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cu = 32 * h2 + 8 * g;                       // + 4*half (in `lo`) + e
+                const int co4 = co_base + cu + 4 * half;
+                float b[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (P.bias) {
+                    if (full_c) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + co4);
+                        b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
+                    } else {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) b[e] = co4 + e < P.Cout ? P.bias[co4 + e] : 0.0f;
+                    }
                 }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = (h2 ? acc1[4 * g + e] : acc0[4 * g + e]) + b[e];
-                float* op = obase + (size_t)(cu + e) * HoWo;       // uniform
-                const bool ok = valid && (full_c || co4 + e < P.Cout);
-                if (simple) {
-                    if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
-                } else {
-                    const int co = co4 + e;
-                    const float rv = (P.res_mode && ok) ? (P.res + ((size_t)n0 * P.Cout + co_base + cu + e) * HoWo)[lo] : 0.0f;
-                    if (P.res_mode == 2) v = v + rv;
-                    if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
-                    else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (P.res_mode == 1) v = v + rv;
-                    if (P.post_scale && co < P.Cout) v = v * P.post_scale[co] + P.post_shift[co];
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = (h2 ? acc1[4 * g + e] : acc0[4 * g + e]) + b[e];
+                    float* op = obase + (size_t)(cu + e) * HoWo;       // uniform
+                    const bool ok = valid && (full_c || co4 + e < P.Cout);
+                    if constexpr (SIMPLE) {
+                        if (relu1) v = v > 0.0f ? v : 0.0f;
+                    } else {
+                        const int co = co4 + e;
+                        const float rv = (P.res_mode && ok) ? (P.res + ((size_t)n0 * P.Cout + co_base + cu + e) * HoWo)[lo] : 0.0f;
+                        if (P.res_mode == 2) v = v + rv;
+                        if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
+                        else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                        if (P.res_mode == 1) v = v + rv;
+                        if (P.post_scale && co < P.Cout) v = v * P.post_scale[co] + P.post_shift[co];
+                    }
+                    if (ok) op[lo] = v;
                 }
-                if (ok) op[lo] = v;
             }
         }
-    }
+    };
+    if (simple) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // ---- wide 1x1 kernel: large GEMMs (transformer projections over N*T tokens, 1x1 convs on big maps) -----------

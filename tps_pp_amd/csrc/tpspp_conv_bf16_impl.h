@@ -3,6 +3,7 @@
 // three-term-split instantiations): two translation units so that the ~70 instantiations compile in parallel.
 #pragma once
 #include "tpspp_common.h"
+#include <type_traits>
 
 typedef unsigned int tpspp_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int tpspp_u32x2 __attribute__((ext_vector_type(2)));
@@ -396,80 +397,89 @@ conv_tiled_bf16_kernel(const BParams P)
     const bool wide_out = !P.out_f32 && full_c && (P.Wo & 7) == 0 && (TW & 7) == 0 && oy0 + TH <= P.Ho && ox0 + TW <= P.Wo &&
                           n0 + NI <= P.N && (reinterpret_cast<size_t>(P.out) & 15) == 0;       // uniform
     unsigned short* const otile = reinterpret_cast<unsigned short*>(sAll) + wv * (32 * kOutPitch);
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
-        const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
-        const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                const int cu = 32 * h2 + 8 * g;                   // + 4*half (in `lo`) + e
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[f][h2][4 * g + e] + bq[h2][g][e];
-                    if (!simple) {
-                        const size_t o = ubase + (size_t)(cu + e) * HoWo + lo;
-                        const int co = co_base + cu + 4 * half + e;
-                        float rv = 0.0f;
-                        if (P.res_mode && valid && co < P.Cout)
-                            rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
-                                           : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
-                        if (P.res_mode == 2) v[e] = v[e] + rv;
-                        if (P.relu == 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                        else if (P.relu == 2) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-                        if (P.res_mode == 1) v[e] = v[e] + rv;
-                        if (P.post_scale && co < P.Cout) v[e] = v[e] * P.post_scale[co] + P.post_shift[co];
-                    } else if (P.relu == 1) {
-                        v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+    // The two forms of the value computation are two separate loops: with the test inside the (fully unrolled) loop the
+    // 128 copies of the general form -- residual loads, inlined erff -- sit between the few instructions the plain
+    // bias + ReLU layers execute, and a workgroup spent 11 k cycles (a third of its life) walking that code.
+    const bool relu1 = P.relu == 1;
+    auto epilogue = [&](auto simple_c) {
+        constexpr bool SIMPLE = decltype(simple_c)::value;
+    #pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int oy = oy0 + fty[f], ox = ox0 + ftx[f], n = n0 + fimg[f];
+            const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
+            const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
+    #pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    const int cu = 32 * h2 + 8 * g;                   // + 4*half (in `lo`) + e
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[f][h2][4 * g + e] + bq[h2][g][e];
+                        if constexpr (!SIMPLE) {
+                            const size_t o = ubase + (size_t)(cu + e) * HoWo + lo;
+                            const int co = co_base + cu + 4 * half + e;
+                            float rv = 0.0f;
+                            if (P.res_mode && valid && co < P.Cout)
+                                rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
+                                               : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
+                            if (P.res_mode == 2) v[e] = v[e] + rv;
+                            if (P.relu == 1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                            else if (P.relu == 2) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+                            if (P.res_mode == 1) v[e] = v[e] + rv;
+                            if (P.post_scale && co < P.Cout) v[e] = v[e] * P.post_scale[co] + P.post_shift[co];
+                        } else if (relu1) {
+                            v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                        }
+                    }
+                    const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
+                    if (P.out_f32) {
+                        float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (valid && (full_c || co4 + e < P.Cout)) (ob + (size_t)e * HoWo)[lo] = v[e];
+                    } else {
+                        unsigned short* ob = reinterpret_cast<unsigned short*>(P.out) + ubase + (size_t)cu * HoWo;
+                        const unsigned p01 = pack2_bf16(v[0], v[1]), p23 = pack2_bf16(v[2], v[3]);
+                        if (wide_out) {
+                            tpspp_u32x2 pk; pk[0] = p01; pk[1] = p23;
+                            *reinterpret_cast<tpspp_u32x2*>(otile + l31 * kOutPitch + cu + 4 * half) = pk;
+                            continue;
+                        }
+                        if (valid && (full_c || co4 < P.Cout)) ob[lo] = (unsigned short)(p01 & 0xffffu);
+                        if (valid && (full_c || co4 + 1 < P.Cout)) (ob + (size_t)HoWo)[lo] = (unsigned short)(p01 >> 16);
+                        if (valid && (full_c || co4 + 2 < P.Cout)) (ob + (size_t)2 * HoWo)[lo] = (unsigned short)(p23 & 0xffffu);
+                        if (valid && (full_c || co4 + 3 < P.Cout)) (ob + (size_t)3 * HoWo)[lo] = (unsigned short)(p23 >> 16);
                     }
                 }
-                const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
-                if (P.out_f32) {
-                    float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (valid && (full_c || co4 + e < P.Cout)) (ob + (size_t)e * HoWo)[lo] = v[e];
-                } else {
-                    unsigned short* ob = reinterpret_cast<unsigned short*>(P.out) + ubase + (size_t)cu * HoWo;
-                    const unsigned p01 = pack2_bf16(v[0], v[1]), p23 = pack2_bf16(v[2], v[3]);
-                    if (wide_out) {
-                        tpspp_u32x2 pk; pk[0] = p01; pk[1] = p23;
-                        *reinterpret_cast<tpspp_u32x2*>(otile + l31 * kOutPitch + cu + 4 * half) = pk;
-                        continue;
-                    }
-                    if (valid && (full_c || co4 < P.Cout)) ob[lo] = (unsigned short)(p01 & 0xffffu);
-                    if (valid && (full_c || co4 + 1 < P.Cout)) (ob + (size_t)HoWo)[lo] = (unsigned short)(p01 >> 16);
-                    if (valid && (full_c || co4 + 2 < P.Cout)) (ob + (size_t)2 * HoWo)[lo] = (unsigned short)(p23 & 0xffffu);
-                    if (valid && (full_c || co4 + 3 < P.Cout)) (ob + (size_t)3 * HoWo)[lo] = (unsigned short)(p23 >> 16);
+            }
+            if (wide_out) {
+                asm volatile("" ::: "memory");
+                const int a = lane & 15, q = lane >> 4;
+                const int tp = (wv * NF + f) * 32 + 8 * q;               // first pixel of this lane's pieces (tile-linear)
+                const int pim_ = tp / (TH * TW), tpi = tp - pim_ * (TH * TW);
+                const int pty = tpi / TW, ptx = tpi - pty * TW;
+                unsigned short* orow = reinterpret_cast<unsigned short*>(P.out) + ubase +
+                                       ((size_t)pim_ * P.Cout) * HoWo + (size_t)(oy0 + pty) * P.Wo + (ox0 + ptx);
+                u32x4 pv[4];
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned short* pp = otile + (8 * q + (a >> 2)) * kOutPitch + 16 * i + 4 * (a & 3);
+                    const tpspp_u32x2 lo2 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) tpspp_s16x4*)pp));
+                    const tpspp_u32x2 hi2 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) tpspp_s16x4*)(pp + 4 * kOutPitch)));
+                    pv[i][0] = lo2[0]; pv[i][1] = lo2[1]; pv[i][2] = hi2[0]; pv[i][3] = hi2[1];
                 }
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(16 * i + a) * HoWo) = pv[i];
+                asm volatile("" ::: "memory");
             }
         }
-        if (wide_out) {
-            asm volatile("" ::: "memory");
-            const int a = lane & 15, q = lane >> 4;
-            const int tp = (wv * NF + f) * 32 + 8 * q;               // first pixel of this lane's pieces (tile-linear)
-            const int pim_ = tp / (TH * TW), tpi = tp - pim_ * (TH * TW);
-            const int pty = tpi / TW, ptx = tpi - pty * TW;
-            unsigned short* orow = reinterpret_cast<unsigned short*>(P.out) + ubase +
-                                   ((size_t)pim_ * P.Cout) * HoWo + (size_t)(oy0 + pty) * P.Wo + (ox0 + ptx);
-            u32x4 pv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned short* pp = otile + (8 * q + (a >> 2)) * kOutPitch + 16 * i + 4 * (a & 3);
-                const tpspp_u32x2 lo2 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) tpspp_s16x4*)pp));
-                const tpspp_u32x2 hi2 = __builtin_bit_cast(tpspp_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) tpspp_s16x4*)(pp + 4 * kOutPitch)));
-                pv[i][0] = lo2[0]; pv[i][1] = lo2[1]; pv[i][2] = hi2[0]; pv[i][3] = hi2[1];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(16 * i + a) * HoWo) = pv[i];
-            asm volatile("" ::: "memory");
-        }
-    }
+    };
+    if (simple) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 }
 
 // wide staging applies: every source bf16 at full resolution, rows made of whole, aligned 16-byte pieces
