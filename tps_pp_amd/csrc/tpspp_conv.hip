@@ -803,14 +803,20 @@ TPSPP_EXPORT int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, co
         P.src[1] = P.src[0]; P.src[2] = P.src[0];
         const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Cout + 31) / 32), 1);
         TPSPP_REQUIRE(grid.y <= 65535, "tpspp_linear_ln_fwd: too many output features");
-        if (K >= 256) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false, 16>), grid, dim3(16 * kWave), 0, st, P, L);
+        // 16 wavefronts split K unless that leaves more workgroups than the chip holds at once (2 x 1024 threads per CU):
+        // a second round costs more than the twice longer MFMA chain of an 8-way split
+        const bool two_rounds = (long)grid.x * grid.y > 512;
+        if (K >= 256 && !two_rounds) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false, 16>), grid, dim3(16 * kWave), 0, st, P, L);
+        else if (K >= 256) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false, 8>), grid, dim3(8 * kWave), 0, st, P, L);
         else          hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<false, 4>), grid, dim3(4 * kWave), 0, st, P, L);
     } else {                               // out (M, Cout): the weight plays the image, x the weights
         P.src[0].p = w_gamma; P.src[0].W = Cout; P.Wi = Cout; P.Wo = Cout; P.Cout = M; P.wt = x;
         P.src[1] = P.src[0]; P.src[2] = P.src[0];
         const dim3 grid((unsigned)((Cout + 31) / 32), (unsigned)((M + 31) / 32), 1);
         TPSPP_REQUIRE(grid.y <= 65535, "tpspp_linear_ln_fwd: too many columns");
-        if (K >= 256) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true, 16>), grid, dim3(16 * kWave), 0, st, P, L);
+        const bool two_rounds = (long)grid.x * grid.y > 512;
+        if (K >= 256 && !two_rounds) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true, 16>), grid, dim3(16 * kWave), 0, st, P, L);
+        else if (K >= 256) hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true, 8>), grid, dim3(8 * kWave), 0, st, P, L);
         else          hipLaunchKernelGGL((conv1x1_skinny_ln_f32_kernel<true, 4>), grid, dim3(4 * kWave), 0, st, P, L);
     }
     return tpspp::check_launch("tpspp_linear_ln_fwd");
