@@ -480,6 +480,22 @@ conv1x1_skinny_f32_kernel(const ConvParams P)
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     constexpr int UB = 16;                             // MFMA steps per batch: 2*UB row loads in flight
     const int nit = (k_hi - k_lo + 1) >> 1;            // wave-uniform trip count
+    if (nit == UB && k_lo + 2 * UB <= K && co0 + 32 <= P.Cout && m0 + 32 <= HoWo) {
+        // the decoder's shapes: one full batch, nothing to guard; with 4 wavefronts per SIMD every instruction of this
+        // prologue is paid four times over (a trace put 1.9 k cycles before the last load's issue), so the row addresses
+        // are two running 32-bit offsets instead of a 64-bit product per load
+        float a[UB], b[UB];
+        unsigned oa = (unsigned)(k_lo + half) * (unsigned)P.Cout, ob = (unsigned)(k_lo + half) * (unsigned)HoWo;
+        const unsigned sa = 2u * (unsigned)P.Cout, sb = 2u * (unsigned)HoWo;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            a[u] = wp[oa]; b[u] = xp[ob];
+            oa += sa; ob += sb;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    } else
     for (int it0 = 0; it0 < nit; it0 += UB) {
         float a[UB], b[UB];
 #pragma unroll
@@ -499,11 +515,14 @@ conv1x1_skinny_f32_kernel(const ConvParams P)
 #pragma unroll
     for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
     __syncthreads();
-    // wavefront w < 4 finishes registers [4w, 4w+4): channels co0 + {0..3} + 8w + 4*half
-    if (!pix_ok || wv >= 4) return;
+    // every wavefront finishes 16 / min(NW, 16) accumulator registers (NW = 16: one output per lane, so that the bias /
+    // residual latencies of the sixteen registers overlap instead of following each other in four wavefronts);
+    // register r holds channel co0 + (r & 3) + 8 (r >> 2) + 4 half
+    constexpr int RPW = NW >= 16 ? 1 : 16 / NW;
+    if (!pix_ok || wv * RPW >= 16) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 4 * wv + q;
+    for (int q = 0; q < RPW; ++q) {
+        const int r = RPW * wv + q;
         const int c = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (c < P.Cout) {
             float v = (sRed[0][r][lane] + sRed[1][r][lane]) + (sRed[2][r][lane] + sRed[3][r][lane]);
@@ -566,6 +585,24 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
     float s1 = 0.0f, s2 = 0.0f;
     constexpr int UB = 16;
     const int nit = (k_hi - k_lo + 1) >> 1;
+    if (nit == UB && k_lo + 2 * UB <= K && co0 + 32 <= P.Cout && m0 + 32 <= HoWo) {      // as in conv1x1_skinny_f32_kernel
+        float a[UB], b[UB];
+        unsigned oa = (unsigned)(k_lo + half) * (unsigned)P.Cout, ob = (unsigned)(k_lo + half) * (unsigned)HoWo;
+        const unsigned sa = 2u * (unsigned)P.Cout, sb = 2u * (unsigned)HoWo;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            a[u] = wp[oa]; b[u] = xp[ob];
+            oa += sa; ob += sb;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const float xv = LN_ON_A ? a[u] : b[u];
+            s1 += xv;
+            s2 = fmaf(xv, xv, s2);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+        }
+    } else
     for (int it0 = 0; it0 < nit; it0 += UB) {
         float a[UB], b[UB];
 #pragma unroll
@@ -592,7 +629,8 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
     sSum[wv * 2 + half][l31] = s1;
     sSq[wv * 2 + half][l31] = s2;
     __syncthreads();
-    if (!pix_ok || wv >= 4) return;
+    constexpr int RPW = NW >= 16 ? 1 : 16 / NW;          // accumulator registers finished per wavefront (see the plain kernel)
+    if (!pix_ok || wv * RPW >= 16) return;
     float mean_l = 0.0f, rstd_l = 0.0f;
     if (!LN_ON_A) {                                        // statistics of this lane's pixel column
         float t1 = 0.0f, t2 = 0.0f;
@@ -602,8 +640,8 @@ conv1x1_skinny_ln_f32_kernel(const ConvParams P, const LnArgs L)
         rstd_l = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean_l * mean_l, 0.0f) + L.eps);
     }
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const int r = 4 * wv + qd;
+    for (int qd = 0; qd < RPW; ++qd) {
+        const int r = RPW * wv + qd;
         const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;    // row inside the tile
         const int c = co0 + cl;
         if (c < P.Cout) {
