@@ -348,9 +348,22 @@ dec_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pos, c
 // per position reads coalesced), Vc[b][h][position][64] (a lane per feature reads coalesced).  The new
 // position is used from registers, so nothing written by this kernel is read back by it.
 // Key p is valid iff p <= step and tokens[b][p] != <PAD>  (nrtr_decoder.py:100-102).
+// KV = float, or unsigned short: bf16 caches (TPSPP_HEAD_BF16; the position being decoded is used from its fp32 registers,
+// earlier positions as they were rounded when they were written)
+__device__ __forceinline__ float kvc_load(const float* p) { return *p; }
+__device__ __forceinline__ float kvc_load(const unsigned short* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
+__device__ __forceinline__ void kvc_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void kvc_store(unsigned short* p, float v)
+{
+    unsigned u = __builtin_bit_cast(unsigned, v);                // round to nearest even (finite activations)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    *p = (unsigned short)(u >> 16);
+}
+
+template <typename KV>
 __global__ void __launch_bounds__(256)
 attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
-                     float* __restrict__ Kc, float* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
+                     KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
                      int pad_idx, float* __restrict__ out)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -362,17 +375,17 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
     const float k = base[C + lane];
     const float v = base[2 * C + lane];
     const size_t bh = (size_t)b * H + h;
-    float* kc = Kc + bh * kDK * Lmax;
-    float* vc = Vc + bh * Lmax * kDK;
-    kc[(size_t)lane * Lmax + step] = k;
-    vc[(size_t)step * kDK + lane] = v;
+    KV* kc = Kc + bh * kDK * Lmax;
+    KV* vc = Vc + bh * Lmax * kDK;
+    kvc_store(kc + (size_t)lane * Lmax + step, k);
+    kvc_store(vc + (size_t)step * kDK + lane, v);
 
     const int pl = lane < step ? lane : 0;                // clamped: lanes >= step are masked below
     float sc = 0.0f;
     if (step > 0) {
         float kv[kDK];                                     // all 64 cached-key loads in flight together
 #pragma unroll
-        for (int d = 0; d < kDK; ++d) kv[d] = kc[(size_t)d * Lmax + pl];
+        for (int d = 0; d < kDK; ++d) kv[d] = kvc_load(kc + (size_t)d * Lmax + pl);
 #pragma unroll
         for (int d = 0; d < kDK; ++d) sc = fmaf(readlane_f(q, d), kv[d], sc);
     }
@@ -388,7 +401,7 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
     for (int p0 = 0; p0 < step; p0 += 16) {                // 16 cached value rows in flight
         float vv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) vv[u] = vc[(size_t)(p0 + u < step ? p0 + u : 0) * kDK + lane];
+        for (int u = 0; u < 16; ++u) vv[u] = kvc_load(vc + (size_t)(p0 + u < step ? p0 + u : 0) * kDK + lane);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const float pw = p0 + u < step ? readlane_f(p, (p0 + u) & (kWave - 1)) : 0.0f;
@@ -839,8 +852,13 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             // x = x + fc(self_attn(LN1(x)))                          transformer_layers.py:150-154
             rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_QKV_W], w[D_QKV_CS], 3 * C, w[D_QKV_B], 0, nullptr, 1, qkv, stream);
             if (rc) return rc;
-            hipLaunchKernelGGL(attn_dec_self_kernel, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
-                               Vc[l], tokens, Lt, padding_idx, a);
+            if (b16)
+                hipLaunchKernelGGL(attn_dec_self_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
+                                   L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
+                                   tokens, Lt, padding_idx, a);
+            else
+                hipLaunchKernelGGL(attn_dec_self_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
+                                   Vc[l], tokens, Lt, padding_idx, a);
             g.cm(w[D_WFC], w[D_BFC], a, C, C, N, y, 0, x);            // y = x + fc(a)
             // x = y + fc(enc_attn(LN2(y), enc, enc))                   transformer_layers.py:156-159
             rc = tpspp_linear_ln_fwd(y, C, N, 1e-5f, w[D_Q_W], w[D_Q_CS], C, w[D_Q_B], 0, nullptr, 1, qkv, stream);
