@@ -217,25 +217,51 @@ conv_tiled_f32_kernel(const ConvParams P)
     ConvSrc cur = P.src[0];
     const int nchunks = (P.Cin + KC - 1) / KC;
 
+    // staging: this thread's patch elements are the same in every chunk -- logical input row (or -1: padding / outside
+    // the tile / beyond the batch), column, channel inside the chunk and image are worked out once.  (Decoding them, two
+    // integer divisions by the upsampling factors and a predicated load per element and chunk made the staging 8.7 vector
+    // instructions per MFMA -- 5 k per wavefront in a 64 -> 64 layer, `SQ_INSTS_VALU` -- and held the matrix pipe at 60 %.)
+    int t_iy[NP], t_ix[NP], t_ci[NP], t_im[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int e = tid + i * kThreads;
+        const int im = NI > 1 ? e / PATCH1 : 0, e1 = e - im * PATCH1;
+        const int ci = e1 / PS, r = e1 - ci * PS;
+        const int py = r / PW, px = r - py * PW;
+        const int iy = iy_base + py, ix = ix_base + px;
+        const bool ok = e < PATCH && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
+        t_iy[i] = ok ? iy : -1; t_ix[i] = ix; t_ci[i] = ci; t_im[i] = im;
+    }
+
     auto prefetch = [&](int chunk) {
         const int c0 = chunk * KC;
         while (c0 >= cbase + cur.C) { cbase += cur.C; ++s; cur = P.src[s]; }
         const int plane = cur.H * cur.W;
-        const float* sp = cur.p + ((size_t)n0 * cur.C + (c0 - cbase)) * plane;
-        const size_t img_stride = (size_t)cur.C * plane;
+        const float* sp = cur.p + ((size_t)n0 * cur.C + (c0 - cbase)) * plane;       // uniform
+        const int img_stride = cur.C * plane;
+        const int cleft = P.Cin - c0;                                 // channels of the concatenation left from c0 on
+        const bool pow2 = ((cur.uh & (cur.uh - 1)) | (cur.uw & (cur.uw - 1))) == 0;   // uniform
+        // every load is unconditional (a predicate per load puts each one in its own basic block behind an s_waitcnt):
+        // invalid elements read the chunk's first element and are zeroed by a select
+        if (pow2) {                                                   // nearest upsampling by 1 / 2 / 4: shifts
+            const int lh = 31 - __builtin_clz(cur.uh), lw = 31 - __builtin_clz(cur.uw);
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int e = tid + i * kThreads;
-            float v = 0.0f;
-            if (e < PATCH) {
-                const int im = NI > 1 ? e / PATCH1 : 0, e1 = e - im * PATCH1;
-                const int ci = e1 / PS, r = e1 - ci * PS;
-                const int py = r / PW, px = r - py * PW;
-                const int iy = iy_base + py, ix = ix_base + px;
-                if (iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (c0 + ci) < P.Cin && (n0 + im) < P.N)
-                    v = sp[im * img_stride + (size_t)ci * plane + (iy / cur.uh) * cur.W + (ix / cur.uw)];
+            for (int i = 0; i < NP; ++i) {
+                const bool ok = t_iy[i] >= 0 && t_ci[i] < cleft;
+                const unsigned off = ok ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + (t_iy[i] >> lh) * cur.W +
+                                                     (t_ix[i] >> lw)) : 0u;
+                const float v = sp[off];
+                rp[i] = ok ? v : 0.0f;
             }
-            rp[i] = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const bool ok = t_iy[i] >= 0 && t_ci[i] < cleft;
+                const unsigned off = ok ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + (t_iy[i] / cur.uh) * cur.W +
+                                                     t_ix[i] / cur.uw) : 0u;
+                const float v = sp[off];
+                rp[i] = ok ? v : 0.0f;
+            }
         }
         // weights: (chunk, tap, ci, cout) -> this chunk's slab is KCK rows of Cout floats
         const float* wp = P.wt + (size_t)chunk * KCK * P.Cout + co_base;
@@ -243,10 +269,9 @@ conv_tiled_f32_kernel(const ConvParams P)
         for (int i = 0; i < NW4; ++i) {
             const int e = tid + i * kThreads;                     // float4 index inside the slab
             const int kk = e / (BN / 4), c4 = e - kk * (BN / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kk < KCK && co_base + 4 * c4 + 3 < P.Cout)
-                v = *reinterpret_cast<const float4*>(wp + (size_t)kk * P.Cout + 4 * c4);
-            rw[i] = v;
+            const bool ok = kk < KCK && co_base + 4 * c4 + 3 < P.Cout;
+            const float4 v = *reinterpret_cast<const float4*>(wp + (ok ? (size_t)kk * P.Cout + 4 * c4 : 0));
+            rw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto commit = [&]() {
