@@ -20,6 +20,10 @@
 namespace {
 
 constexpr int kWave = 64;
+#ifndef FRONT_FENCE
+#define FRONT_FENCE 0
+#endif
+constexpr bool FENCE = FRONT_FENCE;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct FrontParams {
@@ -54,7 +58,7 @@ __device__ __forceinline__ void dense_relu(const float* __restrict__ slab, const
         a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(2 * ks + half) * 64 + 32 + l31], in[ks], a1, 0, 0, 0);
         // fence the scheduler every 8 steps: left alone it hoists every weight-fragment read of the
         // whole tile to the top and spills
-        if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        if (FENCE && (ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int ks = 0; ks < 32; ++ks) {
@@ -74,7 +78,7 @@ __device__ __forceinline__ void accumulate_block(const float* __restrict__ slab,
     for (int ks = 0; ks < 32; ++ks) {
         g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(2 * ks + half) * 64 + l31], f[ks], g0, 0, 0, 0);
         g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(slab[(2 * ks + half) * 64 + 32 + l31], f[ks], g1, 0, 0, 0);
-        if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        if (FENCE && (ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -103,6 +107,12 @@ front_kernel(const FrontParams P)
     const int n = blockIdx.y;
     const int tiles_per_img = (HW + kFrontTile - 1) / kFrontTile;
     for (int tile = blockIdx.x; tile < tiles_per_img; tile += gridDim.x) {
+        // the slabs do not change from tile to tile; hidden from the optimiser, which would otherwise hoist their reads
+        // out of this loop and spill them (tpspp_dgab.hip)
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const float* tW0 = sW0 + opaque; const float* tW1 = sW1 + opaque; const float* tW2 = sW2 + opaque;
+        const float* tWg = sWg + opaque; const float* tB = sB + opaque;
         const int px = tile * kFrontTile + wv * 32 + l31;
         const bool live = px < HW;
         const int pxc = live ? px : HW - 1;
@@ -131,32 +141,32 @@ front_kernel(const FrontParams P)
         for (int i = 0; i < 16; ++i) { g0[i] = 0.0f; g1[i] = 0.0f; }
         float f[32];
         // feat0: compute, store, fold into feat_grid; then feat1, feat2 -- one feature set live at a time
-        dense_relu<16>(sW0, sB, i0, half, l31, f);
+        dense_relu<16>(tW0, tB, i0, half, l31, f);
         if (live) {
             char* q = reinterpret_cast<char*>(P.feat0 + (size_t)n * 64 * HW);
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) *reinterpret_cast<float*>(q + feat(ks, 0) * cstride + out_off) = f[ks];
         }
-        accumulate_block(sWg, f, half, l31, g0, g1);
-        dense_relu<16>(sW1, sB + 64, i1, half, l31, f);
+        accumulate_block(tWg, f, half, l31, g0, g1);
+        dense_relu<16>(tW1, tB + 64, i1, half, l31, f);
         if (live) {
             char* q = reinterpret_cast<char*>(P.feat1 + (size_t)n * 64 * HW);
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) *reinterpret_cast<float*>(q + feat(ks, 0) * cstride + out_off) = f[ks];
         }
-        accumulate_block(sWg + 64 * 64, f, half, l31, g0, g1);
-        dense_relu<32>(sW2, sB + 128, i2, half, l31, f);
+        accumulate_block(tWg + 64 * 64, f, half, l31, g0, g1);
+        dense_relu<32>(tW2, tB + 128, i2, half, l31, f);
         if (live && ((y | xx) & 1) == 0) {                      // one lane of each 2x2 block keeps feat2
             char* q = reinterpret_cast<char*>(P.feat2 + (size_t)n * 64 * h2 * w2);
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) *reinterpret_cast<float*>(q + feat(ks, 0) * cstride2 + out2_off) = f[ks];
         }
-        accumulate_block(sWg + 2 * 64 * 64, f, half, l31, g0, g1);
+        accumulate_block(tWg + 2 * 64 * 64, f, half, l31, g0, g1);
         if (live) {
             char* q = reinterpret_cast<char*>(P.feat_grid + (size_t)n * 64 * HW);
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) {
-                const float v = (ks < 16 ? g0[ks & 15] : g1[ks & 15]) + sB[192 + feat(ks, half)];
+                const float v = (ks < 16 ? g0[ks & 15] : g1[ks & 15]) + tB[192 + feat(ks, half)];
                 *reinterpret_cast<float*>(q + feat(ks, 0) * cstride + out_off) = v > 0.0f ? v : 0.0f;
             }
         }
