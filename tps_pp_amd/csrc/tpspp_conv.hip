@@ -274,16 +274,16 @@ conv_tiled_f32_kernel(const ConvParams P)
             rw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&]() {                  // (only a last, partial round of elements is predicated)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int e = tid + i * kThreads;
-            if (e < PATCH) sP[e] = rp[i];
+            if ((i + 1) * kThreads <= PATCH || e < PATCH) sP[e] = rp[i];
         }
 #pragma unroll
         for (int i = 0; i < NW4; ++i) {
             const int e = tid + i * kThreads;
-            if (e < KCK * BN / 4) reinterpret_cast<float4*>(sW)[e] = rw[i];
+            if ((i + 1) * kThreads <= KCK * BN / 4 || e < KCK * BN / 4) reinterpret_cast<float4*>(sW)[e] = rw[i];
         }
     };
 
