@@ -279,13 +279,13 @@ conv_tiled_bf16_kernel(const BParams P)
 #pragma unroll
             for (int i = 0; i < NPL; ++i) {
                 const int e = tid + i * kThreads;
-                if (e < NPIECE) sR[e] = rq[i];
+                if ((i + 1) * kThreads <= NPIECE || e < NPIECE) sR[e] = rq[i];      // only a partial last round is predicated
             }
         } else
 #pragma unroll
         for (int i = 0; i < NPOS; ++i) {
             const int e = tid + i * kThreads;
-            if (e < PSN) {
+            if ((i + 1) * kThreads <= PSN || e < PSN) {
 #pragma unroll
                 for (int g = 0; g < KG; ++g) {
                     u32x4 v;
@@ -301,7 +301,7 @@ conv_tiled_bf16_kernel(const BParams P)
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
             const int e = tid + i * kThreads;
-            if (e < WSLAB) {
+            if ((i + 1) * kThreads <= WSLAB || e < WSLAB) {
                 sW[e] = rw[i];
                 if constexpr (X3) sW[WSLAB + e] = rwl[i];
             }
