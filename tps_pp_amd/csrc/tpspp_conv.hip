@@ -402,10 +402,12 @@ conv1x1_wide_f32_kernel(const ConvParams P)
         for (int i = 0; i < 4; ++i) {
             const int k = c0 + srow + 8 * i;
             const bool k_ok = k < P.Cin;
-            rx[i] = (k_ok && x_ok) ? *reinterpret_cast<const float4*>(xp + (size_t)k * HoWo + m0 + 4 * sc4)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-            rw[i] = (k_ok && w_ok) ? *reinterpret_cast<const float4*>(P.wt + (size_t)k * P.Cout + co_base + 4 * sc4)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            // unconditional loads (a predicated load sits in its own basic block behind an s_waitcnt); out-of-range
+            // rows / columns re-read the slab's first float4 and are zeroed by the select
+            const float4 vx = *reinterpret_cast<const float4*>(xp + ((k_ok && x_ok) ? (size_t)k * HoWo + m0 + 4 * sc4 : 0));
+            const float4 vw = *reinterpret_cast<const float4*>(P.wt + ((k_ok && w_ok) ? (size_t)k * P.Cout + co_base + 4 * sc4 : 0));
+            rx[i] = (k_ok && x_ok) ? vx : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[i] = (k_ok && w_ok) ? vw : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto commit = [&]() {
@@ -432,7 +434,28 @@ conv1x1_wide_f32_kernel(const ConvParams P)
         __syncthreads();
     }
     const int pix = m0 + wv * 32 + l31;
-    if (pix < HoWo) {
+    // plain layers (bias, optional ReLU, every channel of the tile present) and the general form are two loops (see
+    // conv_tiled_f32_kernel); the bias of a register quad is one float4
+    const bool simple = P.res_mode == 0 && P.post_scale == nullptr && P.relu != 2 && co_base + WBN <= P.Cout && P.bias != nullptr;
+    if (pix < HoWo && simple) {
+        const bool relu1 = P.relu == 1;
+        float* ob = P.out + ((size_t)n * P.Cout + co_base) * HoWo + pix;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = 32 * j + 8 * g + 4 * half;
+                const float4 b4 = *reinterpret_cast<const float4*>(P.bias + co_base + cl);
+                const float bq[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[j][4 * g + e] + bq[e];
+                    if (relu1) v = v > 0.0f ? v : 0.0f;
+                    ob[(size_t)(cl + e) * HoWo] = v;
+                }
+            }
+        }
+    } else if (pix < HoWo) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
