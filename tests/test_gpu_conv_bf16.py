@@ -210,3 +210,22 @@ def test_front_bf16x3_fused_against_fp32_reference(cuda):
         assert g_.dtype == torch.float32
         err = float((g_.cpu().double() - r_).abs().max())
         assert err <= 2e-5 * float(r_.abs().max()), (name, err)
+
+
+def test_front_bf16_persistent_trips_match_single_image_runs(cuda):
+    """The fused front runs persistent workgroups (one per CU, a wavefront walking every 1024th row segment): a batch
+    large enough for several trips per wavefront, and an odd one, must give exactly what image-by-image calls give."""
+    from tps_pp_amd import TPS_PP
+    torch.manual_seed(5)
+    m = TPS_PP().eval().to(cuda)
+    fw = ops.FrontWeightsBf16(m)
+    N, H, W = 21, 32, 128                                   # 21 * 32 * 4 = 2688 segments: 2-3 trips per wavefront
+    o0 = torch.randn(N, 32, H, W, device=cuda).bfloat16()
+    o1 = torch.randn(N, 32, H, W, device=cuda).bfloat16()
+    x = torch.randn(N, 64, H // 2, W // 2, device=cuda).bfloat16()
+    for dt in (torch.bfloat16, torch.float32):
+        whole = ops.front_bf16(o0, o1, x, fw, dt)
+        for n in (0, 7, 20):
+            one = ops.front_bf16(o0[n:n + 1].contiguous(), o1[n:n + 1].contiguous(), x[n:n + 1].contiguous(), fw, dt)
+            for a, b in zip(whole, one):
+                assert torch.equal(a[n:n + 1], b)

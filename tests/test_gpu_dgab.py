@@ -135,3 +135,25 @@ def test_front_matches_pytorch_cpu(cuda):
     for got, ref, nm in ((f0, r0, "feat0"), (f1, r1, "feat1"), (f2, r2, "feat2"), (fg, rg, "feat_grid")):
         assert got.shape == ref.shape
         assert (got.cpu() - ref).abs().max().item() <= 2e-5, nm
+
+
+def test_point_stage_and_dgab_persistent_trips_match_small_batches(cuda):
+    """tpe_points runs one persistent workgroup per CU with two images per trip, the DGAB chain eight wavefronts per
+    workgroup walking 32-row tiles: a batch with several trips and an odd image count gives what slices of it give."""
+    torch.manual_seed(6)
+    m = TPS_PP().eval().to(cuda)
+    N = 1031
+    en = torch.randn(N, 64, 2, 16, device=cuda)
+    ctrl, p = ops.tpe_points(en, m.TPE)
+    for lo, hi in ((0, 3), (512, 517), (1028, 1031)):
+        c1, p1 = ops.tpe_points(en[lo:hi].contiguous(), m.TPE)
+        assert torch.equal(ctrl[lo:hi], c1) and torch.equal(p[lo:hi], p1)
+    blk = m.TPE.atten[0]
+    N2 = 37
+    x = torch.randn(N2, 64, 16, 64, device=cuda)
+    y = torch.randn(N2, 64, 32, device=cuda)
+    for w, fn in ((ops.DgabWeights(blk), ops.dgab), (ops.DgabWeightsBf16(blk), ops.dgab_bf16),
+                  (ops.DgabWeightsBf16(blk, x3=True), ops.dgab_bf16)):
+        whole = fn(x, y, w)
+        for lo, hi in ((0, 1), (17, 20), (36, 37)):
+            assert torch.equal(whole[lo:hi], fn(x[lo:hi].contiguous(), y[lo:hi].contiguous(), w))
