@@ -222,6 +222,8 @@ conv_tiled_f32_kernel(const ConvParams P)
     // integer divisions by the upsampling factors and a predicated load per element and chunk made the staging 8.7 vector
     // instructions per MFMA -- 5 k per wavefront in a 64 -> 64 layer, `SQ_INSTS_VALU` -- and held the matrix pipe at 60 %.)
     int t_iy[NP], t_ix[NP], t_ci[NP], t_im[NP];
+    unsigned t_off[NP];
+    int t_src = -1;                                                   // the source t_off was computed for
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int e = tid + i * kThreads;
@@ -243,7 +245,22 @@ conv_tiled_f32_kernel(const ConvParams P)
         const bool pow2 = ((cur.uh & (cur.uh - 1)) | (cur.uw & (cur.uw - 1))) == 0;   // uniform
         // every load is unconditional (a predicate per load puts each one in its own basic block behind an s_waitcnt):
         // invalid elements read the chunk's first element and are zeroed by a select
-        if (pow2) {                                                   // nearest upsampling by 1 / 2 / 4: shifts
+        if (cur.uh == 1 && cur.uw == 1 && cleft >= KC) {
+            // the common case -- a source at full resolution, a whole chunk: the element's offset from the chunk's first
+            // channel does not depend on the chunk (t_off, worked out when the source was entered), so an element is one
+            // load and one select
+            if (t_src != s) {
+                t_src = s;
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    t_off[i] = t_iy[i] >= 0 ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + t_iy[i] * cur.W + t_ix[i]) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const float v = sp[t_off[i]];
+                rp[i] = t_iy[i] >= 0 ? v : 0.0f;
+            }
+        } else if (pow2) {                                            // nearest upsampling by 1 / 2 / 4: shifts
             const int lh = 31 - __builtin_clz(cur.uh), lw = 31 - __builtin_clz(cur.uw);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
