@@ -43,18 +43,35 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Wavefront-wide reductions on the DPP path of the vector ALU (quad swaps, half-row and row mirrors, row broadcasts,
+// one v_readlane): 7 instructions and no LDS traffic, against 6 ds_bpermute round trips for the __shfl_xor butterfly --
+// the gate kernel does 24 of them per plane.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<0xB1>(0.0f, v);                 // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(0.0f, v);                 // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(0.0f, v);                // row_half_mirror
+    v += dpp_f<0x140>(0.0f, v);                // row_mirror: every lane holds its row's sum
+    v += dpp_f<0x142, 0xa>(0.0f, v);           // row_bcast15 into rows 1 and 3
+    v += dpp_f<0x143, 0xc>(0.0f, v);           // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return readlane_f(v, 63);
 }
 
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v, v));
+    v = fmaxf(v, dpp_f<0x4E>(v, v));
+    v = fmaxf(v, dpp_f<0x141>(v, v));
+    v = fmaxf(v, dpp_f<0x140>(v, v));
+    v = fmaxf(v, dpp_f<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+    return readlane_f(v, 63);
 }
 
 // ------------------------------------------------------------------------------------------------
