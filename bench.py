@@ -10,9 +10,13 @@ grid_sample HIP kernel on a batch of 512 synthetic 3x32x100 fp32 images, 20 fidu
 points = fiducial lattice + 0.05 * noise.  Inputs are resident in HBM before the timed region; the
 steps rotate over enough distinct input/output buffers (> 256 MB) that the Infinity Cache cannot
 hold the working set.  Weak scaling: every rank rectifies its own 512-image batches, there is no
-data-path collective (images are independent).  `value` and `ms_per_step` come from HIP events on the
-launch stream over exactly K steps (max over ranks); the host wall clock around the same K steps
-(barrier + synchronize on both sides) is reported beside it as `wall_ms_per_step`.
+data-path collective (images are independent).  The K steps go round-robin to
+`--streams` HIP streams (default 3): consecutive batches are independent, so a serving loop has no reason to
+serialise their launches, and on one stream every launch waits for the previous one to drain (launch gap + ramp =
+a quarter of a 39-MB step).  `value` and `ms_per_step` come from HIP events -- one before the first launch, one per
+stream after its last launch, the latest one counts -- over exactly K steps (max over ranks); the same K steps on ONE
+stream are timed right after and reported as `roofline.one_stream`; the host wall clock around the K steps
+(barrier + synchronize on both sides) is reported as `wall_ms_per_step`.
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself (torch.distributed.run as a
 child process; the parent never touches a GPU) and passes rank 0's JSON line through.  At N > 1 the line
@@ -345,12 +349,34 @@ def recognizer_sharded(dev, world, rank, per_rank=256):
         for _ in range(3):
             dt, res = once()
             times.append(dt)
-    tt = torch.tensor([min(times)], device=dev, dtype=torch.float64)
+    tt = torch.tensor([min(times), -min(times)], device=dev, dtype=torch.float64)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     payload = per_rank * 40 * 92 * 4
-    return {"images_per_s": n_total / float(tt[0]), "ms_per_batch": float(tt[0]) * 1e3, "images_per_rank": per_rank,
+    # the collective alone (HIP events on the stream the process group enqueues behind): separates compute from the
+    # all-gather in a scaling curve
+    scores = torch.zeros((per_rank, 40, 92), device=dev)
+    for _ in range(3):
+        tdist.all_gather_rows(scores, n_total)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record()
+    for _ in range(20):
+        tdist.all_gather_rows(scores, n_total)
+    g1.record()
+    torch.cuda.synchronize(dev)
+    ag = torch.tensor([g0.elapsed_time(g1) * 1e3 / 20], device=dev, dtype=torch.float64)
+    dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+    return {"images_per_s": n_total / float(tt[0]), "ms_per_batch": float(tt[0]) * 1e3,
+            "ms_per_batch_fastest_rank": -float(tt[1]) * 1e3, "images_per_rank": per_rank,
+            "timing": "host clock around barrier -> decode + all-gather + strings -> synchronize -> barrier, min of 3, "
+                      "max over ranks (a 30 ms step: the ~0.1 ms of the two barriers is inside it)",
+            "all_gather_us": float(ag[0]),
+            "all_gather_timing": "HIP events around 20 back-to-back all-gathers of the same payload, max over ranks",
             "strings_returned": len(res), "collective": "all_gather_into_tensor of (images_per_rank, 40, 92) fp32 scores",
             "all_gather_bytes_per_rank": payload, "backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
+            "env": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG",
+                                                   "MASTER_ADDR", "LOCAL_WORLD_SIZE")},
             "data": "synthetic images, random-init weights (replicated)"}
 
 
@@ -371,6 +397,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the steps are launched on, round-robin (1 = every launch waits for the previous one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--precondition-ms", type=float, default=300.0,
@@ -421,13 +449,23 @@ def main():
         ctrls.append(ident_d[None] + 0.05 * (torch.rand((BATCH, F, 2), generator=g, device=dev) * 2 - 1))
     outs = [torch.empty((BATCH, C, H, W), device=dev) for _ in range(nbuf)]
 
-    # one validated, pre-marshalled tpspp_warp_fwd call per buffer set (ops.WarpPlan): a step is exactly one
-    # foreign call = one kernel launch; per-call tensor checks in Python would cost about a launch period
-    plans = [ops.WarpPlan(imgs[j], ctrls[j], gg.inv_delta_C, gg.P_hat, (H, W), outs[j], P_hat_t=p_hat_t,
-                          table_flags=flags) for j in range(nbuf)]
+    # one validated, pre-marshalled tpspp_warp_fwd call per (buffer set, stream) (ops.WarpPlan: the launch goes to the
+    # stream that is current when the plan is built): a step is exactly one foreign call = one kernel launch; per-call
+    # tensor checks in Python would cost about a launch period
+    S = max(1, min(int(a.streams), 8))
+    main_stream = torch.cuda.current_stream(dev)
+    streams = [main_stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    plans = []
+    for j in range(nbuf):
+        row = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                row.append(ops.WarpPlan(imgs[j], ctrls[j], gg.inv_delta_C, gg.P_hat, (H, W), outs[j], P_hat_t=p_hat_t,
+                                        table_flags=flags))
+        plans.append(row)
 
-    def step(i):
-        plans[i % nbuf].run()
+    def step(i, nstreams=S):
+        plans[i % nbuf][i % nstreams].run()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -444,24 +482,38 @@ def main():
                 j += 1
             torch.cuda.synchronize(dev)
 
+    def timed(nsteps, nstreams, first):
+        """Exactly `nsteps` steps, step i on stream i % nstreams; ms between an event recorded before the first launch
+        (every stream waits for it) and the latest of the per-stream events recorded after the last launches."""
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
+        t0 = time.perf_counter()
+        e0.record(streams[0])
+        for st in streams[1:nstreams]:
+            st.wait_event(e0)
+        for i in range(nsteps):
+            step(first + i, nstreams)
+        for k in range(nstreams):
+            e1[k].record(streams[k])
+        torch.cuda.synchronize(dev)
+        return max(e0.elapsed_time(e) for e in e1), time.perf_counter() - t0
+
     for i in range(a.warmup):
         step(i)
     barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()                                                    # on the launch stream
-    for i in range(a.steps):
-        step(a.warmup + i)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    ev_ms, dt = timed(a.steps, S, a.warmup)
     if world > 1:
         dist.barrier()
-    ev_ms = e0.elapsed_time(e1)
+    # the same steps with every launch behind the previous one (one stream): what a kernel trace shows as the
+    # kernel's own duration; not part of `value`
+    barrier()
+    ev1_ms, _ = timed(a.steps, 1, a.warmup) if S > 1 else (ev_ms, dt)
     if world > 1:
-        tt = torch.tensor([dt, ev_ms], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, ev_ms, ev1_ms, -ev_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ev_ms = float(tt[0]), float(tt[1])
+        dt, ev_ms, ev1_ms, ev_ms_min = float(tt[0]), float(tt[1]), float(tt[2]), -float(tt[3])
+    else:
+        ev_ms_min = ev_ms
 
     # ---- parity spot-check of what was just measured (not timed) ----
     max_err = None
@@ -502,7 +554,9 @@ def main():
     rec = None
     if rank == 0:
         launch_us = ev_ms * 1e3 / a.steps
+        launch1_us = ev1_ms * 1e3 / a.steps
         achieved = BYTES_PER_IMG * BATCH / (launch_us * 1e-6) / 1e9
+        achieved1 = BYTES_PER_IMG * BATCH / (launch1_us * 1e-6) / 1e9
         traffic, traffic_kernel = load_traffic()
         kernel = "tps_warp_pair_kernel<20,3,32,100,32,100,false,false>" if pair_kernel else \
             "tps_warp_lds_mirror_kernel<20,3,32,100,false>"
@@ -525,9 +579,13 @@ def main():
                                    "20 fiducials, inputs resident in HBM",
                        "batch_per_gpu": BATCH, "rotating_buffer_sets": int(nbuf),
                        "working_set_MB": round(nbuf * per_set / 1e6, 1),
-                       "timing": "HIP events on the launch stream around exactly `steps` launches, max over ranks "
-                                 "(`value`, `ms_per_step`); `wall_ms_per_step` = host clock around the same launches "
-                                 "incl. the final synchronize",
+                       "streams": S,
+                       "timing": f"step i is launched on HIP stream i % {S} (consecutive batches are independent); HIP "
+                                 "events: one before the first launch (all streams wait for it), one per stream after "
+                                 "its last launch, the latest counts; exactly `steps` launches, max over ranks (`value`, "
+                                 "`ms_per_step`); `wall_ms_per_step` = host clock around the same launches incl. the "
+                                 "final synchronize; `roofline.one_stream` = the same steps on one stream",
+                       "ms_per_step_min_over_ranks": ev_ms_min / a.steps,
                        "preconditioning": f"{a.precondition_ms:.0f} ms of plain device copies over the bench buffers "
                                           "before the warm-up steps (clock ramp; not steps)"},
             "max_abs_err_vs_oracle": max_err,
@@ -537,6 +595,12 @@ def main():
                                            f"{traffic_kernel}; not re-measured in this run)" if traffic else None,
                          "kernel": kernel,
                          "launch_us": launch_us,
+                         "launch_us_is": f"time of `steps` launches on {S} streams / steps: launches overlap, so this is the "
+                                         "period between launches, not one kernel's start-to-end duration (a kernel trace "
+                                         "shows the latter: compare it with one_stream.launch_us, and launch_us with "
+                                         "(last end - first start) / launches of the trace)",
+                         "one_stream": {"launch_us": launch1_us, "achieved": achieved1, "frac": achieved1 / HBM_PEAK_GBS,
+                                        "note": "every launch waits for the previous one to drain: kernel duration + launch gap"},
                          "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH,
                          "plain_copy_of_the_image_bytes": {
                              "launch_us": copy_us,

@@ -91,11 +91,12 @@ int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, int cols, flo
 int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, int Wo, int F);
 
 /*
- * The prepared form of a mirror-symmetric classic table that the image-pair kernel reads: the (F+3, n) transposed
- * table of tpspp_transpose_p_hat followed by a packed copy in that kernel's thread order (a thread's F+3 values as
- * 16-byte pieces, [wavefront][(F+3+3)/4][lane][4]; thread -> pixel: a half-wavefront owns 4 columns x 8 rows of the
- * left half of the upper half-image).  tpspp_prepared_table_floats: buffer size in floats, 0 when the geometry has
- * no prepared form (needs Ho % 16 == 0, Wo % 4 == 0).  One-off preparation, like the transposition.  Pass the buffer
+ * The prepared form of a mirror-symmetric classic table that the image-pair and in-place kernels read: the (F+3, n)
+ * transposed table of tpspp_transpose_p_hat followed by a packed copy in those kernels' thread order (a thread's F+3
+ * values per quadrant pixel as 16-byte pieces, [wavefront][quadrant pixels per thread][(F+3+3)/4][lane][4]; thread ->
+ * pixel: a half-wavefront owns 4 columns x 8 rows of the left half of the upper half-image, a thread 1 - 3 such rows
+ * groups depending on the geometry).  tpspp_prepared_table_floats: buffer size in floats, 0 when the geometry has no
+ * prepared form (needs Ho % 16 == 0, Wo % 4 == 0, at most 13 wavefronts of quadrant pixels).  One-off preparation, like the transposition.  Pass the buffer
  * as p_hat_t together with TPSPP_TABLE_PACKED (and TPSPP_TABLE_MIRROR4 once the symmetry has been verified).
  * replaces nothing in the reference (its table is a module buffer, tps_preprocessor.py:187-188); see tpspp_warp_fwd.
  */
@@ -354,7 +355,8 @@ int tpspp_conv_set_tuning(int force_generic);
  * kernel choice: 0 = automatic, 1 = force the gather kernel, 2 = require the LDS-staged kernel
  * (TPSPP_EINVAL if the shape does not qualify), 3 = as 2 but ignore TPSPP_TABLE_MIRROR4,
  * 4 = require the plane-streaming kernel, 5 = require the image-pair kernel (classic 32x100 geometry with a
- * tpspp_prepare_mirror_table buffer); bands = workgroups per image pair in the LDS-staged kernel (0 = heuristic).
+ * tpspp_prepare_mirror_table buffer), 6 = require the in-place kernel (32x100, 32x128, 48x160, 32x64 with C = 1 or 3,
+ * same buffer); bands = workgroups per image pair in the LDS-staged kernel (0 = heuristic).
  */
 int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);
 

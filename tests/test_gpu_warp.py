@@ -49,10 +49,10 @@ def test_classic_warp_matches_reference_golden(cuda):
     assert packed == ops.TABLE_PACKED and torch.equal(P_prep, P_hat_t)
     try:
         # 1 = gather, 3 = LDS-staged kernel, 2 = LDS-staged kernel on the mirror-symmetric table,
-        # 5 = image-pair kernel (prepared table), 0 = whatever the library picks for a prepared table
-        for kernel, bands in ((1, 0), (3, 1), (3, 2), (3, 3), (2, 1), (2, 2), (2, 3), (5, 0), (0, 0)):
+        # 5 = image-pair kernel, 6 = in-place kernel (both: prepared table), 0 = whatever the library picks for a prepared table
+        for kernel, bands in ((1, 0), (3, 1), (3, 2), (3, 3), (2, 1), (2, 2), (2, 3), (5, 0), (6, 0), (0, 0)):
             ops.set_warp_tuning(0, 0, kernel, bands)
-            tab, flags = (P_prep, ops.TABLE_MIRROR4 | packed) if kernel in (5, 0) else (P_hat_t, ops.TABLE_MIRROR4)
+            tab, flags = (P_prep, ops.TABLE_MIRROR4 | packed) if kernel in (5, 6, 0) else (P_hat_t, ops.TABLE_MIRROR4)
             for key_in, key_out in (("img", "out"), ("img_smooth", "out_smooth")):
                 out, _, grid, idx = ops.warp(dev(inp[key_in], cuda), dev(inp["ctrl"], cuda), inv,
                                              P_hat, cases.CL_HW, want_grid=True, want_idx=True,
@@ -95,6 +95,21 @@ def test_packed_table_contract(cuda):
         row = np.zeros(24, np.float32)
         row[:23] = ph[r * 100 + c]
         ref[t_ // 64, :, t_ % 64, :] = row.reshape(6, 4)
+    assert (bits(tail) == bits(ref)).all()
+    # 32x128: 16 column groups, a thread owns both row groups -> [8 wavefronts][2][6][64][4]
+    from oracle import tps_oracle as O
+    ph128 = O.classic_constants(20, (32, 128))["P_hat"]
+    p128, f128 = ops.prepare_mirror_table(dev(ph128, cuda), (32, 128))
+    assert f128 == ops.TABLE_PACKED
+    tail = p128._base[23 * 4096:].cpu().numpy().reshape(8, 2, 6, 64, 4)
+    ref = np.zeros((8, 2, 6, 64, 4), np.float32)
+    for t_ in range(512):
+        cg, l5 = t_ >> 5, t_ & 31
+        for j in range(2):
+            r, c = j * 8 + (l5 >> 2), cg * 4 + (l5 & 3)
+            row = np.zeros(24, np.float32)
+            row[:23] = ph128[r * 128 + c]
+            ref[t_ // 64, j, :, t_ % 64, :] = row.reshape(6, 4)
     assert (bits(tail) == bits(ref)).all()
     # shape / device / dtype of caller-supplied outputs are checked before any pointer reaches a kernel
     img, ctrl = dev(inp["img"], cuda), dev(inp["ctrl"], cuda)
@@ -255,6 +270,80 @@ def test_tpspp_warp_vs_oracle(cuda, oracle, N, point, hw, C0, C1, with_score):
             assert_biteq(idx, ref["idx"], f"corner indices (kernel {kernel})")
             assert_biteq(out0, ref["out0"], f"out0 (kernel {kernel})")
             assert_biteq(out1, ref["out1"], f"out1 (kernel {kernel})")
+    finally:
+        ops.set_warp_tuning(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("N,C,H,W,perturb", [
+    (5, 3, 32, 100, 0.3),       # the image-pair kernel's geometry on the in-place kernel; odd batch: a lone last image
+    (9, 1, 32, 100, 0.8),
+    (7, 3, 32, 128, 0.1),       # nrtr_tps++.py:28-33; two quadrant pixels per thread
+    (4, 1, 32, 128, 0.9),       # grids that leave the image: out-of-image taps of every kind
+    (3, 3, 48, 160, 0.2),       # one image per workgroup, three quadrant pixels per thread
+    (5, 1, 48, 160, 0.7),
+    (6, 3, 32, 64, 0.3),
+    (3, 1, 32, 64, 1.5),
+])
+def test_inplace_kernel_vs_oracle(cuda, oracle, N, C, H, W, perturb):
+    """kernel_choice 6: results staged in place of the consumed planes (tpspp_warp_img.h), every instantiated geometry;
+    specials in the image (an out-of-image tap must read as zero, never as 0 * value)."""
+    F = 20
+    Kc = oracle.classic_constants(F, (H, W))
+    ctrl = oracle.classic_initial_ctrl(F)[None] + perturb * synth.dyadic((N, F, 2), "ip.ctrl", N)
+    img = synth.dyadic((N, C, H, W), "ip.img", N + 1)
+    img.reshape(-1)[::97] = -0.0
+    img.reshape(-1)[5::409] = np.inf
+    img.reshape(-1)[6::503] = -np.inf
+    img.reshape(-1)[7::301] = np.nan
+    img.reshape(-1)[11::211] = 1e-42
+    ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
+    P_hat = dev(Kc["P_hat"], cuda)
+    assert ops.table_mirror_symmetry(Kc["P_hat"], (H, W), F) == 1
+    prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
+    assert packed == ops.TABLE_PACKED
+    try:
+        ops.set_warp_tuning(0, 0, 6, 0)
+        for want in (True, False):
+            out, _, grid, idx = ops.warp(dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), P_hat, (H, W),
+                                         want_grid=want, want_idx=want, P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+            if want:
+                assert_biteq(grid, ref["grid"], "grid")
+                assert_biteq(idx, ref["idx"], "corner indices")
+            assert_biteq(out, ref["out0"], "warped")
+        with pytest.raises(_lib.TpsppError):        # a geometry it is not instantiated for is refused, not mis-run
+            z = lambda *s_: torch.zeros(*s_, device=cuda)      # noqa: E731
+            p64 = z(64 * 64, 23)
+            t64, f64 = ops.prepare_mirror_table(p64, (64, 64))
+            ops.warp(z(2, 3, 64, 64), z(2, 20, 2), z(23, 23), p64, (64, 64), P_hat_t=t64, table_flags=ops.TABLE_MIRROR4 | f64)
+    finally:
+        ops.set_warp_tuning(0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_odd_full_batch_pair_and_inplace_kernels(cuda, oracle, C):
+    """Odd N under a full-chip launch (256 workgroups, the last one with a lone image): the image-pair kernel and the
+    in-place kernel against the LDS-staged kernel, bit for bit, repeatedly.  (Round-2 review: the lone image's flag was
+    raised before its DMA had landed; small odd batches passed only because the chip was idle.)"""
+    N, F, H, W = 511, 20, 32, 100
+    Kc = oracle.classic_constants(F, (H, W))
+    inv, P_hat = dev(Kc["inv_delta_C"], cuda), dev(Kc["P_hat"], cuda)
+    g = torch.Generator(device=cuda).manual_seed(5)
+    img = torch.rand((N, C, H, W), generator=g, device=cuda) * 2 - 1
+    ctrl = dev(oracle.classic_initial_ctrl(F), cuda)[None] + 0.1 * (torch.rand((N, F, 2), generator=g, device=cuda) * 2 - 1)
+    prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
+    try:
+        ops.set_warp_tuning(0, 0, 2, 0)
+        ref = ops.warp(img, ctrl, inv, P_hat, (H, W), P_hat_t=ops.transpose_p_hat(P_hat), table_flags=ops.TABLE_MIRROR4)[0]
+        sel = [0, 255, 509, 510]
+        want = oracle.warp(img[sel].cpu().numpy(), ctrl[sel].cpu().numpy(), Kc["inv_delta_C"], Kc["P_hat"], (H, W))["out0"]
+        assert_biteq(ref[sel], want, "LDS-staged kernel vs oracle")
+        for kernel in (5, 6):
+            ops.set_warp_tuning(0, 0, kernel, 0)
+            out = torch.empty_like(ref)
+            for rep in range(25):
+                out.fill_(float("nan"))
+                ops.warp(img, ctrl, inv, P_hat, (H, W), out0=out, P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+                assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), f"kernel {kernel}, repetition {rep}"
     finally:
         ops.set_warp_tuning(0, 0, 0, 0)
 

@@ -23,6 +23,7 @@
 #include "tpspp_warp_dev.h"
 #include "tpspp_warp_stream.h"
 #include "tpspp_warp_pair.h"
+#include "tpspp_warp_img.h"
 
 #include <cstring>
 
@@ -770,7 +771,7 @@ void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStre
 TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice,
                                        int bands)
 {
-    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 5, "kernel_choice must be 0..5");
+    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 6, "kernel_choice must be 0..6");
     TPSPP_REQUIRE(bands >= 0 && bands <= 8, "bands must be in [0, 8]");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
@@ -868,12 +869,27 @@ TPSPP_EXPORT int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, 
     return tpspp::check_launch("tpspp_transpose_p_hat");
 }
 
+namespace {
+// Quadrant pixels per thread of the packed table / the in-place kernel for an output geometry: the smallest divisor
+// of the OH/16 row groups that leaves at most 13 compute wavefronts (0: the geometry has no packed form).  32x100 -> 1
+// (the image-pair kernel's layout), 32x128 -> 2, 48x160 -> 3.
+int img_qp(int Ho, int Wo)
+{
+    if (Ho <= 0 || Wo <= 0 || Wo % 4 != 0 || Ho % 16 != 0) return 0;
+    const int CG = ((Wo / 2) + 3) / 4, RG = Ho / 16;
+    for (int qp = 1; qp <= RG && qp <= 4; ++qp)
+        if (RG % qp == 0 && (CG * (RG / qp) * 32 + kWave - 1) / kWave <= 13) return qp;
+    return 0;
+}
+}  // namespace
+
 TPSPP_EXPORT size_t tpspp_prepared_table_floats(int Ho, int Wo, int F)
 {
-    if (Ho <= 0 || Wo <= 0 || F <= 0 || F + 3 > kMaxK || Wo % 4 != 0 || Ho % 16 != 0) return 0;
+    const int QP = img_qp(Ho, Wo);
+    if (QP == 0 || F <= 0 || F + 3 > kMaxK) return 0;
     const int K = F + 3, KG = (K + 3) / 4;
-    const int PW = ((Wo / 2) + 3) & ~3, nthr = (Ho / 2) * PW, NW = (nthr + kWave - 1) / kWave;
-    return (size_t)K * Ho * Wo + (size_t)NW * KG * kWave * 4;
+    const int CG = ((Wo / 2) + 3) / 4, nthr = CG * ((Ho / 16) / QP) * 32, NW = (nthr + kWave - 1) / kWave;
+    return (size_t)K * Ho * Wo + (size_t)NW * QP * KG * kWave * 4;
 }
 
 TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo, int F,
@@ -881,15 +897,17 @@ TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, in
 {
     TPSPP_REQUIRE(p_hat && prepared, "tpspp_prepare_mirror_table: null pointer");
     TPSPP_REQUIRE(tpspp_prepared_table_floats(Ho, Wo, F) != 0,
-                  "tpspp_prepare_mirror_table: needs Ho %% 16 == 0, Wo %% 4 == 0, 0 < F <= %d", kMaxK - 3);
+                  "tpspp_prepare_mirror_table: needs Ho %% 16 == 0, Wo %% 4 == 0, at most 13 wavefronts of quadrant "
+                  "pixels, 0 < F <= %d", kMaxK - 3);
     TPSPP_REQUIRE(p_hat_ld >= F + 3, "tpspp_prepare_mirror_table: p_hat_ld too small (classic layout: F + 3 columns)");
     const int K = F + 3, KG = (K + 3) / 4, n = Ho * Wo;
     const int rc = tpspp_transpose_p_hat(p_hat, p_hat_ld, n, K, prepared, stream);
     if (rc != TPSPP_OK) return rc;
-    const int PW = ((Wo / 2) + 3) & ~3, nthr = (Ho / 2) * PW, NW = (nthr + kWave - 1) / kWave;
-    const int total = NW * KG * kWave * 4;
-    hipLaunchKernelGGL(tpspp_pair::pack_mirror_table_kernel, dim3((total + 255) / 256), dim3(256), 0,
-                       tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, PW / 4, nthr, K, prepared + (size_t)K * n);
+    const int QP = img_qp(Ho, Wo);
+    const int CG = ((Wo / 2) + 3) / 4, nthr = CG * ((Ho / 16) / QP) * 32, NW = (nthr + kWave - 1) / kWave;
+    const int total = NW * QP * KG * kWave * 4;
+    hipLaunchKernelGGL(tpspp_img::pack_img_table_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, CG, QP, nthr, K, prepared + (size_t)K * n);
     return tpspp::check_launch("tpspp_prepare_mirror_table");
 }
 
@@ -968,18 +986,66 @@ void launch_pair(const float* in, const float* ctrl, const float* inv_delta_c, c
     P.out = out; P.grid = grid; P.idx = idx; P.trace = g_trace;
     const size_t lds = pair_lds_bytes<20, C, 32, 100, 32, 100>(&P.zero_off, &P.out_off);
     const dim3 grid_dim((unsigned)((N + 1) / 2)), block((PairGeo<32, 100>::NW + kPairLoaders) * kWave);
-    auto go = [&](auto kern) {
-        // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and device
-        static bool attr_done[tpspp::kMaxDevices] = {};
-        if (tpspp::first_use_on_device(attr_done)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipGetLastError();
-        }
-        hipLaunchKernelGGL(kern, grid_dim, block, lds, st, P);
-    };
+    // > 64 KB of dynamic LDS needs the opt-in, once per device, for every instantiation that may be launched from here
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_pair_kernel<20, C, 32, 100, 32, 100, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_pair_kernel<20, C, 32, 100, 32, 100, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tps_warp_pair_kernel<20, C, 32, 100, 32, 100, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid_dim, block, lds, st, P); };
     if (g_trace) go(tps_warp_pair_kernel<20, C, 32, 100, 32, 100, false, true>);
     else if (grid || idx) go(tps_warp_pair_kernel<20, C, 32, 100, 32, 100, true, false>);
     else go(tps_warp_pair_kernel<20, C, 32, 100, 32, 100, false, false>);
+}
+
+// In-place kernel (tpspp_warp_img.h): the geometries it is instantiated for.  IMGS / QP / loaders per geometry:
+// two images per workgroup where both fit the LDS beside each other, else one.
+template <int C, int HH, int WW, int IMGS, int QP, int NLOAD>
+void launch_img(const float* in, const float* ctrl, const float* inv_delta_c, const float* packed, int N,
+                float* out, float* grid, int32_t* idx, hipStream_t st)
+{
+    using namespace tpspp_img;
+    static_assert(ImgGeo<HH, WW, QP>::NW + NLOAD <= 16, "too many wavefronts");
+    ImgParams P;
+    P.in = in; P.ctrl = ctrl; P.inv_delta_c = inv_delta_c; P.packed = packed; P.N = N;
+    P.out = out; P.grid = grid; P.idx = idx; P.late_from = 1 << 30; P.trace = g_trace;
+    const size_t lds = ImgLds<20, C, HH, WW, HH, WW, IMGS>::bytes;
+    static_assert(ImgLds<20, C, HH, WW, HH, WW, IMGS>::bytes <= 160 * 1024, "does not fit the LDS");
+    const dim3 grid_dim((unsigned)((N + IMGS - 1) / IMGS)), block((ImgGeo<HH, WW, QP>::NW + NLOAD) * kWave);
+    auto k_plain = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, 1, false, false>;
+    auto k_aux = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, 1, true, false>;
+    auto k_trace = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, 1, false, true>;
+    // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and device
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_aux), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trace), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    if (g_trace) hipLaunchKernelGGL(k_trace, grid_dim, block, lds, st, P);
+    else if (grid || idx) hipLaunchKernelGGL(k_aux, grid_dim, block, lds, st, P);
+    else hipLaunchKernelGGL(k_plain, grid_dim, block, lds, st, P);
+}
+
+// true when (C, H, W) is one of the in-place kernel's geometries (and the launch was enqueued)
+bool launch_img_geo(int C, int H, int W, const float* in, const float* ctrl, const float* inv_delta_c, const float* packed,
+                    int N, float* out, float* grid, int32_t* idx, hipStream_t st)
+{
+#define TPSPP_IMG_GEO(CC, HH, WW, IMGS, QP, NLOAD) \
+    if (C == CC && H == HH && W == WW) { launch_img<CC, HH, WW, IMGS, QP, NLOAD>(in, ctrl, inv_delta_c, packed, N, out, grid, idx, st); return true; }
+    TPSPP_IMG_GEO(3, 32, 100, 2, 1, 3)      // also the image-pair kernel's geometry (kernel_choice 6 selects this one)
+    TPSPP_IMG_GEO(1, 32, 100, 2, 1, 3)
+    TPSPP_IMG_GEO(3, 32, 128, 2, 2, 3)      // configs/textrecog/nrtr/nrtr_tps++.py:28-33
+    TPSPP_IMG_GEO(1, 32, 128, 2, 2, 3)
+    TPSPP_IMG_GEO(3, 48, 160, 1, 3, 3)
+    TPSPP_IMG_GEO(1, 48, 160, 1, 3, 3)
+    TPSPP_IMG_GEO(3, 32, 64, 2, 1, 3)
+    TPSPP_IMG_GEO(1, 32, 64, 2, 1, 1)
+#undef TPSPP_IMG_GEO
+    return false;
 }
 
 }  // namespace
@@ -1018,20 +1084,26 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
         return tpspp::launch_stream_kernel(A, g_trace, st);
     }
 
-    // ---- image-pair kernel: the reference's own geometry, mirror-symmetric table, packed copy available ----
+    // ---- prepared (packed) mirror-symmetric table: image-pair kernel for the reference's own 32x100 geometry, the
+    // in-place kernel for the other geometries it is instantiated for ----
     {
-        const bool pair_ok = (table_flags & TPSPP_TABLE_MIRROR4) && (table_flags & TPSPP_TABLE_PACKED) && p_hat_t &&
-                             !in1 && !score && !p_xy && F == 20 && (C0 == 1 || C0 == 3) && H0 == 32 && W0 == 100 &&
-                             Ho == 32 && Wo == 100 && (reinterpret_cast<uintptr_t>(in0) % 16 == 0) &&
-                             (reinterpret_cast<uintptr_t>(out0) % 16 == 0);
+        const bool packed_ok = (table_flags & TPSPP_TABLE_MIRROR4) && (table_flags & TPSPP_TABLE_PACKED) && p_hat_t &&
+                               !in1 && !score && !p_xy && F == 20 && H0 == Ho && W0 == Wo &&
+                               (reinterpret_cast<uintptr_t>(in0) % 16 == 0) && (reinterpret_cast<uintptr_t>(out0) % 16 == 0);
+        const bool pair_ok = packed_ok && (C0 == 1 || C0 == 3) && Ho == 32 && Wo == 100;
+        const float* packed = p_hat_t ? p_hat_t + (size_t)(F + 3) * Ho * Wo : nullptr;   // second part of the prepared table
         if (g_tune_kernel == 5 && !pair_ok)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the image-pair kernel");
         if (pair_ok && (g_tune_kernel == 0 || g_tune_kernel == 5)) {
-            const float* packed = p_hat_t + (size_t)(F + 3) * Ho * Wo;      // second part of the prepared table
             if (C0 == 1) launch_pair<1>(in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st);
             else         launch_pair<3>(in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st);
             return tpspp::check_launch("tpspp_warp_fwd(pair)");
         }
+        if (packed_ok && (g_tune_kernel == 0 || g_tune_kernel == 6) &&
+            launch_img_geo(C0, Ho, Wo, in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st))
+            return tpspp::check_launch("tpspp_warp_fwd(in-place)");
+        if (g_tune_kernel == 6)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the in-place kernel");
     }
 
     // ---- LDS-staged kernel: single small input, classic layout, transposed table available ----

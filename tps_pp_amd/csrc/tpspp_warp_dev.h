@@ -15,6 +15,7 @@ constexpr int kMaxK = 64;  // F + 3 <= 64: one lane per row of T in the wave-lev
 struct Taps {
     int o00, o01, o10, o11;   // offsets inside one H x W plane (clamped: always readable)
     float nw, ne, sw, se;
+    float wx, wy;             // fractional parts: nw = (1-wy)(1-wx), ne = (1-wy) wx, sw = wy (1-wx), se = wy wx
     bool inx, iny;            // is the east column / south row inside the plane
     int x0, y0;
 };
@@ -35,6 +36,7 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W)
     const int x0 = (int)fx, y0 = (int)fy;
     const float w = ix - fx, e = 1.0f - w, nn = iy - fy, s = 1.0f - nn;
     t.nw = s * e; t.ne = s * w; t.sw = nn * e; t.se = nn * w;
+    t.wx = w; t.wy = nn;
     t.inx = (x0 + 1) < W;
     t.iny = (y0 + 1) < H;
     const int x1 = t.inx ? x0 + 1 : x0;

@@ -162,7 +162,11 @@ tps_warp_pair_kernel(const PairParams P)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPairAwait) : "memory");
 #pragma unroll
         for (int i = 0; i < kPairKB; ++i) { if (piece < pieces) dma(piece); piece += NLOAD; }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPairKB) : "memory");   // vmcnt retires in order: A is complete
+        // vmcnt retires in order: once at most kPairKB requests are outstanding and kPairKB of image B's have been
+        // issued behind image A's, A is complete.  The last workgroup of an odd batch has no image B: nothing was
+        // issued behind A, so A is complete only when nothing at all is outstanding.
+        if (hasB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPairKB) : "memory");
+        else      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(fa), "v"(one) : "memory");
         for (; piece < pieces; piece += NLOAD) dma(piece);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -48,9 +48,11 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None):
     if send.shape[0] != cap:
         pad = torch.zeros((cap - send.shape[0],) + tail, dtype=local.dtype, device=local.device)
         send = torch.cat([send, pad], dim=0)
-    # the code path is chosen up front from the backend: a collective that fails on one rank (comm abort, timeout, size
-    # mismatch) must propagate, not be followed by a different collective on a desynchronised communicator
-    if str(dist.get_backend(group)).lower() == "gloo":   # CPU tests; gloo builds may lack the fused form
+    # the code path is chosen up front from where the tensor lives (a group may carry per-device backends,
+    # "cpu:gloo,cuda:nccl": the backend string alone does not say which one this tensor gets): a collective that fails
+    # on one rank (comm abort, timeout, size mismatch) must propagate, not be followed by a different collective on a
+    # desynchronised communicator
+    if not local.is_cuda:                                # gloo (CPU tests); gloo builds may lack the fused form
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send, group=group)
         recv = torch.cat(parts, dim=0)
