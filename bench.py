@@ -209,6 +209,65 @@ def extra_measurements(dev):
                                                "kernel": "tps_warp_stream_kernel<32,true,true,2>"}}
 
 
+def classic_warp_extra(dev, hw, nstreams):
+    """The classic warp at another geometry (configs/textrecog/nrtr/nrtr_tps++.py:28-33: img_size 32x128, 3 channels,
+    20 fiducials), batch 512, same protocol as the headline: rotating buffer sets > 2x the Infinity Cache, one
+    pre-marshalled call per step, HIP events; on one stream and on `nstreams`."""
+    Hh, Ww = hw
+    mod = TPSPreprocessor(num_fiducial=F, img_size=hw, rectified_img_size=hw, num_img_channel=C).eval().to(dev)
+    gg = mod.GridGenerator
+    p_hat_t, flags = gg.prepared_table()
+    per_set = 2 * BATCH * C * Hh * Ww * 4
+    nbuf = max(2, (2 * CACHE_BYTES + per_set - 1) // per_set)
+    g = torch.Generator(device=dev).manual_seed(99)
+    ident = torch.from_numpy(constants.classic_identity_ctrl(F)).to(dev)
+    imgs = [torch.rand((BATCH, C, Hh, Ww), generator=g, device=dev) * 2 - 1 for _ in range(nbuf)]
+    ctrls = [ident[None] + 0.05 * (torch.rand((BATCH, F, 2), generator=g, device=dev) * 2 - 1) for _ in range(nbuf)]
+    outs = [torch.empty((BATCH, C, Hh, Ww), device=dev) for _ in range(nbuf)]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
+    plans = []
+    for j in range(nbuf):
+        row = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                row.append(ops.WarpPlan(imgs[j], ctrls[j], gg.inv_delta_C, gg.P_hat, hw, outs[j], P_hat_t=p_hat_t,
+                                        table_flags=flags))
+        plans.append(row)
+
+    def timed(nsteps, ns):
+        for i in range(50):
+            plans[i % nbuf][i % ns].run()
+        torch.cuda.synchronize(dev)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(ns)]
+        e0.record(streams[0])
+        for st in streams[1:ns]:
+            st.wait_event(e0)
+        for i in range(nsteps):
+            plans[i % nbuf][i % ns].run()
+        for k in range(ns):
+            e1[k].record(streams[k])
+        torch.cuda.synchronize(dev)
+        return max(e0.elapsed_time(e) for e in e1) * 1e3 / nsteps
+
+    us1, usn = timed(1000, 1), timed(1000, nstreams)
+    # parity of what was timed: four images against the CPU oracle
+    from oracle import tps_oracle as O
+    O.build()
+    plans[0][0].run()
+    torch.cuda.synchronize(dev)
+    sel = [0, 1, 255, 511]
+    ref = O.warp(imgs[0][sel].cpu().numpy(), ctrls[0][sel].cpu().numpy(), gg.inv_delta_C.cpu().numpy(),
+                 gg.P_hat.cpu().numpy(), hw)
+    err = float(np.abs(outs[0][sel].cpu().numpy() - ref["out0"]).max())
+    bytes_launch = BATCH * (2 * C * Hh * Ww * 4 + F * 2 * 4)
+    return {"launch_us": usn, "streams": nstreams, "frac_of_hbm_peak": bytes_launch / (usn * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "one_stream": {"launch_us": us1, "frac_of_hbm_peak": bytes_launch / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "algorithmic_bytes_per_launch": bytes_launch, "max_abs_err_vs_oracle": err,
+            "kernel": f"tps_warp_img_kernel<20,{C},{Hh},{Ww},...> (in-place staging)" if bool(flags & ops.TABLE_PACKED)
+            else "LDS-staged kernel", "rotating_buffer_sets": int(nbuf)}
+
+
 def recognizer_measurement(dev, timeit):
     """BASELINE.json configs[3]/[4] shape at one GPU: the whole NRTR + TPS++ recogniser (backbone, TPS++,
     6+6-layer transformer, greedy 40-step decoding, label conversion) on 3x32x128 images, batch 512,
@@ -609,7 +668,10 @@ def main():
                                      "buffers: the practical ceiling for one launch per 512 images"}},
         }
         if world == 1 and not a.no_extras:
+            del plans, imgs, outs, ctrls
+            torch.cuda.empty_cache()
             rec["extra"] = extra_measurements(dev)
+            rec["extra"]["classic_warp_32x128_batch512_fp32"] = classic_warp_extra(dev, (32, 128), S)
         if sharded is not None:
             rec.setdefault("extra", {})["recognizer_sharded"] = sharded
         if world == 1 and not a.no_cpu_baseline:

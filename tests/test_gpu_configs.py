@@ -174,13 +174,14 @@ def test_config3_and_4_bf16_256_per_gpu(cuda):
     assert [r["text"] for r in res_small[:2]] == o["text"]
 
 
-@pytest.mark.parametrize("mode,tf_min,word_min,char_min", [(torch.bfloat16, 0.98, 0.55, 0.85), ("bf16x3", 0.9995, 0.97, 0.99)])
+@pytest.mark.parametrize("mode,tf_min,word_min,char_min", [(torch.bfloat16, 0.99, 0.72, 0.92), ("bf16x3", 0.9995, 0.97, 0.99)])
 def test_config4_reduced_precision_agreement_on_256_distinct_images(cuda, mode, tf_min, word_min, char_min):
     """BASELINE.json configs[4], "word-accuracy parity check", on 256 DISTINCT synthetic crops with random-init weights
     (classifier spread x8 as in bench.py): decisions of the bf16 / bf16x3 configurations against the exact-fp32 kernels
     of the same model -- which other tests hold to 1e-4 / identical strings against the reference and the CPU oracle.
-    Thresholds: measured 0.993 / 0.75 / 0.96 (bf16) and 1.0 / 1.0 / 1.0 (bf16x3) in round 1; random-init
-    decoding is the worst case for word agreement (40 characters of noise, one flipped near-tie rewrites the tail)."""
+    Thresholds = what was measured minus a margin: bf16 0.995 / 0.80-0.82 / 0.944-0.95 (rounds 2 and 3, driver line
+    BENCH_r02.json) -> 0.99 / 0.72 / 0.92; bf16x3 1.0 / 1.0 / 1.0 -> 0.9995 / 0.97 / 0.99.  Random-init decoding is the
+    worst case for word agreement (40 characters of noise, one flipped near-tie rewrites the tail)."""
     from tps_pp_amd import metrics
     m = build_recognizer(cuda)
     with torch.no_grad():

@@ -119,7 +119,7 @@ def test_variant_is_picked_by_geometry_checkpoint_or_backbone_strides():
     with torch.no_grad(), pytest.raises(ValueError, match="ResNet45v2"):
         v1(x, v2_maps)
     # default: the reference's hard-coded wiring, switched by the first forward with the other geometry ...
-    auto = TPS_PP()
+    auto = TPS_PP().eval()                                     # (fresh + eval mode only: see the end of this test)
     assert auto.type == "ResNet45v2" and not auto.variant_explicit
     with torch.no_grad(), pytest.raises(_lib.TpsppError, match="no CPU fallback"):      # (then the CPU tensor is refused)
         auto(x, v1_maps)
@@ -142,6 +142,40 @@ def test_variant_is_picked_by_geometry_checkpoint_or_backbone_strides():
     # the 60-entry state_dict order of the reference survives a round trip through the other wiring
     rt = TPS_PP().set_variant("ResNet45", explicit=False).set_variant("ResNet45v2", explicit=False)
     assert list(rt.state_dict()) == list(TPS_PP().state_dict())
+    # forward() never re-wires a module that is training (an optimiser may hold its parameters) ...
+    tr = TPS_PP().train()
+    ids = [id(p) for p in tr.parameters()]
+    with pytest.raises(ValueError, match="set_variant"):
+        tr(x, v1_maps)
+    assert tr.type == "ResNet45v2" and ids == [id(p) for p in tr.parameters()]
+    # ... nor one that has loaded anything, a regressor-only (partial) checkpoint included
+    part = TPS_PP()
+    part.load_state_dict({k: v for k, v in TPS_PP().state_dict().items() if k.startswith("TPE.")}, strict=False)
+    with torch.no_grad(), pytest.raises(ValueError, match="set_variant"):
+        part(x, v1_maps)
+    assert part.type == "ResNet45v2"
+
+
+def test_eval_mode_keeps_gradients_when_the_inputs_carry_them(monkeypatch):
+    """The reference is differentiable in eval mode (saliency / adversarial gradients, frozen-BN fine-tuning of the
+    layers upstream): inputs that require grad take the autograd path; plain eval inference does not."""
+    m = TPS_PP().eval()
+    took = []
+    monkeypatch.setattr(m, "_forward_autograd", lambda x, outs: took.append("autograd") or {})
+    monkeypatch.setattr(m, "regress", lambda x, outs: (_ for _ in ()).throw(RuntimeError("hip path")))
+    x = torch.zeros(1, 64, 16, 64, requires_grad=True)
+    maps = [torch.zeros(1, 32, 32, 128), torch.zeros(1, 32, 32, 128)]
+    m(x, maps)
+    assert took == ["autograd"]
+    with torch.no_grad(), pytest.raises(RuntimeError, match="hip path"):
+        m(x, maps)                                             # autograd off: inference path
+    with pytest.raises(RuntimeError, match="hip path"):
+        m(x.detach(), maps)                                    # nothing upstream wants a gradient: inference path (warned once)
+    assert m._warned_detached
+    from tps_pp_amd import TPSPreprocessor
+    pre = TPSPreprocessor(num_fiducial=20, img_size=(32, 100), rectified_img_size=(32, 100), num_img_channel=1).eval()
+    with pytest.raises(_lib.TpsppError, match="no CPU fallback"):      # the autograd branch is the one that asks for a GPU tensor first
+        pre(torch.zeros(1, 1, 32, 100, requires_grad=True))
 
 
 def test_register_into_a_mmocr_like_builder(monkeypatch):

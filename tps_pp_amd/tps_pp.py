@@ -391,6 +391,9 @@ class TPS_PP(nn.Module):
                     raise ValueError(f"TPS_PP(variant={self.type!r}): the checkpoint holds the {want!r} wiring "
                                      f"(down0.conv.weight {tuple(w.shape)})")
                 self._wire(want)
+        # any load -- a partial or regressor-only checkpoint included -- ends the period in which forward() may still
+        # re-wire the module (that would replace loaded or about-to-be-trained layers by freshly initialised ones)
+        if any(k.startswith(prefix) for k in state_dict):
             self._weights_loaded = True
 
     def init_weights(self):
@@ -519,7 +522,9 @@ class TPS_PP(nn.Module):
                "ResNet45" if (g0, g1) == ((2 * h, 2 * w), (h, w)) else None
         if want == self.type:
             return
-        if want is not None and not self.variant_explicit and not self._weights_loaded:
+        # never while training (an optimiser / DDP already holds the parameters the re-wiring would orphan) and never
+        # after a load: only a fresh, eval-mode module built without `variant` may still follow the feature maps
+        if want is not None and not self.variant_explicit and not self._weights_loaded and not self.training:
             import logging
             logging.getLogger("tps_pp_amd").warning(
                 "TPS_PP: feature maps %s / %s for a %s input: switching to the %r wiring (freshly initialised layers)",
@@ -632,12 +637,29 @@ class TPS_PP(nn.Module):
                                            in1=batch_img.float(), P_hat_t=P_hat_t)
         return {"output": output, "logits": None, "mp_img": mp_img, "pc_score": atten_score}
 
+    def _inputs_want_grad(self, batch_img, outs):
+        """Eval mode under enabled autograd: do the inputs carry gradients (then the result must too), and if only the
+        parameters do, say once that the HIP path returns detached tensors."""
+        if not torch.is_grad_enabled():
+            return False
+        if batch_img.requires_grad or any(o.requires_grad for o in outs):
+            return True
+        if not getattr(self, "_warned_detached", False) and any(p.requires_grad for p in self.parameters()):
+            import logging
+            logging.getLogger("tps_pp_amd").warning(
+                "TPS_PP in eval mode with autograd enabled: the HIP inference path records no graph, so no gradient will "
+                "reach this module's parameters (call .train(), or wrap inference in torch.no_grad())")
+            self._warned_detached = True
+        return False
+
     def forward(self, batch_img, outs, **kwargs):
         """batch_img (N,64,16,64), outs = [stage-0 input, stage-1 input] ->
         dict(output, logits=None, mp_img, pc_score)."""
-        if self.training:
-            # training graph; eval mode ALWAYS takes the HIP kernels (wrap the call in torch.no_grad() as the reference's
-            # test loops do: the kernels record no autograd graph)
+        wants_graph = self.training or self._inputs_want_grad(batch_img, outs)
+        if wants_graph:
+            # training graph, or an eval-mode module whose inputs carry gradients (frozen-BN fine-tuning of the layers
+            # upstream, saliency / adversarial gradients w.r.t. the image): the reference is differentiable in eval mode
+            # too.  Plain eval inference takes the HIP kernels (they record no autograd graph).
             if not getattr(self, "_logged_autograd", False):
                 import logging
                 logging.getLogger("tps_pp_amd").warning(

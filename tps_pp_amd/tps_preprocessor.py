@@ -198,10 +198,11 @@ class TPSPreprocessor(BasePreprocessor):
 
     def forward(self, batch_img):
         """(N, C, H, W) -> (N, C, H_r, W_r)."""
-        if self.training:
-            # training graph (SURVEY.md section 8f row F2): HIP warp forward + backward; the localisation
-            # network is the plain PyTorch composition (fp32) so that autograd reaches its parameters.
-            # Eval mode ALWAYS takes the HIP kernels, like the other stages of a recogniser.
+        if self.training or (torch.is_grad_enabled() and batch_img.requires_grad):
+            # training graph (SURVEY.md section 8f row F2), or an eval-mode module whose input carries gradients
+            # (saliency / adversarial gradients w.r.t. the image: the reference is differentiable in eval mode too):
+            # HIP warp forward + backward; the localisation network is the plain PyTorch composition (fp32) so that
+            # autograd reaches its parameters.  Plain eval inference takes the HIP kernels (no autograd graph).
             ops.require_gpu(batch_img, "TPSPreprocessor")
             if not getattr(self, "_logged_autograd", False):
                 import logging
