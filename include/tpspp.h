@@ -144,7 +144,8 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *   g_ctrl (N, F, 2)                                dL/d control points
  *   g_score                                         dL/d score in the layout of `score` ((N, n, F), or
  *                                                  (N, F, n) with TPSPP_SCORE_TRANSPOSED), or NULL
- *   g_grid_ws (N, Ho*Wo, 2)                         scratch; on return dL/d grid
+ *   g_grid_ws                                       scratch of tpspp_warp_bwd_workspace_floats(N, Ho, Wo) floats; on
+ *                                                  return its first N * Ho*Wo * 2 floats hold dL/d grid
  * grid (N, Ho*Wo, 2) is the sampling grid the forward produced (its grid_or_null output) and
  * T (N, F+3, 2) = tpspp_solve_T(inv_delta_c, ctrl); the tables are the forward's.  Gradients follow
  * ATen's CPU grid_sampler_2d_backward (bilinear, border, align_corners=True: zero coordinate gradient
@@ -152,6 +153,7 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  * replaces: autograd through backbones/tps_pp/tps_pp.py:467-496,597-615;
  *           preprocessor/tps_preprocessor.py:71-83,270-282
  */
+size_t tpspp_warp_bwd_workspace_floats(int N, int Ho, int Wo);
 int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
                    const float* g_out1, const float* in1, int C1, int H1, int W1,
                    const float* grid, const float* T, const float* inv_delta_c,

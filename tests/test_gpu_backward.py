@@ -1,6 +1,8 @@
 """-m gpu: backward of the fused warp against the reference's own autograd
-(golden G14) and the CPU oracle.  Gradients are sums over many taps accumulated with float atomics on
-the GPU (order not fixed), so the bar is a relative tolerance, stated per tensor."""
+(golden G14) and the CPU oracle.  Gradients are sums over many taps whose fp32 accumulation order is free (the
+reference's own order is its CPU kernel's), so the bar is a relative tolerance, stated per tensor.  At the TPS_PP
+geometry the input gradients are accumulated in 64-bit fixed point (exact, order-independent): those are also
+checked for run-to-run bit equality and against float64 at a tolerance no fp32 accumulation would meet."""
 import numpy as np
 import pytest
 import torch
@@ -174,3 +176,43 @@ def test_backward_full_size_properties(cuda):
         L.backward()
     close(g_ctrl[pick], cd.grad.float().numpy(), 2e-4, "dL/d control points (rows of batch 512)")
     close(g_score[pick], sd.grad.float().numpy(), 2e-4, "dL/d score (rows of batch 512)")
+
+
+def test_fixed_point_input_gradients_are_exact_and_reproducible(cuda):
+    """TPS_PP geometry (<= 1024 output pixels): dL/d input is summed as round(w * g * 2^s) in 64-bit LDS integers.
+    (i) two runs agree bit for bit (float atomics would not); (ii) against float64 autograd of the reference's
+    sampler on the same fp32 grid the error is that of the fp32 tap weights (the coordinates are fp32 in the reference
+    as well), not of the accumulation; (iii) the scale follows the data: gradients of magnitude 1e-30 and 1e+30 keep that
+    relative accuracy; (iv) a non-finite incoming gradient poisons its own planes only."""
+    import torch.nn.functional as Fn
+    n = 6
+    g = torch.Generator(device=cuda).manual_seed(9)
+    c = O.tpspp_constants(cases.PP_HW, cases.PP_POINT)
+    inv, ph, pxy = dev(c["hat_C"], cuda), dev(c["P_hat"], cuda), dev(c["P_xy"], cuda)
+    from tps_pp_amd import constants
+    fg = torch.rand((n, 5, 32, 128), generator=g, device=cuda)
+    x = torch.rand((n, 3, 16, 64), generator=g, device=cuda)
+    ctrl = dev(constants.tpspp_initial_ctrl((2, 16)), cuda)[None].repeat(n, 1, 1) + \
+        0.3 * (torch.rand((n, 32, 2), generator=g, device=cuda) - 0.5)          # folds and clamps: many taps share pixels
+    _, _, grid, _ = ops.warp(fg, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, want_grid=True)
+    for mag in (1.0, 1e-30, 1e30):
+        g0 = (torch.rand((n, 5, 16, 64), generator=g, device=cuda) - 0.5) * mag
+        g1 = (torch.rand((n, 3, 16, 64), generator=g, device=cuda) - 0.5) * mag
+        a = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
+        b = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
+        assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1].view(torch.int32), b[1].view(torch.int32))
+        with torch.enable_grad():
+            fd, xd = fg.cpu().double().requires_grad_(True), x.cpu().double().requires_grad_(True)
+            gr = grid.cpu().double().reshape(n, 16, 64, 2)
+            L = (Fn.grid_sample(fd, gr, padding_mode="border", align_corners=True) * (g0.cpu().double() / mag)).sum() + \
+                (Fn.grid_sample(xd, gr, padding_mode="border", align_corners=True) * (g1.cpu().double() / mag)).sum()
+            L.backward()
+        for got, want in ((a[0], fd.grad), (a[1], xd.grad)):
+            got = got.cpu().double() / mag
+            assert (got - want).abs().max() <= 2e-5 * want.abs().max(), (mag, float((got - want).abs().max()))
+    g0 = torch.rand((n, 5, 16, 64), generator=g, device=cuda)
+    g1 = torch.rand((n, 3, 16, 64), generator=g, device=cuda)
+    g0[2, 3, 5, 7] = float("inf")
+    r = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
+    assert torch.isnan(r[0][2, 3]).all() and torch.isfinite(r[0][2, :3]).all() and torch.isfinite(r[0][[0, 1, 3, 4, 5]]).all()
+    assert torch.isfinite(r[1]).all()

@@ -56,6 +56,7 @@ __device__ __forceinline__ float wave_sum(float v)
 // hardware's return-less global_atomic_add_f32 (valid on ordinary device allocations; plain atomicAdd on a
 // float compiles to a compare-and-swap loop here, 10x slower).
 constexpr int kCPT = 8;
+constexpr int kBwdMaxG = 8;      // sampling workgroups per (image, input) of kernel A'': bounds the workspace
 
 __global__ void __launch_bounds__(256)
 warp_bwd_sample_kernel(const BwdParams P, int chunks0, float* __restrict__ g_grid)
@@ -197,10 +198,180 @@ warp_bwd_sample_lds_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* 
     for (int e = threadIdx.x; e < 2 * P.n; e += blockDim.x) unsafeAtomicAdd(gg + e, sgg[e]);
 }
 
+// ---- kernel A'' (round 3): input-gradient planes accumulated in LDS as 64-bit FIXED POINT ------------------
+// What bounds A' is one instruction: ds_add_f32 retires 0.33 lane-operations per clock and CU on gfx950 whatever the
+// address pattern (scripts/ubench/lds_atomic_bench.hip: 204 G/s chip-wide; the TPS_PP geometry needs 268 M of them per
+// 512 images = 1.3 ms), while the INTEGER LDS atomics run at 8 (ds_add_u64) to 11 (ds_add_u32) per clock and CU.  So a
+// contribution w * g is added as round(w * g * 2^s) with ds_add_u64; s is chosen per pass from max |g| of the planes
+// in flight so that a term has 50 significant bits and 4096 terms cannot overflow (2^62).  The sum of the rounded terms
+// is exact and order-independent: the result is the correctly rounded fp32 of a sum that is closer to the true value
+// than any fp32 accumulation order (each term is off by <= 2^-51 of the largest |g|), and it is bitwise reproducible
+// from run to run, which float atomics are not.  (fp32 -> fixed point: one fp64 fma against 1.5 * 2^52 and a 64-bit
+// subtraction.)
+// Besides:
+//   * a workgroup is 256 threads with <= 64 KB of planes: two share a CU in different phases;
+//   * a thread owns PPT fixed output pixels: their taps (one offset, two fractions, two flags, the two border-clip
+//     factors) are derived ONCE per workgroup, not once per channel chunk;
+//   * its coordinate gradient is summed in registers over every channel the workgroup handles and leaves as ONE plain
+//     store into the workgroup's own slice of the workspace (kernel B adds the slices): no LDS array, no global atomics,
+//     no memset of g_grid;
+//   * two channel planes per pass share the tap addresses and weights (40 loads per thread in flight).
+// grid = (G groups of input 0 then G groups of input 1, images); workspace (N, 2 G, n, 2).
+template <int PPT>
+__global__ void __launch_bounds__(256, 2)
+warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* __restrict__ g_grid_part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // [cpt][H*W] fixed point
+    __shared__ float sMax[2][4];
+    const int b = blockIdx.y;
+    const int i = (int)blockIdx.x >= G ? 1 : 0;
+    const int grp = (int)blockIdx.x - (i ? G : 0);
+    const int cpt = i ? cpt1 : cpt0;
+    const int H = P.H[i], W = P.W[i], C = P.C[i];
+    const int plane = H * W;
+    const int chunks = (C + cpt - 1) / cpt;
+    const bool want = P.g_in[i] != nullptr;
+    const int tid = threadIdx.x;
+
+    // this thread's pixels: taps once
+    int o00[PPT]; float fw[PPT], fn[PPT], mx[PPT], my[PPT]; bool inx[PPT], iny[PPT], livep[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * 256;
+        livep[k] = p < P.n;
+        const float2 g = reinterpret_cast<const float2*>(P.grid)[(size_t)b * P.n + (livep[k] ? p : 0)];
+        float ix = ((g.x + 1.0f) * 0.5f) * (float)(W - 1);
+        float iy = ((g.y + 1.0f) * 0.5f) * (float)(H - 1);
+        mx[k] = (float)(W - 1) * 0.5f; my[k] = (float)(H - 1) * 0.5f;
+        if (ix <= 0.0f) { ix = 0.0f; mx[k] = 0.0f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); mx[k] = 0.0f; }
+        if (iy <= 0.0f) { iy = 0.0f; my[k] = 0.0f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); my[k] = 0.0f; }
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        fw[k] = ix - fx; fn[k] = iy - fy;
+        inx[k] = (x0 + 1) < W; iny[k] = (y0 + 1) < H;
+        o00[k] = y0 * W + x0;
+    }
+    float gx[PPT], gy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) gx[k] = gy[k] = 0.0f;
+
+    const int n2 = plane;                                  // the two planes of a pass as 16-byte pieces (two fixed-point words each)
+    ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
+    if (want) for (int e = tid; e < n2; e += 256) acc2[e] = make_ulonglong2(0ull, 0ull);
+    __syncthreads();
+    constexpr double kMagic = 6755399441055744.0;          // 1.5 * 2^52: x + kMagic has round(x) in its low mantissa bits
+    for (int ch = grp; ch < chunks; ch += G) {
+        const int c_lo = ch * cpt;
+        const int nc = min(cpt, C - c_lo);
+        const float* in = P.in[i] + ((size_t)b * C + c_lo) * plane;
+        const float* go = P.g_out[i] + ((size_t)b * C + c_lo) * P.n;
+        float* gi = want ? P.g_in[i] + ((size_t)b * C + c_lo) * plane : nullptr;
+        for (int c2 = 0; c2 < nc; c2 += 2) {               // two planes per pass: same taps, same weights
+            const bool two = c2 + 1 < nc;
+            const float* pl0 = in + (size_t)c2 * plane;
+            const float* pl1 = in + (size_t)(two ? c2 + 1 : c2) * plane;
+            float gv[PPT][2], v[PPT][2][4];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {                // every load of the pass in flight together
+                const int p = livep[k] ? tid + k * 256 : 0;
+                const int a01 = inx[k] ? o00[k] + 1 : o00[k], a10 = iny[k] ? o00[k] + W : o00[k];
+                const int a11 = (inx[k] && iny[k]) ? o00[k] + W + 1 : o00[k];
+                gv[k][0] = go[(size_t)c2 * P.n + p];
+                gv[k][1] = go[(size_t)(two ? c2 + 1 : c2) * P.n + p];
+                v[k][0][0] = pl0[o00[k]]; v[k][0][1] = pl0[a01]; v[k][0][2] = pl0[a10]; v[k][0][3] = pl0[a11];
+                v[k][1][0] = pl1[o00[k]]; v[k][1][1] = pl1[a01]; v[k][1][2] = pl1[a10]; v[k][1][3] = pl1[a11];
+            }
+            // fixed-point scale of this pass: 2^(50 - e) with 2^e > max |g| over the two planes (a term then has 50
+            // significant bits, 4096 terms stay below 2^62)
+            double scale = 0.0, inv_scale = 0.0;
+            bool fin[2] = {true, true};                    // a plane whose incoming gradient is not finite comes out as NaN
+            if (want) {
+                float m[2] = {0.0f, 0.0f};
+                bool nan_[2] = {false, false};
+#pragma unroll
+                for (int k = 0; k < PPT; ++k)
+                    if (livep[k]) {
+                        m[0] = fmaxf(m[0], fabsf(gv[k][0])); nan_[0] = nan_[0] || (gv[k][0] != gv[k][0]);
+                        if (two) { m[1] = fmaxf(m[1], fabsf(gv[k][1])); nan_[1] = nan_[1] || (gv[k][1] != gv[k][1]); }
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) m[q] = fmaxf(m[q], __shfl_xor(m[q], o, kWave));
+                    if (__builtin_amdgcn_ballot_w64(nan_[q]) != 0) m[q] = __builtin_inff();
+                    if ((tid & (kWave - 1)) == 0) sMax[q][tid >> 6] = m[q];
+                }
+                __syncthreads();
+                float mm = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    m[q] = fmaxf(fmaxf(sMax[q][0], sMax[q][1]), fmaxf(sMax[q][2], sMax[q][3]));
+                    fin[q] = m[q] < 3.0e38f;
+                    if (fin[q]) mm = fmaxf(mm, m[q]);
+                }
+                if (mm > 0.0f) {
+                    int e2;
+                    (void)frexpf(mm, &e2);                 // mm = f * 2^e2, f in [0.5, 1)
+                    scale = ldexp(1.0, 50 - e2);
+                    inv_scale = ldexp(1.0, e2 - 50);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (!livep[k]) continue;
+                const float w = fw[k], nn = fn[k], e = 1.0f - w, s = 1.0f - nn;
+                const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+                const bool inxy = inx[k] && iny[k];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && !two) break;
+                    const float g = gv[k][q];
+                    const float a01 = inx[k] ? v[k][q][1] : 0.0f, a10 = iny[k] ? v[k][q][2] : 0.0f, a11 = inxy ? v[k][q][3] : 0.0f;
+                    gx[k] += ((a01 - v[k][q][0]) * s + (a11 - a10) * nn) * g;
+                    gy[k] += ((a10 - v[k][q][0]) * e + (a11 - a01) * w) * g;
+                    if (want && scale != 0.0 && fin[q]) {
+                        unsigned long long* ap = acc + (size_t)q * plane + o00[k];
+                        auto fx64 = [&](float t) {
+                            return (unsigned long long)(__double_as_longlong(fma((double)t, scale, kMagic)) - __double_as_longlong(kMagic));
+                        };
+                        atomicAdd(ap, fx64(nw * g));
+                        if (inx[k]) atomicAdd(ap + 1, fx64(ne * g));
+                        if (iny[k]) atomicAdd(ap + W, fx64(sw * g));
+                        if (inxy) atomicAdd(ap + W + 1, fx64(se * g));
+                    }
+                }
+            }
+            if (want) {
+                __syncthreads();
+                // the pass's planes out (fixed point -> fp32, 16-byte stores) and zeroed for the next pass: the same
+                // thread reads and clears a piece
+                const int m4 = ((two ? 2 : 1) * plane) >> 2;
+                float4* gi4 = reinterpret_cast<float4*>(gi + (size_t)c2 * plane);
+                const float nanv = __builtin_nanf("");
+                for (int e = tid; e < m4; e += 256) {
+                    const ulonglong2 r0 = acc2[2 * e], r1 = acc2[2 * e + 1];
+                    acc2[2 * e] = make_ulonglong2(0ull, 0ull);
+                    acc2[2 * e + 1] = make_ulonglong2(0ull, 0ull);
+                    float4 o;
+                    o.x = (float)((double)(long long)r0.x * inv_scale); o.y = (float)((double)(long long)r0.y * inv_scale);
+                    o.z = (float)((double)(long long)r1.x * inv_scale); o.w = (float)((double)(long long)r1.y * inv_scale);
+                    if (!fin[4 * e >= plane ? 1 : 0]) o = make_float4(nanv, nanv, nanv, nanv);   // (planes are whole float4s)
+                    gi4[e] = o;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    float2* part = reinterpret_cast<float2*>(g_grid_part) + ((size_t)b * (2 * G) + blockIdx.x) * P.n;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (livep[k]) part[tid + k * 256] = make_float2(gx[k] * mx[k], gy[k] * my[k]);
+}
+
 // ---- kernel B: parameter gradients from g_grid, one workgroup per image -----------------------------------
 template <int KMAX>
 __global__ void __launch_bounds__(256)
-warp_bwd_params_kernel(const BwdParams P, const float* __restrict__ g_grid)
+warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const float* __restrict__ g_grid_part, int slots)
 {
     __shared__ float sT[kMaxK * 2];
     __shared__ float sRed[4][kMaxK * 2];
@@ -216,7 +387,15 @@ warp_bwd_params_kernel(const BwdParams P, const float* __restrict__ g_grid)
     for (int k = 0; k < KMAX; ++k) aT[k][0] = aT[k][1] = 0.0f;
 
     for (int p = tid; p < P.n; p += blockDim.x) {
-        const float2 gg = reinterpret_cast<const float2*>(g_grid)[(size_t)b * P.n + p];
+        float2 gg;
+        if (slots > 0) {                                       // kernel A'': one slice per sampling workgroup; summed here
+            gg = make_float2(0.0f, 0.0f);                      // (empty slices -- an input that is absent -- hold zeros)
+            const float2* ps = reinterpret_cast<const float2*>(g_grid_part) + (size_t)b * slots * P.n + p;
+            for (int sl = 0; sl < slots; ++sl) { const float2 t = ps[(size_t)sl * P.n]; gg.x += t.x; gg.y += t.y; }
+            reinterpret_cast<float2*>(g_grid)[(size_t)b * P.n + p] = gg;       // dL/d grid, as documented
+        } else {
+            gg = reinterpret_cast<const float2*>(g_grid)[(size_t)b * P.n + p];
+        }
         const float ggx = gg.x, ggy = gg.y;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
@@ -268,6 +447,12 @@ warp_bwd_params_kernel(const BwdParams P, const float* __restrict__ g_grid)
 
 }  // namespace
 
+TPSPP_EXPORT size_t tpspp_warp_bwd_workspace_floats(int N, int Ho, int Wo)
+{
+    if (N <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    return (size_t)N * Ho * Wo * 2 * (1 + 2 * kBwdMaxG);      // dL/d grid + the sampling workgroups' slices
+}
+
 TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
                                 const float* g_out1, const float* in1, int C1, int H1, int W1,
                                 const float* grid, const float* T, const float* inv_delta_c,
@@ -293,13 +478,36 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     P.p_hat_t = p_hat_t_or_null; P.p_xy = p_xy; P.score = score;
     P.score_t = (score && (table_flags & TPSPP_SCORE_TRANSPOSED)) ? 1 : 0;
     P.g_ctrl = g_ctrl; P.g_score = g_score; P.N = N; P.F = F; P.n = Ho * Wo;
-    if (hipMemsetAsync(g_grid_ws, 0, (size_t)N * P.n * 2 * sizeof(float), st) != hipSuccess)
-        return tpspp::check_launch("tpspp_warp_bwd(memset)");
     TPSPP_REQUIRE(N <= 65535, "tpspp_warp_bwd: N > 65535");
     const dim3 block(256);
+    const size_t plane0 = (size_t)H0 * W0 * sizeof(float), plane1 = in1 ? (size_t)H1 * W1 * sizeof(float) : 0;
+    int slots = 0;
+    float* part = g_grid_ws + (size_t)N * P.n * 2;          // behind dL/d grid: the sampling workgroups' slices
+    // kernel A'': two fixed-point planes (8 bytes per element) of a pass in <= 64 KB of LDS, <= 1024 output pixels,
+    // planes of whole 16-byte pieces
+    const size_t kLds2 = 16 * 1024;
+    if (P.n <= 1024 && plane0 <= kLds2 && plane1 <= kLds2 && plane0 % 16 == 0 && plane1 % 16 == 0 &&
+        (!g_in0 || reinterpret_cast<uintptr_t>(g_in0) % 16 == 0) && (!g_in1 || reinterpret_cast<uintptr_t>(g_in1) % 16 == 0)) {
+        // channels per chunk: a chunk is worked off two planes at a time, so the LDS only ever holds two
+        const int cpt0 = 8, cpt1 = 8;
+        const int chunks0 = (C0 + cpt0 - 1) / cpt0, chunks1 = in1 ? (C1 + cpt1 - 1) / cpt1 : 0;
+        const int most = chunks0 > chunks1 ? chunks0 : chunks1;
+        int G = (4096 + N * P.nin - 1) / (N * P.nin);      // ~16 workgroups of 256 threads per CU over the launch
+        G = G < 1 ? 1 : (G > most ? most : G);
+        G = G > kBwdMaxG ? kBwdMaxG : G;
+        slots = 2 * G;
+        const size_t accb = 2 * 2 * (plane0 > plane1 ? plane0 : plane1);      // two planes x 8 bytes per element
+        if (P.nin == 1 && hipMemsetAsync(part, 0, (size_t)N * slots * P.n * 2 * sizeof(float), st) != hipSuccess)
+            return tpspp::check_launch("tpspp_warp_bwd(memset)");     // the second input's slices stay empty
+        const dim3 g2((unsigned)(G * P.nin), (unsigned)N);
+        if (P.n <= 256)      hipLaunchKernelGGL(warp_bwd_sample_lds2_kernel<1>, g2, block, accb, st, P, G, cpt0, cpt1, part);
+        else if (P.n <= 512) hipLaunchKernelGGL(warp_bwd_sample_lds2_kernel<2>, g2, block, accb, st, P, G, cpt0, cpt1, part);
+        else                 hipLaunchKernelGGL(warp_bwd_sample_lds2_kernel<4>, g2, block, accb, st, P, G, cpt0, cpt1, part);
+    } else {
+    if (hipMemsetAsync(g_grid_ws, 0, (size_t)N * P.n * 2 * sizeof(float), st) != hipSuccess)
+        return tpspp::check_launch("tpspp_warp_bwd(memset)");
     // LDS-accumulating sampler backward when whole planes fit (64 KB per workgroup), else global atomics
     const size_t kLdsBudget = 64 * 1024;
-    const size_t plane0 = (size_t)H0 * W0 * sizeof(float), plane1 = in1 ? (size_t)H1 * W1 * sizeof(float) : 0;
     const size_t gg_bytes = (size_t)P.n * 2 * sizeof(float);
     if (plane0 <= kLdsBudget && plane1 <= kLdsBudget && gg_bytes <= 32 * 1024) {
         const int cpt0 = (int)(kLdsBudget / plane0 < (size_t)kCPT ? kLdsBudget / plane0 : (size_t)kCPT);
@@ -327,9 +535,10 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
         hipLaunchKernelGGL(warp_bwd_sample_kernel, dim3((unsigned)((P.n + 255) / 256), (unsigned)(chunks0 + chunks1), (unsigned)N),
                            block, 0, st, P, chunks0, g_grid_ws);
     }
+    }
     const dim3 grid_dim((unsigned)N);
-    if (F + 3 <= 24)      hipLaunchKernelGGL(warp_bwd_params_kernel<24>, grid_dim, block, 0, st, P, g_grid_ws);
-    else if (F + 3 <= 36) hipLaunchKernelGGL(warp_bwd_params_kernel<36>, grid_dim, block, 0, st, P, g_grid_ws);
-    else                  hipLaunchKernelGGL(warp_bwd_params_kernel<64>, grid_dim, block, 0, st, P, g_grid_ws);
+    if (F + 3 <= 24)      hipLaunchKernelGGL(warp_bwd_params_kernel<24>, grid_dim, block, 0, st, P, g_grid_ws, part, slots);
+    else if (F + 3 <= 36) hipLaunchKernelGGL(warp_bwd_params_kernel<36>, grid_dim, block, 0, st, P, g_grid_ws, part, slots);
+    else                  hipLaunchKernelGGL(warp_bwd_params_kernel<64>, grid_dim, block, 0, st, P, g_grid_ws, part, slots);
     return tpspp::check_launch("tpspp_warp_bwd");
 }

@@ -1014,7 +1014,7 @@ def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None
     g_in0 = torch.empty_like(in0) if need_in0 else None
     g_in1 = torch.empty_like(in1) if (in1 is not None and need_in1) else None
     g_ctrl = torch.empty((N, F, 2), device=in0.device, dtype=torch.float32)
-    g_grid = torch.empty((N, n, 2), device=in0.device, dtype=torch.float32)
+    g_grid = torch.empty((int(_lib.lib().tpspp_warp_bwd_workspace_floats(N, Ho, Wo)),), device=in0.device, dtype=torch.float32)
     with torch.cuda.device(in0.device):
         rc = _lib.lib().tpspp_warp_bwd(_ptr(g_out0), _ptr(in0), C0, H0, W0, _ptr(g_out1), _ptr(in1), C1, H1, W1,
                                        _ptr(grid), _ptr(T), _ptr(inv_delta_C), _ptr(P_hat), P_hat.shape[1],
