@@ -302,8 +302,10 @@ int tpspp_conv_chunk_channels(int kernel_size);
 
 /*
  * tpspp_front_fwd on the bf16 matrix cores (the bf16 configuration): inputs and feat0 / feat1 / feat2 are bf16,
- * feat_grid bf16 or fp32 (feat_grid_f32); accumulation, bias and ReLU in fp32; feat_grid is computed from the
- * bf16-rounded feat0 / feat1 / feat2 (what the separate convolutions would read back).
+ * feat_grid bf16 or fp32 (feat_grid_f32 bit 0); accumulation, bias and ReLU in fp32; feat_grid is computed from the
+ * bf16-rounded feat0 / feat1 / feat2 (what the separate convolutions would read back).  feat_grid_f32 bit 1 (value 2):
+ * feat0 / feat1 / feat2 are written in the BLOCKED layout (N, 8, H, W, 8) -- the eight channels of a group next to
+ * each other per pixel -- that tpspp_conv2d_bf16_fwd takes with layout code 2 (same values; feat_grid stays NCHW).
  *   w0 / w1  [2 k-steps][2 halves][64 cout][8] bf16 with value W[cout][16 j + 8 h + e];  w2 the same with 4 k-steps;
  *   wg       [12][2][64][8] with value Wg[cout][16 j + perm[8 h + e]], perm = {0,1,2,3,8,9,10,11,4,5,6,7,12,13,14,15}
  *            (the order in which the matrix core's result registers come back as the next operand);
@@ -321,17 +323,21 @@ int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
 /*
  * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32
  * accumulation; bias / residual / activation / affine in fp32) for the bf16 configurations
- * (BASELINE.json configs[2], configs[4]).  Every tensor is NCHW and independently bf16 or fp32 in memory.
- *   src_ptrs[i]      (N, C_i, H_i, W_i); src_dims + 6*i = {C_i, H_i, W_i, uh_i, uw_i, is_f32_i}; uh, uw in
+ * (BASELINE.json configs[2], configs[4]).  Every tensor is independently bf16 NCHW (layout code 0), fp32 NCHW (1) or
+ * bf16 BLOCKED (2): (N, C/8, H, W, 8), the eight channels of a group next to each other per pixel -- a 16-byte unit
+ * of that layout IS a unit of the kernel's channel-innermost LDS patch, so a blocked source is staged with 16-byte
+ * loads and no transposition, and a blocked output leaves as 8-byte pieces straight from the result registers
+ * (layers that only feed other convolutions use it; C a multiple of 8; not with split3).  Same values in every layout.
+ *   src_ptrs[i]      (N, C_i, H_i, W_i); src_dims + 6*i = {C_i, H_i, W_i, uh_i, uw_i, layout code}; uh, uw in
  *                    {1, 2, 4}; with nsrc > 1 every C_i must be a multiple of
  *                    KC = tpspp_conv_bf16_chunk_channels(K)
  *   weight_arranged  bf16, the PyTorch weight (Cout, Cin, KH, KW) (BatchNorm folded) zero-padded to
  *                    Cout % 64 == 0 and Cin % KC == 0 and laid out
  *                    [Cout/64][Cin/KC][KH*KW][KC/8][64 cout][8 cin]  (the LDS image of each K-chunk)
  *   bias, post_scale, post_shift   (Cout) fp32 or NULL
- *   residual         (N, Cout, Ho, Wo), fp32 when residual_f32 else bf16, or NULL; res_mode as above
+ *   residual         (N, Cout, Ho, Wo), layout code residual_f32, or NULL; res_mode as above
  *   relu             0 none, 1 ReLU, 2 GELU (exact erf form)
- *   out              (N, Cout, Ho, Wo), fp32 when out_f32 else bf16 (round to nearest even)
+ *   out              (N, Cout, Ho, Wo), layout code out_f32 (bf16: round to nearest even)
  *   split3           "bf16x3": every fp32 operand is split into bf16 halves (hi = bf16(x), lo = bf16(x - hi)) and a
  *                    product is hi*hi + hi*lo + lo*hi in fp32: ~5e-6 relative error per layer (fp32: 3e-7, bf16:
  *                    2.5e-3) at three bf16 matrix instructions.  weight_arranged then holds TWO slabs per chunk,

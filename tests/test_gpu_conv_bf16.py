@@ -229,3 +229,56 @@ def test_front_bf16_persistent_trips_match_single_image_runs(cuda):
             one = ops.front_bf16(o0[n:n + 1].contiguous(), o1[n:n + 1].contiguous(), x[n:n + 1].contiguous(), fw, dt)
             for a, b in zip(whole, one):
                 assert torch.equal(a[n:n + 1], b)
+
+
+BLK_CASES = [c for c in CASES if all(s_[0] % 8 == 0 for s_ in c[1]) and c[2] % 8 == 0]
+
+
+@pytest.mark.parametrize("name,srcs,cout,k,stride,relu,res_mode,res_dt,N", BLK_CASES, ids=[c[0] for c in BLK_CASES])
+def test_conv_bf16_blocked_layout_is_the_same_arithmetic(cuda, name, srcs, cout, k, stride, relu, res_mode, res_dt, N):
+    """Layout code 2 (ops.Blocked: (N, C/8, H, W, 8)) for sources, residual and output: the same values, bit for bit, as
+    the NCHW bf16 call -- the layout changes how a patch is staged and how results leave, not what is computed."""
+    xs = [(t(synth.dyadic((N, c, h, w), f"{name}.x{i}", 1)).to(cuda).to(torch.bfloat16), uh, uw)
+          for i, (c, h, w, uh, uw, _) in enumerate(srcs)]
+    cin = sum(s_[0] for s_ in srcs)
+    w = t(synth.dyadic((cout, cin, k, k), name + ".w", 1, 1.0 / np.sqrt(cin * k * k)))
+    b = t(synth.dyadic((cout,), name + ".b", 1, 0.1))
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    plain = ops.conv2d_bf16(xs, cw, stride, relu=relu)
+    res = None
+    if res_mode:
+        res = t(synth.dyadic(tuple(plain.shape), name + ".r", 1)).to(cuda).to(torch.bfloat16)
+    want = ops.conv2d_bf16(xs, cw, stride, relu=relu, residual=res, res_mode=res_mode)
+    bsrc = [(ops.Blocked.from_nchw(x), uh, uw) for x, uh, uw in xs]
+    bres = ops.Blocked.from_nchw(res) if res is not None else None
+    # every combination of blocked / NCHW sources, residual and output (mixed sources: only the first one blocked)
+    got = ops.conv2d_bf16(bsrc, cw, stride, relu=relu, residual=bres, res_mode=res_mode, out_blocked=True)
+    assert isinstance(got, ops.Blocked) and got.shape == tuple(want.shape)
+    assert torch.equal(got.nchw().view(torch.int16), want.view(torch.int16)), "blocked in / blocked out"
+    got2 = ops.conv2d_bf16(bsrc, cw, stride, relu=relu, residual=res, res_mode=res_mode)
+    assert torch.equal(got2.view(torch.int16), want.view(torch.int16)), "blocked in / NCHW out"
+    mixed = [bsrc[0]] + xs[1:]
+    got3 = ops.conv2d_bf16(mixed, cw, stride, relu=relu, residual=bres, res_mode=res_mode, out_blocked=True)
+    assert torch.equal(got3.nchw().view(torch.int16), want.view(torch.int16)), "mixed sources"
+    gotf = ops.conv2d_bf16(bsrc, cw, stride, relu=relu, residual=bres, res_mode=res_mode, out_dtype=torch.float32)
+    wantf = ops.conv2d_bf16(xs, cw, stride, relu=relu, residual=res, res_mode=res_mode, out_dtype=torch.float32)
+    assert torch.equal(gotf.view(torch.int32), wantf.view(torch.int32)), "blocked in / fp32 out"
+    with pytest.raises(ValueError):
+        ops.conv2d_bf16(bsrc, ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda), x3=True), stride)
+
+
+@pytest.mark.parametrize("fg_dtype", [torch.bfloat16, torch.float32])
+def test_front_bf16_blocked_outputs(cuda, fg_dtype):
+    from tps_pp_amd import TPS_PP
+    m = TPS_PP().to(cuda).eval()
+    fw = ops.FrontWeightsBf16(m, False)
+    g = torch.Generator(device=cuda).manual_seed(3)
+    n = 5
+    o0 = torch.rand((n, 32, 32, 128), generator=g, device=cuda).to(torch.bfloat16)
+    o1 = torch.rand((n, 32, 32, 128), generator=g, device=cuda).to(torch.bfloat16)
+    x = torch.rand((n, 64, 16, 64), generator=g, device=cuda).to(torch.bfloat16)
+    a = ops.front_bf16(o0, o1, x, fw, fg_dtype)
+    b = ops.front_bf16(o0, o1, x, fw, fg_dtype, blocked=True)
+    for i in range(3):
+        assert isinstance(b[i], ops.Blocked) and torch.equal(b[i].nchw().view(torch.int16), a[i].view(torch.int16)), i
+    assert torch.equal(a[3], b[3])

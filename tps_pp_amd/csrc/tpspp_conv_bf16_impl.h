@@ -15,7 +15,7 @@ struct BSrc {
     const void* p;
     int C, H, W;              // stored size
     int lh, lw;               // log2 of the nearest upsampling factors
-    int f32;                  // element type: 1 fp32, 0 bf16
+    int f32;                  // element type / layout: 0 bf16 NCHW, 1 fp32 NCHW, 2 bf16 blocked (N, C/8, H, W, 8)
 };
 
 struct BParams {
@@ -27,7 +27,7 @@ struct BParams {
     const float* post_scale;
     const float* post_shift;
     void* out;
-    int res_f32, out_f32;
+    int res_f32, out_f32;     // 0 bf16 NCHW, 1 fp32 NCHW, 2 bf16 blocked (N, C/8, H, W, 8)
     int N, Cin, Cout, Hi, Wi, Ho, Wo, ph, pw;
     int relu, res_mode;
     int nchunks;
@@ -227,6 +227,23 @@ conv_tiled_bf16_kernel(const BParams P)
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 rq[i] = ok ? v : z;
             }
+        } else if (!X3 && cur.f32 == 2) {
+            // blocked source (N, C/8, H, W, 8): a patch position's 8 channels of a group ARE one 16-byte unit of the LDS
+            // patch image -- KG loads per position, no packing, no transposition
+            const u32x4* sp = reinterpret_cast<const u32x4*>(cur.p) + ((size_t)n0 * (cur.C >> 3) + ((c0 - cbase) >> 3)) * plane;
+            const int img_units = (cur.C >> 3) * plane;
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) {
+                const bool ok = piy[i] >= 0;
+                const unsigned lo = ok ? (unsigned)(pim[i] * img_units + (piy[i] >> cur.lh) * cur.W + (pix[i] >> cur.lw)) : 0u;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    const bool have = 8 * g < cleft;                                 // uniform
+                    const u32x4 v = sp[(size_t)(have ? g : 0) * plane + lo];
+                    rp[i][4 * g] = (ok && have) ? v[0] : 0u; rp[i][4 * g + 1] = (ok && have) ? v[1] : 0u;
+                    rp[i][4 * g + 2] = (ok && have) ? v[2] : 0u; rp[i][4 * g + 3] = (ok && have) ? v[3] : 0u;
+                }
+            }
         } else
         // every load is unconditional (a predicate per load would put each one in its own basic block and
         // serialise them behind s_waitcnt): channels beyond the source's last one re-read that last channel
@@ -394,6 +411,7 @@ conv_tiled_bf16_kernel(const BParams P)
     // wavefront's [pixel][64 channels] LDS tile (8 bytes per lane and channel quad) and leave as 16-byte pieces of the
     // NCHW rows, brought into pixel order by transposing reads -- 4 stores per lane and fragment instead of 64 (which
     // were 36 % of a 3x3 64->64 layer's time)
+    const bool blk_out = P.out_f32 == 2, blk_res = P.res_f32 == 2;                                        // uniform
     const bool wide_out = !P.out_f32 && full_c && (P.Wo & 7) == 0 && (TW & 7) == 0 && oy0 + TH <= P.Ho && ox0 + TW <= P.Wo &&
                           n0 + NI <= P.N && (reinterpret_cast<size_t>(P.out) & 15) == 0;       // uniform
     unsigned short* const otile = reinterpret_cast<unsigned short*>(sAll) + wv * (32 * kOutPitch);
@@ -414,6 +432,13 @@ conv_tiled_bf16_kernel(const BParams P)
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
                     const int cu = 32 * h2 + 8 * g;                   // + 4*half (in `lo`) + e
+                    // blocked tensors: this lane's four channels are 8 bytes of the unit (image, channel group, pixel)
+                    const size_t bunit = (((size_t)n * (P.Cout >> 3) + ((co_base + cu) >> 3)) * HoWo + (size_t)(valid ? oy * P.Wo + ox : 0)) * 8 + 4 * half;
+                    tpspp_u32x2 rb; rb[0] = rb[1] = 0u;
+                    if constexpr (!SIMPLE) {
+                        if (blk_res && P.res_mode && valid && co_base + cu + 4 * half < P.Cout)
+                            rb = *reinterpret_cast<const tpspp_u32x2*>(reinterpret_cast<const unsigned short*>(P.res) + bunit);
+                    }
     #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = acc[f][h2][4 * g + e] + bq[h2][g][e];
@@ -421,7 +446,9 @@ conv_tiled_bf16_kernel(const BParams P)
                             const size_t o = ubase + (size_t)(cu + e) * HoWo + lo;
                             const int co = co_base + cu + 4 * half + e;
                             float rv = 0.0f;
-                            if (P.res_mode && valid && co < P.Cout)
+                            if (blk_res)
+                                rv = bf16_bits_to_f32((unsigned short)((rb[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                            else if (P.res_mode && valid && co < P.Cout)
                                 rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
                                                : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
                             if (P.res_mode == 2) v[e] = v[e] + rv;
@@ -434,7 +461,11 @@ conv_tiled_bf16_kernel(const BParams P)
                         }
                     }
                     const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
-                    if (P.out_f32) {
+                    if (blk_out) {
+                        tpspp_u32x2 pk; pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]);
+                        if (valid && co4 < P.Cout)
+                            *reinterpret_cast<tpspp_u32x2*>(reinterpret_cast<unsigned short*>(P.out) + bunit) = pk;
+                    } else if (P.out_f32) {
                         float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
     #pragma unroll
                         for (int e = 0; e < 4; ++e)

@@ -44,6 +44,7 @@ struct FrontBParams {
     unsigned short* feat2;                                // (N, 64, H/2, W/2) bf16
     void* feat_grid;                                      // (N, 64, H, W) bf16 or fp32
     int fg_f32;
+    int blk;                                              // feat0 / feat1 / feat2 in the blocked layout (N, 8, H, W, 8)
     int N, H, W;
 };
 
@@ -162,8 +163,12 @@ __device__ __forceinline__ void gemm(const u32x4* __restrict__ slab, const u32x4
 
 // bias + ReLU + one rounding to bf16; returns the 64 features as chain-ordered B fragments (4 k-steps) and, when
 // `st`, writes them into row `px` of the wavefront's output tile [pixel][64 channels]
+// `gdst` (blocked output, or null): this lane's 8 bytes of channel group 0's unit of its pixel; the groups are
+// `gstride` elements apart -- the two half-wavefronts complete each other's 16-byte units, a wavefront store is 512
+// contiguous bytes, and the output tile / its transposition are not needed
 __device__ __forceinline__ void finish(const f32x16 (&acc)[2], const float* __restrict__ bias, int half,
-                                       unsigned short* tile, int px, bool st, u32x4* __restrict__ out)
+                                       unsigned short* tile, int px, bool st, u32x4* __restrict__ out,
+                                       unsigned short* gdst = nullptr, size_t gstride = 0)
 {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -180,7 +185,8 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[2], const float* __re
             // group g of tile t is k-step 2t + g/2, slots 4(g&1) .. 4(g&1)+3
             out[2 * t + (g >> 1)][2 * (g & 1)] = pk[0];
             out[2 * t + (g >> 1)][2 * (g & 1) + 1] = pk[1];
-            if (st) *reinterpret_cast<u32x2*>(tile + px * kOutPitch + 32 * t + 8 * g + 4 * half) = pk;
+            if (gdst) { if (st) *reinterpret_cast<u32x2*>(gdst + (size_t)(4 * t + g) * gstride) = pk; }
+            else if (st) *reinterpret_cast<u32x2*>(tile + px * kOutPitch + 32 * t + 8 * g + 4 * half) = pk;
         }
     }
 }
@@ -217,7 +223,7 @@ __device__ __forceinline__ void flush_tile(const unsigned short* tile, char* __r
 constexpr int kSlabUnits = (2 + 2 + 4 + 12) * 128;      // 16-byte units: w0 | w1 | w2 | wg
 constexpr int kSlabBytes = kSlabUnits * 16 + 4 * 64 * 4;  // + the four bias vectors
 
-template <bool FG32, int NW>
+template <bool FG32, int NW, bool BLK>
 __global__ void __launch_bounds__(NW * 64)
 front_bf16_kernel(const FrontBParams P)
 {
@@ -298,18 +304,32 @@ front_bf16_kernel(const FrontBParams P)
         const size_t obase = (size_t)n * 64 * plane + seg0;           // uniform
         zero();
         gemm<2>(w0, in0, half, l31, acc);
-        finish(acc, bias, half, to, l31, true, f);
-        flush_tile<32>(to, reinterpret_cast<char*>(P.feat0 + obase), pb, lane);
-        zero();
-        gemm<2>(w1, in1, half, l31, acc);
-        finish(acc, bias + 64, half, to, l31, true, f + 4);
-        flush_tile<32>(to, reinterpret_cast<char*>(P.feat1 + obase), pb, lane);
+        if constexpr (BLK) {
+            // blocked feat0 / feat1 / feat2: 8-byte pieces straight from the result registers
+            const size_t bbase = ((size_t)n * 8 * plane + seg0 + l31) * 8 + 4 * half;
+            finish(acc, bias, half, to, l31, true, f, P.feat0 + bbase, (size_t)plane * 8);
+            zero();
+            gemm<2>(w1, in1, half, l31, acc);
+            finish(acc, bias + 64, half, to, l31, true, f + 4, P.feat1 + bbase, (size_t)plane * 8);
+        } else {
+            finish(acc, bias, half, to, l31, true, f);
+            flush_tile<32>(to, reinterpret_cast<char*>(P.feat0 + obase), pb, lane);
+            zero();
+            gemm<2>(w1, in1, half, l31, acc);
+            finish(acc, bias + 64, half, to, l31, true, f + 4);
+            flush_tile<32>(to, reinterpret_cast<char*>(P.feat1 + obase), pb, lane);
+        }
         zero();
         gemm<4>(w2, in2, half, l31, acc);
         // one lane of every 2x2 block holds the half-resolution pixel: even rows write it, from the even-pixel lanes
         const bool row2 = (y & 1) == 0;                               // uniform
-        finish(acc, bias + 128, half, to, l31 >> 1, row2 && (l31 & 1) == 0, f + 8);
-        if (row2) flush_tile<16>(to, reinterpret_cast<char*>(P.feat2 + (size_t)n * 64 * plane2 + seg2), (size_t)plane2 * 2, lane);
+        if constexpr (BLK) {
+            finish(acc, bias + 128, half, to, l31 >> 1, row2 && (l31 & 1) == 0, f + 8,
+                   P.feat2 + ((size_t)n * 8 * plane2 + seg2 + (l31 >> 1)) * 8 + 4 * half, (size_t)plane2 * 8);
+        } else {
+            finish(acc, bias + 128, half, to, l31 >> 1, row2 && (l31 & 1) == 0, f + 8);
+            if (row2) flush_tile<16>(to, reinterpret_cast<char*>(P.feat2 + (size_t)n * 64 * plane2 + seg2), (size_t)plane2 * 2, lane);
+        }
         zero();
         gemm<12>(wg, f, half, l31, acc);
         if constexpr (FG32) {
@@ -339,10 +359,12 @@ front_bf16_kernel(const FrontBParams P)
             finish(acc, bias + 192, half, to, l31, true, unused);
             flush_tile<32>(to, reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(P.feat_grid) + obase), pb, lane);
         }
-        // stores issued since the fetch: feat0 4, feat1 4, feat2 2 (even rows), feat_grid 4 (bf16) or 8 (fp32)
+        // stores issued since the fetch: feat0 4, feat1 4, feat2 2 (even rows), feat_grid 4 (bf16) or 8 (fp32);
+        // blocked: feat0 8, feat1 8, feat2 8 (even rows)
         if (more) {
-            constexpr int NS = FG32 ? 16 : 12;
-            if (row2) wait_fetched<NS + 2>(pf0, pf1, pf2);
+            constexpr int NS = (FG32 ? 8 : 4) + (BLK ? 16 : 8);
+            constexpr int N2 = BLK ? 8 : 2;
+            if (row2) wait_fetched<NS + N2>(pf0, pf1, pf2);
             else wait_fetched<NS>(pf0, pf1, pf2);
         }
     }
@@ -543,6 +565,7 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
     const long nseg = (long)N * H * (W / 32);
     const long blocks = (nseg + 3) / 4;
     TPSPP_REQUIRE(blocks <= 0x7fffffffL, "tpspp_front_bf16_fwd: grid too large");
+    TPSPP_REQUIRE(!(split3 && (feat_grid_f32 & 2)), "tpspp_front_bf16_fwd: the blocked layout is for the bf16 tensors, not for split3");
     if (split3) {
         FrontXParams X;
         X.o0 = static_cast<const float*>(outs0); X.o1 = static_cast<const float*>(outs1); X.x = static_cast<const float*>(x);
@@ -570,7 +593,8 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
     P.w2 = static_cast<const u32x4*>(w2); P.wg = static_cast<const u32x4*>(wg);
     P.b0 = b0; P.b1 = b1; P.b2 = b2; P.bg = bg;
     P.feat0 = static_cast<unsigned short*>(feat0); P.feat1 = static_cast<unsigned short*>(feat1);
-    P.feat2 = static_cast<unsigned short*>(feat2); P.feat_grid = feat_grid; P.fg_f32 = feat_grid_f32 ? 1 : 0;
+    P.feat2 = static_cast<unsigned short*>(feat2); P.feat_grid = feat_grid; P.fg_f32 = (feat_grid_f32 & 1) ? 1 : 0;
+    P.blk = (feat_grid_f32 & 2) ? 1 : 0;
     P.N = N; P.H = H; P.W = W;
     TPSPP_REQUIRE(((reinterpret_cast<size_t>(outs0) | reinterpret_cast<size_t>(outs1) | reinterpret_cast<size_t>(x) |
                     reinterpret_cast<size_t>(feat0) | reinterpret_cast<size_t>(feat1) | reinterpret_cast<size_t>(feat2) |
@@ -580,20 +604,19 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
     // workgroups of 4 per CU 371 us, non-temporal stores 369 us, consecutive rows per workgroup 351 us.
     static bool attr_done[tpspp::kMaxDevices] = {};
     if (tpspp::first_use_on_device(attr_done)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<true, 8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<false, 4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<true, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<false, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<true, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
     const int nw = P.fg_f32 ? 8 : 4;
     const long wgs = (nseg + nw - 1) / nw;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    if (P.fg_f32)
-        hipLaunchKernelGGL((front_bf16_kernel<true, 8>), dim3(grid), dim3(8 * 64), kSlabBytes + 8 * kTileBytes,
-                           tpspp::as_stream(stream), P);
-    else
-        hipLaunchKernelGGL((front_bf16_kernel<false, 4>), dim3(grid), dim3(4 * 64), kSlabBytes + 4 * kTileBytes,
-                           tpspp::as_stream(stream), P);
+    auto go = [&](auto kern, int nwv) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nwv * 64), kSlabBytes + nwv * kTileBytes, tpspp::as_stream(stream), P);
+    };
+    if (P.fg_f32) { if (P.blk) go(front_bf16_kernel<true, 8, true>, 8); else go(front_bf16_kernel<true, 8, false>, 8); }
+    else          { if (P.blk) go(front_bf16_kernel<false, 4, true>, 4); else go(front_bf16_kernel<false, 4, false>, 4); }
     return tpspp::check_launch("tpspp_front_bf16_fwd");
 }

@@ -479,16 +479,47 @@ def prep_conv_weight_bf16(weight, bn=None, conv_bias=None, eps=1e-5, post_bn=Non
     return ConvWeightBf16(arranged, None if b is None else b.contiguous(), kh, cin, cout, ps, pb, x3)
 
 
-def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out_dtype=torch.bfloat16):
+class Blocked:
+    """A bf16 feature map in the blocked layout (N, C/8, H, W, 8) -- the eight channels of a group next to each other
+    per pixel -- that the bf16 convolutions exchange among themselves (`tpspp_conv2d_bf16_fwd`, layout code 2: a
+    16-byte unit of it is a unit of the kernel's LDS patch).  `shape` is the logical (N, C, H, W)."""
+
+    def __init__(self, t):
+        if t.dtype != torch.bfloat16 or t.dim() != 5 or t.shape[4] != 8 or not t.is_contiguous():
+            raise ValueError("Blocked: needs a contiguous bfloat16 (N, C/8, H, W, 8) tensor")
+        self.t = t
+        self.shape = (t.shape[0], t.shape[1] * 8, t.shape[2], t.shape[3])
+        self.dtype, self.device = t.dtype, t.device
+
+    @staticmethod
+    def from_nchw(x):
+        n, c, h, w = x.shape
+        return Blocked(x.to(torch.bfloat16).reshape(n, c // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous())
+
+    def nchw(self):
+        n, c, h, w = self.shape
+        return self.t.permute(0, 1, 4, 2, 3).reshape(n, c, h, w).contiguous()
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+def _layout_code(t):
+    return 2 if isinstance(t, Blocked) else int(t.dtype == torch.float32)
+
+
+def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out_dtype=torch.bfloat16, out_blocked=False):
     """Fused conv on the bf16 matrix cores (`tpspp_conv2d_bf16_fwd`): same call shape as `conv2d`; every
-    source / the residual may be float32 or bfloat16, the output is `out_dtype`."""
+    source / the residual may be float32 or bfloat16 NCHW or a `Blocked` bf16 map, the output is `out_dtype`
+    (`out_blocked`: a `Blocked` bf16 map, for layers that only feed other convolutions)."""
     import ctypes
     ts, dims = [], []
     for e in srcs:
-        t, uh, uw = (e, 1, 1) if isinstance(e, torch.Tensor) else e
-        t = _chk16("conv source", t, 4)
+        t, uh, uw = e if isinstance(e, tuple) else (e, 1, 1)
+        code = _layout_code(t)
+        t = _BlkView(t) if isinstance(t, Blocked) else _chk16("conv source", t, 4)
         ts.append(t)
-        dims += [t.shape[1], t.shape[2], t.shape[3], int(uh), int(uw), int(t.dtype == torch.float32)]
+        dims += [t.shape[1], t.shape[2], t.shape[3], int(uh), int(uw), code]
     N, dev, Hi, Wi = _chk_conv_sources("conv2d_bf16", ts, dims, 6)
     if sum(t.shape[1] for t in ts) != cw.cin:
         raise ValueError("conv2d_bf16: source channels != Cin of the weight")
@@ -497,29 +528,51 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
     pad = (kernel - 1) // 2
     Ho = (Hi + 2 * pad - kernel) // sh + 1
     Wo = (Wi + 2 * pad - kernel) // sw + 1
-    res_f32 = 0
+    res_code = 0
     if residual is not None:
-        residual = _chk16("residual", residual, 4)
+        if not isinstance(residual, Blocked):
+            residual = _chk16("residual", residual, 4)
         if tuple(residual.shape) != (N, Cout, Ho, Wo) or res_mode not in (1, 2) or residual.device != dev:
             raise ValueError("conv2d_bf16: residual shape / device / res_mode")
-        res_f32 = int(residual.dtype == torch.float32)
+        res_code = _layout_code(residual)
     elif res_mode != 0:
         raise ValueError("conv2d_bf16: res_mode without residual")
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("conv2d_bf16: out_dtype must be float32 or bfloat16")
-    out = torch.empty((N, Cout, Ho, Wo), device=ts[0].device, dtype=out_dtype)
+    if out_blocked:
+        if out_dtype != torch.bfloat16 or Cout % 8 or cw.x3:
+            raise ValueError("conv2d_bf16: a blocked output is bfloat16 with a multiple of 8 channels (not with x3 weights)")
+        out = Blocked(torch.empty((N, Cout // 8, Ho, Wo, 8), device=dev, dtype=torch.bfloat16))
+    else:
+        out = torch.empty((N, Cout, Ho, Wo), device=dev, dtype=out_dtype)
+    if cw.x3 and (res_code == 2 or any(d == 2 for d in dims[5::6])):
+        raise ValueError("conv2d_bf16: blocked tensors are bfloat16 maps (not with x3 weights)")
     if N == 0:          # an empty batch has no device pointer to hand over
         return out
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     dim_arr = (ctypes.c_int * len(dims))(*dims)
-    with torch.cuda.device(ts[0].device):
+    first = ts[0].keep if isinstance(ts[0], _BlkView) else ts[0]
+    with torch.cuda.device(dev):
         rc = _lib.lib().tpspp_conv2d_bf16_fwd(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dim_arr, ctypes.c_void_p),
-                                              len(ts), _ptr(cw.arranged), _ptr(cw.bias), _ptr(residual), res_f32,
+                                              len(ts), _ptr(cw.arranged), _ptr(cw.bias),
+                                              residual.data_ptr() if residual is not None else None, res_code,
                                               _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode), int(relu),
-                                              N, Cout, kernel, kernel, sh, sw, _ptr(out),
-                                              int(out_dtype == torch.float32), Ho, Wo, int(cw.x3), _stream(ts[0]))
+                                              N, Cout, kernel, kernel, sh, sw, out.data_ptr(),
+                                              2 if out_blocked else int(out_dtype == torch.float32), Ho, Wo, int(cw.x3),
+                                              _stream(first))
     _lib.check(rc, "tpspp_conv2d_bf16_fwd")
     return out
+
+
+class _BlkView:
+    """What the shared source checks look at (logical shape, device, is_cuda, dtype, data_ptr) for a `Blocked` map."""
+
+    def __init__(self, b):
+        self.shape, self.device, self.dtype, self.is_cuda = b.shape, b.device, b.dtype, b.t.is_cuda
+        self.keep = b.t
+
+    def data_ptr(self):
+        return self.keep.data_ptr()
 
 
 def _mfma_feature_perm(device):
@@ -706,7 +759,7 @@ def front_bf16_applicable(o0, o1, x, x3=False):
     return all(t.dtype == dt for t in (o0, o1, x)) and o0.shape[2] % 2 == 0 and o0.shape[3] % 32 == 0
 
 
-def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16):
+def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False):
     """`front` on the bf16 matrix cores: bf16 in, bf16 feat0 / feat1 / feat2, feat_grid bf16 or fp32; with x3 weights
     (`FrontWeightsBf16(m, x3=True)`) fp32 in and out, three-term split."""
     o0, o1, x = _chk16("outs[0]", o0, 4), _chk16("outs[1]", o1, 4), _chk16("x", x, 4)
@@ -720,16 +773,24 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16):
     bf = torch.float32 if fw.x3 else torch.bfloat16
     if fw.x3:
         feat_grid_dtype = torch.float32
-    feat0 = torch.empty((N, 64, H, W), device=dev, dtype=bf)
+    blocked = bool(blocked) and not fw.x3       # feat0 / feat1 / feat2 as `Blocked` maps (they only feed convolutions)
+    if blocked:
+        feat0 = torch.empty((N, 8, H, W, 8), device=dev, dtype=bf)
+        feat2 = torch.empty((N, 8, H // 2, W // 2, 8), device=dev, dtype=bf)
+    else:
+        feat0 = torch.empty((N, 64, H, W), device=dev, dtype=bf)
+        feat2 = torch.empty((N, 64, H // 2, W // 2), device=dev, dtype=bf)
     feat1 = torch.empty_like(feat0)
     feat_grid = torch.empty((N, 64, H, W), device=dev, dtype=feat_grid_dtype)
-    feat2 = torch.empty((N, 64, H // 2, W // 2), device=dev, dtype=bf)
     with torch.cuda.device(dev):
         rc = _lib.lib().tpspp_front_bf16_fwd(_ptr(o0), _ptr(o1), _ptr(x), _ptr(fw.w0), _ptr(fw.b0), _ptr(fw.w1),
                                              _ptr(fw.b1), _ptr(fw.w2), _ptr(fw.b2), _ptr(fw.wg), _ptr(fw.bg),
                                              _ptr(feat0), _ptr(feat1), _ptr(feat2), _ptr(feat_grid),
-                                             int(feat_grid_dtype == torch.float32), N, H, W, int(fw.x3), _stream(o0))
+                                             int(feat_grid_dtype == torch.float32) | (2 if blocked else 0), N, H, W,
+                                             int(fw.x3), _stream(o0))
     _lib.check(rc, "tpspp_front_bf16_fwd")
+    if blocked:
+        return Blocked(feat0), Blocked(feat1), Blocked(feat2), feat_grid
     return feat0, feat1, feat2, feat_grid
 
 

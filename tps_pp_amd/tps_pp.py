@@ -464,6 +464,10 @@ class TPS_PP(nn.Module):
         # the fp32 matrix time.  DGAB / score / control points then run on their exact fp32 kernels.
         bf = f32 if x3 else torch.bfloat16
         c16 = (lambda *a, **k: ops.conv2d_bf16(*a, **{"out_dtype": f32, **k})) if x3 else ops.conv2d_bf16
+        # plain bf16: the maps that only convolutions read (feat0 / feat1 / feat2, the stride-2 results, the encoder maps
+        # and the first three decoder maps) live in the BLOCKED layout (ops.Blocked: a convolution stages such a source
+        # with 16-byte loads and no transposition and writes it as 8-byte pieces of its result registers)
+        blk = {} if x3 else {"out_blocked": True}
         x, o0, o1 = batch_img, outs[0], outs[1]
         if self.type == "ResNet45v2":
             # feat_grid is sampled by the warp: bf16 when the module boundary is bf16 (the warp then moves half
@@ -476,25 +480,25 @@ class TPS_PP(nn.Module):
                 fc = getattr(self, "_front16_cache", None)
                 if fc is None or fc[0] != fkey:
                     self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self, x3))
-                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype)
+                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype, blocked=not x3)
             else:
                 feat0 = c16([o0], cw["down0"], 1)
                 feat1 = c16([o1], cw["down1"], 1)
                 feat2 = c16([x], cw["down2"], 1)
                 feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1, out_dtype=fg_dtype)
-            cat_srcs = [c16([feat0], cw["down0_1"], 2), c16([feat1], cw["down1_1"], 2), feat2]
+            cat_srcs = [c16([feat0], cw["down0_1"], 2, **blk), c16([feat1], cw["down1_1"], 2, **blk), feat2]
         else:
-            cat_srcs = [c16([o0], cw["down0"], 2), c16([o1], cw["down1"], 1), c16([x], cw["down2"], 1)]
+            cat_srcs = [c16([o0], cw["down0"], 2, **blk), c16([o1], cw["down1"], 1, **blk), c16([x], cw["down2"], 1, **blk)]
             feat_grid = x
         p = self.MSFA.conv.stride
-        e0 = c16(cat_srcs, cw["enc0"], 1)
-        e1 = c16([e0], cw["enc1"], 2)
-        e2 = c16([e1], cw["enc2"], p)
+        e0 = c16(cat_srcs, cw["enc0"], 1, **blk)
+        e1 = c16([e0], cw["enc1"], 2, **blk)
+        e2 = c16([e1], cw["enc2"], p, **blk)
         e3 = c16([e2], cw["enc3"], (2, 1), out_dtype=f32)
         k = ops.cbam(e3, self.MSFA.conv.atten)
-        k = c16([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1)
-        k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
-        k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
+        k = c16([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1, **blk)
+        k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1, **blk)
+        k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1, **blk)
         de_feat = c16([k], cw["dec3"], 1, out_dtype=f32)
         control_point, atten_score = self._tpe_hip(e3, de_feat, bf16=True, x3=x3)
         return control_point, atten_score, feat_grid
