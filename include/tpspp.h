@@ -478,7 +478,7 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
 /*
  * NRTRDecoder.forward_test (greedy, forced_tokens == NULL) / forward_train (teacher forcing):
  *   enc_cm       (C, N*T) channel-major encoder output (tpspp_nrtr_encoder_fwd's out_cm)
- *   layer_ptrs   n_layers x 18 device pointers, per layer (every LayerNorm folded into the projection that
+ *   layer_ptrs   n_layers x 24 (+ 1) device pointers, per layer (every LayerNorm folded into the projection that
  *                follows it, see tpspp_linear_ln_fwd: w_gamma = diag(norm.weight) W^T-k-major, colsum its
  *                column sums, bias_eff = norm.bias^T W (+ bias)):
  *                  self_attn q|k|v fused (C, 3C): w_gamma, colsum (3C), bias_eff (3C);
@@ -487,7 +487,15 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
  *                  enc_attn.linear_k.weight^T, its bias | NULL;  enc_attn.linear_v.weight^T (no bias);
  *                  enc_attn.fc.weight^T, its bias | NULL;
  *                  mlp.w_1 (C, d_inner): w_gamma, colsum (d_inner), bias_eff (d_inner);
- *                  mlp.w_2.weight^T (d_inner, C), mlp.w_2.bias
+ *                  mlp.w_2.weight^T (d_inner, C), mlp.w_2.bias;
+ *                  then six entries that are NULL in the exact-fp32 configuration and, with TPSPP_HEAD_BF16 or
+ *                  TPSPP_HEAD_BF16X3, hold the six per-step projections (q|k|v with norm1 folded, self fc, enc q with norm2
+ *                  folded, enc fc, w_1 with norm3 folded, w_2) split and arranged for the step GEMM: K-major (K, Co) ->
+ *                  hi = bf16(w), lo = bf16(w - hi), Co zero-padded to a multiple of 32, laid out
+ *                  [Co/32][K/16][hi|lo][2 k halves][32 outputs][8 k] bf16;
+ *                with those flags one more pointer follows the last layer: the classifier (final layer_norm folded)
+ *                arranged the same way.  Every activation of a step is then token-major and the projections run as
+ *                three-term bf16 products (hi*hi + hi*lo + lo*hi, fp32 accumulation: inside the fp32 tolerance)
  *   emb (num_classes, C) trg_word_emb.weight;  pos_table (n_position, C) position_enc.position_table;
  *   w_cls (C, num_out), cls_colsum (num_out), b_cls (num_out): the classifier with the final layer_norm
  *                (eps 1e-6) folded in the same way;  max_seq_len <= 64;  valid_len as above (cross-attention

@@ -52,4 +52,9 @@ for tag, bb, hd in (("bf16x3 backbone/TPS++ (fp32 tensors, <= 1e-4)", "bf16x3", 
     with torch.no_grad():
         t_all = timeit(lambda: m(img, metas, return_loss=False))
         t_feat = timeit(lambda: m.extract_feat(img, test=True))
-    print(f"  {tag}: simple_test {t_all:.1f} ms = {N / t_all * 1e3:,.0f} img/s | backbone+TPS++ {t_feat:.1f} ms")
+        feat = m.extract_feat(img, test=True)["output"]
+        t_enc = timeit(lambda: m.encoder(feat, None))
+        out_enc = m.encoder(feat, None)
+        t_dec = timeit(lambda: m.decoder(feat, out_enc, None, None, train_mode=False))
+    print(f"  {tag}: simple_test {t_all:.1f} ms = {N / t_all * 1e3:,.0f} img/s | backbone+TPS++ {t_feat:.1f} ms | "
+          f"encoder {t_enc:.2f} ms | greedy decoder {t_dec:.1f} ms")

@@ -428,6 +428,7 @@ conv_tiled_bf16_kernel(const BParams P)
             const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
     #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
+                tpspp_u32x2 bpk[4];
     #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float v[4];
@@ -462,9 +463,19 @@ conv_tiled_bf16_kernel(const BParams P)
                     }
                     const int co4 = co_base + cu + 4 * half;          // this lane's first channel of the quad
                     if (blk_out) {
-                        tpspp_u32x2 pk; pk[0] = pack2_bf16(v[0], v[1]); pk[1] = pack2_bf16(v[2], v[3]);
-                        if (valid && co4 < P.Cout)
-                            *reinterpret_cast<tpspp_u32x2*>(reinterpret_cast<unsigned short*>(P.out) + bunit) = pk;
+                        // the two half-wavefronts hold the two halves of a 16-byte unit: v_permlane32_swap pairs them up
+                        // (lower half-wavefront: the unit of group g, upper: that of group g + 1), one 16-byte store
+                        // per two groups
+                        bpk[g][0] = pack2_bf16(v[0], v[1]); bpk[g][1] = pack2_bf16(v[2], v[3]);
+                        if (g & 1) {
+                            const tpspp_u32x2 d0 = __builtin_amdgcn_permlane32_swap(bpk[g - 1][0], bpk[g][0], false, false);
+                            const tpspp_u32x2 d1 = __builtin_amdgcn_permlane32_swap(bpk[g - 1][1], bpk[g][1], false, false);
+                            u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                            const int kg = ((co_base + 32 * h2) >> 3) + (g - 1) + half;
+                            const size_t bu = (((size_t)n * (P.Cout >> 3) + kg) * HoWo + (size_t)(valid ? oy * P.Wo + ox : 0)) * 8;
+                            if (valid && 8 * kg < P.Cout)
+                                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(P.out) + bu) = unit;
+                        }
                     } else if (P.out_f32) {
                         float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
     #pragma unroll

@@ -55,6 +55,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
 
 // ---- data movement -------------------------------------------------------------------------------------------------
 // A lane's MFMA operands are 2-byte elements of 16 (32) different channel planes, and its results are 2-byte elements
@@ -163,15 +164,17 @@ __device__ __forceinline__ void gemm(const u32x4* __restrict__ slab, const u32x4
 
 // bias + ReLU + one rounding to bf16; returns the 64 features as chain-ordered B fragments (4 k-steps) and, when
 // `st`, writes them into row `px` of the wavefront's output tile [pixel][64 channels]
-// `gdst` (blocked output, or null): this lane's 8 bytes of channel group 0's unit of its pixel; the groups are
-// `gstride` elements apart -- the two half-wavefronts complete each other's 16-byte units, a wavefront store is 512
-// contiguous bytes, and the output tile / its transposition are not needed
+// `gdst` (blocked output, or null): channel group 0's 16-byte unit of this lane's pixel; the groups are `gstride`
+// elements apart.  The two half-wavefronts hold the two 8-byte halves of every unit: v_permlane32_swap pairs them up so
+// that the lower half-wavefront owns the whole unit of group g and the upper one that of group g + 1 -- four 16-byte
+// stores per 64 channels, each two 512-byte runs, and no output tile / transposition
 __device__ __forceinline__ void finish(const f32x16 (&acc)[2], const float* __restrict__ bias, int half,
                                        unsigned short* tile, int px, bool st, u32x4* __restrict__ out,
                                        unsigned short* gdst = nullptr, size_t gstride = 0)
 {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+        u32x2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v[4];
@@ -180,13 +183,20 @@ __device__ __forceinline__ void finish(const f32x16 (&acc)[2], const float* __re
                 const float s = acc[t][4 * g + e] + bias[32 * t + 8 * g + 4 * half + e];
                 v[e] = s > 0.0f ? s : 0.0f;
             }
-            u32x2 pk;
-            pk[0] = pack_bf16(v[0], v[1]); pk[1] = pack_bf16(v[2], v[3]);
+            pk[g][0] = pack_bf16(v[0], v[1]); pk[g][1] = pack_bf16(v[2], v[3]);
             // group g of tile t is k-step 2t + g/2, slots 4(g&1) .. 4(g&1)+3
-            out[2 * t + (g >> 1)][2 * (g & 1)] = pk[0];
-            out[2 * t + (g >> 1)][2 * (g & 1) + 1] = pk[1];
-            if (gdst) { if (st) *reinterpret_cast<u32x2*>(gdst + (size_t)(4 * t + g) * gstride) = pk; }
-            else if (st) *reinterpret_cast<u32x2*>(tile + px * kOutPitch + 32 * t + 8 * g + 4 * half) = pk;
+            out[2 * t + (g >> 1)][2 * (g & 1)] = pk[g][0];
+            out[2 * t + (g >> 1)][2 * (g & 1) + 1] = pk[g][1];
+            if (!gdst && st) *reinterpret_cast<u32x2*>(tile + px * kOutPitch + 32 * t + 8 * g + 4 * half) = pk[g];
+        }
+        if (gdst) {
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const u32x2 d0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const u32x2 d1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                if (st) *reinterpret_cast<u32x4*>(gdst + (size_t)(4 * t + g + half) * gstride) = unit;
+            }
         }
     }
 }
@@ -306,7 +316,7 @@ front_bf16_kernel(const FrontBParams P)
         gemm<2>(w0, in0, half, l31, acc);
         if constexpr (BLK) {
             // blocked feat0 / feat1 / feat2: 8-byte pieces straight from the result registers
-            const size_t bbase = ((size_t)n * 8 * plane + seg0 + l31) * 8 + 4 * half;
+            const size_t bbase = ((size_t)n * 8 * plane + seg0 + l31) * 8;
             finish(acc, bias, half, to, l31, true, f, P.feat0 + bbase, (size_t)plane * 8);
             zero();
             gemm<2>(w1, in1, half, l31, acc);
@@ -325,7 +335,7 @@ front_bf16_kernel(const FrontBParams P)
         const bool row2 = (y & 1) == 0;                               // uniform
         if constexpr (BLK) {
             finish(acc, bias + 128, half, to, l31 >> 1, row2 && (l31 & 1) == 0, f + 8,
-                   P.feat2 + ((size_t)n * 8 * plane2 + seg2 + (l31 >> 1)) * 8 + 4 * half, (size_t)plane2 * 8);
+                   P.feat2 + ((size_t)n * 8 * plane2 + seg2 + (l31 >> 1)) * 8, (size_t)plane2 * 8);
         } else {
             finish(acc, bias + 128, half, to, l31 >> 1, row2 && (l31 & 1) == 0, f + 8);
             if (row2) flush_tile<16>(to, reinterpret_cast<char*>(P.feat2 + (size_t)n * 64 * plane2 + seg2), (size_t)plane2 * 2, lane);
@@ -360,10 +370,10 @@ front_bf16_kernel(const FrontBParams P)
             flush_tile<32>(to, reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(P.feat_grid) + obase), pb, lane);
         }
         // stores issued since the fetch: feat0 4, feat1 4, feat2 2 (even rows), feat_grid 4 (bf16) or 8 (fp32);
-        // blocked: feat0 8, feat1 8, feat2 8 (even rows)
+        // blocked: feat0 4, feat1 4, feat2 4 (even rows)
         if (more) {
-            constexpr int NS = (FG32 ? 8 : 4) + (BLK ? 16 : 8);
-            constexpr int N2 = BLK ? 8 : 2;
+            constexpr int NS = (FG32 ? 8 : 4) + 8;
+            constexpr int N2 = BLK ? 4 : 2;
             if (row2) wait_fetched<NS + N2>(pf0, pf1, pf2);
             else wait_fetched<NS>(pf0, pf1, pf2);
         }

@@ -331,13 +331,14 @@ attn_enc_mfma_kernel(const float* __restrict__ qkv, int C, int M, int T, const i
 
 // ---- decoder, one step: embedding + position table ----------------------------------------------------
 // x[c][b] = emb[tokens[b][step]][c] + pos[step][c]      (nrtr_decoder.py:96-98, no scaling)
+// tm: x is token-major (Nb, C) instead of channel-major (C, Nb) (the split-K step GEMM's layout)
 __global__ void __launch_bounds__(256)
 dec_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pos, const int* __restrict__ tokens,
-                 int Lt, int step, int C, int Nb, float* __restrict__ x)
+                 int Lt, int step, int C, int Nb, float* __restrict__ x, int tm)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * Nb) return;
-    const int c = i / Nb, b = i - c * Nb;
+    const int c = tm ? i % C : i / Nb, b = tm ? i / C : i - c * Nb;
     const int tok = tokens[(size_t)b * Lt + step];
     x[i] = emb[(size_t)tok * C + c] + pos[(size_t)step * C + c];
 }
@@ -364,7 +365,7 @@ template <typename KV>
 __global__ void __launch_bounds__(256)
 attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
                      KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
-                     int pad_idx, float* __restrict__ out)
+                     int pad_idx, float* __restrict__ out, int out_tm)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -408,7 +409,8 @@ attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int 
             acc = fmaf(pw, vv[u], acc);
         }
     }
-    out[(size_t)(kDK * h + lane) * Nb + b] = acc;
+    if (out_tm) out[(size_t)b * C + kDK * h + lane] = acc;
+    else out[(size_t)(kDK * h + lane) * Nb + b] = acc;
 }
 
 // ---- decoder, one step: cross-attention against the encoder ------------------------------------------------
@@ -423,7 +425,7 @@ __device__ __forceinline__ float kv_elem(unsigned short v) { return __builtin_bi
 template <typename KV>
 __global__ void __launch_bounds__(256)
 attn_dec_cross_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx, const KV* __restrict__ Vx_t,
-                      int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out)
+                      int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out, int out_tm)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -481,7 +483,8 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx, 
             }
         }
     }
-    out[(size_t)(kDK * h + lane) * Nb + b] = acc;
+    if (out_tm) out[(size_t)b * C + kDK * h + lane] = acc;
+    else out[(size_t)(kDK * h + lane) * Nb + b] = acc;
 }
 
 // ---- decoder, one step: classifier epilogue ------------------------------------------------------------------
@@ -489,21 +492,23 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx, 
 // tokens[b][step+1] = arg-max (first maximum)  (nrtr_decoder.py:168-175).  Forced: out = raw logits.
 __global__ void __launch_bounds__(256)
 dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, int L, int greedy,
-                    float* __restrict__ out, int* __restrict__ tokens, int Lt)
+                    float* __restrict__ out, int* __restrict__ tokens, int Lt, int tm)
 {
     // one wavefront per image, lanes over classes
     const int lane = threadIdx.x & (kWave - 1);
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= Nb) return;
     float* o = out + ((size_t)b * L + step) * Cc;
+    const size_t ls = tm ? 1 : (size_t)Nb;                 // stride between the classes of an image
+    logits += tm ? (size_t)b * Cc : (size_t)b;
     if (!greedy) {
-        for (int c = lane; c < Cc; c += kWave) o[c] = logits[(size_t)c * Nb + b];
+        for (int c = lane; c < Cc; c += kWave) o[c] = logits[(size_t)c * ls];
         return;
     }
     float mx = -INFINITY;
     int am = 0x7fffffff;
     for (int c = lane; c < Cc; c += kWave) {
-        const float v = logits[(size_t)c * Nb + b];
+        const float v = logits[(size_t)c * ls];
         if (v > mx) { mx = v; am = c; }
     }
 #pragma unroll
@@ -513,9 +518,9 @@ dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, 
         if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
     }
     float sum = 0.0f;
-    for (int c = lane; c < Cc; c += kWave) sum += expf(logits[(size_t)c * Nb + b] - mx);
+    for (int c = lane; c < Cc; c += kWave) sum += expf(logits[(size_t)c * ls] - mx);
     sum = wave_sum(sum);
-    for (int c = lane; c < Cc; c += kWave) o[c] = expf(logits[(size_t)c * Nb + b] - mx) / sum;
+    for (int c = lane; c < Cc; c += kWave) o[c] = expf(logits[(size_t)c * ls] - mx) / sum;
     if (lane == 0) tokens[(size_t)b * Lt + step + 1] = am;
 }
 
@@ -528,6 +533,142 @@ dec_init_tokens_kernel(int* __restrict__ tokens, int Nb, int Lt, int start_idx, 
     const int b = i / Lt, p = i - b * Lt;
     if (forced) tokens[i] = p < Lf ? forced[(size_t)b * Lf + p] : pad_idx;
     else tokens[i] = p == 0 ? start_idx : pad_idx;
+}
+
+// ---- decoder, one step: the projections on the bf16 matrix cores with the three-term split ------------------------
+// out (M, Co) = act(LN?(X) W + bias) [+ res], all TOKEN-major, X (M, K) fp32, M = images of the step.
+// Why not the fp32 split-K kernel (conv1x1_skinny_f32_kernel) the exact-fp32 configuration keeps: its operands arrive
+// as 4-byte loads (512 load instructions per 32x32 tile at 16 cycles each in the vector-memory unit: 3.7 us of an 8 us
+// launch) and meet in 16 partial tiles of 64 KB.  Here
+//   * the MFMA runs  D[co][token] = W^T[co][k] X^T[k][token]  so that a lane's B fragment is 8 consecutive k of ITS
+//     token -- two 16-byte loads of the token-major row -- and its results are 4 consecutive outputs of its token
+//     (16-byte stores);
+//   * the weight arrives pre-split (hi = bf16(w), lo = bf16(w - hi)) and pre-arranged on the host in fragment order,
+//     [Co/32][K/16][hi|lo][k half][32 outputs][8 k]: a fragment is one 16-byte load, a wavefront load 1 KB contiguous;
+//   * x is split in registers (two v_cvt_pk_bf16_f32 and a subtraction per pair); a product is hi*hi + hi*lo + lo*hi
+//     accumulated in fp32 (~5e-6 of a layer's scale, as in tpspp_conv2d_bf16_fwd's split3);
+//   * four wavefronts split K (K/64 MFMA k-steps each, every load of a wavefront in flight together), four partial
+//     tiles meet in 16 KB of LDS;
+//   * LayerNorm folded as in tpspp_linear_ln_fwd: sum and sum of squares of the raw row ride on the same loads.
+typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned du32x4 __attribute__((ext_vector_type(4)));
+typedef float df32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dbf16x2 __attribute__((ext_vector_type(2)));
+
+struct DGemm {
+    const float* X; const du32x4* Wp; const float* bias; const float* colsum; const float* res; float* out;
+    int M, K, Co;            // Co: valid outputs (the arranged weight is padded to a multiple of 32)
+    float eps; int act;      // act: 0 none, 2 GELU (erf)
+};
+
+__device__ __forceinline__ unsigned dpack2(float lo, float hi)
+{
+    df32x2 v; v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dbf16x2));
+}
+
+template <int KSW, bool LN>
+__global__ void __launch_bounds__(256)
+dec_gemm_x3_kernel(const DGemm P)
+{
+    __shared__ float sRed[4][16][kWave];
+    __shared__ float sS1[8][32], sS2[8][32];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 32, ct = blockIdx.y, co0 = ct * 32;
+    const int KS = P.K >> 4;
+    const int m = m0 + l31;
+    const int mc = m < P.M ? m : P.M - 1;
+    const float4* xp = reinterpret_cast<const float4*>(P.X + (size_t)mc * P.K + 16 * (wv * KSW) + 8 * half);
+    const du32x4* wp = P.Wp + ((size_t)(ct * KS + wv * KSW) * 4 + half) * 32 + l31;
+    float4 xa[KSW][2];
+    du32x4 ah[KSW], al[KSW];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {                        // every load of the wavefront in flight together
+        xa[j][0] = xp[4 * j]; xa[j][1] = xp[4 * j + 1];
+        ah[j] = wp[(size_t)j * 128]; al[j] = wp[(size_t)j * 128 + 64];
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const float x[8] = {xa[j][0].x, xa[j][0].y, xa[j][0].z, xa[j][0].w, xa[j][1].x, xa[j][1].y, xa[j][1].z, xa[j][1].w};
+        du32x4 bh, bl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned pk = dpack2(x[2 * q], x[2 * q + 1]);
+            const float h0 = __builtin_bit_cast(float, pk << 16), h1 = __builtin_bit_cast(float, pk & 0xffff0000u);
+            bh[q] = pk;
+            bl[q] = dpack2(x[2 * q] - h0, x[2 * q + 1] - h1);
+            if (LN) {
+                s1 += x[2 * q] + x[2 * q + 1];
+                s2 = fmaf(x[2 * q], x[2 * q], s2);
+                s2 = fmaf(x[2 * q + 1], x[2 * q + 1], s2);
+            }
+        }
+        const dbf16x8 Ah = __builtin_bit_cast(dbf16x8, ah[j]), Al = __builtin_bit_cast(dbf16x8, al[j]);
+        const dbf16x8 Bh = __builtin_bit_cast(dbf16x8, bh), Bl = __builtin_bit_cast(dbf16x8, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
+    if (LN) { sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2; }
+    __syncthreads();
+    // wavefront w finishes accumulator registers 4 w .. 4 w + 3: outputs co0 + 8 w + 4 half + (0 .. 3) of token l31
+    const int c = co0 + 8 * wv + 4 * half;
+    if (m >= P.M || c >= P.Co) return;                     // (Co is a multiple of 4: a whole piece is in or out)
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        v[e] = (sRed[0][4 * wv + e][lane] + sRed[1][4 * wv + e][lane]) + (sRed[2][4 * wv + e][lane] + sRed[3][4 * wv + e][lane]);
+    if (LN) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
+        const float mean = t1 / (float)P.K;
+        const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
+        const float4 cs = *reinterpret_cast<const float4*>(P.colsum + c);
+        v[0] = rstd * (v[0] - mean * cs.x); v[1] = rstd * (v[1] - mean * cs.y);
+        v[2] = rstd * (v[2] - mean * cs.z); v[3] = rstd * (v[3] - mean * cs.w);
+    }
+    if (P.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + c);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (P.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    const size_t o = (size_t)m * P.Co + c;
+    if (P.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(P.res + o);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// launches the step GEMM; false when the shape has no instantiation (K must be 256 or 512, Co a multiple of 4)
+bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bias, const float* colsum, float eps,
+                 const float* res, int act, int M, int K, int Co, float* out)
+{
+    if ((K != 256 && K != 512) || (Co & 3) || M <= 0) return false;
+    DGemm P;
+    P.X = X; P.Wp = reinterpret_cast<const du32x4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
+    P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
+    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Co + 31) / 32));
+    if (K == 512) {
+        if (colsum) hipLaunchKernelGGL((dec_gemm_x3_kernel<8, true>), grid, dim3(256), 0, st, P);
+        else        hipLaunchKernelGGL((dec_gemm_x3_kernel<8, false>), grid, dim3(256), 0, st, P);
+    } else {
+        if (colsum) hipLaunchKernelGGL((dec_gemm_x3_kernel<4, true>), grid, dim3(256), 0, st, P);
+        else        hipLaunchKernelGGL((dec_gemm_x3_kernel<4, false>), grid, dim3(256), 0, st, P);
+    }
+    return true;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -700,7 +841,9 @@ TPSPP_EXPORT int tpspp_attn_enc_fwd(const float* qkv, int N, int C, int T, const
 enum { E_LN1G, E_LN1B, E_WQKV, E_BQKV, E_WFC, E_BFC, E_LN2G, E_LN2B, E_W1, E_B1, E_W2, E_B2, E_COUNT };
 // decoder: the three LayerNorms are folded into the projections that follow them (tpspp_linear_ln_fwd)
 enum { D_QKV_W, D_QKV_CS, D_QKV_B, D_WFC, D_BFC, D_Q_W, D_Q_CS, D_Q_B, D_WK, D_BK, D_WV, D_WFC2, D_BFC2, D_W1_W, D_W1_CS,
-       D_W1_B, D_W2, D_B2, D_COUNT };
+       D_W1_B, D_W2, D_B2,
+       // the six per-step projections split and arranged for dec_gemm_x3_kernel (TPSPP_HEAD_BF16 / _BF16X3; else NULL)
+       D_QKV_X, D_WFC_X, D_Q_X, D_WFC2_X, D_W1_X, D_W2_X, D_COUNT };
 
 TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
                                         const float* const* layer_ptrs, const float* ln_g, const float* ln_b,
@@ -844,9 +987,49 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     const int greedy = forced_tokens ? 0 : 1;
     const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
     int rc = 0;
-    for (int s = 0; s < L; ++s) {
+    // Reduced-precision head (TPSPP_HEAD_BF16 / _BF16X3) with arranged per-step weights in the table: every activation of
+    // a step is TOKEN-major and the six projections + the classifier run on dec_gemm_x3_kernel (three-term split: inside
+    // the fp32 tolerance, so the bf16 head takes it as well).  8 launches per layer-step as before, each about half as long.
+    const void* cls_x = (b16 || x3) ? layer_ptrs[(size_t)n_layers * D_COUNT] : nullptr;   // the classifier, arranged (behind the layers)
+    bool fast = (b16 || x3) && cls_x != nullptr && (C == 256 || C == 512) && (d_inner == 256 || d_inner == 512) && (num_out % 4) == 0;
+    for (int l = 0; l < n_layers && fast; ++l) {
+        const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+        fast = w[D_QKV_X] && w[D_WFC_X] && w[D_Q_X] && w[D_WFC2_X] && w[D_W1_X] && w[D_W2_X];
+    }
+    for (int s = 0; s < L && fast; ++s) {
         hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
-                           tokens, Lt, s, C, N, x);
+                           tokens, Lt, s, C, N, x, 1);
+        for (int l = 0; l < n_layers; ++l) {
+            const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+            dec_gemm_x3(st, x, w[D_QKV_X], w[D_QKV_B], w[D_QKV_CS], 1e-5f, nullptr, 0, N, C, 3 * C, qkv);
+            if (b16)
+                hipLaunchKernelGGL(attn_dec_self_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
+                                   L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
+                                   tokens, Lt, padding_idx, a, 1);
+            else
+                hipLaunchKernelGGL(attn_dec_self_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
+                                   Vc[l], tokens, Lt, padding_idx, a, 1);
+            dec_gemm_x3(st, a, w[D_WFC_X], w[D_BFC], nullptr, 0.0f, x, 0, N, C, C, y);              // y = x + fc(a)
+            dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv);
+            if (b16)
+                hipLaunchKernelGGL(attn_dec_cross_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
+                                   reinterpret_cast<const unsigned short*>(Kx[l]),
+                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 1);
+            else
+                hipLaunchKernelGGL(attn_dec_cross_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
+                                   N, H, T, valid_len, a, 1);
+            dec_gemm_x3(st, a, w[D_WFC2_X], w[D_BFC2], nullptr, 0.0f, y, 0, N, C, C, x);            // x = y + fc(a)
+            dec_gemm_x3(st, x, w[D_W1_X], w[D_W1_B], w[D_W1_CS], 1e-5f, nullptr, 2, N, C, d_inner, hid);
+            dec_gemm_x3(st, hid, w[D_W2_X], w[D_B2], nullptr, 0.0f, x, 0, N, d_inner, C, y);        // y = x + w2(...)
+            float* t = x; x = y; y = t;
+        }
+        dec_gemm_x3(st, x, cls_x, b_cls, cls_colsum, 1e-6f, nullptr, 0, N, C, num_out, logits);
+        hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, logits, num_out,
+                           N, s, L, greedy, out, tokens, Lt, 1);
+    }
+    for (int s = 0; s < L && !fast; ++s) {
+        hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
+                           tokens, Lt, s, C, N, x, 0);
         for (int l = 0; l < n_layers; ++l) {
             const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
             // x = x + fc(self_attn(LN1(x)))                          transformer_layers.py:150-154
@@ -855,10 +1038,10 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             if (b16)
                 hipLaunchKernelGGL(attn_dec_self_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
                                    L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
-                                   tokens, Lt, padding_idx, a);
+                                   tokens, Lt, padding_idx, a, 0);
             else
                 hipLaunchKernelGGL(attn_dec_self_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
-                                   Vc[l], tokens, Lt, padding_idx, a);
+                                   Vc[l], tokens, Lt, padding_idx, a, 0);
             g.cm(w[D_WFC], w[D_BFC], a, C, C, N, y, 0, x);            // y = x + fc(a)
             // x = y + fc(enc_attn(LN2(y), enc, enc))                   transformer_layers.py:156-159
             rc = tpspp_linear_ln_fwd(y, C, N, 1e-5f, w[D_Q_W], w[D_Q_CS], C, w[D_Q_B], 0, nullptr, 1, qkv, stream);
@@ -866,10 +1049,10 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             if (b16)
                 hipLaunchKernelGGL(attn_dec_cross_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
                                    reinterpret_cast<const unsigned short*>(Kx[l]),
-                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a);
+                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 0);
             else
                 hipLaunchKernelGGL(attn_dec_cross_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
-                                   N, H, T, valid_len, a);
+                                   N, H, T, valid_len, a, 0);
             g.cm(w[D_WFC2], w[D_BFC2], a, C, C, N, x, 0, y);          // x = y + fc(a)
             // x = x + mlp(LN3(x))                                       transformer_layers.py:161-163
             rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_W1_W], w[D_W1_CS], d_inner, w[D_W1_B], 2, nullptr, 0, hid, stream);
@@ -882,7 +1065,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         rc = tpspp_linear_ln_fwd(x, C, N, 1e-6f, w_cls, cls_colsum, num_out, b_cls, 0, nullptr, 0, logits, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, logits, num_out,
-                           N, s, L, greedy, out, tokens, Lt);
+                           N, s, L, greedy, out, tokens, Lt, 0);
     }
     if (tokens_out)
         (void)hipMemcpyAsync(tokens_out, tokens, (size_t)N * Lt * sizeof(int), hipMemcpyDeviceToDevice, st);

@@ -234,12 +234,15 @@ class NRTRDecoder(nn.Module):
                 qkv = ops.fold_layernorm(lyr.norm1.weight, lyr.norm1.bias, wqkv)
                 q = ops.fold_layernorm(lyr.norm2.weight, lyr.norm2.bias, ops.kmajor(ea.linear_q.weight))
                 w1 = ops.fold_layernorm(lyr.norm3.weight, lyr.norm3.bias, ops.kmajor(lyr.mlp.w_1.weight), lyr.mlp.w_1.bias)
-                ts += [qkv[0], qkv[1], qkv[2], ops.kmajor(sa.fc.weight), None,
+                wfc, wfc2, w2 = ops.kmajor(sa.fc.weight), ops.kmajor(ea.fc.weight), ops.kmajor(lyr.mlp.w_2.weight)
+                ts += [qkv[0], qkv[1], qkv[2], wfc, None,
                        q[0], q[1], q[2], kk(ea.linear_k.weight), None, kv(ea.linear_v.weight),
-                       ops.kmajor(ea.fc.weight), None, w1[0], w1[1], w1[2],
-                       ops.kmajor(lyr.mlp.w_2.weight), _f32(lyr.mlp.w_2.bias)]
+                       wfc2, None, w1[0], w1[1], w1[2], w2, _f32(lyr.mlp.w_2.bias)]
+                # the six per-step projections split and arranged for the step GEMM (reduced-precision head only)
+                ts += [ops.arrange_x3(t) for t in (qkv[0], wfc, q[0], wfc2, w1[0], w2)] if (b16 or x3) else [None] * 6
             cls = ops.fold_layernorm(self.layer_norm.weight, self.layer_norm.bias, ops.kmajor(self.classifier.weight),
                                      self.classifier.bias)
+            ts.append(ops.arrange_x3(cls[0]) if (b16 or x3) else None)     # behind the layers: the classifier
             cache = (key, ops.PtrTable(ts), _f32(self.trg_word_emb.weight), _f32(self.position_enc.position_table[0]),
                      cls)
             self._w_cache = cache

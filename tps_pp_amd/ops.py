@@ -940,6 +940,23 @@ def kmajor(weight):
     return weight.detach().float().t().contiguous()
 
 
+def arrange_x3(w_kmajor):
+    """K-major (K, Co) fp32 weight -> the step GEMM's operand (`dec_gemm_x3_kernel`, include/tpspp.h): hi = bf16(w),
+    lo = bf16(w - hi), Co zero-padded to a multiple of 32, [Co/32][K/16][hi|lo][2 k halves][32 outputs][8 k] bf16."""
+    w = w_kmajor.detach().float()
+    K, Co = w.shape
+    if K % 16:
+        raise ValueError("arrange_x3: K must be a multiple of 16")
+    Cop = (Co + 31) // 32 * 32
+    if Cop != Co:
+        w = torch.cat([w, w.new_zeros((K, Cop - Co))], dim=1)
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    st = torch.stack([hi, lo])                                         # (s, K, Cop)
+    st = st.reshape(2, K // 16, 2, 8, Cop // 32, 32)                   # (s, ks, h, e, ct, r)
+    return st.permute(4, 1, 0, 2, 5, 3).contiguous()                   # (ct, ks, s, h, r, e)
+
+
 class PtrTable:
     """Host array of device pointers (`const float* const*`) + the tensors it points at (kept alive)."""
 
