@@ -487,6 +487,259 @@ attn_dec_cross_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx, 
     else out[(size_t)(kDK * h + lane) * Nb + b] = acc;
 }
 
+// ---- decoder, one step: attention with 16-byte loads (the token-major step pipeline) --------------------------------
+// The kernels above give a lane one 4-byte element per load (a key row per lane, a value row per wavefront): 128 load
+// instructions of 256 bytes per (image, head), and the vector-memory unit takes 16 cycles per instruction whatever its
+// width -- the cross-attention's 134 MB per layer-step moved at 4 TB/s.  Here keys AND values are token-major
+// ((tokens, C) rows, a head's 64 features contiguous), a lane takes 16 bytes (EPL = 4 fp32 or 8 bf16 features) of a
+// token, GS = 64 / EPL lanes share a token and a load instruction covers 64 / GS tokens x one contiguous head row:
+// 4x (8x) fewer instructions for the same bytes.  Scores: per-lane partial dot products, summed inside the GS-lane
+// group on the DPP path (quad swaps, half-row / row mirror); values: per-lane partial sums over the lane's tokens,
+// summed across the groups with a few lane exchanges at the very end.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int GS> __device__ __forceinline__ float group_sum(float v)      // every lane of a GS-lane group: the group's sum
+{
+    v = dpp_add<0xB1>(v);                      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);                      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);                     // row_half_mirror: 8 lanes
+    if (GS == 16) v = dpp_add<0x140>(v);       // row_mirror: 16 lanes
+    return v;
+}
+template <int GS> __device__ __forceinline__ float across_groups_sum(float v)   // sum over the 64 / GS groups (same lane of each)
+{
+    if (GS == 8) v += __shfl_xor(v, 8, kWave);
+    v += __shfl_xor(v, 16, kWave);
+    v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+template <int GS> __device__ __forceinline__ float across_groups_max(float v)
+{
+    if (GS == 8) v = fmaxf(v, __shfl_xor(v, 8, kWave));
+    v = fmaxf(v, __shfl_xor(v, 16, kWave));
+    v = fmaxf(v, __shfl_xor(v, 32, kWave));
+    return v;
+}
+
+template <typename KV> struct Wide;
+template <> struct Wide<float> {
+    static constexpr int EPL = 4;
+    typedef float4 raw;
+    static __device__ __forceinline__ void unpack(const raw& r, float (&f)[4]) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+    static __device__ __forceinline__ raw pack(const float (&f)[4]) { return make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct Wide<unsigned short> {
+    static constexpr int EPL = 8;
+    typedef uint4 raw;
+    static __device__ __forceinline__ void unpack(const raw& r, float (&f)[8])
+    {
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __builtin_bit_cast(float, w[i] << 16); f[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ raw pack(const float (&f)[8])
+    {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // round to nearest even, as kvc_store
+            unsigned a = __builtin_bit_cast(unsigned, f[2 * i]), b = __builtin_bit_cast(unsigned, f[2 * i + 1]);
+            a += 0x7fffu + ((a >> 16) & 1u); b += 0x7fffu + ((b >> 16) & 1u);
+            w[i] = (a >> 16) | (b & 0xffff0000u);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// cross-attention: q_t (Nb, C), Kx_t / Vx_t (Nb*T, C) token-major, out (Nb, C) token-major.  One wavefront per (image, head).
+template <typename KV>
+__global__ void __launch_bounds__(256)
+attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
+                           int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out)
+{
+    typedef Wide<KV> Wd;
+    constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;   // tokens per instruction, pieces per 64 tokens
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair - b * H;
+    const int grp = lane / GS, dl = lane % GS;             // this lane: tokens grp, grp + TPI, ...; features EPL dl ..
+    float q[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] = q_t[(size_t)b * C + kDK * h + EPL * dl + e] * 0.125f;
+    int nvalid = valid_len ? valid_len[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    const typename Wd::raw* kb = reinterpret_cast<const typename Wd::raw*>(Kx_t + ((size_t)b * T) * C + kDK * h + EPL * dl);
+    const typename Wd::raw* vb = reinterpret_cast<const typename Wd::raw*>(Vx_t + ((size_t)b * T) * C + kDK * h + EPL * dl);
+    const size_t rstride = (size_t)C / EPL;                // row pitch in raw pieces
+    float sc[4][NP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) sc[jj][i] = -INFINITY;
+        if (jj * kWave < nvalid) {                         // wave-uniform
+            typename Wd::raw kr[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {                 // every key piece of these 64 tokens in flight together
+                const int t = jj * kWave + TPI * i + grp;
+                kr[i] = kb[(size_t)(t < T ? t : T - 1) * rstride];
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                float kf[EPL];
+                Wd::unpack(kr[i], kf);
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) s = fmaf(q[e], kf[e], s);
+                s = group_sum<GS>(s);
+                const int t = jj * kWave + TPI * i + grp;
+                sc[jj][i] = t < nvalid ? s : -INFINITY;
+                mx = fmaxf(mx, sc[jj][i]);
+            }
+        }
+    }
+    mx = across_groups_max<GS>(mx);
+    float l = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            sc[jj][i] = sc[jj][i] == -INFINITY ? 0.0f : expf(sc[jj][i] - mx);
+            l += sc[jj][i];
+        }
+    l = across_groups_sum<GS>(l);
+    const float inv = 1.0f / l;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (jj * kWave < nvalid) {
+            typename Wd::raw vr[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int t = jj * kWave + TPI * i + grp;
+                vr[i] = vb[(size_t)(t < T ? t : T - 1) * rstride];
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                float vf[EPL];
+                Wd::unpack(vr[i], vf);
+                const float pw = sc[jj][i] * inv;          // 0 for masked tokens
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, vf[e], acc[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
+    if (grp == 0) {
+        float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+    }
+}
+
+// masked self-attention against token-major caches Kc / Vc [image][head][position][64]; qkv_t (Nb, 3C); out (Nb, C).
+// The new position's key / value are used from registers (fp32) and appended to the caches.
+template <typename KV>
+__global__ void __launch_bounds__(256)
+attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
+                          KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
+                          int pad_idx, float* __restrict__ out)
+{
+    typedef Wide<KV> Wd;
+    constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair - b * H;
+    const int grp = lane / GS, dl = lane % GS;
+    const float* base = qkv_t + (size_t)b * 3 * C + kDK * h + EPL * dl;
+    float q[EPL], k[EPL], v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { q[e] = base[e] * 0.125f; k[e] = base[C + e]; v[e] = base[2 * C + e]; }
+    const size_t bh = (size_t)b * H + h;
+    typename Wd::raw* kc = reinterpret_cast<typename Wd::raw*>(Kc + bh * Lmax * kDK + EPL * dl);
+    typename Wd::raw* vc = reinterpret_cast<typename Wd::raw*>(Vc + bh * Lmax * kDK + EPL * dl);
+    constexpr int rstride = GS;                            // a cached row is GS pieces
+    if (grp == 0) { kc[(size_t)step * rstride] = Wd::pack(k); vc[(size_t)step * rstride] = Wd::pack(v); }
+
+    float sc[NP];
+    typename Wd::raw kr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = TPI * i + grp;
+        if (TPI * i < step) kr[i] = kc[(size_t)(p < step ? p : 0) * rstride];      // (uniform test: whole pieces beyond `step` are skipped)
+    }
+    float cur = 0.0f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) cur = fmaf(q[e], k[e], cur);
+    cur = group_sum<GS>(cur);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = TPI * i + grp;
+        float s = -INFINITY;
+        if (TPI * i <= step) {                             // uniform
+            float dot = 0.0f;
+            if (TPI * i < step) {
+                float kf[EPL];
+                Wd::unpack(kr[i], kf);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) dot = fmaf(q[e], kf[e], dot);
+                dot = group_sum<GS>(dot);
+            }
+            if (p == step) dot = cur;
+            const bool valid = p <= step && tokens[(size_t)b * Lt + (p <= step ? p : 0)] != pad_idx;
+            s = valid ? dot : -INFINITY;
+        }
+        sc[i] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = across_groups_max<GS>(mx);
+    float l = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { sc[i] = sc[i] == -INFINITY ? 0.0f : expf(sc[i] - mx); l += sc[i]; }
+    l = across_groups_sum<GS>(l);
+    const float inv = 1.0f / l;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
+    typename Wd::raw vr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = TPI * i + grp;
+        if (TPI * i < step) vr[i] = vc[(size_t)(p < step ? p : 0) * rstride];
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = TPI * i + grp;
+        if (TPI * i <= step) {
+            const float pw = sc[i] * inv;
+            if (p == step) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, v[e], acc[e]);
+            } else if (p < step) {
+                float vf[EPL];
+                Wd::unpack(vr[i], vf);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, vf[e], acc[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
+    if (grp == 0) {
+        float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+    }
+}
+
 // ---- decoder, one step: classifier epilogue ------------------------------------------------------------------
 // logits (Cc, Nb) channel-major.  Greedy: out[b][step][:] = softmax(logits[:, b]) and
 // tokens[b][step+1] = arg-max (first maximum)  (nrtr_decoder.py:168-175).  Forced: out = raw logits.
@@ -759,6 +1012,7 @@ size_t dec_ws_bytes(int N, int C, int T, int Di, int n_layers, int L, int Cc)
     s += align256((size_t)Di * N * 4);                                       // hidden
     s += align256((size_t)Cc * N * 4);                                       // logits
     s += align256((size_t)N * (L + 1) * 4);                                  // tokens
+    s += align256((size_t)C * MT * 4);                                       // keys before their transposition (token-major step pipeline)
     return s;
 }
 
@@ -960,33 +1214,9 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     float* hid = cv.f((size_t)d_inner * N);
     float* logits = cv.f((size_t)num_out * N);
     int* tokens = reinterpret_cast<int*>(cv.f((size_t)N * Lt));
+    float* ktmp = cv.f((size_t)C * MT);
     TPSPP_REQUIRE(cv.ok, "tpspp_nrtr_decoder_fwd: workspace carve failed");
 
-    Gemm g{st};
-    // encoder keys (channel-major) and values (token-major) of every layer, once
-    for (int l = 0; l < n_layers; ++l) {
-        const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
-        if (b16) {
-            // bf16 matrix cores, bf16 keys / values: K channel-major straight from the epilogue; V channel-major
-            // into the upper half of its own (fp32-sized) slot, then transposed to token-major rows
-            unsigned short* vt = reinterpret_cast<unsigned short*>(Vx[l]) + (size_t)C * MT;
-            g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, 0, nullptr);
-            g.cm16(w[D_WV], nullptr, enc_cm, C, C, MT, vt, 0, 0, nullptr);
-            if (g.rc) return g.rc;
-            hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
-                               0, st, vt, C, MT, reinterpret_cast<unsigned short*>(Vx[l]));
-        } else {
-            if (x3) g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 1, 0, nullptr, 1);   // fp32 keys, three-term split
-            else g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, Kx[l], 0, nullptr);
-            g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);        // (a value bias would be per channel = per column here: not supported)
-        }
-    }
-    if (g.rc) return g.rc;
-    hipLaunchKernelGGL(dec_init_tokens_kernel, dim3((unsigned)((N * Lt + 255) / 256)), dim3(256), 0, st, tokens, N,
-                       Lt, start_idx, padding_idx, forced_tokens, L);
-    const int greedy = forced_tokens ? 0 : 1;
-    const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
-    int rc = 0;
     // Reduced-precision head (TPSPP_HEAD_BF16 / _BF16X3) with arranged per-step weights in the table: every activation of
     // a step is TOKEN-major and the six projections + the classifier run on dec_gemm_x3_kernel (three-term split: inside
     // the fp32 tolerance, so the bf16 head takes it as well).  8 launches per layer-step as before, each about half as long.
@@ -996,6 +1226,41 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
         fast = w[D_QKV_X] && w[D_WFC_X] && w[D_Q_X] && w[D_WFC2_X] && w[D_W1_X] && w[D_W2_X];
     }
+    Gemm g{st};
+    // encoder keys (channel-major; token-major for the step pipeline above) and values (token-major) of every layer, once
+    for (int l = 0; l < n_layers; ++l) {
+        const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+        if (b16) {
+            // bf16 matrix cores, bf16 keys / values: K channel-major straight from the epilogue; V channel-major
+            // into the upper half of its own (fp32-sized) slot, then transposed to token-major rows
+            unsigned short* vt = reinterpret_cast<unsigned short*>(Vx[l]) + (size_t)C * MT;
+            unsigned short* kt = fast ? reinterpret_cast<unsigned short*>(Kx[l]) + (size_t)C * MT : reinterpret_cast<unsigned short*>(Kx[l]);
+            g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, kt, 0, 0, nullptr);
+            g.cm16(w[D_WV], nullptr, enc_cm, C, C, MT, vt, 0, 0, nullptr);
+            if (g.rc) return g.rc;
+            hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
+                               0, st, vt, C, MT, reinterpret_cast<unsigned short*>(Vx[l]));
+            if (fast)
+                hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
+                                   0, st, kt, C, MT, reinterpret_cast<unsigned short*>(Kx[l]));
+        } else {
+            float* kdst = fast ? ktmp : Kx[l];
+            if (x3) g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, kdst, 1, 0, nullptr, 1);   // fp32 keys, three-term split
+            else g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, kdst, 0, nullptr);
+            if (fast) {                                     // (C, N*T) -> (N*T, C): the wide-load cross-attention's layout
+                if (g.rc) return g.rc;
+                const int rc_t = tpspp_transpose2d(ktmp, C, MT, Kx[l], stream);
+                if (rc_t) return rc_t;
+            }
+            g.tm(w[D_WV], enc_cm, C, C, MT, Vx[l]);        // (a value bias would be per channel = per column here: not supported)
+        }
+    }
+    if (g.rc) return g.rc;
+    hipLaunchKernelGGL(dec_init_tokens_kernel, dim3((unsigned)((N * Lt + 255) / 256)), dim3(256), 0, st, tokens, N,
+                       Lt, start_idx, padding_idx, forced_tokens, L);
+    const int greedy = forced_tokens ? 0 : 1;
+    const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
+    int rc = 0;
     for (int s = 0; s < L && fast; ++s) {
         hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
                            tokens, Lt, s, C, N, x, 1);
@@ -1003,21 +1268,21 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
             dec_gemm_x3(st, x, w[D_QKV_X], w[D_QKV_B], w[D_QKV_CS], 1e-5f, nullptr, 0, N, C, 3 * C, qkv);
             if (b16)
-                hipLaunchKernelGGL(attn_dec_self_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
+                hipLaunchKernelGGL(attn_dec_self_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
                                    L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
-                                   tokens, Lt, padding_idx, a, 1);
+                                   tokens, Lt, padding_idx, a);
             else
-                hipLaunchKernelGGL(attn_dec_self_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
-                                   Vc[l], tokens, Lt, padding_idx, a, 1);
+                hipLaunchKernelGGL(attn_dec_self_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
+                                   Vc[l], tokens, Lt, padding_idx, a);
             dec_gemm_x3(st, a, w[D_WFC_X], w[D_BFC], nullptr, 0.0f, x, 0, N, C, C, y);              // y = x + fc(a)
             dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv);
             if (b16)
-                hipLaunchKernelGGL(attn_dec_cross_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
+                hipLaunchKernelGGL(attn_dec_cross_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
                                    reinterpret_cast<const unsigned short*>(Kx[l]),
-                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 1);
+                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a);
             else
-                hipLaunchKernelGGL(attn_dec_cross_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
-                                   N, H, T, valid_len, a, 1);
+                hipLaunchKernelGGL(attn_dec_cross_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
+                                   N, H, T, valid_len, a);
             dec_gemm_x3(st, a, w[D_WFC2_X], w[D_BFC2], nullptr, 0.0f, y, 0, N, C, C, x);            // x = y + fc(a)
             dec_gemm_x3(st, x, w[D_W1_X], w[D_W1_B], w[D_W1_CS], 1e-5f, nullptr, 2, N, C, d_inner, hid);
             dec_gemm_x3(st, hid, w[D_W2_X], w[D_B2], nullptr, 0.0f, x, 0, N, d_inner, C, y);        // y = x + w2(...)
