@@ -297,6 +297,9 @@ def recognizer_measurement(dev, timeit):
         m.backbone.compute_dtype = m.tpsnet.compute_dtype = m.encoder.compute_dtype = m.decoder.compute_dtype = "bf16x3"
         t_allx3 = timeit(lambda: m(img, metas, return_loss=False), 3, 1)
         t_featx3 = timeit(lambda: m.extract_feat(img, test=True), 3, 1)
+        t_encx3 = timeit(lambda: m.encoder(feat, None), 3, 1)
+        out_encx3 = m.encoder(feat, None)
+        t_decx3 = timeit(lambda: m.decoder(feat, out_encx3, None, None, train_mode=False), 3, 1)
         gotx3 = [r["text"] for r in m(img[:k], metas[:k], return_loss=False)]
         m.tpsnet.compute_dtype = m.encoder.compute_dtype = m.decoder.compute_dtype = None
         # BASELINE.json configs[4]: backbone + TPS++ convolutions on the bf16 matrix cores (head stays fp32)
@@ -322,6 +325,7 @@ def recognizer_measurement(dev, timeit):
             "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
             "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
             "bf16x3": {"images_per_s": n / (t_allx3 * 1e-3), "ms_per_batch": t_allx3, "ms_backbone_tpspp": t_featx3,
+                       "ms_encoder": t_encx3, "ms_greedy_decoder_40_steps": t_decx3,
                        "strings_equal_to_fp32_cpu_oracle": f"{sum(a == b for a, b in zip(gotx3, want))}/{k}",
                        "agreement_with_fp32_kernels_256_images": agreex3},
             "bf16_backbone": {"images_per_s": n / (t_all16 * 1e-3), "ms_per_batch": t_all16,

@@ -745,7 +745,9 @@ attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H,
 // tokens[b][step+1] = arg-max (first maximum)  (nrtr_decoder.py:168-175).  Forced: out = raw logits.
 __global__ void __launch_bounds__(256)
 dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, int L, int greedy,
-                    float* __restrict__ out, int* __restrict__ tokens, int Lt, int tm)
+                    float* __restrict__ out, int* __restrict__ tokens, int Lt, int tm,
+                    const float* __restrict__ emb = nullptr, const float* __restrict__ pos = nullptr,
+                    float* __restrict__ x_next = nullptr, int C = 0)
 {
     // one wavefront per image, lanes over classes
     const int lane = threadIdx.x & (kWave - 1);
@@ -754,8 +756,18 @@ dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, 
     float* o = out + ((size_t)b * L + step) * Cc;
     const size_t ls = tm ? 1 : (size_t)Nb;                 // stride between the classes of an image
     logits += tm ? (size_t)b * Cc : (size_t)b;
+    // x_next (token-major step pipeline): the next step's embedding row of this image is written here as well, from the
+    // token this step decided (or was given) -- one launch per step instead of two
+    auto embed_next = [&](int tok) {
+        if (x_next) {
+            const float* er = emb + (size_t)tok * C;
+            const float* pr = pos + (size_t)(step + 1) * C;
+            for (int c = lane; c < C; c += kWave) x_next[(size_t)b * C + c] = er[c] + pr[c];
+        }
+    };
     if (!greedy) {
         for (int c = lane; c < Cc; c += kWave) o[c] = logits[(size_t)c * ls];
+        embed_next(tokens[(size_t)b * Lt + step + 1]);
         return;
     }
     float mx = -INFINITY;
@@ -775,6 +787,7 @@ dec_classify_kernel(const float* __restrict__ logits, int Cc, int Nb, int step, 
     sum = wave_sum(sum);
     for (int c = lane; c < Cc; c += kWave) o[c] = expf(logits[(size_t)c * ls] - mx) / sum;
     if (lane == 0) tokens[(size_t)b * Lt + step + 1] = am;
+    embed_next(am);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1262,8 +1275,9 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
     int rc = 0;
     for (int s = 0; s < L && fast; ++s) {
-        hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
-                           tokens, Lt, s, C, N, x, 1);
+        if (s == 0)
+            hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
+                               tokens, Lt, s, C, N, x, 1);
         for (int l = 0; l < n_layers; ++l) {
             const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
             dec_gemm_x3(st, x, w[D_QKV_X], w[D_QKV_B], w[D_QKV_CS], 1e-5f, nullptr, 0, N, C, 3 * C, qkv);
@@ -1289,8 +1303,12 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             float* t = x; x = y; y = t;
         }
         dec_gemm_x3(st, x, cls_x, b_cls, cls_colsum, 1e-6f, nullptr, 0, N, C, num_out, logits);
+        // (x holds this step's final activations, read by the classifier launch above; the next step's embedding goes to y,
+        //  which becomes x)
+        const bool more = s + 1 < L;
         hipLaunchKernelGGL(dec_classify_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, logits, num_out,
-                           N, s, L, greedy, out, tokens, Lt, 1);
+                           N, s, L, greedy, out, tokens, Lt, 1, emb, pos_table, more ? y : nullptr, C);
+        if (more) { float* t = x; x = y; y = t; }
     }
     for (int s = 0; s < L && !fast; ++s) {
         hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,
