@@ -1,0 +1,24 @@
+"""Classic warp at the other instantiated geometries, batch 512: the in-place kernel (kernel_choice 6) against the
+round-1 LDS-staged kernel (2), one stream and three (bench.py's protocol: rotating buffers, pre-marshalled calls)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from tps_pp_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+for hw in ((32, 100), (32, 128), (48, 160), (32, 64)):
+    for kern in (2, 6):
+        ops.set_warp_tuning(0, 0, kern, 0)
+        try:
+            r = bench.classic_warp_extra(dev, hw, 3)
+        except Exception as e:          # a geometry the forced kernel does not take
+            print(hw, "kernel", kern, "--", str(e)[:80])
+            continue
+        finally:
+            ops.set_warp_tuning(0, 0, 0, 0)
+        print(hw, "kernel", kern, "3 streams", round(r["launch_us"], 2), round(r["frac_of_hbm_peak"], 3), "| one stream",
+              round(r["one_stream"]["launch_us"], 2), round(r["one_stream"]["frac_of_hbm_peak"], 3), "| err", r["max_abs_err_vs_oracle"])

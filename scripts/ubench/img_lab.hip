@@ -247,7 +247,7 @@ int main(int argc, char** argv)
         std::vector<float> pk((size_t)Geo::NW * QP * KG * 64 * 4, 0.0f);
         for (int t = 0; t < Geo::nthr; ++t)
             for (int j = 0; j < QP; ++j) {
-                int r, c; img_thread_pixel(t, j, Geo::CG, QP, &r, &c);
+                int r, c; img_thread_pixel(t, j, Geo::CG, QP, Geo::BW, &r, &c);
                 const int w = t / 64, l = t % 64;
                 for (int q = 0; q < K; ++q) pk[((((size_t)w * QP + j) * KG + q / 4) * 64 + l) * 4 + q % 4] = hphat[(size_t)(r * W + c) * K + q];
             }
@@ -289,7 +289,8 @@ int main(int argc, char** argv)
     vars.push_back(img_variant<2, 1, 3, 1>("duo", 1 << 30));
     vars.push_back(img_variant<2, 1, 3, 2>("duo", 1 << 30));
     vars.push_back(img_variant<1, 2, 1, 2>("solo", 1 << 30));
-    vars.push_back(img_variant<1, 2, 2, 2>("solo", 1 << 30));
+    vars.push_back(img_variant<1, 2, 1, 3>("solo", 1 << 30));
+    vars.push_back(img_variant<1, 2, 1, 3>("solo", 256));
     const int img1 = C * n * 4;
     CK(hipFuncSetAttribute((const void*)copy_img_k<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     vars.push_back({"copy, same shape: 512 x 512 thr, regs, nt ld/st", [=](const Bufs& Bf, int s, float* o, float*, int32_t*, long long*, hipStream_t st) {

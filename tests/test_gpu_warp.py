@@ -96,7 +96,8 @@ def test_packed_table_contract(cuda):
         row[:23] = ph[r * 100 + c]
         ref[t_ // 64, :, t_ % 64, :] = row.reshape(6, 4)
     assert (bits(tail) == bits(ref)).all()
-    # 32x128: 16 column groups, a thread owns both row groups -> [8 wavefronts][2][6][64][4]
+    # 32x128 (a row pitch that is a multiple of 32 banks): a half-wavefront owns 32 columns of ONE row, a thread two rows
+    # -> 2 column groups x 8 row-group pairs = 16 half-wavefronts, [8 wavefronts][2][6][64][4]
     from oracle import tps_oracle as O
     ph128 = O.classic_constants(20, (32, 128))["P_hat"]
     p128, f128 = ops.prepare_mirror_table(dev(ph128, cuda), (32, 128))
@@ -104,9 +105,10 @@ def test_packed_table_contract(cuda):
     tail = p128._base[23 * 4096:].cpu().numpy().reshape(8, 2, 6, 64, 4)
     ref = np.zeros((8, 2, 6, 64, 4), np.float32)
     for t_ in range(512):
-        cg, l5 = t_ >> 5, t_ & 31
+        hw, l5 = t_ >> 5, t_ & 31
+        rgb, cg = divmod(hw, 2)
         for j in range(2):
-            r, c = j * 8 + (l5 >> 2), cg * 4 + (l5 & 3)
+            r, c = rgb * 2 + j, cg * 32 + l5
             row = np.zeros(24, np.float32)
             row[:23] = ph128[r * 128 + c]
             ref[t_ // 64, j, :, t_ % 64, :] = row.reshape(6, 4)

@@ -871,15 +871,23 @@ TPSPP_EXPORT int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, 
 
 namespace {
 // Quadrant pixels per thread of the packed table / the in-place kernel for an output geometry: the smallest divisor
-// of the OH/16 row groups that leaves at most 13 compute wavefronts (0: the geometry has no packed form).  32x100 -> 1
-// (the image-pair kernel's layout), 32x128 -> 2, 48x160 -> 3.
+// of the row groups (tpspp_warp_img.h: ImgGeo) that leaves at most 13 compute wavefronts (0: the geometry has no packed
+// form).  32x100 -> 1 (the image-pair kernel's layout), 32x128 -> 2, 48x160 -> 3.
 int img_qp(int Ho, int Wo)
 {
     if (Ho <= 0 || Wo <= 0 || Wo % 4 != 0 || Ho % 16 != 0) return 0;
-    const int CG = ((Wo / 2) + 3) / 4, RG = Ho / 16;
+    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
+    const int CG = ((Wo / 2) + BW - 1) / BW, RG = (Ho / 2) / BH;
+    if (CG * BW > Wo) return 0;
     for (int qp = 1; qp <= RG && qp <= 4; ++qp)
         if (RG % qp == 0 && (CG * (RG / qp) * 32 + kWave - 1) / kWave <= 13) return qp;
     return 0;
+}
+// compute threads of that mapping
+int img_nthr(int Ho, int Wo, int QP)
+{
+    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
+    return (((Wo / 2) + BW - 1) / BW) * (((Ho / 2) / BH) / QP) * 32;
 }
 }  // namespace
 
@@ -888,7 +896,7 @@ TPSPP_EXPORT size_t tpspp_prepared_table_floats(int Ho, int Wo, int F)
     const int QP = img_qp(Ho, Wo);
     if (QP == 0 || F <= 0 || F + 3 > kMaxK) return 0;
     const int K = F + 3, KG = (K + 3) / 4;
-    const int CG = ((Wo / 2) + 3) / 4, nthr = CG * ((Ho / 16) / QP) * 32, NW = (nthr + kWave - 1) / kWave;
+    const int NW = (img_nthr(Ho, Wo, QP) + kWave - 1) / kWave;
     return (size_t)K * Ho * Wo + (size_t)NW * QP * KG * kWave * 4;
 }
 
@@ -904,10 +912,11 @@ TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, in
     const int rc = tpspp_transpose_p_hat(p_hat, p_hat_ld, n, K, prepared, stream);
     if (rc != TPSPP_OK) return rc;
     const int QP = img_qp(Ho, Wo);
-    const int CG = ((Wo / 2) + 3) / 4, nthr = CG * ((Ho / 16) / QP) * 32, NW = (nthr + kWave - 1) / kWave;
+    const int BW = tpspp_img::img_block_w(Wo);
+    const int CG = ((Wo / 2) + BW - 1) / BW, nthr = img_nthr(Ho, Wo, QP), NW = (nthr + kWave - 1) / kWave;
     const int total = NW * QP * KG * kWave * 4;
     hipLaunchKernelGGL(tpspp_img::pack_img_table_kernel, dim3((total + 255) / 256), dim3(256), 0,
-                       tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, CG, QP, nthr, K, prepared + (size_t)K * n);
+                       tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, CG, QP, BW, nthr, K, prepared + (size_t)K * n);
     return tpspp::check_launch("tpspp_prepare_mirror_table");
 }
 
@@ -1002,7 +1011,7 @@ void launch_pair(const float* in, const float* ctrl, const float* inv_delta_c, c
 
 // In-place kernel (tpspp_warp_img.h): the geometries it is instantiated for.  IMGS / QP / loaders per geometry:
 // two images per workgroup where both fit the LDS beside each other, else one.
-template <int C, int HH, int WW, int IMGS, int QP, int NLOAD>
+template <int C, int HH, int WW, int IMGS, int QP, int NLOAD, int WPC = 1>
 void launch_img(const float* in, const float* ctrl, const float* inv_delta_c, const float* packed, int N,
                 float* out, float* grid, int32_t* idx, hipStream_t st)
 {
@@ -1014,9 +1023,9 @@ void launch_img(const float* in, const float* ctrl, const float* inv_delta_c, co
     const size_t lds = ImgLds<20, C, HH, WW, HH, WW, IMGS>::bytes;
     static_assert(ImgLds<20, C, HH, WW, HH, WW, IMGS>::bytes <= 160 * 1024, "does not fit the LDS");
     const dim3 grid_dim((unsigned)((N + IMGS - 1) / IMGS)), block((ImgGeo<HH, WW, QP>::NW + NLOAD) * kWave);
-    auto k_plain = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, 1, false, false>;
-    auto k_aux = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, 1, true, false>;
-    auto k_trace = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, 1, false, true>;
+    auto k_plain = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, WPC, false, false>;
+    auto k_aux = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, WPC, true, false>;
+    auto k_trace = tps_warp_img_kernel<20, C, HH, WW, HH, WW, IMGS, QP, NLOAD, WPC, false, true>;
     // > 64 KB of dynamic LDS needs the opt-in, once per instantiation and device
     static bool attr_done[tpspp::kMaxDevices] = {};
     if (tpspp::first_use_on_device(attr_done)) {
@@ -1034,16 +1043,19 @@ void launch_img(const float* in, const float* ctrl, const float* inv_delta_c, co
 bool launch_img_geo(int C, int H, int W, const float* in, const float* ctrl, const float* inv_delta_c, const float* packed,
                     int N, float* out, float* grid, int32_t* idx, hipStream_t st)
 {
-#define TPSPP_IMG_GEO(CC, HH, WW, IMGS, QP, NLOAD) \
-    if (C == CC && H == HH && W == WW) { launch_img<CC, HH, WW, IMGS, QP, NLOAD>(in, ctrl, inv_delta_c, packed, N, out, grid, idx, st); return true; }
-    TPSPP_IMG_GEO(3, 32, 100, 2, 1, 3)      // also the image-pair kernel's geometry (kernel_choice 6 selects this one)
-    TPSPP_IMG_GEO(1, 32, 100, 2, 1, 3)
-    TPSPP_IMG_GEO(3, 32, 128, 2, 2, 3)      // configs/textrecog/nrtr/nrtr_tps++.py:28-33
-    TPSPP_IMG_GEO(1, 32, 128, 2, 2, 3)
-    TPSPP_IMG_GEO(3, 48, 160, 1, 3, 3)
-    TPSPP_IMG_GEO(1, 48, 160, 1, 3, 3)
-    TPSPP_IMG_GEO(3, 32, 64, 2, 1, 3)
-    TPSPP_IMG_GEO(1, 32, 64, 2, 1, 1)
+#define TPSPP_IMG_GEO(CC, HH, WW, IMGS, QP, NLOAD, WPC) \
+    if (C == CC && H == HH && W == WW) { launch_img<CC, HH, WW, IMGS, QP, NLOAD, WPC>(in, ctrl, inv_delta_c, packed, N, out, grid, idx, st); return true; }
+    // (IMGS, QP, loaders, workgroups per CU): an image pair per workgroup where 13 compute wavefronts cover a quadrant with
+    // one pixel per thread (32x100, 32x64); else one image per workgroup, two pixels per thread and two workgroups per CU
+    // (32x128: the pair form would leave 8 compute wavefronts alone on a CU: 21 us per 512 images against 13)
+    TPSPP_IMG_GEO(3, 32, 100, 2, 1, 3, 1)      // also the image-pair kernel's geometry (kernel_choice 6 selects this one)
+    TPSPP_IMG_GEO(1, 32, 100, 2, 1, 3, 1)
+    TPSPP_IMG_GEO(3, 32, 128, 1, 2, 1, 2)      // configs/textrecog/nrtr/nrtr_tps++.py:28-33
+    TPSPP_IMG_GEO(1, 32, 128, 1, 2, 1, 2)
+    TPSPP_IMG_GEO(3, 48, 160, 1, 3, 3, 1)
+    TPSPP_IMG_GEO(1, 48, 160, 1, 3, 3, 1)
+    TPSPP_IMG_GEO(3, 32, 64, 2, 1, 3, 1)
+    TPSPP_IMG_GEO(1, 32, 64, 2, 1, 1, 1)
 #undef TPSPP_IMG_GEO
     return false;
 }

@@ -48,23 +48,29 @@ struct ImgParams {
 };
 
 // geometry of the thread -> pixel mapping (shared with the table packing).  The quadrant (upper left quarter of the
-// output) is tiled by blocks of 4 columns x 8 rows, one per half-wavefront; a thread owns QP of the OH/16 row groups.
+// output) is tiled by blocks of BW columns x BH rows = 32 pixels, one per half-wavefront, shaped so that a block's rows
+// start on different LDS banks at a row pitch of OW floats (input and output sizes are equal): 4 x 8 for OW = 100
+// (rows 4 banks apart), 32 x 1 where OW is a multiple of 32 (every row starts on the same bank: a 4 x 8 block would
+// be an 8-way conflict on every tap read -- 32x128 measured 21 us per 512 images that way, slower than the round-1
+// kernel).  A thread owns QP of the (OH/2)/BH row groups.
+__host__ __device__ constexpr int img_block_w(int OW) { return (OW % 32) == 0 ? 32 : ((OW % 32) & -(OW % 32)); }
 template <int OH, int OW, int QP>
 struct ImgGeo {
     static constexpr int halfW = OW / 2;
-    static constexpr int CG = (halfW + 3) / 4;               // 4-column groups per half-row
-    static constexpr int RG = OH / 16;                       // 8-row groups of the upper half
-    static_assert(OW % 2 == 0 && OH % 16 == 0 && CG * 4 <= OW, "needs whole 4 x 8 pixel blocks");
+    static constexpr int BW = img_block_w(OW), BH = 32 / BW;
+    static constexpr int CG = (halfW + BW - 1) / BW;         // column groups per half-row
+    static constexpr int RG = (OH / 2) / BH;                 // row groups of the upper half
+    static_assert(OW % 4 == 0 && OH % 16 == 0 && CG * BW <= OW, "needs whole pixel blocks");
     static_assert(RG % QP == 0, "quadrant pixels per thread must divide the row groups");
     static constexpr int nthr = CG * (RG / QP) * 32;         // compute threads
     static constexpr int NW = (nthr + kWave - 1) / kWave;    // compute wavefronts
 };
 // thread t, its quadrant pixel j -> (r, c)
-__host__ __device__ inline void img_thread_pixel(int t, int j, int CG, int QP, int* r, int* c)
+__host__ __device__ inline void img_thread_pixel(int t, int j, int CG, int QP, int BW, int* r, int* c)
 {
     const int hw = t >> 5, l5 = t & 31, rgb = hw / CG, cg = hw - rgb * CG;
-    *r = (rgb * QP + j) * 8 + (l5 >> 2);
-    *c = cg * 4 + (l5 & 3);
+    *r = (rgb * QP + j) * (32 / BW) + l5 / BW;
+    *c = cg * BW + l5 % BW;
 }
 
 constexpr int kImgAwait = 6;   // image B's requests start when <= 6 of a loader's requests for A are outstanding,
@@ -182,21 +188,20 @@ tps_warp_img_kernel(const ImgParams P)
     // ================= compute wavefronts =================
     const bool live = tid < nthr;
     const int tt = live ? tid : nthr - 1;
-    unsigned poff[QP][4];                                    // byte offsets of the 4 mirror pixels in a plane
+    // byte offsets of the 4 mirror pixels of quadrant pixel j in a plane: derived from the thread index where they are
+    // needed (the staging writes, the optional grid / index stores) instead of living in 4 QP registers across the kernel
     bool xdup;                                               // middle group: its x-mirror is another thread's pixel
     {
         int r, c;
-        img_thread_pixel(tt, 0, Geo::CG, QP, &r, &c);
-        xdup = (c & ~3) + 4 > Geo::halfW;
-#pragma unroll
-        for (int j = 0; j < QP; ++j) {
-            img_thread_pixel(tt, j, Geo::CG, QP, &r, &c);
-            poff[j][0] = 4u * (unsigned)(r * OW + c);
-            poff[j][1] = 4u * (unsigned)(r * OW + (OW - 1 - c));
-            poff[j][2] = 4u * (unsigned)((OH - 1 - r) * OW + c);
-            poff[j][3] = 4u * (unsigned)((OH - 1 - r) * OW + (OW - 1 - c));
-        }
+        img_thread_pixel(tt, 0, Geo::CG, QP, Geo::BW, &r, &c);
+        xdup = (c & ~(Geo::BW - 1)) + Geo::BW > Geo::halfW;
     }
+    auto pixel_off = [&](int t_, int j, int m) -> unsigned {
+        int r, c;
+        img_thread_pixel(t_, j, Geo::CG, QP, Geo::BW, &r, &c);
+        const int rr = (m & 2) ? OH - 1 - r : r, cc = (m & 1) ? OW - 1 - c : c;
+        return 4u * (unsigned)(rr * OW + cc);
+    };
 
     // packed table: [wavefront][QP][KG][lane] x 16 bytes = this thread's K values per quadrant pixel
     constexpr int KG = (K + 3) / 4;
@@ -303,10 +308,10 @@ tps_warp_img_kernel(const ImgParams P)
                 if constexpr (AUX) {
                     const bool st = live && !((m & 1) && xdup) && (im == 0 || hasB);
                     if (P.grid && st)
-                        *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid) + (size_t)b * 2 * row_bytes + 2u * poff[j][m]) =
+                        *reinterpret_cast<float2*>(reinterpret_cast<char*>(P.grid) + (size_t)b * 2 * row_bytes + 2u * pixel_off(tt, j, m)) =
                             make_float2(gx[im][j][m], gy[im][j][m]);
                     if (P.idx && st)
-                        *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx) + (size_t)b * 2 * row_bytes + 2u * poff[j][m]) =
+                        *reinterpret_cast<int2*>(reinterpret_cast<char*>(P.idx) + (size_t)b * 2 * row_bytes + 2u * pixel_off(tt, j, m)) =
                             make_int2(t.x0, t.y0);
                 }
                 ta[im][j][m] = img_lds + 4u * (unsigned)t.o00;
@@ -341,21 +346,24 @@ tps_warp_img_kernel(const ImgParams P)
         float res[QP][4][C];
         // wavefronts whose pixels all have their four taps inside the image (most of them) skip the zero selects
         const bool any_oob = __builtin_amdgcn_ballot_w64(oob[im] != 0u) != 0;
-        static_for<QP>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            float tv[4][C][4];
+        // MB mirror pixels' taps in flight at a time: 4 where the register budget is a whole CU per workgroup, 2 where two
+        // workgroups share it
+        constexpr int MB = WPC >= 2 ? 2 : 4;
+        static_for<QP * (4 / MB)>([&](auto jc) {
+            constexpr int j = decltype(jc)::value / (4 / MB), mb0 = (decltype(jc)::value % (4 / MB)) * MB;
+            float tv[MB][C][4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                lds_cfloat* a = (lds_cfloat*)(size_t)(ta[im][j][m]);
+            for (int mm = 0; mm < MB; ++mm) {
+                lds_cfloat* a = (lds_cfloat*)(size_t)(ta[im][j][mb0 + mm]);
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                    tv[m][ch][0] = a[ch * HW];
-                    tv[m][ch][1] = a[ch * HW + 1];
-                    tv[m][ch][2] = a[ch * HW + W];
-                    tv[m][ch][3] = a[ch * HW + W + 1];
+                    tv[mm][ch][0] = a[ch * HW];
+                    tv[mm][ch][1] = a[ch * HW + 1];
+                    tv[mm][ch][2] = a[ch * HW + W];
+                    tv[mm][ch][3] = a[ch * HW + W + 1];
                 }
             }
-            if (im == 1 && j == 0) {
+            if (im == 1 && decltype(jc)::value == 0) {
                 // image A's output pieces leave while the LDS serves image B's tap reads: their issue is back-pressured
                 // by HBM and would otherwise sit on the critical path between the two images
                 __builtin_amdgcn_sched_barrier(0);
@@ -365,7 +373,9 @@ tps_warp_img_kernel(const ImgParams P)
             auto combine = [&](auto oobc) {
                 constexpr bool OOB = decltype(oobc)::value;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int mm = 0; mm < MB; ++mm) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int m = mb0 + mm;
                     const unsigned fl = oob[im] >> (2 * (4 * j + m));
                     const bool inx = !(fl & 1u), iny = !(fl & 2u), inxy = !(fl & 3u);
                     const float w = tf[im][j][m][0], nn = tf[im][j][m][1];
@@ -373,10 +383,10 @@ tps_warp_img_kernel(const ImgParams P)
                     const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
 #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
-                        const float v01 = (!OOB || inx) ? tv[m][ch][1] : 0.0f;
-                        const float v10 = (!OOB || iny) ? tv[m][ch][2] : 0.0f;
-                        const float v11 = (!OOB || inxy) ? tv[m][ch][3] : 0.0f;
-                        float acc = tv[m][ch][0] * nw;
+                        const float v01 = (!OOB || inx) ? tv[mm][ch][1] : 0.0f;
+                        const float v10 = (!OOB || iny) ? tv[mm][ch][2] : 0.0f;
+                        const float v11 = (!OOB || inxy) ? tv[mm][ch][3] : 0.0f;
+                        float acc = tv[mm][ch][0] * nw;
                         acc = fmaf(v01, ne, acc);
                         acc = fmaf(v10, sw, acc);
                         acc = fmaf(v11, se, acc);
@@ -389,13 +399,17 @@ tps_warp_img_kernel(const ImgParams P)
         lds_only_barrier();                                  // every tap of the image is in registers: its planes are free
         // results in place of the image, in the output's own layout (C, OH, OW)
         char* stage = reinterpret_cast<char*>(sImg + im * img_elems);
+        int tq = tt;
+        asm volatile("" : "+v"(tq));                         // (keeps the offsets' arithmetic here, not hoisted to the top)
 #pragma unroll
         for (int j = 0; j < QP; ++j)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                const unsigned po = pixel_off(tq, j, m);
 #pragma unroll
                 for (int ch = 0; ch < C; ++ch)
-                    if (live) *reinterpret_cast<float*>(stage + ch * (int)row_bytes + poff[j][m]) = res[j][m][ch];
+                    if (live) *reinterpret_cast<float*>(stage + ch * (int)row_bytes + po) = res[j][m][ch];
+            }
         lds_only_barrier();                                  // results staged
         if (im == 0) IMG_STAMP(3);
 #pragma unroll
@@ -431,7 +445,7 @@ tps_warp_img_kernel(const ImgParams P)
 
 // [wavefront][QP][KG][lane][4]: the table values of thread (wavefront, lane)'s quadrant pixel j, q = 4 g .. 4 g + 3
 __global__ void __launch_bounds__(256)
-pack_img_table_kernel(const float* __restrict__ p_hat, int p_hat_ld, int OW, int CG, int QP, int nthr, int K,
+pack_img_table_kernel(const float* __restrict__ p_hat, int p_hat_ld, int OW, int CG, int QP, int BW, int nthr, int K,
                       float* __restrict__ packed)
 {
     const int KG = (K + 3) / 4;
@@ -447,7 +461,7 @@ pack_img_table_kernel(const float* __restrict__ p_hat, int p_hat_ld, int OW, int
     float val = 0.0f;
     if (t < nthr && q < K) {
         int r, c;
-        img_thread_pixel(t, j, CG, QP, &r, &c);
+        img_thread_pixel(t, j, CG, QP, BW, &r, &c);
         val = p_hat[(size_t)(r * OW + c) * p_hat_ld + q];
     }
     packed[i] = val;
