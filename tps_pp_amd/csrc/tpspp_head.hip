@@ -343,152 +343,14 @@ dec_embed_kernel(const float* __restrict__ emb, const float* __restrict__ pos, c
     x[i] = emb[(size_t)tok * C + c] + pos[(size_t)step * C + c];
 }
 
-// ---- decoder, one step: masked self-attention against the cache ------------------------------------------
-// qkv_t (Nb, 3C) TOKEN-major (this step's projections).  One wavefront per (image, head); lane = feature
-// while loading / accumulating, lane = position while scoring.  Cache: Kc[b][h][feature][Lmax] (a lane
-// per position reads coalesced), Vc[b][h][position][64] (a lane per feature reads coalesced).  The new
-// position is used from registers, so nothing written by this kernel is read back by it.
-// Key p is valid iff p <= step and tokens[b][p] != <PAD>  (nrtr_decoder.py:100-102).
-// KV = float, or unsigned short: bf16 caches (TPSPP_HEAD_BF16; the position being decoded is used from its fp32 registers,
-// earlier positions as they were rounded when they were written)
-__device__ __forceinline__ float kvc_load(const float* p) { return *p; }
-__device__ __forceinline__ float kvc_load(const unsigned short* p) { return __builtin_bit_cast(float, (unsigned)*p << 16); }
-__device__ __forceinline__ void kvc_store(float* p, float v) { *p = v; }
-__device__ __forceinline__ void kvc_store(unsigned short* p, float v)
-{
-    unsigned u = __builtin_bit_cast(unsigned, v);                // round to nearest even (finite activations)
-    u += 0x7fffu + ((u >> 16) & 1u);
-    *p = (unsigned short)(u >> 16);
-}
-
-template <typename KV>
-__global__ void __launch_bounds__(256)
-attn_dec_self_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
-                     KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
-                     int pad_idx, float* __restrict__ out, int out_tm)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pair >= Nb * H) return;
-    const int b = pair / H, h = pair - b * H;
-    const float* base = qkv_t + (size_t)b * 3 * C + kDK * h;
-    const float q = base[lane] * 0.125f;
-    const float k = base[C + lane];
-    const float v = base[2 * C + lane];
-    const size_t bh = (size_t)b * H + h;
-    KV* kc = Kc + bh * kDK * Lmax;
-    KV* vc = Vc + bh * Lmax * kDK;
-    kvc_store(kc + (size_t)lane * Lmax + step, k);
-    kvc_store(vc + (size_t)step * kDK + lane, v);
-
-    const int pl = lane < step ? lane : 0;                // clamped: lanes >= step are masked below
-    float sc = 0.0f;
-    if (step > 0) {
-        float kv[kDK];                                     // all 64 cached-key loads in flight together
-#pragma unroll
-        for (int d = 0; d < kDK; ++d) kv[d] = kvc_load(kc + (size_t)d * Lmax + pl);
-#pragma unroll
-        for (int d = 0; d < kDK; ++d) sc = fmaf(readlane_f(q, d), kv[d], sc);
-    }
-    const float cur = wave_sum(q * k);
-    if (lane == step) sc = cur;
-    const bool valid = lane <= step && tokens[(size_t)b * Lt + (lane <= step ? lane : 0)] != pad_idx;
-    sc = valid ? sc : -INFINITY;
-    const float mx = wave_max(sc);
-    float p = valid ? expf(sc - mx) : 0.0f;
-    const float l = wave_sum(p);
-    p = p / l;
-    float acc = readlane_f(p, step) * v;
-    for (int p0 = 0; p0 < step; p0 += 16) {                // 16 cached value rows in flight
-        float vv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) vv[u] = kvc_load(vc + (size_t)(p0 + u < step ? p0 + u : 0) * kDK + lane);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const float pw = p0 + u < step ? readlane_f(p, (p0 + u) & (kWave - 1)) : 0.0f;
-            acc = fmaf(pw, vv[u], acc);
-        }
-    }
-    if (out_tm) out[(size_t)b * C + kDK * h + lane] = acc;
-    else out[(size_t)(kDK * h + lane) * Nb + b] = acc;
-}
-
-// ---- decoder, one step: cross-attention against the encoder ------------------------------------------------
-// q_t (Nb, C) token-major; Kx (C, Nb*T) channel-major (a lane per encoder token reads coalesced);
-// Vx_t (Nb*T, C) token-major (a lane per feature reads coalesced).  One wavefront per (image, head),
-// T <= 256 (four tokens per lane).  Keys >= valid_len[b] are masked (nrtr_decoder.py:115-129).
-__device__ __forceinline__ float kv_elem(float v) { return v; }
-__device__ __forceinline__ float kv_elem(unsigned short v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
-
-// KV = float, or unsigned short: bf16 keys / values (TPSPP_HEAD_BF16: the 128 MB of encoder K/V per layer are the
-// only HBM-bound operand of a decoder step; scores, softmax and the weighted sum stay fp32)
-template <typename KV>
-__global__ void __launch_bounds__(256)
-attn_dec_cross_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx, const KV* __restrict__ Vx_t,
-                      int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out, int out_tm)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pair >= Nb * H) return;
-    const int b = pair / H, h = pair - b * H;
-    const float q = q_t[(size_t)b * C + kDK * h + lane] * 0.125f;
-    int nvalid = valid_len ? valid_len[b] : T;
-    nvalid = nvalid < T ? nvalid : T;
-    const size_t MT = (size_t)Nb * T;
-    const KV* kbase = Kx + (size_t)(kDK * h) * MT + (size_t)b * T;
-    float sc[4];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        sc[jj] = -INFINITY;
-        if (jj * kWave < nvalid) {                         // wave-uniform
-            const int t = jj * kWave + lane;
-            const int tt = t < T ? t : T - 1;
-            float kv[kDK];                                 // all 64 row loads in flight together
-#pragma unroll
-            for (int d = 0; d < kDK; ++d) kv[d] = kv_elem(kbase[(size_t)d * MT + tt]);
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < kDK; ++d) s = fmaf(readlane_f(q, d), kv[d], s);
-            sc[jj] = t < nvalid ? s : -INFINITY;
-            mx = fmaxf(mx, sc[jj]);
-        }
-    }
-    mx = wave_max(mx);
-    float l = 0.0f;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        sc[jj] = sc[jj] == -INFINITY ? 0.0f : expf(sc[jj] - mx);
-        l += sc[jj];
-    }
-    l = wave_sum(l);
-    const float inv = 1.0f / l;
-    const KV* vbase = Vx_t + ((size_t)b * T) * C + kDK * h + lane;
-    float acc = 0.0f;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int cnt = min(kWave, nvalid - jj * kWave);   // wave-uniform
-        const float pj = sc[jj] * inv;                     // 0 for masked tokens
-        for (int t0 = 0; t0 < cnt; t0 += 16) {             // 16 value rows in flight
-            float vv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int tl = t0 + u < cnt ? t0 + u : cnt - 1;
-                vv[u] = kv_elem(vbase[(size_t)(jj * kWave + tl) * C]);
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const float pw = t0 + u < cnt ? readlane_f(pj, (t0 + u) & (kWave - 1)) : 0.0f;
-                acc = fmaf(pw, vv[u], acc);
-            }
-        }
-    }
-    if (out_tm) out[(size_t)b * C + kDK * h + lane] = acc;
-    else out[(size_t)(kDK * h + lane) * Nb + b] = acc;
-}
-
-// ---- decoder, one step: attention with 16-byte loads (the token-major step pipeline) --------------------------------
-// The kernels above give a lane one 4-byte element per load (a key row per lane, a value row per wavefront): 128 load
+// ---- decoder, one step: attention against the caches / the encoder, 16-byte loads -----------------------------------
+// qkv_t (Nb, 3C) / q_t (Nb, C) TOKEN-major (this step's projections); one wavefront per (image, head).
+// Self-attention (nrtr_decoder.py:100-102): key p is valid iff p <= step and tokens[b][p] != <PAD>; the new position is
+// used from registers, so nothing written by the kernel is read back by it.  Cross-attention (nrtr_decoder.py:115-129):
+// keys >= valid_len[b] are masked.  KV = float, or unsigned short: bf16 caches / encoder keys and values
+// (TPSPP_HEAD_BF16: the encoder K/V are the only HBM-bound operand of a step; the position being decoded is used from its
+// fp32 registers, earlier positions as they were rounded when written; scores, softmax, weighted sum in fp32).
+// Rounds 1-2 gave a lane one 4-byte element per load (a key row per lane, a value row per wavefront): 128 load
 // instructions of 256 bytes per (image, head), and the vector-memory unit takes 16 cycles per instruction whatever its
 // width -- the cross-attention's 134 MB per layer-step moved at 4 TB/s.  Here keys AND values are token-major
 // ((tokens, C) rows, a head's 64 features contiguous), a lane takes 16 bytes (EPL = 4 fp32 or 8 bf16 features) of a
@@ -557,7 +419,7 @@ template <> struct Wide<unsigned short> {
 template <typename KV>
 __global__ void __launch_bounds__(256)
 attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
-                           int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out)
+                           int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out, int out_cm)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;   // tokens per instruction, pieces per 64 tokens
@@ -637,9 +499,14 @@ attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
     if (grp == 0) {
-        float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+        if (out_cm) {                                      // channel-major (C, Nb): the exact-fp32 step GEMMs' operand layout
 #pragma unroll
-        for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            for (int e = 0; e < EPL; ++e) out[(size_t)(kDK * h + EPL * dl + e) * Nb + b] = acc[e];
+        } else {
+            float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+        }
     }
 }
 
@@ -649,7 +516,7 @@ template <typename KV>
 __global__ void __launch_bounds__(256)
 attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
                           KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
-                          int pad_idx, float* __restrict__ out)
+                          int pad_idx, float* __restrict__ out, int out_cm)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;
@@ -734,9 +601,14 @@ attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H,
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
     if (grp == 0) {
-        float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+        if (out_cm) {                                      // channel-major (C, Nb): the exact-fp32 step GEMMs' operand layout
 #pragma unroll
-        for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            for (int e = 0; e < EPL; ++e) out[(size_t)(kDK * h + EPL * dl + e) * Nb + b] = acc[e];
+        } else {
+            float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+        }
     }
 }
 
@@ -1247,20 +1119,19 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             // bf16 matrix cores, bf16 keys / values: K channel-major straight from the epilogue; V channel-major
             // into the upper half of its own (fp32-sized) slot, then transposed to token-major rows
             unsigned short* vt = reinterpret_cast<unsigned short*>(Vx[l]) + (size_t)C * MT;
-            unsigned short* kt = fast ? reinterpret_cast<unsigned short*>(Kx[l]) + (size_t)C * MT : reinterpret_cast<unsigned short*>(Kx[l]);
+            unsigned short* kt = reinterpret_cast<unsigned short*>(Kx[l]) + (size_t)C * MT;
             g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, kt, 0, 0, nullptr);
             g.cm16(w[D_WV], nullptr, enc_cm, C, C, MT, vt, 0, 0, nullptr);
             if (g.rc) return g.rc;
             hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
                                0, st, vt, C, MT, reinterpret_cast<unsigned short*>(Vx[l]));
-            if (fast)
-                hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
-                                   0, st, kt, C, MT, reinterpret_cast<unsigned short*>(Kx[l]));
+            hipLaunchKernelGGL(transpose2d_b16_kernel, dim3((unsigned)((MT + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256),
+                               0, st, kt, C, MT, reinterpret_cast<unsigned short*>(Kx[l]));
         } else {
-            float* kdst = fast ? ktmp : Kx[l];
+            float* kdst = ktmp;
             if (x3) g.cm16(w[D_WK], w[D_BK], enc_cm, C, C, MT, kdst, 1, 0, nullptr, 1);   // fp32 keys, three-term split
             else g.cm(w[D_WK], w[D_BK], enc_cm, C, C, MT, kdst, 0, nullptr);
-            if (fast) {                                     // (C, N*T) -> (N*T, C): the wide-load cross-attention's layout
+            {                                               // (C, N*T) -> (N*T, C): the wide-load cross-attention's layout
                 if (g.rc) return g.rc;
                 const int rc_t = tpspp_transpose2d(ktmp, C, MT, Kx[l], stream);
                 if (rc_t) return rc_t;
@@ -1284,19 +1155,19 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             if (b16)
                 hipLaunchKernelGGL(attn_dec_self_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
                                    L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
-                                   tokens, Lt, padding_idx, a);
+                                   tokens, Lt, padding_idx, a, 0);
             else
                 hipLaunchKernelGGL(attn_dec_self_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
-                                   Vc[l], tokens, Lt, padding_idx, a);
+                                   Vc[l], tokens, Lt, padding_idx, a, 0);
             dec_gemm_x3(st, a, w[D_WFC_X], w[D_BFC], nullptr, 0.0f, x, 0, N, C, C, y);              // y = x + fc(a)
             dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv);
             if (b16)
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
                                    reinterpret_cast<const unsigned short*>(Kx[l]),
-                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a);
+                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 0);
             else
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
-                                   N, H, T, valid_len, a);
+                                   N, H, T, valid_len, a, 0);
             dec_gemm_x3(st, a, w[D_WFC2_X], w[D_BFC2], nullptr, 0.0f, y, 0, N, C, C, x);            // x = y + fc(a)
             dec_gemm_x3(st, x, w[D_W1_X], w[D_W1_B], w[D_W1_CS], 1e-5f, nullptr, 2, N, C, d_inner, hid);
             dec_gemm_x3(st, hid, w[D_W2_X], w[D_B2], nullptr, 0.0f, x, 0, N, d_inner, C, y);        // y = x + w2(...)
@@ -1319,23 +1190,23 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_QKV_W], w[D_QKV_CS], 3 * C, w[D_QKV_B], 0, nullptr, 1, qkv, stream);
             if (rc) return rc;
             if (b16)
-                hipLaunchKernelGGL(attn_dec_self_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
+                hipLaunchKernelGGL(attn_dec_self_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
                                    L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
-                                   tokens, Lt, padding_idx, a, 0);
+                                   tokens, Lt, padding_idx, a, 1);
             else
-                hipLaunchKernelGGL(attn_dec_self_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
-                                   Vc[l], tokens, Lt, padding_idx, a, 0);
+                hipLaunchKernelGGL(attn_dec_self_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
+                                   Vc[l], tokens, Lt, padding_idx, a, 1);
             g.cm(w[D_WFC], w[D_BFC], a, C, C, N, y, 0, x);            // y = x + fc(a)
             // x = y + fc(enc_attn(LN2(y), enc, enc))                   transformer_layers.py:156-159
             rc = tpspp_linear_ln_fwd(y, C, N, 1e-5f, w[D_Q_W], w[D_Q_CS], C, w[D_Q_B], 0, nullptr, 1, qkv, stream);
             if (rc) return rc;
             if (b16)
-                hipLaunchKernelGGL(attn_dec_cross_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
+                hipLaunchKernelGGL(attn_dec_cross_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
                                    reinterpret_cast<const unsigned short*>(Kx[l]),
-                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 0);
+                                   reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 1);
             else
-                hipLaunchKernelGGL(attn_dec_cross_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
-                                   N, H, T, valid_len, a, 0);
+                hipLaunchKernelGGL(attn_dec_cross_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
+                                   N, H, T, valid_len, a, 1);
             g.cm(w[D_WFC2], w[D_BFC2], a, C, C, N, x, 0, y);          // x = y + fc(a)
             // x = x + mlp(LN3(x))                                       transformer_layers.py:161-163
             rc = tpspp_linear_ln_fwd(x, C, N, 1e-5f, w[D_W1_W], w[D_W1_CS], d_inner, w[D_W1_B], 2, nullptr, 0, hid, stream);
