@@ -488,14 +488,14 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
  *                  enc_attn.fc.weight^T, its bias | NULL;
  *                  mlp.w_1 (C, d_inner): w_gamma, colsum (d_inner), bias_eff (d_inner);
  *                  mlp.w_2.weight^T (d_inner, C), mlp.w_2.bias;
- *                  then six entries that are NULL in the exact-fp32 configuration and, with TPSPP_HEAD_BF16 or
- *                  TPSPP_HEAD_BF16X3, hold the six per-step projections (q|k|v with norm1 folded, self fc, enc q with norm2
- *                  folded, enc fc, w_1 with norm3 folded, w_2) split and arranged for the step GEMM: K-major (K, Co) ->
- *                  hi = bf16(w), lo = bf16(w - hi), Co zero-padded to a multiple of 32, laid out
- *                  [Co/32][K/16][hi|lo][2 k halves][32 outputs][8 k] bf16;
- *                with those flags one more pointer follows the last layer: the classifier (final layer_norm folded)
- *                arranged the same way.  Every activation of a step is then token-major and the projections run as
- *                three-term bf16 products (hi*hi + hi*lo + lo*hi, fp32 accumulation: inside the fp32 tolerance)
+ *                  then six entries (or NULL: the round-2 channel-major step kernels are used) with the six per-step
+ *                  projections (q|k|v with norm1 folded, self fc, enc q with norm2 folded, enc fc, w_1 with norm3 folded,
+ *                  w_2) arranged in MFMA fragment order for the token-major step GEMM, Co zero-padded to a multiple of 32:
+ *                  exact fp32 (no flag):  [Co/32][K/8][2 k halves][32 outputs][4 k] fp32, k = 8 u + 4 half + e;
+ *                  TPSPP_HEAD_BF16 / _BF16X3: hi = bf16(w), lo = bf16(w - hi),
+ *                  [Co/32][K/16][hi|lo][2 k halves][32 outputs][8 k] bf16 (products hi*hi + hi*lo + lo*hi, fp32
+ *                  accumulation: inside the fp32 tolerance);
+ *                one more pointer follows the last layer: the classifier (final layer_norm folded) arranged the same way
  *   emb (num_classes, C) trg_word_emb.weight;  pos_table (n_position, C) position_enc.position_table;
  *   w_cls (C, num_out), cls_colsum (num_out), b_cls (num_out): the classifier with the final layer_norm
  *                (eps 1e-6) folded in the same way;  max_seq_len <= 64;  valid_len as above (cross-attention

@@ -790,15 +790,109 @@ dec_gemm_x3_kernel(const DGemm P)
     *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// The same GEMM with exact fp32 products (v_mfma_f32_32x32x2_f32) for the exact-fp32 configuration: the weight arrives
+// as fp32 in fragment order, [Co/32][K/8][k half][32 outputs][4 k] with k = 8 u + 4 half + e, x as 16-byte pieces of the
+// token-major row (the lane's four k of the step), four MFMAs per 16-byte pair; eight wavefronts split K.
+struct DGemmF {
+    const float* X; const float4* Wp; const float* bias; const float* colsum; const float* res; float* out;
+    int M, K, Co; float eps; int act;
+};
+template <int KUW, bool LN>
+__global__ void __launch_bounds__(512)
+dec_gemm_f32_kernel(const DGemmF P)
+{
+    __shared__ float sRed[8][16][kWave];
+    __shared__ float sS1[16][32], sS2[16][32];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.x * 32, ct = blockIdx.y, co0 = ct * 32;
+    const int KU = P.K >> 3;
+    const int m = m0 + l31;
+    const int mc = m < P.M ? m : P.M - 1;
+    const float4* xp = reinterpret_cast<const float4*>(P.X + (size_t)mc * P.K + 8 * (wv * KUW) + 4 * half);
+    const float4* wp = P.Wp + ((size_t)(ct * KU + wv * KUW) * 2 + half) * 32 + l31;
+    float4 xa[KUW], wa[KUW];
+#pragma unroll
+    for (int j = 0; j < KUW; ++j) { xa[j] = xp[2 * j]; wa[j] = wp[(size_t)j * 64]; }
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KUW; ++j) {
+        const float x[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+        const float w[4] = {wa[j].x, wa[j].y, wa[j].z, wa[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (LN) { s1 += x[e]; s2 = fmaf(x[e], x[e], s2); }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
+    if (LN) { sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2; }
+    __syncthreads();
+    // wavefronts 0 - 3 finish accumulator registers 4 w .. 4 w + 3: outputs co0 + 8 w + 4 half + (0 .. 3) of token l31
+    if (wv >= 4) return;
+    const int c = co0 + 8 * wv + 4 * half;
+    if (m >= P.M || c >= P.Co) return;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = 0.0f;
+#pragma unroll
+        for (int pz = 0; pz < 8; pz += 2) t += sRed[pz][4 * wv + e][lane] + sRed[pz + 1][4 * wv + e][lane];
+        v[e] = t;
+    }
+    if (LN) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
+        const float mean = t1 / (float)P.K;
+        const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
+        const float4 cs = *reinterpret_cast<const float4*>(P.colsum + c);
+        v[0] = rstd * (v[0] - mean * cs.x); v[1] = rstd * (v[1] - mean * cs.y);
+        v[2] = rstd * (v[2] - mean * cs.z); v[3] = rstd * (v[3] - mean * cs.w);
+    }
+    if (P.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + c);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (P.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    }
+    const size_t o = (size_t)m * P.Co + c;
+    if (P.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(P.res + o);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // launches the step GEMM; false when the shape has no instantiation (K must be 256 or 512, Co a multiple of 4)
 bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bias, const float* colsum, float eps,
-                 const float* res, int act, int M, int K, int Co, float* out)
+                 const float* res, int act, int M, int K, int Co, float* out, bool f32 = false)
 {
     if ((K != 256 && K != 512) || (Co & 3) || M <= 0) return false;
+    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Co + 31) / 32));
+    if (f32) {
+        DGemmF P;
+        P.X = X; P.Wp = reinterpret_cast<const float4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
+        P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
+        if (K == 512) {
+            if (colsum) hipLaunchKernelGGL((dec_gemm_f32_kernel<8, true>), grid, dim3(512), 0, st, P);
+            else        hipLaunchKernelGGL((dec_gemm_f32_kernel<8, false>), grid, dim3(512), 0, st, P);
+        } else {
+            if (colsum) hipLaunchKernelGGL((dec_gemm_f32_kernel<4, true>), grid, dim3(512), 0, st, P);
+            else        hipLaunchKernelGGL((dec_gemm_f32_kernel<4, false>), grid, dim3(512), 0, st, P);
+        }
+        return true;
+    }
     DGemm P;
     P.X = X; P.Wp = reinterpret_cast<const du32x4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
     P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
-    const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Co + 31) / 32));
     if (K == 512) {
         if (colsum) hipLaunchKernelGGL((dec_gemm_x3_kernel<8, true>), grid, dim3(256), 0, st, P);
         else        hipLaunchKernelGGL((dec_gemm_x3_kernel<8, false>), grid, dim3(256), 0, st, P);
@@ -981,7 +1075,7 @@ enum { E_LN1G, E_LN1B, E_WQKV, E_BQKV, E_WFC, E_BFC, E_LN2G, E_LN2B, E_W1, E_B1,
 // decoder: the three LayerNorms are folded into the projections that follow them (tpspp_linear_ln_fwd)
 enum { D_QKV_W, D_QKV_CS, D_QKV_B, D_WFC, D_BFC, D_Q_W, D_Q_CS, D_Q_B, D_WK, D_BK, D_WV, D_WFC2, D_BFC2, D_W1_W, D_W1_CS,
        D_W1_B, D_W2, D_B2,
-       // the six per-step projections split and arranged for dec_gemm_x3_kernel (TPSPP_HEAD_BF16 / _BF16X3; else NULL)
+       // the six per-step projections arranged for the step GEMM: split hi / lo bf16 (TPSPP_HEAD_BF16 / _BF16X3) or fp32
        D_QKV_X, D_WFC_X, D_Q_X, D_WFC2_X, D_W1_X, D_W2_X, D_COUNT };
 
 TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, int n_layers,
@@ -1105,8 +1199,9 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     // Reduced-precision head (TPSPP_HEAD_BF16 / _BF16X3) with arranged per-step weights in the table: every activation of
     // a step is TOKEN-major and the six projections + the classifier run on dec_gemm_x3_kernel (three-term split: inside
     // the fp32 tolerance, so the bf16 head takes it as well).  8 launches per layer-step as before, each about half as long.
-    const void* cls_x = (b16 || x3) ? layer_ptrs[(size_t)n_layers * D_COUNT] : nullptr;   // the classifier, arranged (behind the layers)
-    bool fast = (b16 || x3) && cls_x != nullptr && (C == 256 || C == 512) && (d_inner == 256 || d_inner == 512) && (num_out % 4) == 0;
+    const void* cls_x = layer_ptrs[(size_t)n_layers * D_COUNT];       // the classifier, arranged (behind the layers), or NULL
+    const bool gemm_f32 = !(b16 || x3);                               // exact fp32 products; else the three-term split
+    bool fast = cls_x != nullptr && (C == 256 || C == 512) && (d_inner == 256 || d_inner == 512) && (num_out % 4) == 0;
     for (int l = 0; l < n_layers && fast; ++l) {
         const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
         fast = w[D_QKV_X] && w[D_WFC_X] && w[D_Q_X] && w[D_WFC2_X] && w[D_W1_X] && w[D_W2_X];
@@ -1151,7 +1246,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                                tokens, Lt, s, C, N, x, 1);
         for (int l = 0; l < n_layers; ++l) {
             const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
-            dec_gemm_x3(st, x, w[D_QKV_X], w[D_QKV_B], w[D_QKV_CS], 1e-5f, nullptr, 0, N, C, 3 * C, qkv);
+            dec_gemm_x3(st, x, w[D_QKV_X], w[D_QKV_B], w[D_QKV_CS], 1e-5f, nullptr, 0, N, C, 3 * C, qkv, gemm_f32);
             if (b16)
                 hipLaunchKernelGGL(attn_dec_self_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s,
                                    L, reinterpret_cast<unsigned short*>(Kc[l]), reinterpret_cast<unsigned short*>(Vc[l]),
@@ -1159,8 +1254,8 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             else
                 hipLaunchKernelGGL(attn_dec_self_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
                                    Vc[l], tokens, Lt, padding_idx, a, 0);
-            dec_gemm_x3(st, a, w[D_WFC_X], w[D_BFC], nullptr, 0.0f, x, 0, N, C, C, y);              // y = x + fc(a)
-            dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv);
+            dec_gemm_x3(st, a, w[D_WFC_X], w[D_BFC], nullptr, 0.0f, x, 0, N, C, C, y, gemm_f32);              // y = x + fc(a)
+            dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv, gemm_f32);
             if (b16)
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
                                    reinterpret_cast<const unsigned short*>(Kx[l]),
@@ -1168,12 +1263,12 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             else
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
                                    N, H, T, valid_len, a, 0);
-            dec_gemm_x3(st, a, w[D_WFC2_X], w[D_BFC2], nullptr, 0.0f, y, 0, N, C, C, x);            // x = y + fc(a)
-            dec_gemm_x3(st, x, w[D_W1_X], w[D_W1_B], w[D_W1_CS], 1e-5f, nullptr, 2, N, C, d_inner, hid);
-            dec_gemm_x3(st, hid, w[D_W2_X], w[D_B2], nullptr, 0.0f, x, 0, N, d_inner, C, y);        // y = x + w2(...)
+            dec_gemm_x3(st, a, w[D_WFC2_X], w[D_BFC2], nullptr, 0.0f, y, 0, N, C, C, x, gemm_f32);            // x = y + fc(a)
+            dec_gemm_x3(st, x, w[D_W1_X], w[D_W1_B], w[D_W1_CS], 1e-5f, nullptr, 2, N, C, d_inner, hid, gemm_f32);
+            dec_gemm_x3(st, hid, w[D_W2_X], w[D_B2], nullptr, 0.0f, x, 0, N, d_inner, C, y, gemm_f32);        // y = x + w2(...)
             float* t = x; x = y; y = t;
         }
-        dec_gemm_x3(st, x, cls_x, b_cls, cls_colsum, 1e-6f, nullptr, 0, N, C, num_out, logits);
+        dec_gemm_x3(st, x, cls_x, b_cls, cls_colsum, 1e-6f, nullptr, 0, N, C, num_out, logits, gemm_f32);
         // (x holds this step's final activations, read by the classifier launch above; the next step's embedding goes to y,
         //  which becomes x)
         const bool more = s + 1 < L;

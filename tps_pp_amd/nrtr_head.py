@@ -238,11 +238,13 @@ class NRTRDecoder(nn.Module):
                 ts += [qkv[0], qkv[1], qkv[2], wfc, None,
                        q[0], q[1], q[2], kk(ea.linear_k.weight), None, kv(ea.linear_v.weight),
                        wfc2, None, w1[0], w1[1], w1[2], w2, _f32(lyr.mlp.w_2.bias)]
-                # the six per-step projections split and arranged for the step GEMM (reduced-precision head only)
-                ts += [ops.arrange_x3(t) for t in (qkv[0], wfc, q[0], wfc2, w1[0], w2)] if (b16 or x3) else [None] * 6
+                # the six per-step projections arranged for the step GEMM: fp32 fragments, or split hi / lo bf16 for the
+                # reduced-precision head
+                arr = ops.arrange_x3 if (b16 or x3) else ops.arrange_f32
+                ts += [arr(t) for t in (qkv[0], wfc, q[0], wfc2, w1[0], w2)]
             cls = ops.fold_layernorm(self.layer_norm.weight, self.layer_norm.bias, ops.kmajor(self.classifier.weight),
                                      self.classifier.bias)
-            ts.append(ops.arrange_x3(cls[0]) if (b16 or x3) else None)     # behind the layers: the classifier
+            ts.append((ops.arrange_x3 if (b16 or x3) else ops.arrange_f32)(cls[0]))     # behind the layers: the classifier
             cache = (key, ops.PtrTable(ts), _f32(self.trg_word_emb.weight), _f32(self.position_enc.position_table[0]),
                      cls)
             self._w_cache = cache

@@ -957,6 +957,19 @@ def arrange_x3(w_kmajor):
     return st.permute(4, 1, 0, 2, 5, 3).contiguous()                   # (ct, ks, s, h, r, e)
 
 
+def arrange_f32(w_kmajor):
+    """K-major (K, Co) fp32 weight -> the exact-fp32 step GEMM's operand (`dec_gemm_f32_kernel`): Co zero-padded to a
+    multiple of 32, [Co/32][K/8][2 k halves][32 outputs][4 k] fp32 with k = 8 u + 4 half + e."""
+    w = w_kmajor.detach().float()
+    K, Co = w.shape
+    if K % 8:
+        raise ValueError("arrange_f32: K must be a multiple of 8")
+    Cop = (Co + 31) // 32 * 32
+    if Cop != Co:
+        w = torch.cat([w, w.new_zeros((K, Cop - Co))], dim=1)
+    return w.reshape(K // 8, 2, 4, Cop // 32, 32).permute(3, 0, 1, 4, 2).contiguous()     # (u, h, e, ct, r) -> (ct, u, h, r, e)
+
+
 class PtrTable:
     """Host array of device pointers (`const float* const*`) + the tensors it points at (kept alive)."""
 
