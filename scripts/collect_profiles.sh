@@ -9,9 +9,12 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 STEPS=${STEPS:-400}
-# 1. kernel trace + stats of the bench command
+# 1. kernel trace + stats of the bench command (steps round-robin on 3 streams: launches overlap), and of the same steps on
+#    ONE stream (the kernel's own start-to-end duration)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- \
     python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline --no-extras > $OUT/bench_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o bench -- \
+    python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline --no-extras --streams 1 > $OUT/bench_trace1.log 2>&1
 # 2. PMC passes (own runs, nothing but --pmc)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- \

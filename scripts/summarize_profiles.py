@@ -92,8 +92,56 @@ GRBM_GUI_ACTIVE summed over the 8 XCDs); utilisation below = the same ratio of a
                 f.write(f"| `{k[:100]}` | {n} | {100 * u:.1f} % |\n")
 
 
+def timeline(trace_csv, kernel_substr, steps):
+    """From a rocprofv3 kernel trace: the last `steps` dispatches of the warp kernel (the timed region; the one-stream
+    re-run of bench.py follows it on stream 0, so the region is found by its streams) -> average start-to-end duration
+    of a kernel, and the period between launches = (last end - first start) / launches."""
+    rows = [r for r in csv.DictReader(open(trace_csv)) if kernel_substr in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    return rows
+
+
+def timeline_summary():
+    out = []
+    for tag, sub in (("three streams (the bench command)", "trace"), ("one stream (`--streams 1`)", "trace1")):
+        pth = os.path.join(SRC, sub, "bench_kernel_trace.csv")
+        log = os.path.join(SRC, "bench_trace.log" if sub == "trace" else "bench_trace1.log")
+        if not (os.path.exists(pth) and os.path.exists(log)):
+            continue
+        bench = json.loads([l for l in open(log) if l.startswith("{")][-1])
+        steps, warm = bench["steps"], bench["warmup"]
+        rows = timeline(pth, KERNEL, steps)
+        # dispatch order of bench.py: warm-up steps, the timed steps, [the one-stream re-run of the same steps], 1 parity step
+        lo = warm
+        sel = rows[lo:lo + steps]
+        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
+        span = max(int(r["End_Timestamp"]) for r in sel) - min(int(r["Start_Timestamp"]) for r in sel)
+        queues = sorted({r.get("Queue_Id", "?") for r in sel})
+        overlap = sum(1 for a, b in zip(sel, sel[1:]) if int(b["Start_Timestamp"]) < int(a["End_Timestamp"]))
+        out.append((tag, len(sel), sum(dur) / len(dur) / 1e3, span / len(sel) / 1e3, len(queues), overlap,
+                    bench["roofline"]["launch_us"], bench["roofline"]["frac"]))
+    if not out:
+        return
+    with open(os.path.join(DST, f"{TAG}_bench_kernel_timeline.md"), "w") as f:
+        f.write(f"""# {TAG}: the timed region of `python3 bench.py` in the rocprofv3 kernel trace (MI355X, 1 GPU)
+
+bench.py launches step i on HIP stream i % 3.  Launches on different streams overlap, so two different numbers describe
+the same region: a kernel's own start-to-end DURATION (what `--stats` averages) and the PERIOD between launches,
+(last end - first start) / launches, which is what `ms_per_step` / `roofline.launch_us` of the bench line measure.  On one
+stream the two coincide up to the launch gap.  Computed by scripts/summarize_profiles.py from the `*_kernel_trace.csv` of
+each run (the `steps` dispatches of `{KERNEL}` that follow the warm-up).
+
+| run | launches | average duration, us | period, us | HIP queues | launches that start before the previous one ends | bench line launch_us (same run) | frac |
+|---|---|---|---|---|---|---|---|
+""")
+        for tag, n, d, pd, q, ov, lu, fr in out:
+            f.write(f"| {tag} | {n} | {d:.2f} | {pd:.2f} | {q} | {ov} | {lu:.2f} | {fr:.3f} |\n")
+        f.write("\n(profiled runs are slower than un-profiled ones: rocprofv3 adds per-dispatch work)\n")
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
+    timeline_summary()
     # rocprofv3's own summary, kernel names cut to 200 characters (PyTorch's RNG kernels have 5-KB names)
     with open(os.path.join(SRC, "trace", "bench_kernel_stats.csv")) as fin, \
             open(os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"), "w", newline="") as fout:
