@@ -354,8 +354,9 @@ int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* src_dims, int 
 /* Channels per K-chunk of the bf16 conv kernel for a 1x1 / 3x3 kernel (layout of weight_arranged). */
 int tpspp_conv_bf16_chunk_channels(int kernel_size);
 
-/* Tuning / testing: non-zero forces the generic conv kernel even when weight_tiled is given. */
-int tpspp_conv_set_tuning(int force_generic);
+/* Tuning / testing (results do not depend on it).  Bit 0: tpspp_conv2d_fwd uses its generic kernel even when
+ * weight_tiled is given.  Bit 1: tpspp_conv2d_bf16_fwd does not use the persistent kernel for blocked 3x3 layers. */
+int tpspp_conv_set_tuning(int flags);
 
 /*
  * Launch-shape override for tpspp_warp_fwd (tuning / benchmarking only; results do not depend on

@@ -120,6 +120,45 @@ def test_conv_bf16_argument_errors(cuda):
         ops.conv2d_bf16([torch.zeros((1, 32, 8, 8), device=cuda)], cw, stride=(1, 2))   # no such kernel
 
 
+PERSIST_CASES = [
+    # name, sources [(C,H,W,uh,uw)], stride, res_mode, fp32 output, N   (tiles: 2 per 16x64 image, 8 per stride-2 image;
+    # a workgroup takes two tiles per trip, 256 workgroups)
+    ("dec3 64->64 @16x64, fp32 out, 3 trips", [(64, 16, 64, 1, 1)], (1, 1), 0, True, 601),
+    ("dec2 up2 + skip @16x64, 2 trips, ragged", [(64, 8, 32, 2, 2)], (1, 1), 1, False, 301),
+    ("enc0 192->64 @16x64 (streamed weight), 2 trips", [(64, 16, 64, 1, 1)] * 3, (1, 1), 0, False, 290),
+    ("down0_1 s2 64->64 @32x128, 2 trips, ragged", [(64, 32, 128, 1, 1)], (2, 2), 0, False, 67),
+    ("two chunks only 32->64 @16x64", [(32, 16, 64, 1, 1)], (1, 1), 2, False, 5),
+    ("one tile", [(64, 8, 64, 1, 1)], (1, 1), 0, False, 1),
+]
+
+
+@pytest.mark.parametrize("name,srcs,stride,res_mode,f32_out,N", PERSIST_CASES, ids=[c[0] for c in PERSIST_CASES])
+def test_conv_bf16_persistent_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, srcs, stride, res_mode, f32_out, N):
+    """tpspp_conv_bf16_persist.hip (persistent workgroups, two teams per workgroup, LDS-DMA patch) against the tiled kernel on the
+    same blocked tensors (tpspp_conv_set_tuning bit 1 switches it off): several trips per workgroup, a last trip that only
+    some workgroups make, upsampled and concatenated sources, blocked residual, both output forms."""
+    from tps_pp_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(len(name))
+    xs = [(ops.Blocked.from_nchw(torch.randn((N, c, h, w), generator=g).to(cuda)), uh, uw) for c, h, w, uh, uw in srcs]
+    cin = sum(s_[0] for s_ in srcs)
+    w = torch.randn((64, cin, 3, 3), generator=g) / np.sqrt(cin * 9.0)
+    b = torch.randn((64,), generator=g) * 0.1
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    Ho, Wo = srcs[0][1] * srcs[0][3] // stride[0], srcs[0][2] * srcs[0][4] // stride[1]
+    res = ops.Blocked.from_nchw(torch.randn((N, 64, Ho, Wo), generator=g).to(cuda)) if res_mode else None
+    kw = dict(relu=True, residual=res, res_mode=res_mode)
+    kw.update({"out_dtype": torch.float32} if f32_out else {"out_blocked": True})
+    raw = lambda o: o.view(torch.int32) if f32_out else o.t.view(torch.int16)
+    try:
+        _lib.lib().tpspp_conv_set_tuning(2)
+        want = raw(ops.conv2d_bf16(xs, cw, stride, **kw)).clone()
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
+    for _ in range(2):                                      # twice: no state survives a launch
+        got = raw(ops.conv2d_bf16(xs, cw, stride, **kw))
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("fg_dtype", ["bf16", "f32"])
 def test_front_bf16_fused_against_cpu_reference(cuda, fg_dtype):
     """tpspp_front_bf16_fwd (down0 / down1 / down2 / cat + Upsample + down_feat in one register-chained kernel)

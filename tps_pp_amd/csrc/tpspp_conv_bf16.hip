@@ -89,6 +89,9 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     TPSPP_REQUIRE((long)N * ((Cout + BN - 1) / BN) <= 65535, "tpspp_conv2d_bf16_fwd: grid too large");
     hipStream_t st = tpspp::as_stream(stream);
     bool ok = false;
+    // the big blocked 3x3 layers: persistent, LDS-DMA-fed kernel (tpspp_conv_bf16_persist.hip); bit-identical results
+    if (!split3 && KH == 3 && !tpspp::g_conv_bf16_no_persist && tpspp::conv_bf16_persist_launch(P, sh, sw, st))
+        return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
     if (split3) {
         ok = tpspp::conv_bf16x3_launch(P, KH, sh, sw, st);
     } else {

@@ -599,4 +599,7 @@ bool launch_by_shape(const BParams& P, hipStream_t st)
 namespace tpspp {
 // defined in tpspp_conv_bf16x3.hip: dispatches the split3 instantiations; false when no kernel fits
 bool conv_bf16x3_launch(const BParams& P, int KH, int sh, int sw, hipStream_t st);
+// defined in tpspp_conv_bf16_persist.hip: the persistent kernel for blocked 3x3 layers; false when it does not apply
+bool conv_bf16_persist_launch(const BParams& P, int sh, int sw, hipStream_t st);
+extern int g_conv_bf16_no_persist;           // tpspp_conv_set_tuning bit 1
 }  // namespace tpspp
