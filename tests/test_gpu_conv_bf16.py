@@ -129,6 +129,8 @@ PERSIST_CASES = [
     ("down0_1 s2 64->64 @32x128, 2 trips, ragged", [(64, 32, 128, 1, 1)], (2, 2), 0, False, 67),
     ("two chunks only 32->64 @16x64", [(32, 16, 64, 1, 1)], (1, 1), 2, False, 5),
     ("one tile", [(64, 8, 64, 1, 1)], (1, 1), 0, False, 1),
+    ("dec1 up2 + skip @8x32 (8x32 tiles)", [(64, 4, 16, 2, 2)], (1, 1), 1, False, 515),
+    ("enc1 s2 @16x64 -> 8x32 (4x32 tiles)", [(64, 16, 64, 1, 1)], (2, 2), 0, False, 259),
 ]
 
 

@@ -426,8 +426,9 @@ bool conv_bf16_persist_launch(const BParams& P, int sh, int sw, hipStream_t st)
     if (P.out_f32 != 2 && P.out_f32 != 1) return false;
     for (int i = 0; i < P.nsrc; ++i)
         if (P.src[i].f32 != 2 || (P.src[i].C % kPKC)) return false;
-    if (sh == 1 && sw == 1) return launch_p<1, 1, 4, 64, 2>(P, st);
-    if (sh == 2 && sw == 2) return launch_p<2, 2, 2, 64, 1>(P, st);
+    // 64-wide maps: 4 x 64 (stride 2: 2 x 64) tiles; 32-wide maps (the 8x32 level of the MSFA): 8 x 32 (4 x 32)
+    if (sh == 1 && sw == 1) return P.Wo % 64 == 0 ? launch_p<1, 1, 4, 64, 2>(P, st) : launch_p<1, 1, 8, 32, 2>(P, st);
+    if (sh == 2 && sw == 2) return P.Wo % 64 == 0 ? launch_p<2, 2, 2, 64, 1>(P, st) : launch_p<2, 2, 4, 32, 1>(P, st);
     return false;
 }
 
