@@ -21,6 +21,6 @@ cd.tpspp_debug_conv_trace(buf, 4096)
 t = np.array(buf[:]).reshape(16, 256)
 t0 = t[0, 0]; span = max(int(r[r > 0].max()) for r in t if (r > 0).any()) - t0
 print(f"{which}: launch {us:.1f} us (event), workgroup 0 spans {span} ticks -> {us / span * 1e3:.3f} ns per tick")
-for wv in (0, 4, 8, 9):
+for wv in (0, 4, 8, 12):
     r = t[wv]; r = r[r > 0]
     print(f"wavefront {wv}: n={len(r)}", " ".join(f"{(x - t0) * us / span:.2f}" for x in r[:90]))

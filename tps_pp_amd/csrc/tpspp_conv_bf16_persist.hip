@@ -38,7 +38,7 @@
 namespace {
 
 constexpr int kPTW = 4;                          // MFMA wavefronts per team (two teams)
-constexpr int kPLoaders = 4;                     // loader wavefronts
+constexpr int kPLoaders = 8;                     // loader wavefronts (4 -> 8: stride 2 73 -> 67 us, 192 -> 64 123 -> 118; 128 VGPRs)
 constexpr int kPThreads = (2 * kPTW + kPLoaders) * kWave;
 constexpr int kPKC = 16, kPKG = 2;               // channels / channel groups per chunk (the arranged weight's chunking)
 constexpr int kPSlab = 9 * kPKG * BN;            // 16-byte units of a chunk's weight slab
