@@ -38,8 +38,10 @@
 namespace {
 
 constexpr int kPTW = 4;                          // MFMA wavefronts per team (two teams)
-constexpr int kPLoaders = 8;                     // loader wavefronts (4 -> 8: stride 2 73 -> 67 us, 192 -> 64 123 -> 118; 128 VGPRs)
-constexpr int kPThreads = (2 * kPTW + kPLoaders) * kWave;
+constexpr int kPD = 2;                           // taps whose fragments are requested ahead of the products
+// loader wavefronts: 8 where the MFMA wavefronts fit 128 registers (one fragment each: the stride-2 layers, which are
+// bound by their fill: 73 -> 67 us), else 4
+template <int NF> struct PLoaders { static constexpr int N = NF == 1 ? 8 : 4; };
 constexpr int kPKC = 16, kPKG = 2;               // channels / channel groups per chunk (the arranged weight's chunking)
 constexpr int kPSlab = 9 * kPKG * BN;            // 16-byte units of a chunk's weight slab
 constexpr int kPSlabDma = kPSlab / kWave;        // 18 LDS-DMA instructions
@@ -62,7 +64,7 @@ __device__ long long g_trace[16 * 256];
 // Patch geometry.  Stride 2 (along x): a patch row is stored as [even columns | odd columns], so that the 32 output
 // pixels of a fragment read 32 consecutive units for every tap (dense rows would put them 32 bytes apart: 2-way bank
 // conflicts on every B fragment); the DMA lanes simply fetch the positions in that order.
-template <int SH, int SW, int TH, int TW, bool WRES>
+template <int SH, int SW, int TH, int TW, bool WRES, int CPB>
 struct PCfg {
     static constexpr int PH = (TH - 1) * SH + 3, PW = (TW - 1) * SW + 3;
     static constexpr int PWH = (PW + 1) / 2;               // columns per parity (stride 2)
@@ -70,12 +72,15 @@ struct PCfg {
     static constexpr int PS = PH * PWL;                    // units per channel group
     static constexpr int NPI = (PS + kWave - 1) / kWave;   // DMA instructions per channel group (the last one's window is
                                                            // shifted back so that it ends at PS: no padding in LDS)
-    static constexpr int PATCH = kPKG * PS;                // units of a chunk's patch
-    static constexpr int BUF = PATCH + (WRES ? 0 : kPSlab);   // a buffer: the patch and, when streamed, the weight slab
+    static constexpr int PATCH = CPB * kPKG * PS;          // units of a slot's patch: CPB chunks of 16 channels
+    // a buffer: resident weight -- one team's patch; streamed weight -- BOTH teams' patches of the same chunk index and
+    // the chunk's slab once (the slab is then fetched per 2 tiles: the 192 -> 64 layer is bound by the bytes through the
+    // LDS-DMA path, 0.75 GB per launch at 6.4 TB/s with a slab per tile)
+    static constexpr int BUF = WRES ? PATCH : 2 * PATCH + CPB * kPSlab;
     // buffers in the ring: what fits beside the flags / bias and a resident weight of up to 64 input channels
     static constexpr int NBFIT = (kPLdsMax / 16 - kFlagUnits - (WRES ? 4 * kPSlab : 0)) / BUF;
     static constexpr int NB = NBFIT > 7 ? 7 : NBFIT;          // (2 NB + 1 flag words)
-    static_assert(NB >= 3, "ring too short");
+    static_assert(NB >= 1, "no room for a ring");
     static_assert(PS >= kWave, "a DMA window is 64 positions");
     static __device__ __forceinline__ constexpr int tap_off(int ky, int kx)
     {
@@ -108,21 +113,21 @@ __device__ __forceinline__ void lds_await(const int* p, int want)
 }
 
 // Two teams of kPTW MFMA wavefronts (one wavefront of each team per SIMD; 32 x NF pixels x 64 channels per wavefront), each
-// team on its own tile; kPLoaders loader wavefronts; NB buffers in one ring.
+// team on its own tile; 4 or 8 loader wavefronts; NB buffers in one ring.
 // Ring order ("slots"): team A's chunks and team B's chunks alternate, B lagging half a tile (D = nchunks / 2 chunks), so
 // that one team's epilogue and flag waits sit under the other team's matrix instructions:
 //     slot q < D: A[q];   slot D + 2 j: A[D + j];   slot D + 2 j + 1: B[j]          (A[k] = team A's k-th chunk)
-// Slot q lives in buffer q % NB and is its (q / NB)-th fill; loader q % kPLoaders fills it.  A slot past its team's last
+// Slot q lives in buffer q % NB and is its (q / NB)-th fill; loader q % (number of loaders) fills it.  A slot past its team's last
 // chunk is empty: its loader counts it as drained and nobody waits for it.
 // EPI: 0 blocked bf16 output; 1 blocked output + blocked residual (res_mode 1 / 2); 2 fp32 NCHW output.
 // flags (ints at the start of LDS):  landed[b] = flags[b]: fills of buffer b that are complete;
 //                                    drained[b] = flags[NB + b]: (MFMA wavefronts x fills) that are done reading it
 //                                    wready = flags[2 NB]: MFMA wavefronts whose part of the resident weight is in LDS
-template <int SH, int SW, int TH, int TW, int NF, bool WRES, int EPI>
-__global__ void __launch_bounds__(kPThreads, 1)
+template <int SH, int SW, int TH, int TW, int NF, bool WRES, int EPI, int CPB>
+__global__ void __launch_bounds__((2 * kPTW + PLoaders<NF>::N) * kWave, 1)
 conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
 {
-    using Cfg = PCfg<SH, SW, TH, TW, WRES>;
+    using Cfg = PCfg<SH, SW, TH, TW, WRES, CPB>;
     constexpr int PW = Cfg::PW, PWL = Cfg::PWL, PS = Cfg::PS, NPI = Cfg::NPI, BUF = Cfg::BUF, NB = Cfg::NB;
     constexpr int CW = 2 * kPTW;
     static_assert(TH * TW == kPTW * 32 * NF, "tile = kPTW wavefronts x NF fragments of 32 pixels");
@@ -137,7 +142,7 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);      // uniform: buffer addresses live in SGPRs
-    const int nchunks = P.nchunks;
+    const int nchunks = P.nchunks / CPB;                  // slots per tile: CPB chunks of 16 channels each
     const int HoWo = P.Ho * P.Wo;
 
     TRACE_INIT();
@@ -161,34 +166,46 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
         const int L = wv - CW;
         const char* const zero = reinterpret_cast<const char*>(&g_zero_unit);
         const int tailA = KA > D ? KA - D : 0;
-        const int Q = D + 2 * (tailA > KB ? tailA : KB);
-        for (int q = L; q < Q; q += kPLoaders) {
+        const int Q = WRES ? D + 2 * (tailA > KB ? tailA : KB) : KA;         // streamed weight: one slot per chunk of a tile PAIR
+        for (int q = L; q < Q; q += PLoaders<NF>::N) {
             const int b = q % NB, use = q / NB;
             int team = 0, k = q;
-            if (q >= D) { const int j = (q - D) >> 1; team = (q - D) & 1; k = team ? j : D + j; }
-            if (k >= (team ? KB : KA)) {
-                // empty slot: counted as drained -- in its turn (an early count would let an EARLIER fill of this buffer
-                // start before the content before it has been read)
-                if (use > 0) lds_await(flags + NB + b, kPTW * use);
-                if (lane == 0) for (int i = 0; i < kPTW; ++i) lds_bump(flags + NB + b);
-                continue;
+            if constexpr (WRES) {
+                if (q >= D) { const int j = (q - D) >> 1; team = (q - D) & 1; k = team ? j : D + j; }
+                if (k >= (team ? KB : KA)) {
+                    // empty slot: counted as drained -- in its turn (an early count would let an EARLIER fill of this
+                    // buffer start before the content before it has been read)
+                    if (use > 0) lds_await(flags + NB + b, kPTW * use);
+                    if (lane == 0) for (int i = 0; i < kPTW; ++i) lds_bump(flags + NB + b);
+                    continue;
+                }
             }
+            const unsigned dst = (unsigned)(size_t)(sB + b * BUF);
+            // streamed weight: a slot is read by both teams, except the slots of an odd count's last pair (one tile)
+            int want = kPTW * use;
+            if constexpr (!WRES) {
+                const int first_single = (my_tiles & 1) ? (my_tiles >> 1) * nchunks : 0x7fffffff;
+                const int singles = q >= first_single ? (q - first_single) / NB : 0;     // earlier fills of this buffer among them
+                want = CW * use - kPTW * singles;
+            }
+            if (use > 0) lds_await(flags + NB + b, want);
+            for (int tm = 0; tm < (WRES ? 1 : 2); ++tm) {
+            if (!WRES) team = tm;
             const int kt = k / nchunks, chunk = k - kt * nchunks;
+            if (2 * kt + team >= my_tiles) continue;
             const int tile = blockIdx.x + (2 * kt + team) * gridDim.x;
             const int n = tile / (ntx * nty), t1 = tile - n * (ntx * nty);
             const int ty = t1 / ntx, tx = t1 - ty * ntx;
             const int iy_base = ty * TH * SH - 1, ix_base = tx * TW * SW - 1;
-            const int c0 = chunk * kPKC;
+            for (int c2 = 0; c2 < CPB; ++c2) {
+            const int c0 = (chunk * CPB + c2) * kPKC;
             int cbase = 0, s = 0;
             while (c0 >= cbase + P.src[s].C) { cbase += P.src[s].C; ++s; }
             const BSrc cur = P.src[s];
             const int plane = cur.H * cur.W;
             const char* sp = reinterpret_cast<const char*>(reinterpret_cast<const u32x4*>(cur.p) +
                                                            ((size_t)n * (cur.C >> 3) + ((c0 - cbase) >> 3)) * plane);
-            const unsigned dst = (unsigned)(size_t)(sB + b * BUF);
-            STAMP();
-            if (use > 0) lds_await(flags + NB + b, kPTW * use);
-            STAMP();
+            const unsigned dstp = dst + (WRES ? 0u : (unsigned)team * (Cfg::PATCH * 16u)) + (unsigned)c2 * (kPKG * PS * 16u);
 #pragma unroll
             for (int i = 0; i < NPI; ++i) {
                 constexpr int kLast = PS - kWave;
@@ -208,13 +225,16 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
 #pragma unroll
                 for (int g = 0; g < kPKG; ++g) {
                     const char* src = ok ? sp + (size_t)g * plane * 16 + off : zero;
-                    dma16(src, dst + (unsigned)(g * PS + start) * 16u);
+                    dma16(src, dstp + (unsigned)(g * PS + start) * 16u);
                 }
             }
+            }   // c2
+            }   // team
             if constexpr (!WRES) {
-                const char* wp = reinterpret_cast<const char*>(P.wt + (size_t)chunk * kPSlab) + lane * 16;
+                const int chunk = q % nchunks;
+                const char* wp = reinterpret_cast<const char*>(P.wt + (size_t)chunk * CPB * kPSlab) + lane * 16;
 #pragma unroll
-                for (int i = 0; i < kPSlabDma; ++i) dma16(wp + i * 1024, dst + (unsigned)(Cfg::PATCH * 16 + i * 1024));
+                for (int i = 0; i < CPB * kPSlabDma; ++i) dma16(wp + i * 1024, dst + (unsigned)(2 * Cfg::PATCH * 16 + i * 1024));
             }
             STAMP();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -228,7 +248,7 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
     if constexpr (WRES) {
         // the resident weight: copied by the MFMA wavefronts while the loaders already fetch the first patches
         constexpr int T = CW * kWave, U = 3;
-        const int total = nchunks * kPSlab;
+        const int total = P.nchunks * kPSlab;
         for (int base = 0; base < total; base += U * T) {
             u32x4 v[U];
 #pragma unroll
@@ -266,18 +286,20 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
                 for (int i = 0; i < 16; ++i) acc[f][h2][i] = 0.0f;
 
         for (int chunk = 0; chunk < nchunks; ++chunk, ++k) {
-            const int q = team ? D + 2 * k + 1 : (k < D ? k : D + 2 * (k - D));
+            // resident weight: the interleaved ring order; streamed weight: slot k holds chunk k of both teams' tiles
+            const int q = !WRES ? k : (team ? D + 2 * k + 1 : (k < D ? k : D + 2 * (k - D)));
             const int b = q % NB;
             STAMP();
             lds_await(flags + b, q / NB + 1);
             if (WRES && k == 0) lds_await(flags + 2 * NB, CW);
             STAMP();
-            const u32x4* const pb = sB + b * BUF;
-            const u32x4* const wb = WRES ? sWr + chunk * kPSlab : pb + Cfg::PATCH;
+            for (int c2 = 0; c2 < CPB; ++c2) {
+            const u32x4* const pb = sB + b * BUF + (WRES ? 0 : team * Cfg::PATCH) + c2 * (kPKG * PS);
+            const u32x4* const wb = WRES ? sWr + (chunk * CPB + c2) * kPSlab : sB + b * BUF + 2 * Cfg::PATCH + c2 * kPSlab;
             // register double buffer over the taps: tap t + 1's fragments are requested before tap t's products are
             // issued; the scheduling barriers keep that order (without them the reads sink below the products, or all of
             // them are hoisted to the top)
-            bf16x8 fa[2][2], fb[2][NF];
+            bf16x8 fa[kPD + 1][2], fb[kPD + 1][NF];
             auto fetch = [&](int tap, int slot) {
                 const int ky = tap / 3, kx = tap - ky * 3;
                 fa[slot][0] = __builtin_bit_cast(bf16x8, wb[(tap * kPKG + half) * BN + l31]);
@@ -285,18 +307,20 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) fb[slot][f] = __builtin_bit_cast(bf16x8, pb[fpos[f] + Cfg::tap_off(ky, kx)]);
             };
-            fetch(0, 0);
+#pragma unroll
+            for (int t0 = 0; t0 < kPD; ++t0) fetch(t0, t0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                if (tap + 1 < 9) fetch(tap + 1, (tap + 1) & 1);
+                if (tap + kPD < 9) fetch(tap + kPD, (tap + kPD) % (kPD + 1));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][0], fb[tap & 1][f], acc[f][0], 0, 0, 0);
-                    acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][1], fb[tap & 1][f], acc[f][1], 0, 0, 0);
+                    acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap % (kPD + 1)][0], fb[tap % (kPD + 1)][f], acc[f][0], 0, 0, 0);
+                    acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap % (kPD + 1)][1], fb[tap % (kPD + 1)][f], acc[f][1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }   // c2
             // this wavefront's LDS reads were issued before the counter update and LDS serves a wavefront in order
             asm volatile("" ::: "memory");
             if (lane == 0) lds_bump(flags + NB + b);
@@ -392,10 +416,10 @@ bool launch_k(K kfn, bool& attr_done, int grid, int threads, size_t lds, hipStre
     return true;
 }
 
-template <int SH, int SW, int TH, int TW, int NF, bool WRES, int EPI>
-bool launch_pe(const BParams& P, hipStream_t st)
+template <int SH, int SW, int TH, int TW, int NF, bool WRES, int EPI, int CPB>
+bool launch_pc(const BParams& P, hipStream_t st)
 {
-    using Cfg = PCfg<SH, SW, TH, TW, WRES>;
+    using Cfg = PCfg<SH, SW, TH, TW, WRES, CPB>;
     const int ntx = P.Wo / TW, nty = P.Ho / TH;
     const long nt = (long)P.N * ntx * nty;
     if (nt > 0x3fffffffL) return false;
@@ -408,10 +432,21 @@ bool launch_pe(const BParams& P, hipStream_t st)
     }
     const long pairs = (nt + 1) / 2;                         // a workgroup works on two tiles at a time
     const int grid = (int)(pairs < ncu ? pairs : ncu);
-    const size_t lds = (size_t)(kFlagUnits + Cfg::NB * Cfg::BUF + (WRES ? P.nchunks * kPSlab : 0)) * 16;
+    const size_t lds = (size_t)(kFlagUnits + Cfg::NB * Cfg::BUF + (WRES ? P.nchunks * kPSlab : 0)) * 16;   // (BUF: see PCfg)
     if (lds > (size_t)kPLdsMax) return false;
     static bool attr = false;
-    return launch_k(conv3_blk_persist_kernel<SH, SW, TH, TW, NF, WRES, EPI>, attr, grid, kPThreads, lds, st, P, ntx, nty, (int)nt);
+    return launch_k(conv3_blk_persist_kernel<SH, SW, TH, TW, NF, WRES, EPI, CPB>, attr, grid, (2 * kPTW + PLoaders<NF>::N) * kWave, lds, st, P, ntx, nty, (int)nt);
+}
+
+// resident weight and an even chunk count: two chunks (32 channels) per ring slot -- half the flag hand-offs, 72 matrix
+// instructions per wait
+template <int SH, int SW, int TH, int TW, int NF, bool WRES, int EPI>
+bool launch_pe(const BParams& P, hipStream_t st)
+{
+    if constexpr (WRES && PCfg<SH, SW, TH, TW, true, 2>::NBFIT >= 3) {
+        if (P.nchunks % 2 == 0) return launch_pc<SH, SW, TH, TW, NF, WRES, EPI, 2>(P, st);
+    }
+    return launch_pc<SH, SW, TH, TW, NF, WRES, EPI, 1>(P, st);
 }
 
 template <int SH, int SW, int TH, int TW, int NF>
