@@ -7,7 +7,7 @@
 //  * a 16-byte unit of a blocked source IS a unit of the channel-innermost LDS patch, so the patch is not staged
 //    through registers at all: LOADER wavefronts issue global_load_lds_dwordx4 (LDS-DMA, 64 patch positions per
 //    instruction; padding positions point at a 16-byte zero unit in global memory) into a ring of NB (4-7) buffers, one
-//    16-channel chunk of one tile per buffer; a loader fills, waits (s_waitcnt vmcnt(0)), announces ("landed") and
+//    slot of 16 or 32 channels of a tile per buffer; a loader fills, waits (s_waitcnt vmcnt(0)), announces ("landed") and
 //    moves on to its next slot, so every buffer that is not being multiplied is in flight, across tile boundaries;
 //  * eight MFMA wavefronts in two TEAMS of four (one wavefront of each team per SIMD, 32 x NF pixels x 64 channels
 //    per wavefront), each team on its own tile, half a tile out of phase: one team's epilogue (conversion, stores)
@@ -18,12 +18,11 @@
 //    stays in LDS for the life of the workgroup, otherwise the chunk's slab travels with the patch;
 //  * stride 2: a patch row is stored [even columns | odd columns] (the DMA lanes fetch in that order), so a
 //    fragment's 32 pixels read 32 consecutive units for every tap.
-// Measured (batch 512, scripts/debug/bench_conv16.py; tiled kernel -> this one): dec2 (upsampled source + skip) 88 ->
-// 49 us, dec3 (fp32 output) 66 -> 51, 64 -> 64 48 -> 42, enc0 (192 -> 64, streamed weight) 131 -> 122, stride 2 78 ->
-// 75.  What is left (scripts/debug/trace_conv.py, -DTPSPP_CONV_TRACE): a wavefront's chunk of 36 MFMAs takes ~1.25 us
-// beside its partner (0.96 at the pipe's rate: flag wait + first fragment read per chunk are exposed), the epilogue
-// ~1.9 us per 256-pixel tile, the first chunk lands 5-6 us after launch (every CU fetching weight + patches at once);
-// the 192 -> 64 layer is bound by the fill path (the 18 KB slab is re-streamed for every 256-pixel tile chunk).
+// Measured (batch 512, scripts/debug/bench_conv16.py; tiled kernel -> this one): dec2 (upsampled source + skip) 86 ->
+// 49 us, dec3 (fp32 output) 64 -> 49, 64 -> 64 47 -> 41, enc0 (192 -> 64, streamed weight) 124 -> 121, stride 2 77 ->
+// 70, dec1 (8x32) 26 -> 18.  DESIGN.md section 4e has what was varied without effect and the phase stamps
+// (scripts/debug/trace_conv.py, -DTPSPP_CONV_TRACE): in the steady state the multiply runs at the matrix pipe's rate at
+// the ~1.7 GHz the chip holds under this load; the first chunk lands 5-6 us after launch.
 //
 // The DMA and the flag traffic are inline asm: an LDS-DMA the compiler can see makes it order every later LDS access
 // of the wavefront behind s_waitcnt vmcnt(0) (tpspp_warp_pair.h has the same note), which is exactly the overlap
