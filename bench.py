@@ -10,13 +10,15 @@ grid_sample HIP kernel on a batch of 512 synthetic 3x32x100 fp32 images, 20 fidu
 points = fiducial lattice + 0.05 * noise.  Inputs are resident in HBM before the timed region; the
 steps rotate over enough distinct input/output buffers (> 256 MB) that the Infinity Cache cannot
 hold the working set.  Weak scaling: every rank rectifies its own 512-image batches, there is no
-data-path collective (images are independent).  The K steps go round-robin to
-`--streams` HIP streams (default 3): consecutive batches are independent, so a serving loop has no reason to
-serialise their launches, and on one stream every launch waits for the previous one to drain (launch gap + ramp =
-a quarter of a 39-MB step).  `value` and `ms_per_step` come from HIP events -- one before the first launch, one per
-stream after its last launch, the latest one counts -- over exactly K steps (max over ranks); the same K steps on ONE
-stream are timed right after and reported as `roofline.one_stream`; the host wall clock around the K steps
-(barrier + synchronize on both sides) is reported as `wall_ms_per_step`.
+data-path collective (images are independent).  Two launch protocols are timed over exactly K steps each: the steps
+round-robin on `--streams` HIP streams (default: 2 for K <= 200, else 3 -- consecutive batches are independent, so a
+serving loop has no reason to serialise their launches, and on one stream every launch waits for the previous one to
+drain: launch gap + ramp = a quarter of a 39-MB step), and all steps on ONE stream.  Each protocol's region is repeated
+(`--repeats`, default 5 for K <= 200: a 20-step region is 0.2 ms and at the mercy of the queues' wake-up after the
+synchronize) with barrier + synchronize before each, the fastest region counts; `value` and `ms_per_step` come from the
+faster protocol (`config.streams` says which), both are in `roofline.multi_stream` / `roofline.one_stream`.  Times are HIP
+events -- every stream records one before its first and one after its last launch, a region is latest end - earliest
+start -- max over ranks; the host wall clock around the region is reported as `wall_ms_per_step`.
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself (torch.distributed.run as a
 child process; the parent never touches a GPU) and passes rank 0's JSON line through.  At N > 1 the line
@@ -460,8 +462,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the steps are launched on, round-robin (1 = every launch waits for the previous one)")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of `steps` steps per launch protocol, the fastest counts (0 = 5 when steps <= 200, else 1)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the steps are launched on, round-robin (1 = every launch waits for the previous one; "
+                         "0 = 2 when steps <= 200, else 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--precondition-ms", type=float, default=300.0,
@@ -515,7 +520,10 @@ def main():
     # one validated, pre-marshalled tpspp_warp_fwd call per (buffer set, stream) (ops.WarpPlan: the launch goes to the
     # stream that is current when the plan is built): a step is exactly one foreign call = one kernel launch; per-call
     # tensor checks in Python would cost about a launch period
-    S = max(1, min(int(a.streams), 8))
+    # 0 = auto: short regions (the driver's 20 steps) pay for every extra queue's wake-up after the synchronize -- two streams
+    # measured best there (8.5-8.9 us against 8.9-9.0 with three and 9.6-9.9 with one); long runs gain a little from a third
+    S = int(a.streams) if int(a.streams) > 0 else (2 if a.steps <= 200 else 3)
+    S = max(1, min(S, 8))
     main_stream = torch.cuda.current_stream(dev)
     streams = [main_stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
     plans = []
@@ -546,37 +554,48 @@ def main():
             torch.cuda.synchronize(dev)
 
     def timed(nsteps, nstreams, first):
-        """Exactly `nsteps` steps, step i on stream i % nstreams; ms between an event recorded before the first launch
-        (every stream waits for it) and the latest of the per-stream events recorded after the last launches."""
-        e0 = torch.cuda.Event(enable_timing=True)
+        """Exactly `nsteps` steps, step i on stream i % nstreams.  Every stream records an event before its first and after
+        its last launch; the region's time is latest end - earliest start (the maximum over all (start, end) pairs)."""
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
         t0 = time.perf_counter()
-        e0.record(streams[0])
-        for st in streams[1:nstreams]:
-            st.wait_event(e0)
+        for k in range(nstreams):
+            e0[k].record(streams[k])
         for i in range(nsteps):
             step(first + i, nstreams)
         for k in range(nstreams):
             e1[k].record(streams[k])
         torch.cuda.synchronize(dev)
-        return max(e0.elapsed_time(e) for e in e1), time.perf_counter() - t0
+        return max(b.elapsed_time(e) for e in e1 for b in e0), time.perf_counter() - t0
+
+    def best_of(nstreams, first):
+        """`repeats` timed regions of exactly `steps` steps each (barrier + synchronize before each); the fastest counts.
+        A 20-step region is 0.2 ms: one region alone is at the mercy of the queues' wake-up after the synchronize."""
+        res = []
+        for r in range(R):
+            barrier()
+            res.append(timed(a.steps, nstreams, first + r * a.steps))
+        return min(res)
 
     for i in range(a.warmup):
         step(i)
-    barrier()
-    ev_ms, dt = timed(a.steps, S, a.warmup)
-    if world > 1:
-        dist.barrier()
+    R = a.repeats if a.repeats > 0 else (5 if a.steps <= 200 else 1)
+    ev_ms, dt = best_of(S, a.warmup)
     # the same steps with every launch behind the previous one (one stream): what a kernel trace shows as the
-    # kernel's own duration; not part of `value`
-    barrier()
-    ev1_ms, _ = timed(a.steps, 1, a.warmup) if S > 1 else (ev_ms, dt)
+    # kernel's own duration
+    ev1_ms, dt1 = best_of(1, a.warmup) if S > 1 else (ev_ms, dt)
     if world > 1:
-        tt = torch.tensor([dt, ev_ms, ev1_ms, -ev_ms], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt, ev_ms, ev1_ms, -ev_ms, dt1, -ev1_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ev_ms, ev1_ms, ev_ms_min = float(tt[0]), float(tt[1]), float(tt[2]), -float(tt[3])
+        dt, ev_ms, ev1_ms, ev_ms_min, dt1, ev1_ms_min = float(tt[0]), float(tt[1]), float(tt[2]), -float(tt[3]), float(tt[4]), -float(tt[5])
     else:
-        ev_ms_min = ev_ms
+        ev_ms_min, ev1_ms_min = ev_ms, ev1_ms
+    # `value` is the better of the two launch protocols for THIS step count (both are reported): with few steps per region
+    # the extra queues' wake-up can cost more than the overlap of consecutive launches gains
+    ms_multi, ms_one = ev_ms, ev1_ms
+    used_streams = S if ms_multi <= ms_one else 1
+    if used_streams == 1:
+        ev_ms, dt, ev_ms_min = ev1_ms, dt1, ev1_ms_min
 
     # ---- parity spot-check of what was just measured (not timed) ----
     max_err = None
@@ -617,9 +636,11 @@ def main():
     rec = None
     if rank == 0:
         launch_us = ev_ms * 1e3 / a.steps
-        launch1_us = ev1_ms * 1e3 / a.steps
+        launch1_us = ms_one * 1e3 / a.steps
+        launchm_us = ms_multi * 1e3 / a.steps
         achieved = BYTES_PER_IMG * BATCH / (launch_us * 1e-6) / 1e9
         achieved1 = BYTES_PER_IMG * BATCH / (launch1_us * 1e-6) / 1e9
+        achievedm = BYTES_PER_IMG * BATCH / (launchm_us * 1e-6) / 1e9
         traffic, traffic_kernel = load_traffic()
         kernel = "tps_warp_pair_kernel<20,3,32,100,32,100,false,false>" if pair_kernel else \
             "tps_warp_lds_mirror_kernel<20,3,32,100,false>"
@@ -642,12 +663,15 @@ def main():
                                    "20 fiducials, inputs resident in HBM",
                        "batch_per_gpu": BATCH, "rotating_buffer_sets": int(nbuf),
                        "working_set_MB": round(nbuf * per_set / 1e6, 1),
-                       "streams": S,
-                       "timing": f"step i is launched on HIP stream i % {S} (consecutive batches are independent); HIP "
-                                 "events: one before the first launch (all streams wait for it), one per stream after "
-                                 "its last launch, the latest counts; exactly `steps` launches, max over ranks (`value`, "
-                                 "`ms_per_step`); `wall_ms_per_step` = host clock around the same launches incl. the "
-                                 "final synchronize; `roofline.one_stream` = the same steps on one stream",
+                       "streams": used_streams, "streams_tried": sorted({1, S}), "repeats": R,
+                       "timing": f"two launch protocols are timed, each over `repeats` regions of exactly `steps` launches "
+                                 f"(barrier + synchronize before each region, the fastest region counts): step i on HIP "
+                                 f"stream i % {S} (consecutive batches are independent), and all steps on one stream; "
+                                 "`value` / `ms_per_step` come from the faster protocol (`streams`), both are in "
+                                 "`roofline.multi_stream` / `roofline.one_stream`.  HIP events: every stream records one "
+                                 "before its first and one after its last launch, the region is latest end - earliest "
+                                 "start; max over ranks; `wall_ms_per_step` = host clock around the same region incl. "
+                                 "the final synchronize",
                        "ms_per_step_min_over_ranks": ev_ms_min / a.steps,
                        "preconditioning": f"{a.precondition_ms:.0f} ms of plain device copies over the bench buffers "
                                           "before the warm-up steps (clock ramp; not steps)"},
@@ -658,10 +682,12 @@ def main():
                                            f"{traffic_kernel}; not re-measured in this run)" if traffic else None,
                          "kernel": kernel,
                          "launch_us": launch_us,
-                         "launch_us_is": f"time of `steps` launches on {S} streams / steps: launches overlap, so this is the "
-                                         "period between launches, not one kernel's start-to-end duration (a kernel trace "
-                                         "shows the latter: compare it with one_stream.launch_us, and launch_us with "
-                                         "(last end - first start) / launches of the trace)",
+                         "launch_us_is": f"time of `steps` launches on {used_streams} stream(s) / steps; with several streams "
+                                         "launches overlap, so this is the period between launches, not one kernel's "
+                                         "start-to-end duration (a kernel trace shows the latter: compare it with "
+                                         "one_stream.launch_us, and launch_us with (last end - first start) / launches)",
+                         "multi_stream": {"streams": S, "launch_us": launchm_us, "achieved": achievedm,
+                                          "frac": achievedm / HBM_PEAK_GBS},
                          "one_stream": {"launch_us": launch1_us, "achieved": achieved1, "frac": achieved1 / HBM_PEAK_GBS,
                                         "note": "every launch waits for the previous one to drain: kernel duration + launch gap"},
                          "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH,
