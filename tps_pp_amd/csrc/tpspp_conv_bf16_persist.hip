@@ -404,12 +404,14 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
 }
 
 template <typename K>
-bool launch_k(K kfn, bool& attr_done, int grid, int threads, size_t lds, hipStream_t st, const BParams& P, int ntx, int nty, int nt)
+bool launch_k(K kfn, bool (&attr_done)[tpspp::kMaxDevices], int grid, int threads, size_t lds, hipStream_t st, const BParams& P,
+              int ntx, int nty, int nt)
 {
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax) != hipSuccess)
+    if (tpspp::first_use_on_device(attr_done)) {             // per device: the opt-in is a property of the loaded code object
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kPLdsMax) != hipSuccess) {
+            (void)hipGetLastError();
             return false;
-        attr_done = true;
+        }
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(threads), lds, st, P, ntx, nty, nt);
     return true;
@@ -422,18 +424,17 @@ bool launch_pc(const BParams& P, hipStream_t st)
     const int ntx = P.Wo / TW, nty = P.Ho / TH;
     const long nt = (long)P.N * ntx * nty;
     if (nt > 0x3fffffffL) return false;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+        (void)hipGetLastError();
+        return false;
     }
     const long pairs = (nt + 1) / 2;                         // a workgroup works on two tiles at a time
     const int grid = (int)(pairs < ncu ? pairs : ncu);
     const size_t lds = (size_t)(kFlagUnits + Cfg::NB * Cfg::BUF + (WRES ? P.nchunks * kPSlab : 0)) * 16;   // (BUF: see PCfg)
     if (lds > (size_t)kPLdsMax) return false;
-    static bool attr = false;
+    static bool attr[tpspp::kMaxDevices] = {};
     return launch_k(conv3_blk_persist_kernel<SH, SW, TH, TW, NF, WRES, EPI, CPB>, attr, grid, (2 * kPTW + PLoaders<NF>::N) * kWave, lds, st, P, ntx, nty, (int)nt);
 }
 
