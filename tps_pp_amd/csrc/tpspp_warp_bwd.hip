@@ -217,12 +217,13 @@ warp_bwd_sample_lds_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* 
 //     no memset of g_grid;
 //   * two channel planes per pass share the tap addresses and weights (40 loads per thread in flight).
 // grid = (G groups of input 0 then G groups of input 1, images); workspace (N, 2 G, n, 2).
-template <int PPT>
-__global__ void __launch_bounds__(256, 2)
+// NT threads: 256 (two workgroups per CU; up to 1024 output pixels) or 1024 (the classic 32x100 geometry: 3200 pixels)
+template <int PPT, int NT>
+__global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* __restrict__ g_grid_part)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // [cpt][H*W] fixed point
-    __shared__ float sMax[2][4];
+    __shared__ float sMax[2][NT / 64];
     const int b = blockIdx.y;
     const int i = (int)blockIdx.x >= G ? 1 : 0;
     const int grp = (int)blockIdx.x - (i ? G : 0);
@@ -237,7 +238,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
     int o00[PPT]; float fw[PPT], fn[PPT], mx[PPT], my[PPT]; bool inx[PPT], iny[PPT], livep[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const int p = tid + k * 256;
+        const int p = tid + k * NT;
         livep[k] = p < P.n;
         const float2 g = reinterpret_cast<const float2*>(P.grid)[(size_t)b * P.n + (livep[k] ? p : 0)];
         float ix = ((g.x + 1.0f) * 0.5f) * (float)(W - 1);
@@ -257,7 +258,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
 
     const int n2 = plane;                                  // the two planes of a pass as 16-byte pieces (two fixed-point words each)
     ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
-    if (want) for (int e = tid; e < n2; e += 256) acc2[e] = make_ulonglong2(0ull, 0ull);
+    if (want) for (int e = tid; e < n2; e += NT) acc2[e] = make_ulonglong2(0ull, 0ull);
     __syncthreads();
     constexpr double kMagic = 6755399441055744.0;          // 1.5 * 2^52: x + kMagic has round(x) in its low mantissa bits
     for (int ch = grp; ch < chunks; ch += G) {
@@ -273,7 +274,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
             float gv[PPT][2], v[PPT][2][4];
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {                // every load of the pass in flight together
-                const int p = livep[k] ? tid + k * 256 : 0;
+                const int p = livep[k] ? tid + k * NT : 0;
                 const int a01 = inx[k] ? o00[k] + 1 : o00[k], a10 = iny[k] ? o00[k] + W : o00[k];
                 const int a11 = (inx[k] && iny[k]) ? o00[k] + W + 1 : o00[k];
                 gv[k][0] = go[(size_t)c2 * P.n + p];
@@ -305,7 +306,9 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
                 float mm = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    m[q] = fmaxf(fmaxf(sMax[q][0], sMax[q][1]), fmaxf(sMax[q][2], sMax[q][3]));
+                    m[q] = sMax[q][0];
+#pragma unroll
+                    for (int w_ = 1; w_ < NT / 64; ++w_) m[q] = fmaxf(m[q], sMax[q][w_]);
                     fin[q] = m[q] < 3.0e38f;
                     if (fin[q]) mm = fmaxf(mm, m[q]);
                 }
@@ -348,7 +351,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
                 const int m4 = ((two ? 2 : 1) * plane) >> 2;
                 float4* gi4 = reinterpret_cast<float4*>(gi + (size_t)c2 * plane);
                 const float nanv = __builtin_nanf("");
-                for (int e = tid; e < m4; e += 256) {
+                for (int e = tid; e < m4; e += NT) {
                     const ulonglong2 r0 = acc2[2 * e], r1 = acc2[2 * e + 1];
                     acc2[2 * e] = make_ulonglong2(0ull, 0ull);
                     acc2[2 * e + 1] = make_ulonglong2(0ull, 0ull);
@@ -365,7 +368,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
     float2* part = reinterpret_cast<float2*>(g_grid_part) + ((size_t)b * (2 * G) + blockIdx.x) * P.n;
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
-        if (livep[k]) part[tid + k * 256] = make_float2(gx[k] * mx[k], gy[k] * my[k]);
+        if (livep[k]) part[tid + k * NT] = make_float2(gx[k] * mx[k], gy[k] * my[k]);
 }
 
 // ---- kernel B: parameter gradients from g_grid, one workgroup per image -----------------------------------
@@ -483,16 +486,17 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     const size_t plane0 = (size_t)H0 * W0 * sizeof(float), plane1 = in1 ? (size_t)H1 * W1 * sizeof(float) : 0;
     int slots = 0;
     float* part = g_grid_ws + (size_t)N * P.n * 2;          // behind dL/d grid: the sampling workgroups' slices
-    // kernel A'': two fixed-point planes (8 bytes per element) of a pass in <= 64 KB of LDS, <= 1024 output pixels,
-    // planes of whole 16-byte pieces
+    // kernel A'': two fixed-point planes (8 bytes per element) of a pass in <= 64 KB of LDS, <= 4096 output pixels
+    // (1024-thread workgroups above 1024: the classic 32x100 geometry), planes of whole 16-byte pieces
     const size_t kLds2 = 16 * 1024;
-    if (P.n <= 1024 && plane0 <= kLds2 && plane1 <= kLds2 && plane0 % 16 == 0 && plane1 % 16 == 0 &&
+    if (P.n <= 4096 && plane0 <= kLds2 && plane1 <= kLds2 && plane0 % 16 == 0 && plane1 % 16 == 0 &&
         (!g_in0 || reinterpret_cast<uintptr_t>(g_in0) % 16 == 0) && (!g_in1 || reinterpret_cast<uintptr_t>(g_in1) % 16 == 0)) {
         // channels per chunk: a chunk is worked off two planes at a time, so the LDS only ever holds two
         const int cpt0 = 8, cpt1 = 8;
         const int chunks0 = (C0 + cpt0 - 1) / cpt0, chunks1 = in1 ? (C1 + cpt1 - 1) / cpt1 : 0;
         const int most = chunks0 > chunks1 ? chunks0 : chunks1;
-        int G = (4096 + N * P.nin - 1) / (N * P.nin);      // ~16 workgroups of 256 threads per CU over the launch
+        const bool big = P.n > 1024;                        // 1024-thread workgroups, 4 pixels per thread
+        int G = ((big ? 1024 : 4096) + N * P.nin - 1) / (N * P.nin);      // ~16 (4) workgroups of 256 (1024) threads per CU
         G = G < 1 ? 1 : (G > most ? most : G);
         G = G > kBwdMaxG ? kBwdMaxG : G;
         slots = 2 * G;
@@ -500,9 +504,10 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
         if (P.nin == 1 && hipMemsetAsync(part, 0, (size_t)N * slots * P.n * 2 * sizeof(float), st) != hipSuccess)
             return tpspp::check_launch("tpspp_warp_bwd(memset)");     // the second input's slices stay empty
         const dim3 g2((unsigned)(G * P.nin), (unsigned)N);
-        if (P.n <= 256)      hipLaunchKernelGGL(warp_bwd_sample_lds2_kernel<1>, g2, block, accb, st, P, G, cpt0, cpt1, part);
-        else if (P.n <= 512) hipLaunchKernelGGL(warp_bwd_sample_lds2_kernel<2>, g2, block, accb, st, P, G, cpt0, cpt1, part);
-        else                 hipLaunchKernelGGL(warp_bwd_sample_lds2_kernel<4>, g2, block, accb, st, P, G, cpt0, cpt1, part);
+        if (P.n <= 256)       hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<1, 256>), g2, block, accb, st, P, G, cpt0, cpt1, part);
+        else if (P.n <= 512)  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<2, 256>), g2, block, accb, st, P, G, cpt0, cpt1, part);
+        else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256>), g2, block, accb, st, P, G, cpt0, cpt1, part);
+        else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part);
     } else {
     if (hipMemsetAsync(g_grid_ws, 0, (size_t)N * P.n * 2 * sizeof(float), st) != hipSuccess)
         return tpspp::check_launch("tpspp_warp_bwd(memset)");
