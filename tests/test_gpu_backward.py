@@ -216,3 +216,27 @@ def test_fixed_point_input_gradients_are_exact_and_reproducible(cuda):
     r = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
     assert torch.isnan(r[0][2, 3]).all() and torch.isfinite(r[0][2, :3]).all() and torch.isfinite(r[0][[0, 1, 3, 4, 5]]).all()
     assert torch.isfinite(r[1]).all()
+
+
+def test_fixed_point_input_gradients_classic_geometry(cuda):
+    """The classic 32x100 geometry takes the same fixed-point kernel with 1024-thread workgroups (3200 output pixels, four per
+    thread): bitwise reproducible, and against float64 autograd of the sampler on the same grid within the fp32 tap weights'
+    accuracy; odd channel count (the second pass has one plane), a batch that is not a multiple of anything."""
+    import torch.nn.functional as Fn
+    n, hw = 5, (32, 100)
+    g = torch.Generator(device=cuda).manual_seed(11)
+    c = O.classic_constants(20, hw)
+    inv, ph = dev(c["inv_delta_C"], cuda), dev(c["P_hat"], cuda)
+    img = torch.rand((n, 3, 32, 100), generator=g, device=cuda)
+    ctrl = dev(c["C"].astype("float32"), cuda)[None].repeat(n, 1, 1) + 0.2 * (torch.rand((n, 20, 2), generator=g, device=cuda) - 0.5)
+    _, _, grid, _ = ops.warp(img, ctrl, inv, ph, hw, want_grid=True)
+    g0 = torch.rand((n, 3, 32, 100), generator=g, device=cuda) - 0.5
+    a = ops.warp_backward(g0, img, grid, ctrl, inv, ph, hw)
+    b = ops.warp_backward(g0, img, grid, ctrl, inv, ph, hw)
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    with torch.enable_grad():
+        fd = img.cpu().double().requires_grad_(True)
+        (Fn.grid_sample(fd, grid.cpu().double().reshape(n, 32, 100, 2), padding_mode="border", align_corners=True) *
+         g0.cpu().double()).sum().backward()
+    err = (a[0].cpu().double() - fd.grad).abs().max()
+    assert err <= 2e-5 * fd.grad.abs().max(), float(err)
