@@ -151,8 +151,13 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
     __syncthreads();                                        // the only barrier of the kernel: counters are zero
     STAMP();
 
-    // this workgroup's tiles: blockIdx.x + s * gridDim.x, s = 0 .. my_tiles - 1; team A takes the even s, team B the odd
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // this workgroup's tiles: a CONTIGUOUS run tile0 + s, s = 0 .. my_tiles - 1 (team A takes the even s, team B the odd):
+    // consecutive tiles are vertically adjacent pieces of one image, so the halo rows two tiles share are requested by the
+    // same CU at about the same time (one of the two requests hits in L1 / this XCD's L2 instead of going to HBM from two
+    // XCDs: with tiles strided by the grid, the 8 row tiles of an image sat on 8 different XCDs)
+    const int per_wg = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = (int)blockIdx.x * per_wg;
+    const int my_tiles = tile0 >= ntiles ? 0 : (ntiles - tile0 < per_wg ? ntiles - tile0 : per_wg);
     const int KA = ((my_tiles + 1) >> 1) * nchunks, KB = (my_tiles >> 1) * nchunks;   // chunks per team
     const int D = nchunks >> 1;
 
@@ -192,7 +197,7 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
             if (!WRES) team = tm;
             const int kt = k / nchunks, chunk = k - kt * nchunks;
             if (2 * kt + team >= my_tiles) continue;
-            const int tile = blockIdx.x + (2 * kt + team) * gridDim.x;
+            const int tile = tile0 + 2 * kt + team;
             const int n = tile / (ntx * nty), t1 = tile - n * (ntx * nty);
             const int ty = t1 / ntx, tx = t1 - ty * ntx;
             const int iy_base = ty * TH * SH - 1, ix_base = tx * TW * SW - 1;
@@ -272,7 +277,7 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
 
     int k = 0;                                               // this team's chunk counter
     for (int tseq = team; tseq < my_tiles; tseq += 2) {
-        const int tile = blockIdx.x + tseq * gridDim.x;
+        const int tile = tile0 + tseq;
         const int n = tile / (ntx * nty), t1 = tile - n * (ntx * nty);
         const int ty = t1 / ntx, tx = t1 - ty * ntx;
         const int oy0 = ty * TH, ox0 = tx * TW;
