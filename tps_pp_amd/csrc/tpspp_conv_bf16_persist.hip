@@ -36,11 +36,15 @@
 
 namespace {
 
-constexpr int kPTW = 4;                          // MFMA wavefronts per team (two teams)
 constexpr int kPD = 2;                           // taps whose fragments are requested ahead of the products
 // loader wavefronts: 8 where the MFMA wavefronts fit 128 registers (one fragment each: the stride-2 layers, which are
 // bound by their fill: 73 -> 67 us), else 4
-template <int NF> struct PLoaders { static constexpr int N = NF == 1 ? 8 : 4; };
+// MFMA wavefronts per team (two teams): the tile's fragments / NF
+template <int TH, int TW, int NF> struct PTeam {
+    static constexpr int W = TH * TW / (32 * NF);
+    static_assert(W == 4, "a workgroup is at most 16 wavefronts: two teams of four and up to eight loaders");
+};
+template <int NF, int PTW> struct PLoaders { static constexpr int N = (NF == 1 && PTW == 4) ? 8 : 4; };
 constexpr int kPKC = 16, kPKG = 2;               // channels / channel groups per chunk (the arranged weight's chunking)
 constexpr int kPSlab = 9 * kPKG * BN;            // 16-byte units of a chunk's weight slab
 constexpr int kPSlabDma = kPSlab / kWave;        // 18 LDS-DMA instructions
@@ -123,11 +127,12 @@ __device__ __forceinline__ void lds_await(const int* p, int want)
 //                                    drained[b] = flags[NB + b]: (MFMA wavefronts x fills) that are done reading it
 //                                    wready = flags[2 NB]: MFMA wavefronts whose part of the resident weight is in LDS
 template <int SH, int SW, int TH, int TW, int NF, bool WRES, int EPI, int CPB>
-__global__ void __launch_bounds__((2 * kPTW + PLoaders<NF>::N) * kWave, 1)
+__global__ void __launch_bounds__((2 * PTeam<TH, TW, NF>::W + PLoaders<NF, PTeam<TH, TW, NF>::W>::N) * kWave, 1)
 conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
 {
     using Cfg = PCfg<SH, SW, TH, TW, WRES, CPB>;
     constexpr int PW = Cfg::PW, PWL = Cfg::PWL, PS = Cfg::PS, NPI = Cfg::NPI, BUF = Cfg::BUF, NB = Cfg::NB;
+    constexpr int kPTW = PTeam<TH, TW, NF>::W;
     constexpr int CW = 2 * kPTW;
     static_assert(TH * TW == kPTW * 32 * NF, "tile = kPTW wavefronts x NF fragments of 32 pixels");
     static_assert(TW % 32 == 0, "a fragment is 32 pixels of one row");
@@ -171,7 +176,7 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
         const char* const zero = reinterpret_cast<const char*>(&g_zero_unit);
         const int tailA = KA > D ? KA - D : 0;
         const int Q = WRES ? D + 2 * (tailA > KB ? tailA : KB) : KA;         // streamed weight: one slot per chunk of a tile PAIR
-        for (int q = L; q < Q; q += PLoaders<NF>::N) {
+        for (int q = L; q < Q; q += PLoaders<NF, kPTW>::N) {
             const int b = q % NB, use = q / NB;
             int team = 0, k = q;
             if constexpr (WRES) {
@@ -440,7 +445,8 @@ bool launch_pc(const BParams& P, hipStream_t st)
     const size_t lds = (size_t)(kFlagUnits + Cfg::NB * Cfg::BUF + (WRES ? P.nchunks * kPSlab : 0)) * 16;   // (BUF: see PCfg)
     if (lds > (size_t)kPLdsMax) return false;
     static bool attr[tpspp::kMaxDevices] = {};
-    return launch_k(conv3_blk_persist_kernel<SH, SW, TH, TW, NF, WRES, EPI, CPB>, attr, grid, (2 * kPTW + PLoaders<NF>::N) * kWave, lds, st, P, ntx, nty, (int)nt);
+    return launch_k(conv3_blk_persist_kernel<SH, SW, TH, TW, NF, WRES, EPI, CPB>, attr, grid,
+                    (2 * PTeam<TH, TW, NF>::W + PLoaders<NF, PTeam<TH, TW, NF>::W>::N) * kWave, lds, st, P, ntx, nty, (int)nt);
 }
 
 // resident weight and an even chunk count: two chunks (32 channels) per ring slot -- half the flag hand-offs, 72 matrix
