@@ -356,6 +356,30 @@ __device__ __forceinline__ float gelu_as(float z)
     return 0.5f * z * (1.0f + erf_u);
 }
 
+// two values at a time on the packed fp32 instructions (v_pk_mul / v_pk_fma / v_pk_add: the same IEEE operations in the
+// same order, so the same bits); at this kernel's two wavefronts per SIMD the packed forms issue a third faster
+// (scripts/ubench/valu_bench.hip)
+__device__ __forceinline__ f32x2 gelu_as2(f32x2 z)
+{
+    const f32x2 c_rs2 = {0.70710678118654752440f, 0.70710678118654752440f};
+    const f32x2 u = z * c_rs2;
+    f32x2 ax; ax[0] = fabsf(u[0]); ax[1] = fabsf(u[1]);
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, ax, one);
+    f32x2 t; t[0] = __builtin_amdgcn_rcpf(d[0]); t[1] = __builtin_amdgcn_rcpf(d[1]);
+    f32x2 p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    p = p * t;
+    const f32x2 sq = -(ax * ax) * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
+    f32x2 e; e[0] = __builtin_amdgcn_exp2f(sq[0]); e[1] = __builtin_amdgcn_exp2f(sq[1]);
+    const f32x2 erf_abs = __builtin_elementwise_fma(-p, e, one);
+    f32x2 erf_u; erf_u[0] = __builtin_copysignf(erf_abs[0], u[0]); erf_u[1] = __builtin_copysignf(erf_abs[1], u[1]);
+    const f32x2 halfv = {0.5f, 0.5f};
+    return halfv * z * (one + erf_u);
+}
+
 // acc[t] += slab^T in over 4 k-steps (64 k), both 32-row tiles of the 64 outputs
 __device__ __forceinline__ void gemm64b(const u32x4* __restrict__ slab, const u32x4 (&in)[4], int half, int l31,
                                         f32x16 (&acc)[2])
@@ -541,9 +565,12 @@ dgab_chain_bf16_kernel(const ChainBParams P)
             else gemm64b(tW1 + hb * SL, xb, half, l31, hh);
             float hid[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                const int f = 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3) + 4 * half;
-                hid[i] = gelu_as(hh[i >> 4][i & 15] + tB[64 + hb * 64 + f]);
+            for (int i = 0; i < 32; i += 2) {
+                const int f = 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3) + 4 * half;      // f and f + 1: one 8-byte bias read
+                const f32x2 bb2 = *reinterpret_cast<const f32x2*>(tB + 64 + hb * 64 + f);
+                f32x2 zz; zz[0] = hh[i >> 4][i & 15]; zz[1] = hh[i >> 4][(i & 15) + 1];
+                const f32x2 g2v = gelu_as2(zz + bb2);
+                hid[i] = g2v[0]; hid[i + 1] = g2v[1];
             }
             u32x4 hb4[4], hb4l[4];
             if constexpr (X3) {
