@@ -120,6 +120,35 @@ def test_conv_bf16_argument_errors(cuda):
         ops.conv2d_bf16([torch.zeros((1, 32, 8, 8), device=cuda)], cw, stride=(1, 2))   # no such kernel
 
 
+BLK_CASES = [c for c in CASES if all(s_[0] % 8 == 0 for s_ in c[1]) and c[2] % 8 == 0]
+
+
+@pytest.mark.parametrize("name,srcs,cout,k,stride,relu,res_mode,res_dt,N", BLK_CASES, ids=[c[0] for c in BLK_CASES])
+def test_conv_bf16x3_fp32_blocked_layout_is_the_same_arithmetic(cuda, name, srcs, cout, k, stride, relu, res_mode, res_dt, N):
+    """Layout code 3 (ops.Blocked32: (N, C/8, H, W, 8) float32) with the three-term split: the same bits as the fp32 NCHW
+    call for blocked sources / residual / output and for a mix of blocked and NCHW sources."""
+    xs = [(t(synth.dyadic((N, c, h, w), f"{name}.x{i}", 1)).to(cuda), uh, uw) for i, (c, h, w, uh, uw, _) in enumerate(srcs)]
+    cin = sum(s_[0] for s_ in srcs)
+    w = t(synth.dyadic((cout, cin, k, k), name + ".w", 1, 1.0 / np.sqrt(cin * k * k)))
+    b = t(synth.dyadic((cout,), name + ".b", 1, 0.1))
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda), x3=True)
+    f32 = torch.float32
+    plain = ops.conv2d_bf16(xs, cw, stride, relu=relu, out_dtype=f32)
+    res = t(synth.dyadic(tuple(plain.shape), name + ".r", 1)).to(cuda) if res_mode else None
+    want = ops.conv2d_bf16(xs, cw, stride, relu=relu, residual=res, res_mode=res_mode, out_dtype=f32)
+    bsrc = [(ops.Blocked32.from_nchw(x), uh, uw) for x, uh, uw in xs]
+    bres = ops.Blocked32.from_nchw(res) if res is not None else None
+    got = ops.conv2d_bf16(bsrc, cw, stride, relu=relu, residual=bres, res_mode=res_mode, out_dtype=f32, out_blocked=True)
+    assert isinstance(got, ops.Blocked32) and got.shape == tuple(want.shape)
+    assert torch.equal(got.nchw().view(torch.int32), want.view(torch.int32)), "blocked in / blocked out"
+    got2 = ops.conv2d_bf16([bsrc[0]] + xs[1:], cw, stride, relu=relu, residual=res, res_mode=res_mode, out_dtype=f32)
+    assert torch.equal(got2.view(torch.int32), want.view(torch.int32)), "mixed sources, NCHW residual and output"
+    with pytest.raises(ValueError):                        # bf16 blocked maps do not go with x3 weights, nor Blocked32 without
+        ops.conv2d_bf16([(ops.Blocked.from_nchw(xs[0][0]), xs[0][1], xs[0][2])] + xs[1:], cw, stride)
+    with pytest.raises(ValueError):
+        ops.conv2d_bf16(bsrc, ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda)), stride)
+
+
 PERSIST_CASES = [
     # name, sources [(C,H,W,uh,uw)], stride, res_mode, fp32 output, N   (tiles: 2 per 16x64 image, 8 per stride-2 image;
     # a workgroup takes two tiles per trip, 256 workgroups)
@@ -272,7 +301,6 @@ def test_front_bf16_persistent_trips_match_single_image_runs(cuda):
                 assert torch.equal(a[n:n + 1], b)
 
 
-BLK_CASES = [c for c in CASES if all(s_[0] % 8 == 0 for s_ in c[1]) and c[2] % 8 == 0]
 
 
 @pytest.mark.parametrize("name,srcs,cout,k,stride,relu,res_mode,res_dt,N", BLK_CASES, ids=[c[0] for c in BLK_CASES])

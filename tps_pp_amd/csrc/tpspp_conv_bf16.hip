@@ -64,8 +64,9 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
         P.src[i].p = src_ptrs[i];
         P.src[i].C = d[0]; P.src[i].H = d[1]; P.src[i].W = d[2];
         P.src[i].lh = d[3] >> 1; P.src[i].lw = d[4] >> 1;      // 1,2,4 -> 0,1,2
-        TPSPP_REQUIRE(d[5] >= 0 && d[5] <= 2 && (d[5] != 2 || (d[0] % 8 == 0 && !split3)),
-                      "tpspp_conv2d_bf16_fwd: source %d: layout code must be 0 / 1 / 2 (blocked: channels a multiple of 8, not with split3)", i);
+        TPSPP_REQUIRE(d[5] >= 0 && d[5] <= 3 && (d[5] != 2 || (d[0] % 8 == 0 && !split3)) && (d[5] != 3 || (d[0] % 8 == 0 && split3)),
+                      "tpspp_conv2d_bf16_fwd: source %d: layout code must be 0 / 1 / 2 / 3 (blocked: channels a multiple of 8; 2 bf16 "
+                      "not with split3, 3 fp32 only with split3)", i);
         P.src[i].f32 = d[5];
         const int lh = d[1] * d[3], lw = d[2] * d[4];
         TPSPP_REQUIRE(Hi < 0 || (Hi == lh && Wi == lw), "tpspp_conv2d_bf16_fwd: sources disagree on the logical size");
@@ -78,9 +79,11 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     TPSPP_REQUIRE(Ho == (Hi + 2 * P.ph - KH) / sh + 1 && Wo == (Wi + 2 * P.pw - KW) / sw + 1,
                   "tpspp_conv2d_bf16_fwd: output size does not match input size / stride ('same' padding)");
     P.wt = reinterpret_cast<const u32x4*>(weight_arranged);
-    TPSPP_REQUIRE(residual_f32 >= 0 && residual_f32 <= 2 && out_f32 >= 0 && out_f32 <= 2 &&
-                      ((residual_f32 != 2 && out_f32 != 2) || (Cout % 8 == 0 && !split3)),
-                  "tpspp_conv2d_bf16_fwd: residual / output layout code must be 0 / 1 / 2 (blocked: Cout a multiple of 8, not with split3)");
+    TPSPP_REQUIRE(residual_f32 >= 0 && residual_f32 <= 3 && out_f32 >= 0 && out_f32 <= 3 &&
+                      ((residual_f32 != 2 && out_f32 != 2) || (Cout % 8 == 0 && !split3)) &&
+                      ((residual_f32 != 3 && out_f32 != 3) || (Cout % 8 == 0 && split3)),
+                  "tpspp_conv2d_bf16_fwd: residual / output layout code must be 0 / 1 / 2 / 3 (blocked: Cout a multiple of 8; 2 bf16 "
+                  "not with split3, 3 fp32 only with split3)");
     P.bias = bias; P.res = residual; P.res_f32 = residual_f32; P.out = out; P.out_f32 = out_f32;
     P.post_scale = post_scale; P.post_shift = post_shift;
     P.relu = relu; P.res_mode = res_mode;

@@ -15,7 +15,8 @@ struct BSrc {
     const void* p;
     int C, H, W;              // stored size
     int lh, lw;               // log2 of the nearest upsampling factors
-    int f32;                  // element type / layout: 0 bf16 NCHW, 1 fp32 NCHW, 2 bf16 blocked (N, C/8, H, W, 8)
+    int f32;                  // element type / layout: 0 bf16 NCHW, 1 fp32 NCHW, 2 bf16 blocked (N, C/8, H, W, 8),
+                              // 3 fp32 blocked (the same shape in fp32: the three-term-split configuration's maps)
 };
 
 struct BParams {
@@ -27,7 +28,7 @@ struct BParams {
     const float* post_scale;
     const float* post_shift;
     void* out;
-    int res_f32, out_f32;     // 0 bf16 NCHW, 1 fp32 NCHW, 2 bf16 blocked (N, C/8, H, W, 8)
+    int res_f32, out_f32;     // 0 bf16 NCHW, 1 fp32 NCHW, 2 bf16 blocked (N, C/8, H, W, 8), 3 fp32 blocked
     int N, Cin, Cout, Hi, Wi, Ho, Wo, ph, pw;
     int relu, res_mode;
     int nchunks;
@@ -244,6 +245,31 @@ conv_tiled_bf16_kernel(const BParams P)
                     rp[i][4 * g + 2] = (ok && have) ? v[2] : 0u; rp[i][4 * g + 3] = (ok && have) ? v[3] : 0u;
                 }
             }
+        } else if (X3 && cur.f32 == 3) {
+            // fp32 blocked source (N, C/8, H, W, 8): a position's 8 channels of a group are 32 contiguous bytes -- two 16-byte
+            // loads instead of eight 4-byte ones from eight planes; split into hi / lo halves here as for NCHW fp32
+            const u32x4* sp = reinterpret_cast<const u32x4*>(cur.p) + 2 * (((size_t)n0 * (cur.C >> 3) + ((c0 - cbase) >> 3)) * plane);
+            const int img_units = (cur.C >> 3) * plane;
+#pragma unroll
+            for (int i = 0; i < NPOS; ++i) {
+                const bool ok = piy[i] >= 0;
+                const unsigned lo = ok ? (unsigned)(pim[i] * img_units + (piy[i] >> cur.lh) * cur.W + (pix[i] >> cur.lw)) : 0u;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    const bool have = 8 * g < cleft;                                 // uniform
+                    const float4* q = reinterpret_cast<const float4*>(sp + 2 * ((size_t)(have ? g : 0) * plane + lo));
+                    const float4 v0 = q[0], v1 = q[1];
+                    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2) {
+                        const unsigned pk = pack2_bf16(f[2 * c2], f[2 * c2 + 1]);
+                        const float h0 = __builtin_bit_cast(float, pk << 16), h1 = __builtin_bit_cast(float, pk & 0xffff0000u);
+                        const unsigned pl = pack2_bf16(f[2 * c2] - h0, f[2 * c2 + 1] - h1);
+                        rp[i][4 * g + c2] = (ok && have) ? pk : 0u;
+                        if constexpr (X3) rpl[i][4 * g + c2] = (ok && have) ? pl : 0u;
+                    }
+                }
+            }
         } else
         // every load is unconditional (a predicate per load would put each one in its own basic block and
         // serialise them behind s_waitcnt): channels beyond the source's last one re-read that last channel
@@ -412,6 +438,7 @@ conv_tiled_bf16_kernel(const BParams P)
     // NCHW rows, brought into pixel order by transposing reads -- 4 stores per lane and fragment instead of 64 (which
     // were 36 % of a 3x3 64->64 layer's time)
     const bool blk_out = P.out_f32 == 2, blk_res = P.res_f32 == 2;                                        // uniform
+    const bool blk32_out = P.out_f32 == 3, blk32_res = P.res_f32 == 3;                                    // fp32 blocked
     const bool wide_out = !P.out_f32 && full_c && (P.Wo & 7) == 0 && (TW & 7) == 0 && oy0 + TH <= P.Ho && ox0 + TW <= P.Wo &&
                           n0 + NI <= P.N && (reinterpret_cast<size_t>(P.out) & 15) == 0;       // uniform
     unsigned short* const otile = reinterpret_cast<unsigned short*>(sAll) + wv * (32 * kOutPitch);
@@ -436,9 +463,12 @@ conv_tiled_bf16_kernel(const BParams P)
                     // blocked tensors: this lane's four channels are 8 bytes of the unit (image, channel group, pixel)
                     const size_t bunit = (((size_t)n * (P.Cout >> 3) + ((co_base + cu) >> 3)) * HoWo + (size_t)(valid ? oy * P.Wo + ox : 0)) * 8 + 4 * half;
                     tpspp_u32x2 rb; rb[0] = rb[1] = 0u;
+                    float4 rb32 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if constexpr (!SIMPLE) {
                         if (blk_res && P.res_mode && valid && co_base + cu + 4 * half < P.Cout)
                             rb = *reinterpret_cast<const tpspp_u32x2*>(reinterpret_cast<const unsigned short*>(P.res) + bunit);
+                        if (blk32_res && P.res_mode && valid && co_base + cu + 4 * half < P.Cout)
+                            rb32 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(P.res) + bunit);
                     }
     #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -449,6 +479,8 @@ conv_tiled_bf16_kernel(const BParams P)
                             float rv = 0.0f;
                             if (blk_res)
                                 rv = bf16_bits_to_f32((unsigned short)((rb[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                            else if (blk32_res)
+                                rv = e == 0 ? rb32.x : (e == 1 ? rb32.y : (e == 2 ? rb32.z : rb32.w));
                             else if (P.res_mode && valid && co < P.Cout)
                                 rv = P.res_f32 ? reinterpret_cast<const float*>(P.res)[o]
                                                : bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(P.res)[o]);
@@ -476,6 +508,10 @@ conv_tiled_bf16_kernel(const BParams P)
                             if (valid && 8 * kg < P.Cout)
                                 *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(P.out) + bu) = unit;
                         }
+                    } else if (blk32_out) {
+                        // fp32 blocked: this lane's four channels are 16 bytes of the unit (image, channel group, pixel)
+                        if (valid && co4 < P.Cout)
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.out) + bunit) = make_float4(v[0], v[1], v[2], v[3]);
                     } else if (P.out_f32) {
                         float* ob = reinterpret_cast<float*>(P.out) + ubase + (size_t)cu * HoWo;      // uniform
     #pragma unroll

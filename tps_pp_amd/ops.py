@@ -504,7 +504,27 @@ class Blocked:
         return self.t.data_ptr()
 
 
+class Blocked32(Blocked):
+    """The blocked layout in float32, (N, C/8, H, W, 8) fp32 -- what the maps of the three-term-split ("bf16x3") configuration
+    use between convolutions (layout code 3: a patch position's 8 channels are two 16-byte loads instead of eight 4-byte
+    loads from eight planes)."""
+
+    def __init__(self, t):
+        if t.dtype != torch.float32 or t.dim() != 5 or t.shape[4] != 8 or not t.is_contiguous():
+            raise ValueError("Blocked32: needs a contiguous float32 (N, C/8, H, W, 8) tensor")
+        self.t = t
+        self.shape = (t.shape[0], t.shape[1] * 8, t.shape[2], t.shape[3])
+        self.dtype, self.device = t.dtype, t.device
+
+    @staticmethod
+    def from_nchw(x):
+        n, c, h, w = x.shape
+        return Blocked32(x.float().reshape(n, c // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous())
+
+
 def _layout_code(t):
+    if isinstance(t, Blocked32):
+        return 3
     return 2 if isinstance(t, Blocked) else int(t.dtype == torch.float32)
 
 
@@ -540,13 +560,21 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("conv2d_bf16: out_dtype must be float32 or bfloat16")
     if out_blocked:
-        if out_dtype != torch.bfloat16 or Cout % 8 or cw.x3:
-            raise ValueError("conv2d_bf16: a blocked output is bfloat16 with a multiple of 8 channels (not with x3 weights)")
-        out = Blocked(torch.empty((N, Cout // 8, Ho, Wo, 8), device=dev, dtype=torch.bfloat16))
+        if Cout % 8:
+            raise ValueError("conv2d_bf16: a blocked output needs a multiple of 8 channels")
+        if cw.x3:                                   # the three-term split: fp32 maps, fp32 blocked
+            if out_dtype != torch.float32:
+                raise ValueError("conv2d_bf16: with x3 weights a blocked output is float32 (Blocked32)")
+            out = Blocked32(torch.empty((N, Cout // 8, Ho, Wo, 8), device=dev, dtype=torch.float32))
+        else:
+            if out_dtype != torch.bfloat16:
+                raise ValueError("conv2d_bf16: a blocked output is bfloat16 (float32 with x3 weights)")
+            out = Blocked(torch.empty((N, Cout // 8, Ho, Wo, 8), device=dev, dtype=torch.bfloat16))
     else:
         out = torch.empty((N, Cout, Ho, Wo), device=dev, dtype=out_dtype)
-    if cw.x3 and (res_code == 2 or any(d == 2 for d in dims[5::6])):
-        raise ValueError("conv2d_bf16: blocked tensors are bfloat16 maps (not with x3 weights)")
+    codes = list(dims[5::6]) + [res_code]
+    if (cw.x3 and 2 in codes) or (not cw.x3 and 3 in codes):
+        raise ValueError("conv2d_bf16: Blocked (bfloat16) maps go with plain bf16 weights, Blocked32 (float32) maps with x3 weights")
     if N == 0:          # an empty batch has no device pointer to hand over
         return out
     ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
@@ -558,7 +586,7 @@ def conv2d_bf16(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, o
                                               residual.data_ptr() if residual is not None else None, res_code,
                                               _ptr(cw.post_scale), _ptr(cw.post_shift), int(res_mode), int(relu),
                                               N, Cout, kernel, kernel, sh, sw, out.data_ptr(),
-                                              2 if out_blocked else int(out_dtype == torch.float32), Ho, Wo, int(cw.x3),
+                                              (3 if cw.x3 else 2) if out_blocked else int(out_dtype == torch.float32), Ho, Wo, int(cw.x3),
                                               _stream(first))
     _lib.check(rc, "tpspp_conv2d_bf16_fwd")
     return out
