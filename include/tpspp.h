@@ -311,7 +311,8 @@ int tpspp_conv_chunk_channels(int kernel_size);
  *            (the order in which the matrix core's result registers come back as the next operand);
  *   b0 / b1 / b2 / bg (64) fp32.  Needs H even and W a multiple of 32.
  *   split3: the three-term "bf16x3" split on fp32 tensors -- inputs and all four outputs fp32, every slab holds its hi
- *   and lo halves ([hi|lo][k-steps][2][64][8]), feat0 / feat1 / feat2 are chained without an intermediate rounding.
+ *   and lo halves ([hi|lo][k-steps][2][64][8]), feat0 / feat1 / feat2 are chained without an intermediate rounding;
+ *   feat_grid_f32 bit 1 then means the fp32 blocked layout (N, 8, H, W, 8) (tpspp_conv2d_bf16_fwd's code 3).
  * replaces: backbones/tps_pp/tps_pp.py:560-562,581-585
  */
 int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
@@ -327,7 +328,9 @@ int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
  * bf16 BLOCKED (2): (N, C/8, H, W, 8), the eight channels of a group next to each other per pixel -- a 16-byte unit
  * of that layout IS a unit of the kernel's channel-innermost LDS patch, so a blocked source is staged with 16-byte
  * loads and no transposition, and a blocked output leaves as 8-byte pieces straight from the result registers
- * (layers that only feed other convolutions use it; C a multiple of 8; not with split3).  Same values in every layout.
+ * (layers that only feed other convolutions use it; C a multiple of 8; not with split3); with split3 there is code 3,
+ * the same blocked shape in fp32 (sources, residual, output: a patch position's 8 channels are two 16-byte loads).
+ * Same values in every layout.
  *   src_ptrs[i]      (N, C_i, H_i, W_i); src_dims + 6*i = {C_i, H_i, W_i, uh_i, uw_i, layout code}; uh, uw in
  *                    {1, 2, 4}; with nsrc > 1 every C_i must be a multiple of
  *                    KC = tpspp_conv_bf16_chunk_channels(K)

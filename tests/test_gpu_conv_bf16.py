@@ -351,3 +351,21 @@ def test_front_bf16_blocked_outputs(cuda, fg_dtype):
     for i in range(3):
         assert isinstance(b[i], ops.Blocked) and torch.equal(b[i].nchw().view(torch.int16), a[i].view(torch.int16)), i
     assert torch.equal(a[3], b[3])
+
+
+def test_front_bf16x3_blocked_outputs(cuda):
+    """The three-term-split front with feat0 / feat1 / feat2 in the fp32 blocked layout (16-byte stores of the result
+    registers): the same bits as its NCHW outputs; feat_grid unchanged."""
+    from tps_pp_amd import TPS_PP
+    m = TPS_PP().to(cuda).eval()
+    fw = ops.FrontWeightsBf16(m, True)
+    g = torch.Generator(device=cuda).manual_seed(4)
+    n = 5
+    o0 = torch.rand((n, 32, 32, 128), generator=g, device=cuda)
+    o1 = torch.rand((n, 32, 32, 128), generator=g, device=cuda)
+    x = torch.rand((n, 64, 16, 64), generator=g, device=cuda)
+    a = ops.front_bf16(o0, o1, x, fw)
+    b = ops.front_bf16(o0, o1, x, fw, blocked=True)
+    for i in range(3):
+        assert isinstance(b[i], ops.Blocked32) and torch.equal(b[i].nchw().view(torch.int32), a[i].view(torch.int32)), i
+    assert torch.equal(a[3], b[3])

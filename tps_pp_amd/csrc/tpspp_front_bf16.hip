@@ -391,6 +391,7 @@ struct FrontXParams {
     const float* b0; const float* b1; const float* b2; const float* bg;
     float* feat0; float* feat1; float* feat2; float* feat_grid;
     int N, H, W;
+    int blk;                     // feat0 / feat1 / feat2 in the fp32 blocked layout (N, 8, H, W, 8) (tpspp_conv2d_bf16_fwd code 3)
 };
 
 __device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo)
@@ -441,9 +442,12 @@ __device__ __forceinline__ void gemm3(const u32x4* __restrict__ slab, const u32x
 }
 
 // bias + ReLU in fp32, fp32 store, and the result as chain-ordered hi / lo operands (4 k-steps)
+// `bdst` (fp32 blocked output, or null): this lane's 16 bytes of channel group 0's unit of its pixel (+ 4 half floats already
+// applied by the caller); the groups are `bstride` floats apart -- one 16-byte store per 4 results instead of four 4-byte ones
 __device__ __forceinline__ void finish3(const f32x16 (&acc)[2], const float* __restrict__ bias, int half,
                                         float* __restrict__ dst, unsigned so, int plane, bool st,
-                                        u32x4* __restrict__ outh, u32x4* __restrict__ outl)
+                                        u32x4* __restrict__ outh, u32x4* __restrict__ outl,
+                                        float* __restrict__ bdst = nullptr, size_t bstride = 0)
 {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -460,7 +464,9 @@ __device__ __forceinline__ void finish3(const f32x16 (&acc)[2], const float* __r
             split2(v[2], v[3], h23, l23);
             outh[2 * t + (g >> 1)][2 * (g & 1)] = h01; outl[2 * t + (g >> 1)][2 * (g & 1)] = l01;
             outh[2 * t + (g >> 1)][2 * (g & 1) + 1] = h23; outl[2 * t + (g >> 1)][2 * (g & 1) + 1] = l23;
-            if (st) {
+            if (st && bdst) {
+                *reinterpret_cast<float4*>(bdst + (size_t)(4 * t + g) * bstride) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (st) {
                 float* d = dst + (size_t)(32 * t + 8 * g) * plane;                   // uniform
 #pragma unroll
                 for (int e = 0; e < 4; ++e) (d + (size_t)e * plane)[so] = v[e];
@@ -527,14 +533,16 @@ front_x3_kernel(const FrontXParams P)
             load_b3<2>(P.o0 + (size_t)n * 32 * plane + seg0, lo, plane, ih, il);
             zero();
             gemm3<2>(w0, ih, il, half, l31, acc);
-            finish3(acc, bias, half, P.feat0 + obase, so, plane, true, fh, fl);
+            finish3(acc, bias, half, P.feat0 + obase, so, plane, true, fh, fl,
+                    P.blk ? P.feat0 + ((size_t)n * 8 * plane + seg0 + l31) * 8 + 4 * half : nullptr, (size_t)plane * 8);
         }
         {
             u32x4 ih[2], il[2];
             load_b3<2>(P.o1 + (size_t)n * 32 * plane + seg0, lo, plane, ih, il);
             zero();
             gemm3<2>(w1, ih, il, half, l31, acc);
-            finish3(acc, bias + 64, half, P.feat1 + obase, so, plane, true, fh + 4, fl + 4);
+            finish3(acc, bias + 64, half, P.feat1 + obase, so, plane, true, fh + 4, fl + 4,
+                    P.blk ? P.feat1 + ((size_t)n * 8 * plane + seg0 + l31) * 8 + 4 * half : nullptr, (size_t)plane * 8);
         }
         {
             u32x4 ih[4], il[4];
@@ -542,7 +550,8 @@ front_x3_kernel(const FrontXParams P)
             zero();
             gemm3<4>(w2, ih, il, half, l31, acc);
             finish3(acc, bias + 128, half, P.feat2 + (size_t)n * 64 * plane2 + seg2, (unsigned)((l31 >> 1) + 4 * half * plane2),
-                    plane2, ((y | xx) & 1) == 0, fh + 8, fl + 8);
+                    plane2, ((y | xx) & 1) == 0, fh + 8, fl + 8,
+                    P.blk ? P.feat2 + ((size_t)n * 8 * plane2 + seg2 + (l31 >> 1)) * 8 + 4 * half : nullptr, (size_t)plane2 * 8);
         }
         zero();
         gemm3<12>(wg, fh, fl, half, l31, acc);
@@ -575,7 +584,6 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
     const long nseg = (long)N * H * (W / 32);
     const long blocks = (nseg + 3) / 4;
     TPSPP_REQUIRE(blocks <= 0x7fffffffL, "tpspp_front_bf16_fwd: grid too large");
-    TPSPP_REQUIRE(!(split3 && (feat_grid_f32 & 2)), "tpspp_front_bf16_fwd: the blocked layout is for the bf16 tensors, not for split3");
     if (split3) {
         FrontXParams X;
         X.o0 = static_cast<const float*>(outs0); X.o1 = static_cast<const float*>(outs1); X.x = static_cast<const float*>(x);
@@ -585,6 +593,7 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
         X.feat0 = static_cast<float*>(feat0); X.feat1 = static_cast<float*>(feat1); X.feat2 = static_cast<float*>(feat2);
         X.feat_grid = static_cast<float*>(feat_grid);
         X.N = N; X.H = H; X.W = W;
+        X.blk = (feat_grid_f32 & 2) ? 1 : 0;
         static bool x3_attr_done[tpspp::kMaxDevices] = {};
         if (tpspp::first_use_on_device(x3_attr_done)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_x3_kernel),

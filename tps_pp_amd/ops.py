@@ -801,7 +801,7 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False):
     bf = torch.float32 if fw.x3 else torch.bfloat16
     if fw.x3:
         feat_grid_dtype = torch.float32
-    blocked = bool(blocked) and not fw.x3       # feat0 / feat1 / feat2 as `Blocked` maps (they only feed convolutions)
+    blocked = bool(blocked)                     # feat0 / feat1 / feat2 as `Blocked` / `Blocked32` maps (they only feed convolutions)
     if blocked:
         feat0 = torch.empty((N, 8, H, W, 8), device=dev, dtype=bf)
         feat2 = torch.empty((N, 8, H // 2, W // 2, 8), device=dev, dtype=bf)
@@ -818,7 +818,8 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False):
                                              int(fw.x3), _stream(o0))
     _lib.check(rc, "tpspp_front_bf16_fwd")
     if blocked:
-        return Blocked(feat0), Blocked(feat1), Blocked(feat2), feat_grid
+        B = Blocked32 if fw.x3 else Blocked
+        return B(feat0), B(feat1), B(feat2), feat_grid
     return feat0, feat1, feat2, feat_grid
 
 

@@ -464,10 +464,10 @@ class TPS_PP(nn.Module):
         # the fp32 matrix time.  DGAB / score / control points then run on their exact fp32 kernels.
         bf = f32 if x3 else torch.bfloat16
         c16 = (lambda *a, **k: ops.conv2d_bf16(*a, **{"out_dtype": f32, **k})) if x3 else ops.conv2d_bf16
-        # plain bf16: the maps that only convolutions read (feat0 / feat1 / feat2, the stride-2 results, the encoder maps
-        # and the first three decoder maps) live in the BLOCKED layout (ops.Blocked: a convolution stages such a source
-        # with 16-byte loads and no transposition and writes it as 8-byte pieces of its result registers)
-        blk = {} if x3 else {"out_blocked": True}
+        # the maps that only convolutions read (feat0 / feat1 / feat2, the stride-2 results, the encoder maps and the first
+        # three decoder maps) live in the BLOCKED layout (ops.Blocked, bf16; ops.Blocked32, fp32, with x3): a convolution
+        # stages such a source with 16-byte loads and no transposition and writes it as 8 / 16-byte pieces of its results
+        blk = {"out_blocked": True}
         x, o0, o1 = batch_img, outs[0], outs[1]
         if self.type == "ResNet45v2":
             # feat_grid is sampled by the warp: bf16 when the module boundary is bf16 (the warp then moves half
@@ -480,7 +480,7 @@ class TPS_PP(nn.Module):
                 fc = getattr(self, "_front16_cache", None)
                 if fc is None or fc[0] != fkey:
                     self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self, x3))
-                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype, blocked=not x3)
+                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype, blocked=True)
             else:
                 feat0 = c16([o0], cw["down0"], 1)
                 feat1 = c16([o1], cw["down1"], 1)
