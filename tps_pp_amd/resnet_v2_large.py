@@ -79,13 +79,21 @@ class BasicBlock(nn.Module):
             setattr(self, name, cache)
         return cache[1]
 
-    def _forward_hip_bf16(self, x, out_dtype=torch.bfloat16, x3=False):
+    def _forward_hip_bf16(self, x, out_dtype=torch.bfloat16, x3=False, out_blocked=False):
         """The block on the bf16 matrix cores (BatchNorm folded in fp32, then rounded): activations bf16 in
-        HBM, accumulation / bias / residual add / ReLU in fp32.  x3: fp32 activations, three-term bf16 split."""
+        HBM, accumulation / bias / residual add / ReLU in fp32.  x3: fp32 activations, three-term bf16 split.
+        The map between the block's two convolutions, and with `out_blocked` the block's result, are in the blocked layout
+        (`ops.Blocked` / `ops.Blocked32`: 16-byte loads per patch position in the 3x3 convolution); `x` may be blocked."""
         c1, c2, cd = self._weights_bf16(x3)
         mid = torch.float32 if x3 else torch.bfloat16
-        out = ops.conv2d_bf16([x], c1, self.conv1.stride, True, out_dtype=mid)
-        residual = x if cd is None else ops.conv2d_bf16([x], cd, self.downsample[0].stride, False, out_dtype=mid)
+        out = ops.conv2d_bf16([x], c1, self.conv1.stride, True, out_dtype=mid, out_blocked=True)
+        if cd is None:
+            residual = x
+        else:
+            residual = ops.conv2d_bf16([x], cd, self.downsample[0].stride, False, out_dtype=mid, out_blocked=True)
+        if out_blocked:
+            return ops.conv2d_bf16([out], c2, self.conv2.stride, True, residual=residual, res_mode=2, out_dtype=mid,
+                                   out_blocked=True)
         return ops.conv2d_bf16([out], c2, self.conv2.stride, True, residual=residual, res_mode=2,
                                out_dtype=out_dtype)
 
@@ -170,14 +178,14 @@ class ResNetABI_v2_large(nn.Module):
             # activations in HBM (also through `tpsnet`, which follows its input dtype); the feature map handed
             # to the encoder leaves the last block in fp32
             last = getattr(self, self.res_layers[-1])[-1]
-            return self._run(x, tpsnet, self._stem_bf16, lambda blk, t: blk._forward_hip_bf16(
-                t, torch.float32 if blk is last else torch.bfloat16), **kwargs)
+            return self._run(x, tpsnet, self._stem_bf16, lambda blk, t, inner: blk._forward_hip_bf16(
+                t, torch.float32 if blk is last else torch.bfloat16, out_blocked=inner), **kwargs)
         if self.compute_dtype == "bf16x3":
             # fp32 tensors everywhere, every convolution product the three-term bf16 split (~5e-6 per layer); a
             # `tpsnet` that should do the same needs its own compute_dtype = "bf16x3"
             return self._run(x.float(), tpsnet, lambda t: self._stem_bf16(t, True),
-                             lambda blk, t: blk._forward_hip_bf16(t, torch.float32, True), **kwargs)
-        return self._run(x, tpsnet, self._stem, lambda blk, t: blk(t), **kwargs)
+                             lambda blk, t, inner: blk._forward_hip_bf16(t, torch.float32, True, out_blocked=inner), **kwargs)
+        return self._run(x, tpsnet, self._stem, lambda blk, t, inner: blk(t), **kwargs)
 
     def _stem_bf16(self, x, x3=False):
         mods = [self.conv1, self.bn1]
@@ -202,11 +210,14 @@ class ResNetABI_v2_large(nn.Module):
                 if outputs.get("output", None) is not None:
                     x = outputs["output"]
             outs.append(x)
-            for blk in getattr(self, name):
-                x = apply_block(blk, x)
+            blocks = list(getattr(self, name))
+            for j, blk in enumerate(blocks):
+                # `inner`: the result only feeds the next block of this stage (a stage's last result is seen by `tpsnet` /
+                # the caller and stays NCHW)
+                x = apply_block(blk, x, j + 1 < len(blocks))
         return {"output": x, "img_ref": outputs.get("output", None) if outputs is not None else None}
 
     def _forward_torch(self, x, tpsnet=None, **kwargs):
         """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
         return self._run(x, tpsnet, lambda t: self.relu1(self.bn1(self.conv1(t))),
-                         lambda blk, t: blk._forward_torch(t), **kwargs)
+                         lambda blk, t, inner: blk._forward_torch(t), **kwargs)
