@@ -986,12 +986,13 @@ bool launch_lds(const LdsParams& P, int ppt, int threads, size_t lds, hipStream_
 
 
 template <int C>
-void launch_pair(const float* in, const float* ctrl, const float* inv_delta_c, const float* packed, int N,
-                 float* out, float* grid, int32_t* idx, hipStream_t st)
+void launch_pair(const float* in, const float* ctrl, const float* inv_delta_c, const float* packed,
+                 const float* p_hat, int p_hat_ld, int N, float* out, float* grid, int32_t* idx, hipStream_t st)
 {
     using namespace tpspp_pair;
     PairParams P;
     P.in = in; P.ctrl = ctrl; P.inv_delta_c = inv_delta_c; P.packed = packed; P.N = N;
+    P.p_hat = p_hat; P.p_hat_ld = p_hat_ld;
     P.out = out; P.grid = grid; P.idx = idx; P.trace = g_trace;
     const size_t lds = pair_lds_bytes<20, C, 32, 100, 32, 100>(&P.zero_off, &P.out_off);
     const dim3 grid_dim((unsigned)((N + 1) / 2)), block((PairGeo<32, 100>::NW + kPairLoaders) * kWave);
@@ -1107,8 +1108,8 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
         if (g_tune_kernel == 5 && !pair_ok)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the image-pair kernel");
         if (pair_ok && (g_tune_kernel == 0 || g_tune_kernel == 5)) {
-            if (C0 == 1) launch_pair<1>(in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st);
-            else         launch_pair<3>(in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st);
+            if (C0 == 1) launch_pair<1>(in0, ctrl, inv_delta_c, packed, p_hat, p_hat_ld, N, out0, grid_or_null, idx_or_null, st);
+            else         launch_pair<3>(in0, ctrl, inv_delta_c, packed, p_hat, p_hat_ld, N, out0, grid_or_null, idx_or_null, st);
             return tpspp::check_launch("tpspp_warp_fwd(pair)");
         }
         if (packed_ok && (g_tune_kernel == 0 || g_tune_kernel == 6) &&
