@@ -171,8 +171,7 @@ tps_warp_pair_kernel(const PairParams P)
     static_assert(NW + NLOAD <= 16, "too many wavefronts");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float4* sT = reinterpret_cast<float4*>(smem);          // K x (TxA, TyA, TxB, TyB)
-    float* sInv = smem + 4 * K;                            // 2 x K*K (one copy per solving wavefront)
-    float* sFlag = sInv + 2 * ((K * K + 3) & ~3);          // [0] T rows published, [1] loaders done with A, [2] with B
+    float* sFlag = smem + 4 * K + 2 * ((K * K + 3) & ~3);  // (the gap: the T solve's LDS copy of inv_delta_C until round 3)          // [0] T rows published, [1] loaders done with A, [2] with B
     float* sImg = sFlag + kPairFlags;
     float* sZero = sImg + P.zero_off;
     float* sOut = sImg + P.out_off;
@@ -193,9 +192,11 @@ tps_warp_pair_kernel(const PairParams P)
 
     // the T-solve inputs are requested before anything else on this CU (wavefront g -> image b0 + g; lane i keeps
     // control point i); the loaders are held at the entry barrier until these requests are on their way
-    constexpr int KK = K * K;
-    constexpr int NINV = (KK + kWave - 1) / kWave;
-    float invv[NINV];
+    // Row `lane` of inv_delta_C comes straight from global memory, 16 bytes at a time (round 4; through an LDS copy
+    // before: T ready 0.15 us later).  Pieces 0 .. KGI-2 hold columns 4j .. 4j+3; the last piece starts at column K-4
+    // so that the last row does not read past the matrix.
+    constexpr int KGI = (K + 3) / 4;
+    float hrowv[KGI * 4];
     float cx = 0.0f, cy = 0.0f;
     if (wv < 2) {
         if (lane < F) {
@@ -203,10 +204,12 @@ tps_warp_pair_kernel(const PairParams P)
             const float2 cc = reinterpret_cast<const float2*>(P.ctrl + (size_t)b * F * 2)[lane];
             cx = cc.x; cy = cc.y;
         }
+        const float* row = P.inv_delta_c + (lane < K ? lane : K - 1) * K;
 #pragma unroll
-        for (int i = 0; i < NINV; ++i) {
-            const int e = lane + i * kWave;
-            invv[i] = P.inv_delta_c[e < KK ? e : KK - 1];
+        for (int j = 0; j < KGI; ++j) {
+            const int c0 = (j == KGI - 1) ? K - 4 : 4 * j;
+            const v4f_a4 x = *reinterpret_cast<const v4f_a4*>(row + c0);
+            hrowv[4 * j] = x[0]; hrowv[4 * j + 1] = x[1]; hrowv[4 * j + 2] = x[2]; hrowv[4 * j + 3] = x[3];
         }
     }
     if (tid < kPairFlags) reinterpret_cast<int*>(sFlag)[tid] = 0;
@@ -292,20 +295,13 @@ tps_warp_pair_kernel(const PairParams P)
     }
     if (tid < C) sZero[tid * HW] = 0.0f;                     // read by out-of-image taps (before wave 0 raises flag T)
     if (wv < 2) {
-#pragma unroll
-        for (int i = 0; i < NINV; ++i) {
-            const int e = lane + i * kWave;
-            if (e < KK) sInv[wv * ((KK + 3) & ~3) + e] = invv[i];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes visible to own reads
-        const float* hrow = sInv + wv * ((KK + 3) & ~3) + (lane < K ? lane : K - 1) * K;   // stride K is odd: no conflicts
         float ax = 0.0f, ay = 0.0f;
-#pragma unroll
-        for (int q = 0; q < K; ++q) {                        // ordered broadcast: the sum is the reference's FMA chain
-            const float hv = hrow[q];
-            ax = fmaf(hv, readlane_f(cx, q), ax);
-            ay = fmaf(hv, readlane_f(cy, q), ay);
-        }
+        static_for<K>([&](auto qc) {                         // ordered broadcast: the sum is the reference's FMA chain
+            constexpr int q = decltype(qc)::value;
+            constexpr int idx = (q / 4 < KGI - 1) ? q : 4 * (KGI - 1) + (q - (K - 4));   // column q's slot in hrowv
+            ax = fmaf(hrowv[idx], readlane_f(cx, q), ax);
+            ay = fmaf(hrowv[idx], readlane_f(cy, q), ay);
+        });
         if (lane < K) {
             float* dst = reinterpret_cast<float*>(sT + lane) + 2 * wv;
             dst[0] = ax; dst[1] = ay;
