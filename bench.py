@@ -575,27 +575,37 @@ def main():
         for r in range(R):
             barrier()
             res.append(timed(a.steps, nstreams, first + r * a.steps))
-        return min(res)
+        return res
 
     for i in range(a.warmup):
         step(i)
     R = a.repeats if a.repeats > 0 else (5 if a.steps <= 200 else 1)
-    ev_ms, dt = best_of(S, a.warmup)
+    reg_m = best_of(S, a.warmup)
     # the same steps with every launch behind the previous one (one stream): what a kernel trace shows as the
     # kernel's own duration
-    ev1_ms, dt1 = best_of(1, a.warmup) if S > 1 else (ev_ms, dt)
+    reg_1 = best_of(1, a.warmup) if S > 1 else reg_m
+    # a region's time is the MAX over ranks (every rank times the same R regions behind the same barriers); the
+    # estimator is then the fastest region, with the median and every region's time reported beside it
+    tt = torch.tensor([[list(x) for x in reg_m], [list(x) for x in reg_1]], device=dev, dtype=torch.float64)   # (2, R, 2)
+    tt_min = tt.clone()
     if world > 1:
-        tt = torch.tensor([dt, ev_ms, ev1_ms, -ev_ms, dt1, -ev1_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ev_ms, ev1_ms, ev_ms_min, dt1, ev1_ms_min = float(tt[0]), float(tt[1]), float(tt[2]), -float(tt[3]), float(tt[4]), -float(tt[5])
-    else:
-        ev_ms_min, ev1_ms_min = ev_ms, ev1_ms
+        dist.all_reduce(tt_min, op=dist.ReduceOp.MIN)
+    tt, tt_min = tt.cpu(), tt_min.cpu()
+    regions_m = [float(x) for x in tt[0, :, 0]]              # ms per region, `steps` launches each
+    regions_1 = [float(x) for x in tt[1, :, 0]]
+    km, k1 = int(np.argmin(regions_m)), int(np.argmin(regions_1))
+    ev_ms, dt, ev_ms_min = regions_m[km], float(tt[0, km, 1]), float(tt_min[0, km, 0])
+    ev1_ms, dt1, ev1_ms_min = regions_1[k1], float(tt[1, k1, 1]), float(tt_min[1, k1, 0])
     # `value` is the better of the two launch protocols for THIS step count (both are reported): with few steps per region
     # the extra queues' wake-up can cost more than the overlap of consecutive launches gains
     ms_multi, ms_one = ev_ms, ev1_ms
     used_streams = S if ms_multi <= ms_one else 1
+    regions_used = regions_m
     if used_streams == 1:
         ev_ms, dt, ev_ms_min = ev1_ms, dt1, ev1_ms_min
+        regions_used = regions_1
+    to_us = lambda ms: ms * 1e3 / a.steps                    # noqa: E731  (ms per region -> us per launch)
 
     # ---- parity spot-check of what was just measured (not timed) ----
     max_err = None
@@ -664,6 +674,8 @@ def main():
                        "batch_per_gpu": BATCH, "rotating_buffer_sets": int(nbuf),
                        "working_set_MB": round(nbuf * per_set / 1e6, 1),
                        "streams": used_streams, "streams_tried": sorted({1, S}), "repeats": R,
+                       "estimator": f"min of {R} regions of `steps` launches, better of 2 launch protocols "
+                                    f"({S} streams / 1 stream); median and every region in roofline.*.regions_us",
                        "timing": f"two launch protocols are timed, each over `repeats` regions of exactly `steps` launches "
                                  f"(barrier + synchronize before each region, the fastest region counts): step i on HIP "
                                  f"stream i % {S} (consecutive batches are independent), and all steps on one stream; "
@@ -682,13 +694,19 @@ def main():
                                            f"{traffic_kernel}; not re-measured in this run)" if traffic else None,
                          "kernel": kernel,
                          "launch_us": launch_us,
+                         "launch_us_median": float(np.median([to_us(x) for x in regions_used])),
+                         "frac_at_median": BYTES_PER_IMG * BATCH / (float(np.median([to_us(x) for x in regions_used])) * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "launch_us_is": f"time of `steps` launches on {used_streams} stream(s) / steps; with several streams "
                                          "launches overlap, so this is the period between launches, not one kernel's "
                                          "start-to-end duration (a kernel trace shows the latter: compare it with "
                                          "one_stream.launch_us, and launch_us with (last end - first start) / launches)",
                          "multi_stream": {"streams": S, "launch_us": launchm_us, "achieved": achievedm,
-                                          "frac": achievedm / HBM_PEAK_GBS},
+                                          "frac": achievedm / HBM_PEAK_GBS,
+                                          "regions_us": [round(to_us(x), 4) for x in regions_m],
+                                          "median_us": float(np.median([to_us(x) for x in regions_m]))},
                          "one_stream": {"launch_us": launch1_us, "achieved": achieved1, "frac": achieved1 / HBM_PEAK_GBS,
+                                        "regions_us": [round(to_us(x), 4) for x in regions_1],
+                                        "median_us": float(np.median([to_us(x) for x in regions_1])),
                                         "note": "every launch waits for the previous one to drain: kernel duration + launch gap"},
                          "algorithmic_bytes_per_launch": BYTES_PER_IMG * BATCH,
                          "plain_copy_of_the_image_bytes": {

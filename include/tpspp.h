@@ -144,8 +144,10 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *   g_ctrl (N, F, 2)                                dL/d control points
  *   g_score                                         dL/d score in the layout of `score` ((N, n, F), or
  *                                                  (N, F, n) with TPSPP_SCORE_TRANSPOSED), or NULL
- *   g_grid_ws                                       scratch of tpspp_warp_bwd_workspace_floats(N, Ho, Wo) floats; on
- *                                                  return its first N * Ho*Wo * 2 floats hold dL/d grid
+ *   g_grid_ws, g_grid_ws_floats                     scratch and its size in floats, at least
+ *                                                  tpspp_warp_bwd_workspace_floats(N, Ho, Wo) (checked: TPSPP_EINVAL
+ *                                                  otherwise; the size grew in round 3); on return its first
+ *                                                  N * Ho*Wo * 2 floats hold dL/d grid
  * grid (N, Ho*Wo, 2) is the sampling grid the forward produced (its grid_or_null output) and
  * T (N, F+3, 2) = tpspp_solve_T(inv_delta_c, ctrl); the tables are the forward's.  Gradients follow
  * ATen's CPU grid_sampler_2d_backward (bilinear, border, align_corners=True: zero coordinate gradient
@@ -159,8 +161,8 @@ int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0
                    const float* grid, const float* T, const float* inv_delta_c,
                    const float* p_hat, int p_hat_ld, const float* p_xy, const float* score,
                    const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
-                   float* g_in0, float* g_in1, float* g_ctrl, float* g_score, float* g_grid_ws,
-                   tpspp_stream_t stream);
+                   float* g_in0, float* g_in1, float* g_ctrl, float* g_score,
+                   float* g_grid_ws, size_t g_grid_ws_floats, tpspp_stream_t stream);
 
 /*
  * out = act(conv2d(cat_c(up(src_0), up(src_1), up(src_2)), W) + bias [+ residual]) [+ residual]
@@ -482,7 +484,9 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
 /*
  * NRTRDecoder.forward_test (greedy, forced_tokens == NULL) / forward_train (teacher forcing):
  *   enc_cm       (C, N*T) channel-major encoder output (tpspp_nrtr_encoder_fwd's out_cm)
- *   layer_ptrs   n_layers x 24 (+ 1) device pointers, per layer (every LayerNorm folded into the projection that
+ *   layer_ptrs, layer_ptrs_len   the table and its length in pointers, which must be n_layers x 24 + 1 (checked: a
+ *                table in the 12- or 18-pointer layout of earlier rounds is refused, not read out of bounds);
+ *                per layer (every LayerNorm folded into the projection that
  *                follows it, see tpspp_linear_ln_fwd: w_gamma = diag(norm.weight) W^T-k-major, colsum its
  *                column sums, bias_eff = norm.bias^T W (+ bias)):
  *                  self_attn q|k|v fused (C, 3C): w_gamma, colsum (3C), bias_eff (3C);
@@ -514,7 +518,7 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
  * replaces: textrecog/decoders/nrtr_decoder.py:95-113,131-177, common/layers/transformer_layers.py:133-163
  */
 int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
-                           const float* const* layer_ptrs,
+                           const float* const* layer_ptrs, int layer_ptrs_len,
                            const float* emb, const float* pos_table, int n_position,
                            const float* w_cls, const float* cls_colsum, const float* b_cls, int num_out,
                            int max_seq_len,

@@ -15,6 +15,10 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
     python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline --no-extras > $OUT/bench_trace.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o bench -- \
     python3 bench.py --steps $STEPS --warmup 50 --no-cpu-baseline --no-extras --streams 1 > $OUT/bench_trace1.log 2>&1
+# 1b. the driver's own command, untouched: `python bench.py --gpus 1 --steps 20 --warmup 5` (two streams at this step count,
+#     5 regions per protocol, extras and CPU baseline included); the summary lists period and duration of every region
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_driver -o bench -- \
+    python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_trace_driver.log 2>&1
 # 2. PMC passes (own runs, nothing but --pmc)
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- \

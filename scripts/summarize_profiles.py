@@ -102,41 +102,76 @@ def timeline(trace_csv, kernel_substr, steps):
 
 
 def timeline_summary():
-    out = []
-    for tag, sub in (("three streams (the bench command)", "trace"), ("one stream (`--streams 1`)", "trace1")):
+    """Per traced run of bench.py: the dispatch order is warm-up, `repeats` regions of `steps` launches on S streams,
+    `repeats` regions on one stream (when S > 1), then the parity step / extras.  For every region: the kernels' average
+    start-to-end duration and the period (last end - first start) / launches, next to the bench line's own
+    regions_us of the same run."""
+    runs = (("the driver's command: `python3 bench.py --gpus 1 --steps 20 --warmup 5`", "trace_driver", "bench_trace_driver.log"),
+            ("`--steps 400 --warmup 50` (long regions)", "trace", "bench_trace.log"),
+            ("`--steps 400 --warmup 50 --streams 1`", "trace1", "bench_trace1.log"))
+    blocks = []
+    for tag, sub, logname in runs:
         pth = os.path.join(SRC, sub, "bench_kernel_trace.csv")
-        log = os.path.join(SRC, "bench_trace.log" if sub == "trace" else "bench_trace1.log")
+        log = os.path.join(SRC, logname)
         if not (os.path.exists(pth) and os.path.exists(log)):
             continue
-        bench = json.loads([l for l in open(log) if l.startswith("{")][-1])
+        lines = [l for l in open(log) if l.startswith("{")]
+        if not lines:
+            continue
+        bench = json.loads(lines[-1])
         steps, warm = bench["steps"], bench["warmup"]
+        R = int(bench["config"].get("repeats", 1))
+        tried = bench["config"].get("streams_tried", [bench["config"]["streams"]])
+        S = max(tried)
         rows = timeline(pth, KERNEL, steps)
-        # dispatch order of bench.py: warm-up steps, the timed steps, [the one-stream re-run of the same steps], 1 parity step
+        protos = [(S, bench["roofline"].get("multi_stream", {}).get("regions_us"))]
+        if S > 1:
+            protos.append((1, bench["roofline"].get("one_stream", {}).get("regions_us")))
         lo = warm
-        sel = rows[lo:lo + steps]
-        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
-        span = max(int(r["End_Timestamp"]) for r in sel) - min(int(r["Start_Timestamp"]) for r in sel)
-        queues = sorted({r.get("Queue_Id", "?") for r in sel})
-        overlap = sum(1 for a, b in zip(sel, sel[1:]) if int(b["Start_Timestamp"]) < int(a["End_Timestamp"]))
-        out.append((tag, len(sel), sum(dur) / len(dur) / 1e3, span / len(sel) / 1e3, len(queues), overlap,
-                    bench["roofline"]["launch_us"], bench["roofline"]["frac"]))
-    if not out:
+        out = []
+        for streams, line_regions in protos:
+            for r in range(R):
+                sel = rows[lo:lo + steps]
+                lo += steps
+                if len(sel) < steps:
+                    break
+                dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
+                span = max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)
+                queues = sorted({x.get("Queue_Id", "?") for x in sel})
+                overlap = sum(1 for p, q in zip(sel, sel[1:]) if int(q["Start_Timestamp"]) < int(p["End_Timestamp"]))
+                out.append((streams, r, len(sel), sum(dur) / len(dur) / 1e3, span / len(sel) / 1e3, len(queues), overlap,
+                            line_regions[r] if line_regions and r < len(line_regions) else None))
+        blocks.append((tag, bench, out))
+    if not blocks:
         return
     with open(os.path.join(DST, f"{TAG}_bench_kernel_timeline.md"), "w") as f:
-        f.write(f"""# {TAG}: the timed region of `python3 bench.py` in the rocprofv3 kernel trace (MI355X, 1 GPU)
+        f.write(f"""# {TAG}: the timed regions of `bench.py` in the rocprofv3 kernel trace (MI355X, 1 GPU)
 
-bench.py launches step i on HIP stream i % 3.  Launches on different streams overlap, so two different numbers describe
-the same region: a kernel's own start-to-end DURATION (what `--stats` averages) and the PERIOD between launches,
-(last end - first start) / launches, which is what `ms_per_step` / `roofline.launch_us` of the bench line measure.  On one
-stream the two coincide up to the launch gap.  Computed by scripts/summarize_profiles.py from the `*_kernel_trace.csv` of
-each run (the `steps` dispatches of `{KERNEL}` that follow the warm-up).
+bench.py times two launch protocols, each over `repeats` regions of exactly `steps` launches: step i on HIP stream i % S
+(S = `config.streams_tried[-1]`; launches on different streams overlap) and all steps on one stream.  Two different numbers
+describe a region: a kernel's own start-to-end DURATION (what `--stats` averages) and the PERIOD between launches,
+(last end - first start) / launches, which is what `ms_per_step` / `roofline.*.regions_us` of the bench line measure.  On
+one stream the two coincide up to the launch gap.  Computed by scripts/summarize_profiles.py from the
+`*_kernel_trace.csv` of each run (the dispatches of `{KERNEL}` in dispatch order: warm-up, the S-stream regions, the
+one-stream regions).  Profiled runs are slower than un-profiled ones (rocprofv3 adds per-dispatch work), so the trace's
+period is compared with the bench line of THE SAME run.
 
-| run | launches | average duration, us | period, us | HIP queues | launches that start before the previous one ends | bench line launch_us (same run) | frac |
-|---|---|---|---|---|---|---|---|
 """)
-        for tag, n, d, pd, q, ov, lu, fr in out:
-            f.write(f"| {tag} | {n} | {d:.2f} | {pd:.2f} | {q} | {ov} | {lu:.2f} | {fr:.3f} |\n")
-        f.write("\n(profiled runs are slower than un-profiled ones: rocprofv3 adds per-dispatch work)\n")
+        for tag, bench, out in blocks:
+            rf = bench["roofline"]
+            f.write(f"## {tag}\n\nbench line of this (profiled) run: streams = {bench['config']['streams']}, launch_us = "
+                    f"{rf['launch_us']:.2f} (min), median {rf.get('launch_us_median', float('nan')):.2f}, frac = {rf['frac']:.3f}; "
+                    f"one stream {rf['one_stream']['launch_us']:.2f} us.\n\n"
+                    "| streams | region | launches | average duration, us | period, us | HIP queues | launches that start before the previous one ends | bench line, same region, us |\n"
+                    "|---|---|---|---|---|---|---|---|\n")
+            for streams, r, n, d, pd, q, ov, lr in out:
+                f.write(f"| {streams} | {r} | {n} | {d:.2f} | {pd:.2f} | {q} | {ov} | {'' if lr is None else f'{lr:.2f}'} |\n")
+            for streams in sorted({o[0] for o in out}, reverse=True):
+                pds = sorted(o[4] for o in out if o[0] == streams)
+                drs = [o[3] for o in out if o[0] == streams]
+                f.write(f"\n{streams} stream(s): period min {pds[0]:.2f} / median {pds[len(pds) // 2]:.2f} us, "
+                        f"average kernel duration {sum(drs) / len(drs):.2f} us.\n")
+            f.write("\n")
 
 
 def main():

@@ -44,7 +44,7 @@ _SIGNATURES = {
     "tpspp_warp_set_trace": ([_f], _i),
     "tpspp_warp_bwd_workspace_floats": ([_i, _i, _i], ctypes.c_size_t),
     "tpspp_warp_bwd": ([_f, _f, _i, _i, _i, _f, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _i,
-                        _f, _f, _f, _f, _f, _f], _i),
+                        _f, _f, _f, _f, _f, ctypes.c_size_t, _f], _i),
     "tpspp_transpose2d": ([_f, _i, _i, _f, _f], _i),
     "tpspp_layernorm_cm_fwd": ([_f, _f, _f, _i, _i, ctypes.c_float, _f, _f], _i),
     "tpspp_attn_enc_fwd": ([_f, _i, _i, _i, _f, _f, _f], _i),
@@ -53,7 +53,7 @@ _SIGNATURES = {
     "tpspp_nrtr_encoder_workspace": ([_i, _i, _i, _i], ctypes.c_size_t),
     "tpspp_nrtr_decoder_workspace": ([_i] * 7, ctypes.c_size_t),
     "tpspp_nrtr_encoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, ctypes.c_size_t, _f, _f, _i, _f], _i),
-    "tpspp_nrtr_decoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _f,
+    "tpspp_nrtr_decoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _f,
                                 _f, ctypes.c_size_t, _f, _f, _i, _f], _i),
 }
 

@@ -91,9 +91,11 @@ struct PCfg {
     }
 };
 
+// s_nop 0: a SALU write of M0 needs one wait state before an LDS-DMA instruction reads it (the hazard recogniser does
+// not look inside inline asm); m0 is declared clobbered so that the compiler re-materialises its own uses of it.
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory", "m0");
 }
 __device__ __forceinline__ int lds_peek(const int* p)
 {

@@ -1149,7 +1149,7 @@ TPSPP_EXPORT int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, 
 }
 
 TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
-                                        const float* const* layer_ptrs,
+                                        const float* const* layer_ptrs, int layer_ptrs_len,
                                         const float* emb, const float* pos_table, int n_position,
                                         const float* w_cls, const float* cls_colsum, const float* b_cls, int num_out,
                                         int max_seq_len,
@@ -1157,6 +1157,9 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                                         const int* forced_tokens, void* workspace, size_t workspace_bytes,
                                         float* out, int* tokens_out, int flags, tpspp_stream_t stream)
 {
+    TPSPP_REQUIRE(n_layers > 0 && layer_ptrs_len == n_layers * D_COUNT + 1,
+                  "tpspp_nrtr_decoder_fwd: layer_ptrs_len must be n_layers * %d + 1 (24 pointers per layer, then the "
+                  "arranged classifier)", D_COUNT);
     const bool b16 = (flags & TPSPP_HEAD_BF16) != 0;
     const bool x3 = !b16 && (flags & TPSPP_HEAD_BF16X3) != 0;
     TPSPP_REQUIRE(enc_cm && layer_ptrs && emb && pos_table && w_cls && cls_colsum && workspace && out,

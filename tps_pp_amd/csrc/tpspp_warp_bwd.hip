@@ -461,9 +461,11 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
                                 const float* grid, const float* T, const float* inv_delta_c,
                                 const float* p_hat, int p_hat_ld, const float* p_xy, const float* score,
                                 const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
-                                float* g_in0, float* g_in1, float* g_ctrl, float* g_score, float* g_grid_ws,
-                                tpspp_stream_t stream)
+                                float* g_in0, float* g_in1, float* g_ctrl, float* g_score,
+                                float* g_grid_ws, size_t g_grid_ws_floats, tpspp_stream_t stream)
 {
+    TPSPP_REQUIRE(g_grid_ws_floats >= tpspp_warp_bwd_workspace_floats(N, Ho, Wo),
+                  "tpspp_warp_bwd: g_grid_ws too small (needs tpspp_warp_bwd_workspace_floats(N, Ho, Wo) floats)");
     TPSPP_REQUIRE(g_out0 && in0 && grid && T && inv_delta_c && p_hat && g_ctrl && g_grid_ws, "tpspp_warp_bwd: null pointer");
     TPSPP_REQUIRE((g_out1 == nullptr) == (in1 == nullptr), "tpspp_warp_bwd: g_out1 and in1 come together");
     TPSPP_REQUIRE(N >= 0 && F > 0 && F + 3 <= kMaxK && Ho > 0 && Wo > 0, "tpspp_warp_bwd: bad sizes (F <= %d)", kMaxK - 3);

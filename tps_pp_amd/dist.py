@@ -28,6 +28,24 @@ def shard_batch(t: torch.Tensor, rank: int, world_size: int):
     return t[lo:hi]
 
 
+def _fused_gather(local: torch.Tensor, group) -> bool:
+    """True when this tensor's collective runs on RCCL (backend "nccl"): only then is the fused
+    `all_gather_into_tensor` taken -- some gloo builds lack it, also for CUDA tensors on a gloo-only group.  The
+    answer depends on the tensor's device and the group's (possibly per-device) backend, both the same on every rank."""
+    if not local.is_cuda:
+        return False
+    try:
+        backend = str(dist.get_backend(group)).lower()
+    except Exception:
+        return False
+    # "nccl", or a per-device map such as "cpu:gloo,cuda:nccl"
+    for part in backend.split(","):
+        dev, _, name = part.rpartition(":")
+        if name == "nccl" and dev in ("", "cuda"):
+            return True
+    return False
+
+
 def all_gather_rows(local: torch.Tensor, n_total: int, group=None):
     """Gather the per-rank row blocks produced by `shard_batch` back into the (n_total, ...) tensor,
     on every rank.  Ragged shards are padded to the largest shard for the collective (one
@@ -52,7 +70,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None):
     # "cpu:gloo,cuda:nccl": the backend string alone does not say which one this tensor gets): a collective that fails
     # on one rank (comm abort, timeout, size mismatch) must propagate, not be followed by a different collective on a
     # desynchronised communicator
-    if not local.is_cuda:                                # gloo (CPU tests); gloo builds may lack the fused form
+    if not _fused_gather(local, group):                  # gloo (CPU tests, or a CUDA tensor on a gloo-only group)
         parts = [torch.empty_like(send) for _ in range(world)]
         dist.all_gather(parts, send, group=group)
         recv = torch.cat(parts, dim=0)

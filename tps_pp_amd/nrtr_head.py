@@ -223,6 +223,10 @@ class NRTRDecoder(nn.Module):
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != key:
             ts = []
+            # the token-major step pipeline (tpspp_head.hip) takes these shapes only; for every other one the arranged
+            # entries stay NULL and the channel-major step kernels run (no arrangement constraint, no wasted copies)
+            d_inner = self.layer_stack[0].mlp.w_1.weight.shape[0]
+            fast = self.d_model in (256, 512) and d_inner in (256, 512) and self.classifier.weight.shape[0] % 4 == 0
             # the one-off key / value projections of the encoder output: bf16 both; bf16x3 the keys only
             kk = (lambda w: _arranged16(w, x3)) if (b16 or x3) else ops.kmajor
             kv = _arranged16 if b16 else ops.kmajor
@@ -241,10 +245,11 @@ class NRTRDecoder(nn.Module):
                 # the six per-step projections arranged for the step GEMM: fp32 fragments, or split hi / lo bf16 for the
                 # reduced-precision head
                 arr = ops.arrange_x3 if (b16 or x3) else ops.arrange_f32
-                ts += [arr(t) for t in (qkv[0], wfc, q[0], wfc2, w1[0], w2)]
+                ts += [arr(t) if fast else None for t in (qkv[0], wfc, q[0], wfc2, w1[0], w2)]
             cls = ops.fold_layernorm(self.layer_norm.weight, self.layer_norm.bias, ops.kmajor(self.classifier.weight),
                                      self.classifier.bias)
-            ts.append((ops.arrange_x3 if (b16 or x3) else ops.arrange_f32)(cls[0]))     # behind the layers: the classifier
+            # behind the layers: the classifier
+            ts.append((ops.arrange_x3 if (b16 or x3) else ops.arrange_f32)(cls[0]) if fast else None)
             cache = (key, ops.PtrTable(ts), _f32(self.trg_word_emb.weight), _f32(self.position_enc.position_table[0]),
                      cls)
             self._w_cache = cache

@@ -1008,6 +1008,9 @@ class PtrTable:
         self.arr = (ctypes.c_void_p * len(self.keep))(*[None if t is None else t.data_ptr() for t in self.keep])
         self.ptr = ctypes.cast(self.arr, ctypes.c_void_p)
 
+    def __len__(self):
+        return len(self.keep)
+
 
 def _workspace(holder, nbytes, device):
     """Scratch of the encoder / decoder, cached on the module per (device, stream): two calls on different HIP streams
@@ -1065,7 +1068,7 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_fol
                 not forced_tokens.is_contiguous() or forced_tokens.device != enc_cm.device:
             raise ValueError("nrtr_decoder: forced_tokens must be a contiguous (N, max_seq_len) int32 device tensor")
     with torch.cuda.device(enc_cm.device):
-        rc = L.tpspp_nrtr_decoder_fwd(_ptr(enc_cm), N, C, T, d_inner, n_layers, table.ptr,
+        rc = L.tpspp_nrtr_decoder_fwd(_ptr(enc_cm), N, C, T, d_inner, n_layers, table.ptr, len(table),
                                       _ptr(emb), _ptr(pos_table), pos_table.shape[0], _ptr(w_cls), _ptr(cls_colsum),
                                       _ptr(b_cls), num_out, max_seq_len, int(start_idx), int(padding_idx), _ptr(valid_len),
                                       _ptr(forced_tokens), ws.data_ptr(), ws.numel(), _ptr(out), _ptr(tokens),
@@ -1140,7 +1143,7 @@ def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None
                                        _ptr(grid), _ptr(T), _ptr(inv_delta_C), _ptr(P_hat), P_hat.shape[1],
                                        _ptr(P_xy), _ptr(score), _ptr(P_hat_t), flags, N, F, Ho, Wo,
                                        _ptr(g_in0), _ptr(g_in1), _ptr(g_ctrl), _ptr(g_score), _ptr(g_grid),
-                                       _stream(in0))
+                                       g_grid.numel(), _stream(in0))
     _lib.check(rc, "tpspp_warp_bwd")
     if g_score is not None and (flags & SCORE_TRANSPOSED):
         g_score = g_score.transpose(1, 2)                  # back to the logical (N, n, F) view
