@@ -156,6 +156,11 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *           preprocessor/tps_preprocessor.py:71-83,270-282
  */
 size_t tpspp_warp_bwd_workspace_floats(int N, int Ho, int Wo);
+/* How dL/d input is accumulated in LDS when whole planes fit: 0 (default) = fp64 atomics (every term's fp32 bits kept
+ * whatever the spread of magnitudes; a non-finite gradient poisons the four taps it touches, as ATen does), 1 = round 3's
+ * 64-bit fixed point (exact and order-independent within 2^-50 of a pass's largest |g|; a non-finite gradient turns the
+ * whole plane NaN).  Process-wide; for measurements (scripts/bench_backward.py). */
+int tpspp_warp_bwd_set_accumulator(int fixed_point);
 int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
                    const float* g_out1, const float* in1, int C1, int H1, int W1,
                    const float* grid, const float* T, const float* inv_delta_c,

@@ -10,6 +10,9 @@ from tps_pp_amd import TPS_PP, TPSPreprocessor, ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+if "fixed" in sys.argv[2:]:            # round 3's fixed-point LDS accumulator instead of the fp64 atomics
+    ops.set_warp_bwd_accumulator(True)
+    print("accumulator: 64-bit fixed point")
 
 
 def timeit(fn, iters=10, warm=3):

@@ -33,6 +33,8 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, long long* cyc)
                 do { assumed = old; old = atomicCAS(up, assumed, __float_as_uint(__uint_as_float(assumed) + 1.0f)); } while (old != assumed);
             }
             else if (MODE == 5) atomicAdd(reinterpret_cast<unsigned long long*>(pl) + (ad >> 1), 1ull);
+            else if (MODE == 6) atomicAdd(reinterpret_cast<double*>(pl) + (ad >> 1), 1.0);
+            else if (MODE == 7) unsafeAtomicAdd(reinterpret_cast<double*>(pl) + (ad >> 1), 1.0);
             else acc += pl[ad];
         }
     }
@@ -72,6 +74,9 @@ int main()
     run<0, 2>("ds_add_f32, pairs share a word", out, cyc);
     run<0, 3>("ds_add_f32, 4 lanes share a word", out, cyc);
     run<0, 4>("ds_add_f32, scattered", out, cyc);
+    run<6, 0>("atomicAdd(double) in LDS, consecutive 8-byte words", out, cyc);
+    run<6, 2>("atomicAdd(double) in LDS, pairs share a word", out, cyc);
+    run<7, 0>("unsafeAtomicAdd(double) in LDS, consecutive", out, cyc);
     run<1, 0>("ds_add_u32, consecutive", out, cyc);
     run<1, 2>("ds_add_u32, pairs share a word", out, cyc);
     run<1, 4>("ds_add_u32, scattered", out, cyc);

@@ -18,6 +18,8 @@
 // Bound: L2 atomics + HBM (every g_out element read once, 4 atomics per tap set).
 #include "tpspp_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int kWave = 64;
@@ -41,13 +43,6 @@ struct BwdParams {
     float* g_score;                // same layout as score, or null
     int N, F, n;
 };
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
 
 // ---- kernel A: sampler backward.  Thread = one output pixel x kCPT channels of one input ---------------
 // grid = (pixel blocks, channel chunks of input 0 then input 1, images).  dL/d input goes out as float
@@ -218,7 +213,13 @@ warp_bwd_sample_lds_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* 
 //   * two channel planes per pass share the tap addresses and weights (40 loads per thread in flight).
 // grid = (G groups of input 0 then G groups of input 1, images); workspace (N, 2 G, n, 2).
 // NT threads: 256 (two workgroups per CU; up to 1024 output pixels) or 1024 (the classic 32x100 geometry: 3200 pixels)
-template <int PPT, int NT>
+// F64 (round 4, the default): the accumulators are doubles and a term is added with ds_add_f64 (3.1 lane-operations per
+// clock and CU in scripts/ubench/lds_atomic_bench.hip: 9x ds_add_f32, 0.4-0.6x ds_add_u64).  No scale, so a plane with
+// gradients of very different magnitudes keeps every term's fp32 bits (the fixed-point form drops what lies 2^-50 below
+// the pass's largest |g|), and a non-finite incoming gradient poisons exactly the four taps it touches, as ATen's
+// kernel does.  The sum of fp32 terms in fp64 is exact up to 2^-53 relative per addition: the fp32 result is the
+// correctly rounded sum except for ties broken by the order of arrival.
+template <int PPT, int NT, bool F64>
 __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
 warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* __restrict__ g_grid_part)
 {
@@ -286,7 +287,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
             // significant bits, 4096 terms stay below 2^62)
             double scale = 0.0, inv_scale = 0.0;
             bool fin[2] = {true, true};                    // a plane whose incoming gradient is not finite comes out as NaN
-            if (want) {
+            if (want && !F64) {
                 float m[2] = {0.0f, 0.0f};
                 bool nan_[2] = {false, false};
 #pragma unroll
@@ -332,7 +333,15 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
                     const float a01 = inx[k] ? v[k][q][1] : 0.0f, a10 = iny[k] ? v[k][q][2] : 0.0f, a11 = inxy ? v[k][q][3] : 0.0f;
                     gx[k] += ((a01 - v[k][q][0]) * s + (a11 - a10) * nn) * g;
                     gy[k] += ((a10 - v[k][q][0]) * e + (a11 - a01) * w) * g;
-                    if (want && scale != 0.0 && fin[q]) {
+                    if constexpr (F64) {
+                        if (want) {
+                            double* ap = reinterpret_cast<double*>(acc) + (size_t)q * plane + o00[k];
+                            unsafeAtomicAdd(ap, (double)(nw * g));
+                            if (inx[k]) unsafeAtomicAdd(ap + 1, (double)(ne * g));
+                            if (iny[k]) unsafeAtomicAdd(ap + W, (double)(sw * g));
+                            if (inxy) unsafeAtomicAdd(ap + W + 1, (double)(se * g));
+                        }
+                    } else if (want && scale != 0.0 && fin[q]) {
                         unsigned long long* ap = acc + (size_t)q * plane + o00[k];
                         auto fx64 = [&](float t) {
                             return (unsigned long long)(__double_as_longlong(fma((double)t, scale, kMagic)) - __double_as_longlong(kMagic));
@@ -356,9 +365,14 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
                     acc2[2 * e] = make_ulonglong2(0ull, 0ull);
                     acc2[2 * e + 1] = make_ulonglong2(0ull, 0ull);
                     float4 o;
+                    if constexpr (F64) {
+                        o.x = (float)__longlong_as_double((long long)r0.x); o.y = (float)__longlong_as_double((long long)r0.y);
+                        o.z = (float)__longlong_as_double((long long)r1.x); o.w = (float)__longlong_as_double((long long)r1.y);
+                    } else {
                     o.x = (float)((double)(long long)r0.x * inv_scale); o.y = (float)((double)(long long)r0.y * inv_scale);
                     o.z = (float)((double)(long long)r1.x * inv_scale); o.w = (float)((double)(long long)r1.y * inv_scale);
                     if (!fin[4 * e >= plane ? 1 : 0]) o = make_float4(nanv, nanv, nanv, nanv);   // (planes are whole float4s)
+                    }
                     gi4[e] = o;
                 }
                 __syncthreads();
@@ -371,89 +385,154 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
         if (livep[k]) part[tid + k * NT] = make_float2(gx[k] * mx[k], gy[k] * my[k]);
 }
 
-// ---- kernel B: parameter gradients from g_grid, one workgroup per image -----------------------------------
-template <int KMAX>
+// ---- kernel B: parameter gradients from g_grid.  B1: S workgroups per image, each over n / S pixels: dL/d score,
+// dL/d grid (sum of the sampling workgroups' slices) and a partial dL/dT per workgroup; B2: one workgroup per image
+// sums the S partials in a fixed order and applies inv_delta_C^T.  (Round 3 had one workgroup per image do all of it:
+// 129 us of the 551 us backward at batch 512, latency-bound with 2 workgroups per CU.)
+constexpr int kBwdMaxS = 8;
+
+// TABLE: 0 = classic table [1, x, y, rbf] (K columns), 1 = TPS_PP (rbf only + p_xy);  TRANSPOSED: p_hat_t (cols, n) given;
+// SCORE: 0 none, 1 (N, n, F), 2 transposed (N, F, n);  GSCORE: dL/d score wanted.
+// Work split (round 4): a workgroup walks its pixels 256 at a time.  Phase 1, thread = pixel: dL/d grid = sum of the
+// sampling workgroups' slices, stored and left in LDS.  Phase 2, wavefront w = table columns [w KPW, (w + 1) KPW),
+// lane = pixel (4 x 64 per chunk): everything a (pixel, column group) needs is requested before the first use, the
+// running dL/dT of the column group stays in 2 KPW registers.  (Round 3: thread = pixel over ALL columns -- a loop that
+// waited for memory once per column, 129 us per 512 images against ~30 us of traffic; unrolled with the loads batched
+// it needs 316 registers: one wavefront per SIMD.)  At the end a wavefront sums its own columns over its 64 lanes
+// through LDS in fp64: dL/dC' = inv_delta_C^T dL/dT cancels heavily (|inv_delta_C| up to ~220), the order of an fp32
+// reduction over thousands of pixels would show in the 4th digit of the result.
+template <int KMAX, int TABLE, bool TRANSPOSED, int SCORE, bool GSCORE>
 __global__ void __launch_bounds__(256)
-warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const float* __restrict__ g_grid_part, int slots)
+warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const float* __restrict__ g_grid_part, int slots,
+                       int S, double* __restrict__ gT_part)
 {
+    constexpr int KPW = KMAX / 4;                              // table columns per wavefront
     __shared__ float sT[kMaxK * 2];
-    __shared__ float sRed[4][kMaxK * 2];
-    __shared__ float sGT[kMaxK * 2];
-    const int b = blockIdx.x;
+    __shared__ float2 sGG[256];
+    __shared__ float sPart[4][2 * KPW][kWave + 1];
+    const int b = blockIdx.x / S, sl_ = blockIdx.x - b * S;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
-    const int K = P.F + 3;
+    const int K = P.F + 3, F = P.F, n = P.n;
     for (int i = tid; i < 2 * K; i += blockDim.x) sT[i] = P.T[(size_t)b * K * 2 + i];
-    __syncthreads();
 
-    float aT[KMAX][2];
+    float aT[KPW][2];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) aT[k][0] = aT[k][1] = 0.0f;
+    for (int j = 0; j < KPW; ++j) aT[j][0] = aT[j][1] = 0.0f;
 
-    for (int p = tid; p < P.n; p += blockDim.x) {
-        float2 gg;
-        if (slots > 0) {                                       // kernel A'': one slice per sampling workgroup; summed here
-            gg = make_float2(0.0f, 0.0f);                      // (empty slices -- an input that is absent -- hold zeros)
-            const float2* ps = reinterpret_cast<const float2*>(g_grid_part) + (size_t)b * slots * P.n + p;
-            for (int sl = 0; sl < slots; ++sl) { const float2 t = ps[(size_t)sl * P.n]; gg.x += t.x; gg.y += t.y; }
-            reinterpret_cast<float2*>(g_grid)[(size_t)b * P.n + p] = gg;       // dL/d grid, as documented
-        } else {
-            gg = reinterpret_cast<const float2*>(g_grid)[(size_t)b * P.n + p];
-        }
-        const float ggx = gg.x, ggy = gg.y;
+    const int per = (n + S - 1) / S;
+    const int p_lo = sl_ * per, p_hi = min(n, p_lo + per);
+    for (int p0 = p_lo; p0 < p_hi; p0 += 256) {
+        __syncthreads();                                       // sT written / the previous chunk's sGG consumed
+        {   // ---- phase 1: dL/d grid of pixel p0 + tid (the slices in ascending order) ----
+            const int p = p0 + tid;
+            float2 gg = make_float2(0.0f, 0.0f);
+            if (p < p_hi) {
+                if (slots > 0) {
+                    float2 part[2 * kBwdMaxG];
+                    const float2* ps = reinterpret_cast<const float2*>(g_grid_part) + (size_t)b * slots * n + p;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k < K) {
-                float v;
-                if (P.p_xy) {                                  // TPS_PP table: rbf only, [1, P.x, P.y] separate
-                    if (k == 0) v = 1.0f;
-                    else if (k < 3) v = P.p_xy[(size_t)p * 2 + (k - 1)];
-                    else v = P.p_hat_t ? P.p_hat_t[(size_t)(k - 3) * P.n + p] : P.p_hat[(size_t)p * P.p_hat_ld + (k - 3)];
+                    for (int sl = 0; sl < 2 * kBwdMaxG; ++sl) part[sl] = sl < slots ? ps[(size_t)sl * n] : make_float2(0.0f, 0.0f);
+                    gg = part[0];
+#pragma unroll
+                    for (int sl = 1; sl < 2 * kBwdMaxG; ++sl) if (sl < slots) { gg.x += part[sl].x; gg.y += part[sl].y; }
+                    reinterpret_cast<float2*>(g_grid)[(size_t)b * n + p] = gg;      // dL/d grid, as documented
                 } else {
-                    v = P.p_hat_t ? P.p_hat_t[(size_t)k * P.n + p] : P.p_hat[(size_t)p * P.p_hat_ld + k];
+                    gg = reinterpret_cast<const float2*>(g_grid)[(size_t)b * n + p];
                 }
-                if (k >= 3 && P.score) {
-                    const size_t so = P.score_t ? ((size_t)b * P.F + (k - 3)) * P.n + p
-                                                : ((size_t)b * P.n + p) * P.F + (k - 3);
-                    const float sc = P.score[so];
-                    if (P.g_score) P.g_score[so] = 0.5f * v * (ggx * sT[2 * k] + ggy * sT[2 * k + 1]);
-                    v = v * (0.5f * sc + 1.0f);
+            }
+            sGG[tid] = gg;
+        }
+        __syncthreads();
+        // ---- phase 2: this wavefront's columns of the chunk's pixels ----
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int p = p0 + it * kWave + lane;
+            if (p0 + it * kWave >= p_hi) break;
+            const bool livep = p < p_hi;
+            const int pc = livep ? p : p_hi - 1;
+            float v[KPW], sc[KPW];
+            float2 pxy = make_float2(0.0f, 0.0f);
+            if (TABLE == 1 && wv == 0) pxy = reinterpret_cast<const float2*>(P.p_xy)[pc];
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const int k = wv * KPW + j;
+                const int col = TABLE == 1 ? k - 3 : k;        // column of the table that holds row(p)[k]
+                v[j] = 0.0f; sc[j] = 0.0f;
+                if (k < K && col >= 0)
+                    v[j] = TRANSPOSED ? P.p_hat_t[(size_t)col * n + pc] : P.p_hat[(size_t)pc * P.p_hat_ld + col];
+                if (SCORE != 0 && k >= 3 && k < K)
+                    sc[j] = P.score[SCORE == 2 ? ((size_t)b * F + (k - 3)) * n + pc : ((size_t)b * n + pc) * F + (k - 3)];
+            }
+            if (TABLE == 1 && wv == 0) { v[0] = 1.0f; v[1] = pxy.x; v[2] = pxy.y; }
+            const float2 gg = livep ? sGG[it * kWave + lane] : make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < KPW; ++j) {
+                const int k = wv * KPW + j;
+                if (k < K) {
+                    float vv = v[j];
+                    if (SCORE != 0 && k >= 3) {
+                        if (GSCORE && livep) {
+                            const size_t so = SCORE == 2 ? ((size_t)b * F + (k - 3)) * n + p : ((size_t)b * n + p) * F + (k - 3);
+                            P.g_score[so] = 0.5f * vv * (gg.x * sT[2 * k] + gg.y * sT[2 * k + 1]);
+                        }
+                        vv = vv * (0.5f * sc[j] + 1.0f);
+                    }
+                    aT[j][0] = fmaf(vv, gg.x, aT[j][0]);
+                    aT[j][1] = fmaf(vv, gg.y, aT[j][1]);
                 }
-                aT[k][0] = fmaf(v, ggx, aT[k][0]);
-                aT[k][1] = fmaf(v, ggy, aT[k][1]);
             }
         }
     }
-    // ---- dL/dT: wavefront shuffle sums, then across the four wavefronts ----
+    // ---- the wavefront's columns: 64 partials each, added in lane order in fp64 ----
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
+    for (int j = 0; j < KPW; ++j) { sPart[wv][2 * j][lane] = aT[j][0]; sPart[wv][2 * j + 1][lane] = aT[j][1]; }
+    __syncthreads();
+    if (lane < 2 * KPW) {
+        const int k = wv * KPW + (lane >> 1);
         if (k < K) {
-            const float a = wave_sum(aT[k][0]), c = wave_sum(aT[k][1]);
-            if (lane == 0) { sRed[wv][2 * k] = a; sRed[wv][2 * k + 1] = c; }
+            double a = 0.0;
+            for (int j = 0; j < kWave; ++j) a += (double)sPart[wv][lane][j];
+            gT_part[((size_t)b * S + sl_) * (2 * kMaxK) + 2 * k + (lane & 1)] = a;
         }
     }
-    __syncthreads();
-    const int nw_ = blockDim.x >> 6;
+}
+
+// B2: dL/dT = sum of the S partials (ascending), dL/dC'[f] = sum_k inv_delta_C[k][f] dL/dT[k], in fp64, rounded once
+__global__ void __launch_bounds__(128)
+warp_bwd_ctrl_kernel(const BwdParams P, int S, const double* __restrict__ gT_part)
+{
+    __shared__ double sGT[kMaxK * 2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int K = P.F + 3;
     for (int i = tid; i < 2 * K; i += blockDim.x) {
-        float a = 0.0f;
-        for (int w2 = 0; w2 < nw_; ++w2) a += sRed[w2][i];
+        double a = 0.0;
+        for (int sl = 0; sl < S; ++sl) a += gT_part[((size_t)b * S + sl) * (2 * kMaxK) + i];
         sGT[i] = a;
     }
     __syncthreads();
-    // ---- dL/dC'[f] = sum_k inv_delta_C[k][f] dL/dT[k] ----
     for (int i = tid; i < 2 * P.F; i += blockDim.x) {
         const int f = i >> 1, xy = i & 1;
-        float a = 0.0f;
-        for (int k = 0; k < K; ++k) a = fmaf(P.inv_delta_c[(size_t)k * K + f], sGT[2 * k + xy], a);
-        P.g_ctrl[(size_t)b * P.F * 2 + i] = a;
+        double a = 0.0;
+        for (int k = 0; k < K; ++k) a = fma((double)P.inv_delta_c[(size_t)k * K + f], sGT[2 * k + xy], a);
+        P.g_ctrl[(size_t)b * P.F * 2 + i] = (float)a;
     }
 }
 
 }  // namespace
 
+namespace { int g_bwd_fixed_point = 0; }
+
+TPSPP_EXPORT int tpspp_warp_bwd_set_accumulator(int fixed_point)
+{
+    g_bwd_fixed_point = fixed_point ? 1 : 0;
+    return TPSPP_OK;
+}
+
 TPSPP_EXPORT size_t tpspp_warp_bwd_workspace_floats(int N, int Ho, int Wo)
 {
     if (N <= 0 || Ho <= 0 || Wo <= 0) return 0;
-    return (size_t)N * Ho * Wo * 2 * (1 + 2 * kBwdMaxG);      // dL/d grid + the sampling workgroups' slices
+    return (size_t)N * Ho * Wo * 2 * (1 + 2 * kBwdMaxG)       // dL/d grid + the sampling workgroups' slices
+         + (size_t)N * kBwdMaxS * 2 * kMaxK * 2 + 2;           // + the parameter kernel's partial dL/dT (fp64) per workgroup
 }
 
 TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
@@ -506,10 +585,15 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
         if (P.nin == 1 && hipMemsetAsync(part, 0, (size_t)N * slots * P.n * 2 * sizeof(float), st) != hipSuccess)
             return tpspp::check_launch("tpspp_warp_bwd(memset)");     // the second input's slices stay empty
         const dim3 g2((unsigned)(G * P.nin), (unsigned)N);
-        if (P.n <= 256)       hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<1, 256>), g2, block, accb, st, P, G, cpt0, cpt1, part);
-        else if (P.n <= 512)  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<2, 256>), g2, block, accb, st, P, G, cpt0, cpt1, part);
-        else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256>), g2, block, accb, st, P, G, cpt0, cpt1, part);
-        else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part);
+        auto go = [&](auto f64) {
+            constexpr bool F64 = decltype(f64)::value;
+            if (P.n <= 256)       hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<1, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
+            else if (P.n <= 512)  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<2, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
+            else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
+            else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024, F64>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part);
+        };
+        if (g_bwd_fixed_point) go(std::false_type{});
+        else go(std::true_type{});
     } else {
     if (hipMemsetAsync(g_grid_ws, 0, (size_t)N * P.n * 2 * sizeof(float), st) != hipSuccess)
         return tpspp::check_launch("tpspp_warp_bwd(memset)");
@@ -543,9 +627,34 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
                            block, 0, st, P, chunks0, g_grid_ws);
     }
     }
-    const dim3 grid_dim((unsigned)N);
-    if (F + 3 <= 24)      hipLaunchKernelGGL(warp_bwd_params_kernel<24>, grid_dim, block, 0, st, P, g_grid_ws, part, slots);
-    else if (F + 3 <= 36) hipLaunchKernelGGL(warp_bwd_params_kernel<36>, grid_dim, block, 0, st, P, g_grid_ws, part, slots);
-    else                  hipLaunchKernelGGL(warp_bwd_params_kernel<64>, grid_dim, block, 0, st, P, g_grid_ws, part, slots);
+    // parameter gradients: S workgroups per image (about eight workgroups per CU in all, at least 256 pixels each), then
+    // the reduction over S
+    int S = (2048 + N - 1) / N;
+    S = S < 1 ? 1 : (S > kBwdMaxS ? kBwdMaxS : S);
+    while (S > 1 && (P.n + S - 1) / S < 256) --S;
+    // (fp64, behind the slices, at an 8-byte boundary)
+    double* gT_part = reinterpret_cast<double*>(
+        (reinterpret_cast<uintptr_t>(g_grid_ws + (size_t)N * P.n * 2 * (1 + 2 * kBwdMaxG)) + 7) & ~(uintptr_t)7);
+    const dim3 grid_dim((unsigned)(N * S));
+    auto launch_b = [&](auto kmax, auto table, auto transposed, auto scorem, auto gscore) {
+        auto kern = warp_bwd_params_kernel<decltype(kmax)::value, decltype(table)::value, decltype(transposed)::value,
+                                           decltype(scorem)::value, decltype(gscore)::value>;
+        hipLaunchKernelGGL(kern, grid_dim, block, 0, st, P, g_grid_ws, part, slots, S, gT_part);
+    };
+    auto pick_score = [&](auto kmax, auto table, auto transposed) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if (!score) launch_b(kmax, table, transposed, I0{}, std::false_type{});
+        else if (P.score_t) { if (g_score) launch_b(kmax, table, transposed, I2{}, std::true_type{}); else launch_b(kmax, table, transposed, I2{}, std::false_type{}); }
+        else { if (g_score) launch_b(kmax, table, transposed, I1{}, std::true_type{}); else launch_b(kmax, table, transposed, I1{}, std::false_type{}); }
+    };
+    auto pick_table = [&](auto kmax) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        if (p_xy) { if (p_hat_t_or_null) pick_score(kmax, I1{}, std::true_type{}); else pick_score(kmax, I1{}, std::false_type{}); }
+        else { if (p_hat_t_or_null) pick_score(kmax, I0{}, std::true_type{}); else pick_score(kmax, I0{}, std::false_type{}); }
+    };
+    if (F + 3 <= 24)      pick_table(std::integral_constant<int, 24>{});
+    else if (F + 3 <= 36) pick_table(std::integral_constant<int, 36>{});
+    else                  pick_table(std::integral_constant<int, 64>{});
+    hipLaunchKernelGGL(warp_bwd_ctrl_kernel, dim3((unsigned)N), dim3(128), 0, st, P, S, gT_part);
     return tpspp::check_launch("tpspp_warp_bwd");
 }

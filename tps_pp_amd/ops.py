@@ -893,6 +893,12 @@ def linear(x, cw, relu=False):
     return y.view(-1, n).t().contiguous()
 
 
+def set_warp_bwd_accumulator(fixed_point: bool = False):
+    """`tpspp_warp_bwd_set_accumulator`: how dL/d input is accumulated in LDS (default: fp64 atomics; True: round 3's
+    64-bit fixed point, bitwise reproducible but with a per-pass scale).  Process-wide; tests and measurements only."""
+    _lib.check(_lib.lib().tpspp_warp_bwd_set_accumulator(1 if fixed_point else 0), "tpspp_warp_bwd_set_accumulator")
+
+
 def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
     """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel, 3 the same without the mirror trick, 4 plane-streaming
     kernel, 5 image-pair kernel (2..5: error if not applicable);
