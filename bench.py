@@ -323,6 +323,17 @@ def recognizer_measurement(dev, timeit):
     from tps_pp_amd import metrics
     agree16 = metrics.precision_agreement(m, img[:256], metas[:256], torch.bfloat16)
     agreex3 = metrics.precision_agreement(m, img[:256], metas[:256], "bf16x3")
+    # where the bf16 configuration's flipped decisions come from: one stage in bf16 at a time (the decoder's per-step
+    # projections and the classifier are on the three-term split in EVERY reduced mode, include/tpspp.h)
+    bf = torch.bfloat16
+    stages = {}
+    for name, md in (("bf16_backbone__fp32_head", dict(backbone=bf)),
+                     ("fp32_backbone__bf16_head", dict(encoder=bf, decoder=bf)),
+                     ("fp32_backbone__bf16_encoder_only", dict(encoder=bf)),
+                     ("fp32_backbone__bf16_decoder_keys_values_only", dict(decoder=bf)),
+                     ("bf16_backbone__bf16x3_head", dict(backbone=bf, encoder="bf16x3", decoder="bf16x3"))):
+        r = metrics.precision_agreement(m, img[:256], metas[:256], md)
+        stages[name] = {k: r[k] for k in ("teacher_forced_argmax_agreement", "greedy_word_agreement", "greedy_char_agreement")}
     return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
             "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
             "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
@@ -337,7 +348,8 @@ def recognizer_measurement(dev, timeit):
                                        "ms_encoder": t_enc16, "ms_greedy_decoder_40_steps": t_dec16,
                                        "strings_equal_to_fp32_cpu_oracle":
                                            f"{sum(a == b for a, b in zip(got16h, want))}/{k}",
-                                       "agreement_with_fp32_kernels_256_images": agree16},
+                                       "agreement_with_fp32_kernels_256_images": agree16,
+                                       "agreement_by_stage_256_images": stages},
             "data": "synthetic images, random-init weights"}
 
 

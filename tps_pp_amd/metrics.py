@@ -68,7 +68,7 @@ def eval_ocr_metric(pred_texts, gt_texts, all_metrics=False):
 
 def precision_agreement(model, img, img_metas, mode):
     """How far a reduced-precision configuration of a recogniser (`mode`: torch.bfloat16 or "bf16x3", see
-    `EncodeDecodeRecognizer.set_compute_dtype`) moves its decisions away from the exact-fp32 kernels of the SAME model on
+    `EncodeDecodeRecognizer.set_compute_dtype`, or a dict with one such mode per stage: backbone / encoder / decoder) moves its decisions away from the exact-fp32 kernels of the SAME model on
     the same images (BASELINE.json configs[4], "word-accuracy parity check"):
       * teacher forcing: the reduced-precision model is fed the fp32 run's greedy tokens; fraction of positions (up to and
         including the fp32 run's <EOS>) whose arg-max is the fp32 one -- every position is an independent decision;
@@ -89,6 +89,22 @@ def precision_agreement(model, img, img_metas, mode):
             return dec(feat, out_enc, None, metas, train_mode=False)
         return dec(feat, out_enc, dict(padded_targets=forced), metas, train_mode=True)
 
+    def apply(md):
+        """`md`: one mode for every stage, or a dict per stage (keys backbone / encoder / decoder; missing = fp32) --
+        the per-stage form is how bench.py locates which stage's bf16 arithmetic flips decisions."""
+        if not isinstance(md, dict):
+            model.set_compute_dtype(md)
+            return
+        model.set_compute_dtype(None)
+        bb = md.get("backbone")
+        model.backbone.compute_dtype = bb
+        if model.tpsnet is not None:
+            model.tpsnet.compute_dtype = bb if bb == "bf16x3" else None
+        if model.encoder is not None and hasattr(model.encoder, "compute_dtype"):
+            model.encoder.compute_dtype = md.get("encoder")
+        if model.decoder is not None and hasattr(model.decoder, "compute_dtype"):
+            model.decoder.compute_dtype = md.get("decoder")
+
     with torch.no_grad():
         model.set_compute_dtype(None)
         ref = run()                                                   # (N, L, num_classes - 1) softmax scores
@@ -98,7 +114,7 @@ def precision_agreement(model, img, img_metas, mode):
         start = torch.full((n, 1), dec.start_idx, dtype=ref_tok.dtype, device=ref_tok.device)
         forced = torch.cat([start, ref_tok[:, :L - 1]], dim=1)        # position t sees <BOS>, tok_0 .. tok_{t-1}
         self_tf = run(forced).argmax(-1)                              # sanity: the fp32 kernels reproduce themselves
-        model.set_compute_dtype(mode)
+        apply(mode)
         low_tf = run(forced).argmax(-1)
         low = run()
         low_txt = conv.idx2str(conv.tensor2idx(low)[0])
