@@ -266,8 +266,10 @@ def classic_warp_extra(dev, hw, nstreams):
     return {"launch_us": usn, "streams": nstreams, "frac_of_hbm_peak": bytes_launch / (usn * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "one_stream": {"launch_us": us1, "frac_of_hbm_peak": bytes_launch / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS},
             "algorithmic_bytes_per_launch": bytes_launch, "max_abs_err_vs_oracle": err,
-            "kernel": f"tps_warp_img_kernel<20,{C},{Hh},{Ww},...> (in-place staging)" if bool(flags & ops.TABLE_PACKED)
-            else "LDS-staged kernel", "rotating_buffer_sets": int(nbuf)}
+            "kernel": ("tps_warp_img_kernel<20,{},{},{},...> (in-place staging)".format(C, Hh, Ww)
+                       if (Hh, Ww) in ((32, 100), (32, 128), (48, 160), (32, 64), (32, 160))
+                       else "tps_warp_geo_kernel<20,{},QP,...> (in-place staging, run-time geometry)".format(C))
+            if bool(flags & ops.TABLE_PACKED) else "LDS-staged kernel", "rotating_buffer_sets": int(nbuf)}
 
 
 def recognizer_measurement(dev, timeit):
@@ -732,6 +734,10 @@ def main():
             torch.cuda.empty_cache()
             rec["extra"] = extra_measurements(dev)
             rec["extra"]["classic_warp_32x128_batch512_fp32"] = classic_warp_extra(dev, (32, 128), S)
+            # the reference's recog-config test shape (tests/test_models/test_recog_config.py:103-157), and a geometry
+            # that only the run-time-geometry in-place kernel takes (tpspp_warp_geo.h)
+            rec["extra"]["classic_warp_32x160_batch512_fp32"] = classic_warp_extra(dev, (32, 160), S)
+            rec["extra"]["classic_warp_64x200_batch512_fp32"] = classic_warp_extra(dev, (64, 200), S)
         if sharded is not None:
             rec.setdefault("extra", {})["recognizer_sharded"] = sharded
         if world == 1 and not a.no_cpu_baseline:

@@ -10,8 +10,8 @@ import bench  # noqa: E402
 from tps_pp_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-for hw in ((32, 100), (32, 128), (48, 160), (32, 64)):
-    for kern in (2, 6):
+for hw in ((32, 100), (32, 128), (48, 160), (32, 64), (32, 160), (64, 256), (64, 200)):
+    for kern in (2, 6, 7):          # round-1 LDS kernel, instantiated in-place kernel, in-place kernel with run-time geometry
         ops.set_warp_tuning(0, 0, kern, 0)
         try:
             r = bench.classic_warp_extra(dev, hw, 3)

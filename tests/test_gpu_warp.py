@@ -208,6 +208,10 @@ def test_tpspp_warp_bf16_io(cuda, oracle):
     (4, 3, 48, 160, 48, 160, 20, 0.1),      # pair = 180 KB: too big for the pair kernel
     (6, 3, 16, 64, 16, 64, 20, 0.3),        # small planes: LDS kernel with 2 pixel slots
     (3, 3, 32, 100, 31, 99, 20, 0.2),       # odd output size: table is not mirror-symmetric
+    (3, 3, 32, 160, 32, 160, 20, 0.1),      # the reference's recog-config test shape (test_recog_config.py:103-157): run-time-geometry in-place kernel
+    (2, 1, 64, 256, 64, 256, 20, 0.1),      # ... 64 KB plane, two workgroups ("bands") per image
+    (3, 4, 48, 160, 48, 160, 20, 0.3),      # ... four channels, 123 KB per image
+    (5, 3, 64, 200, 64, 200, 20, 0.6),      # ... W % 32 = 8: pixel blocks of 8 x 4; clamped and out-of-image taps
 ])
 def test_classic_warp_vs_oracle(cuda, oracle, N, C, H, W, Ho, Wo, F, perturb):
     Kc = oracle.classic_constants(F, (Ho, Wo))
@@ -444,3 +448,36 @@ def test_bad_arguments_fail_loudly(cuda):
         ops.warp(z(1, 1, 4, 4), z(1, 70, 2), z(73, 73), z(16, 73), (4, 4))   # F + 3 > 64
     with pytest.raises(ValueError):
         ops.warp(z(1, 1, 4, 4), z(1, 4, 2), z(7, 7), z(15, 7), (4, 4))       # P_hat rows != n
+
+
+@pytest.mark.parametrize("N,C,H,W", [(3, 3, 32, 160), (2, 1, 64, 256), (3, 4, 48, 160), (5, 3, 64, 200), (4, 3, 32, 100),
+                                     (2, 1, 16, 64), (3, 3, 32, 64), (1, 4, 32, 128)])
+def test_runtime_geometry_kernel_forced(cuda, oracle, N, C, H, W):
+    """`kernel_choice` 7 = REQUIRE the in-place kernel with run-time geometry (an error if the shape does not qualify, so
+    a pass proves which kernel ran): bit for bit the oracle, grid and tap indices included, with specials in the image
+    (a NaN / inf tap must poison exactly the outputs the oracle's taps reach) -- also for the geometries that normally
+    take the instantiated kernels."""
+    F = 20
+    Kc = oracle.classic_constants(F, (H, W))
+    ctrl = oracle.classic_initial_ctrl(F)[None] + 0.4 * synth.dyadic((N, F, 2), "g.ctrl", N)
+    img = synth.dyadic((N, C, H, W), "g.img", N + 3).copy()
+    flat = img.reshape(-1)
+    flat[5::1013] = np.inf
+    flat[7::2027] = -np.inf
+    flat[11::3001] = np.nan
+    flat[13::997] = -0.0
+    ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
+    P_hat = dev(Kc["P_hat"], cuda)
+    prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
+    assert packed == ops.TABLE_PACKED
+    ops.set_warp_tuning(kernel_choice=7)
+    try:
+        for want in (True, False):
+            out, _, grid, idx = ops.warp(dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), P_hat, (H, W),
+                                         want_grid=want, want_idx=want, P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+            assert_biteq(out, ref["out0"], "warped")
+            if want:
+                assert_biteq(grid, ref["grid"], "grid")
+                assert_biteq(idx, ref["idx"], "corner indices")
+    finally:
+        ops.set_warp_tuning()

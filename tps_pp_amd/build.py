@@ -22,6 +22,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ff
          "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+# per-file extra flags: tpspp_warp_geo.hip without the SLP vectoriser (it packs the grid chains into v_pk_fma_f32: slower)
+EXTRA = {"tpspp_warp_geo.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -68,7 +72,7 @@ def _build_locked(force, verbose):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             return obj, None
-        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + cflags + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -24,6 +24,7 @@
 #include "tpspp_warp_stream.h"
 #include "tpspp_warp_pair.h"
 #include "tpspp_warp_img.h"
+#include "tpspp_warp_geo_launch.h"
 
 #include <cstring>
 
@@ -771,10 +772,11 @@ void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStre
 TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice,
                                        int bands)
 {
-    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 6, "kernel_choice must be 0..6");
+    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 7, "kernel_choice must be 0..7");
     TPSPP_REQUIRE(bands >= 0 && bands <= 8, "bands must be in [0, 8]");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
+    tpspp::geo_set_bands(kernel_choice == 7 ? bands : 0);
     g_tune_bands = bands;
     TPSPP_REQUIRE(images_per_group >= 0 && images_per_group <= 64, "images_per_group out of range");
     TPSPP_REQUIRE(threads_per_group == 0 || (threads_per_group % 64 == 0 && threads_per_group >= 64 &&
@@ -870,25 +872,10 @@ TPSPP_EXPORT int tpspp_transpose_p_hat(const float* p_hat, int p_hat_ld, int n, 
 }
 
 namespace {
-// Quadrant pixels per thread of the packed table / the in-place kernel for an output geometry: the smallest divisor
-// of the row groups (tpspp_warp_img.h: ImgGeo) that leaves at most 13 compute wavefronts (0: the geometry has no packed
-// form).  32x100 -> 1 (the image-pair kernel's layout), 32x128 -> 2, 48x160 -> 3.
-int img_qp(int Ho, int Wo)
-{
-    if (Ho <= 0 || Wo <= 0 || Wo % 4 != 0 || Ho % 16 != 0) return 0;
-    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
-    const int CG = ((Wo / 2) + BW - 1) / BW, RG = (Ho / 2) / BH;
-    if (CG * BW > Wo) return 0;
-    for (int qp = 1; qp <= RG && qp <= 4; ++qp)
-        if (RG % qp == 0 && (CG * (RG / qp) * 32 + kWave - 1) / kWave <= 13) return qp;
-    return 0;
-}
-// compute threads of that mapping
-int img_nthr(int Ho, int Wo, int QP)
-{
-    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
-    return (((Wo / 2) + BW - 1) / BW) * (((Ho / 2) / BH) / QP) * 32;
-}
+// Quadrant pixels per thread of the packed table: tpspp::geo_qp (tpspp_warp_geo.hip).  32x100 -> 1 (the image-pair
+// kernel's layout), 32x128 -> 2, 48x160 -> 3; geometries with more than 13 wavefronts of quadrant pixels: up to 4.
+int img_qp(int Ho, int Wo) { return tpspp::geo_qp(Ho, Wo); }
+int img_nthr(int Ho, int Wo, int QP) { return tpspp::geo_nthr(Ho, Wo, QP); }
 }  // namespace
 
 TPSPP_EXPORT size_t tpspp_prepared_table_floats(int Ho, int Wo, int F)
@@ -1055,6 +1042,8 @@ bool launch_img_geo(int C, int H, int W, const float* in, const float* ctrl, con
     TPSPP_IMG_GEO(1, 32, 128, 1, 2, 1, 2)
     TPSPP_IMG_GEO(3, 48, 160, 1, 3, 3, 1)
     TPSPP_IMG_GEO(1, 48, 160, 1, 3, 3, 1)
+    TPSPP_IMG_GEO(3, 32, 160, 1, 2, 2, 1)      // the reference's recog-config test shape (tests/test_models/test_recog_config.py:103-157)
+    TPSPP_IMG_GEO(1, 32, 160, 1, 2, 1, 2)
     TPSPP_IMG_GEO(3, 32, 64, 2, 1, 3, 1)
     TPSPP_IMG_GEO(1, 32, 64, 2, 1, 1, 1)
 #undef TPSPP_IMG_GEO
@@ -1117,6 +1106,12 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
             return tpspp::check_launch("tpspp_warp_fwd(in-place)");
         if (g_tune_kernel == 6)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the in-place kernel");
+        // every other geometry that fits the LDS: the in-place kernel with run-time geometry (tpspp_warp_geo.h)
+        if (packed_ok && (g_tune_kernel == 0 || g_tune_kernel == 7) &&
+            tpspp::launch_geo_kernel(C0, Ho, Wo, F, in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st))
+            return tpspp::check_launch("tpspp_warp_fwd(in-place, run-time geometry)");
+        if (g_tune_kernel == 7)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the run-time-geometry in-place kernel");
     }
 
     // ---- LDS-staged kernel: single small input, classic layout, transposed table available ----

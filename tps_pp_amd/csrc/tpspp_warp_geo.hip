@@ -1,0 +1,124 @@
+// Launcher of the run-time-geometry in-place warp kernel (tpspp_warp_geo.h): geometry planning + the (C, QP, AUX)
+// instantiations.  Its own translation unit: compiled with -fno-slp-vectorize (tps_pp_amd/build.py) -- the vectoriser
+// packs the (x, y) pairs of the grid chains into v_pk_fma_f32, which is slower here (profiles/r04_warp_lab.txt: a
+// packed FMA occupies the SIMD for two passes and the kernel is bound by VALU time, not by issue slots).
+#include "tpspp_common.h"
+#include "tpspp_warp_geo.h"
+#include "tpspp_warp_geo_launch.h"
+
+namespace tpspp {
+
+using tpspp_dev::kWave;
+
+// the packed table's quadrant pixels per thread for an output geometry (0: no packed form).  The smallest divisor of the
+// row groups that leaves at most 13 compute wavefronts per image -- the layout the image-pair kernel and the
+// instantiated in-place kernels (tpspp_warp_img.h) were built for --, else the largest divisor <= 4: the run-time
+// kernel then splits an image over several workgroups ("bands").
+int geo_qp(int Ho, int Wo)
+{
+    if (Ho <= 0 || Wo <= 0 || Wo % 4 != 0 || Ho % 16 != 0) return 0;
+    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
+    const int CG = ((Wo / 2) + BW - 1) / BW, RG = (Ho / 2) / BH;
+    if (CG * BW > Wo || RG < 1) return 0;
+    for (int qp = 1; qp <= RG && qp <= 4; ++qp)
+        if (RG % qp == 0 && (CG * (RG / qp) * 32 + kWave - 1) / kWave <= 13) return qp;
+    for (int qp = 4; qp >= 1; --qp)
+        if (RG % qp == 0) return qp;
+    return 0;
+}
+
+int geo_nthr(int Ho, int Wo, int QP)
+{
+    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
+    return (((Wo / 2) + BW - 1) / BW) * (((Ho / 2) / BH) / QP) * 32;
+}
+
+namespace {
+
+struct Plan { int QP, BW, CG, RGB, bands, nthr, NW, nload; size_t lds; };
+
+int g_geo_force_bands = 0;   // lab knob (tpspp_warp_set_tuning's `bands` with kernel_choice 7): 0 = heuristic
+
+bool plan_geo(int C, int H, int W, int F, Plan* p)
+{
+    if (!(C == 1 || C == 3 || C == 4) || F != 20) return false;
+    const int QP = geo_qp(H, W);
+    if (QP == 0 || (H * W) % 4 != 0) return false;
+    p->QP = QP;
+    p->BW = tpspp_img::img_block_w(W);
+    const int BH = 32 / p->BW;
+    p->CG = ((W / 2) + p->BW - 1) / p->BW;
+    p->RGB = ((H / 2) / BH) / QP;
+    p->lds = tpspp_geo::geo_lds_bytes(F + 3, C, H, W);
+    if (p->lds > 160 * 1024) return false;
+    // loaders: one per ~40 KB of image; workgroup size: <= 16 wavefronts, <= 12 from QP = 3 on (register budget)
+    p->nload = (int)((size_t)C * H * W * 4 / (40 * 1024)) + 1;
+    if (p->nload > 3) p->nload = 3;
+    const int max_waves = QP >= 3 ? 12 : 16;
+    for (int B = 1; B <= p->RGB; ++B) {
+        if (p->RGB % B) continue;
+        if (g_geo_force_bands > 0 && B != g_geo_force_bands && B < p->RGB) continue;
+        const int nthr = p->CG * (p->RGB / B) * 32;
+        const int NW = (nthr + kWave - 1) / kWave;
+        if (NW + p->nload <= max_waves && NW <= 13) { p->bands = B; p->nthr = nthr; p->NW = NW; return true; }
+    }
+    return false;
+}
+
+template <int C, int QP, bool AUX>
+void launch_one(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
+{
+    auto kern = tpspp_geo::tps_warp_geo_kernel<20, C, QP, AUX>;
+    static bool attr_done[kMaxDevices] = {};
+    if (first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(P.N * pl.bands)), dim3((unsigned)((pl.NW + pl.nload) * kWave)), pl.lds, st, P);
+}
+
+template <int C, int QP>
+void launch_aux(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
+{
+    if (P.grid || P.idx) launch_one<C, QP, true>(P, pl, st);
+    else launch_one<C, QP, false>(P, pl, st);
+}
+
+template <int C>
+void launch_qp(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
+{
+    switch (pl.QP) {
+    case 1: launch_aux<C, 1>(P, pl, st); break;
+    case 2: launch_aux<C, 2>(P, pl, st); break;
+    case 3: launch_aux<C, 3>(P, pl, st); break;
+    default: launch_aux<C, 4>(P, pl, st); break;
+    }
+}
+
+}  // namespace
+
+void geo_set_bands(int bands) { g_geo_force_bands = bands; }
+
+bool geo_kernel_applicable(int C, int H, int W, int F)
+{
+    Plan pl;
+    return plan_geo(C, H, W, F, &pl);
+}
+
+bool launch_geo_kernel(int C, int H, int W, int F, const float* in, const float* ctrl, const float* inv_delta_c,
+                       const float* packed, int N, float* out, float* grid, int32_t* idx, hipStream_t st)
+{
+    Plan pl;
+    if (!plan_geo(C, H, W, F, &pl)) return false;
+    tpspp_geo::GeoParams P;
+    P.in = in; P.ctrl = ctrl; P.inv_delta_c = inv_delta_c; P.packed = packed; P.N = N;
+    P.out = out; P.grid = grid; P.idx = idx;
+    P.H = H; P.W = W; P.BW = pl.BW; P.CG = pl.CG; P.RGB = pl.RGB; P.bands = pl.bands; P.nthr = pl.nthr; P.NW = pl.NW;
+    P.img_off = tpspp_geo::geo_img_off(F + 3);
+    if (C == 1) launch_qp<1>(P, pl, st);
+    else if (C == 3) launch_qp<3>(P, pl, st);
+    else launch_qp<4>(P, pl, st);
+    return true;
+}
+
+}  // namespace tpspp

@@ -37,6 +37,9 @@ using tpspp_pair::perm_y;
 using tpspp_pair::store16_nt;
 using tpspp_pair::v4f;
 using tpspp_pair::wait_flag;
+using tpspp_pair::wait_flag_lds;
+using tpspp_pair::make_taps_lite;
+using tpspp_pair::TapsLite;
 
 struct ImgParams {
     const float* in; const float* ctrl; const float* inv_delta_c;
@@ -235,7 +238,7 @@ tps_warp_img_kernel(const ImgParams P)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<int*>(sFlag), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    wait_flag(sFlag + 0, IMGS);
+    wait_flag_lds(sFlag + 0, IMGS);                          // (LDS-instruction poll: tpspp_warp_pair.h)
     IMG_STAMP(0);                                            // T ready
 
     // ---- 8 QP IMGS FMA chains: QP quadrant pixels x 4 mirror pixels x IMGS images x (x, y), each k-ascending from zero ----
@@ -304,7 +307,7 @@ tps_warp_img_kernel(const ImgParams P)
         for (int j = 0; j < QP; ++j)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const Taps t = make_taps(gx[im][j][m], gy[im][j][m], H, W);
+                const TapsLite t = make_taps_lite(gx[im][j][m], gy[im][j][m], H, W);   // same bits, fewer VALU instructions
                 if constexpr (AUX) {
                     const bool st = live && !((m & 1) && xdup) && (im == 0 || hasB);
                     if (P.grid && st)
@@ -339,7 +342,7 @@ tps_warp_img_kernel(const ImgParams P)
     static_for<IMGS>([&](auto imc) {
         constexpr int im = decltype(imc)::value;
         if (im == 1 && !hasB) { store_image(b0); return; }   // odd batch: the last workgroup has no image B
-        wait_flag(sFlag + 1 + im, NLOAD);                    // image `im` has landed
+        wait_flag_lds(sFlag + 1 + im, NLOAD);                // image `im` has landed
         if (im == 0) IMG_STAMP(2);
         // the four taps of every channel at immediate offsets from the pixel's address; a tap outside the image is read
         // anyway (the word exists: next row, next plane, next image or the pad behind the last one)
@@ -444,7 +447,7 @@ tps_warp_img_kernel(const ImgParams P)
 }
 
 // [wavefront][QP][KG][lane][4]: the table values of thread (wavefront, lane)'s quadrant pixel j, q = 4 g .. 4 g + 3
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 pack_img_table_kernel(const float* __restrict__ p_hat, int p_hat_ld, int OW, int CG, int QP, int BW, int nthr, int K,
                       float* __restrict__ packed)
 {

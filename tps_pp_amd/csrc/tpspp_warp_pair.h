@@ -91,6 +91,7 @@ __device__ __forceinline__ void flag_add(unsigned addr, int one)
 struct TapsLite {
     int o00;                  // offset of the north-west tap inside a plane
     float nw, ne, sw, se;
+    float wx, wy;             // fractional parts: nw = (1-wy)(1-wx), ne = (1-wy) wx, sw = wy (1-wx), se = wy wx
     bool inx, iny;            // is the east column / south row inside the plane
     int x0, y0;
 };
@@ -110,6 +111,7 @@ __device__ __forceinline__ TapsLite make_taps_lite(float gx, float gy, int H, in
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(y0) : "v"(iy));
     const float e = 1.0f - w, s = 1.0f - nn;
     t.nw = s * e; t.ne = s * w; t.sw = nn * e; t.se = nn * w;
+    t.wx = w; t.wy = nn;
     t.inx = ix < limx;              // x0 + 1 < W  <=>  floor(ix) < W - 1  <=>  ix < W - 1
     t.iny = iy < limy;
     t.o00 = __mul24(y0, W) + x0;
@@ -166,7 +168,7 @@ tps_warp_pair_kernel(const PairParams P)
     using Geo = PairGeo<OH, OW>;
     constexpr int K = F + 3;
     constexpr int H = HC, W = WC;
-    constexpr int nthr = Geo::nthr, NW = Geo::NW, NLOAD = kPairLoaders;
+    constexpr int NW = Geo::NW, NLOAD = kPairLoaders;
     constexpr int n = OH * OW;
     static_assert(NW + NLOAD <= 16, "too many wavefronts");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -526,25 +528,8 @@ tps_warp_pair_kernel(const PairParams P)
 #undef PAIR_STAMP
 }
 
-// [wavefront][KG][lane][4]: the table values of thread (wavefront, lane)'s pixel, q = 4 j .. 4 j + 3
-__global__ void __launch_bounds__(256)
-pack_mirror_table_kernel(const float* __restrict__ p_hat, int p_hat_ld, int OW, int CG, int nthr, int K,
-                         float* __restrict__ packed)
-{
-    const int KG = (K + 3) / 4;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // index into packed
-    const int total = ((nthr + kWave - 1) / kWave) * KG * kWave * 4;
-    if (i >= total) return;
-    const int comp = i & 3, l = (i >> 2) & (kWave - 1), j = (i >> 8) % KG, w = (i >> 8) / KG;
-    const int t = w * kWave + l, q = 4 * j + comp;
-    float val = 0.0f;
-    if (t < nthr && q < K) {
-        int r, c;
-        pair_thread_pixel(t, CG, &r, &c);
-        val = p_hat[(size_t)(r * OW + c) * p_hat_ld + q];
-    }
-    packed[i] = val;
-}
+// (The packed table -- [wavefront][KG][lane] x 16 bytes in the thread order of the round-2 mapping, 13 column groups of
+// 4 per row group -- is written by tpspp_img::pack_img_table_kernel with QP = 1: tpspp_prepare_mirror_table.)
 
 // LDS bytes of one workgroup and the offsets the kernel needs
 template <int F, int C, int HC, int WC, int OH, int OW>
