@@ -86,20 +86,31 @@ def cpu_baseline(img, ctrl, inv, p_hat, budget_s=10.0):
     O.build()
     threads = O.max_threads()
 
+    out_buf = np.empty((img.shape[0], C, H, W), dtype=np.float32)   # reused: no first-touch page faults inside the timing
+
     def sample(nthreads, budget):
         O.set_threads(nthreads)
-        O.warp(img, ctrl, inv, p_hat, (H, W))                       # warm-up (page faults, OpenMP)
+        O.warp(img, ctrl, inv, p_hat, (H, W), out0=out_buf)         # warm-up (page faults, OpenMP)
         t0 = time.perf_counter()
         reps = 0
         while True:
-            O.warp(img, ctrl, inv, p_hat, (H, W))
+            O.warp(img, ctrl, inv, p_hat, (H, W), out0=out_buf)
             reps += 1
-            if time.perf_counter() - t0 >= budget or reps >= 2000:
+            if time.perf_counter() - t0 >= budget or reps >= 20000:
                 break
         return reps, time.perf_counter() - t0
 
-    reps1, dt1 = sample(1, 5.0)
-    reps, dt = sample(threads, budget_s)
+    reps1, dt1 = sample(1, 4.0)
+    # thread sweep (1.5 s each): a 512-image batch is 27 ms of work on one core, so beyond a few dozen threads a call is
+    # dominated by the OpenMP fork / join and the Python call; the baseline is quoted at the best count
+    sweep = {}
+    for t in sorted({min(threads, x) for x in (8, 16, 32, 64, threads)}):
+        r_, d_ = sample(t, 1.5)
+        sweep[t] = r_ * BATCH / d_
+    best_t = max(sweep, key=sweep.get)
+    reps, dt = sample(best_t, budget_s - 2.0)
+    all_threads_rate = sweep[threads]
+    threads_used = best_t
     O.set_threads(threads)
     # the same arithmetic as the reference composes it, on PyTorch's CPU kernels (torch.bmm x2 +
     # F.grid_sample; tps_preprocessor.py:71-83,270-282), all host threads, ~6 s sample
@@ -120,10 +131,15 @@ def cpu_baseline(img, ctrl, inv, p_hat, budget_s=10.0):
             ref_step()
             treps += 1
         tdt = time.perf_counter() - t1
-    return {"value": reps * BATCH / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(),
+    return {"value": reps * BATCH / dt, "unit": "images/s", "cores": threads_used, "kind": "port",
+            "cpu_model": cpu_model(), "host_threads_available": threads,
             "sample": f"{reps} batches of {BATCH} images (3x32x100, F=20) in {dt:.1f} s, "
-                      f"oracle/tps_oracle.c with {threads} OpenMP threads",
+                      f"oracle/tps_oracle.c with {threads_used} OpenMP threads (the best of the sweep below), output "
+                      "buffer reused between calls",
+            "thread_sweep_images_per_s": {str(k): v for k, v in sweep.items()},
+            "all_host_threads": {"value": all_threads_rate, "cores": threads,
+                                 "note": "one 512-image batch per call is ~27 ms of single-core work: with every host "
+                                         "thread a call is mostly OpenMP fork / join + the ctypes call"},
             "one_thread": {"value": reps1 * BATCH / dt1, "unit": "images/s", "cores": 1,
                            "sample": f"{reps1} batches of {BATCH} in {dt1:.1f} s, same code, 1 thread"},
             "pytorch_cpu_composition": {"value": treps * BATCH / tdt, "unit": "images/s",

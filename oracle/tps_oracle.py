@@ -201,15 +201,20 @@ def grid_sample(inp, grid, out_hw, weight_form=2, return_idx=False):
 
 
 def warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
-         want_grid=False, want_idx=False):
-    """Fused hot path; returns dict(out0, out1?, grid?, idx?)."""
+         want_grid=False, want_idx=False, out0=None):
+    """Fused hot path; returns dict(out0, out1?, grid?, idx?).  `out0`: a preallocated (N, C0, Ho, Wo) float32 array to
+    write into (bench.py's CPU baseline: a fresh 19.7 MB array per call is 4,800 first-touch page faults spread over the
+    OpenMP threads -- at 128 threads that, not the arithmetic, was the time of a call)."""
     in0, in1, ctrl, score = _c(in0), _c(in1), _c(ctrl), _c(score)
     inv_delta_C, P_hat, P_xy = _c(inv_delta_C), _c(P_hat), _c(P_xy)
     N, C0, H0, W0 = in0.shape
     F = ctrl.shape[1]
     Ho, Wo = out_hw
     n = Ho * Wo
-    out0 = np.empty((N, C0, Ho, Wo), dtype=np.float32)
+    if out0 is None:
+        out0 = np.empty((N, C0, Ho, Wo), dtype=np.float32)
+    elif out0.shape != (N, C0, Ho, Wo) or out0.dtype != np.float32 or not out0.flags["C_CONTIGUOUS"]:
+        raise ValueError("warp: out0 must be a C-contiguous float32 array of shape (N, C0, Ho, Wo)")
     C1 = H1 = W1 = 0
     out1 = None
     if in1 is not None:
