@@ -212,7 +212,7 @@ def extra_measurements(dev):
             "tpspp_warp_backward_batch512_fp32": {"us_per_batch": t_bwd * 1e3,
                                                   "achieved_GBps": bwd_bytes_img * n / (t_bwd * 1e-3) / 1e9,
                                                   "algorithmic_bytes_per_image": bwd_bytes_img,
-                                                  "kernels": "warp_bwd_sample_lds2_kernel (64-bit fixed-point LDS accumulation) + warp_bwd_params_kernel<36>"},
+                                                  "kernels": "warp_bwd_sample_lds2_kernel (fp64 LDS atomics) + warp_bwd_params_kernel<36,...> (table columns per wavefront) + warp_bwd_ctrl_kernel"},
             "tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
                                            "gflop_per_image": 0.82},
             "tpspp_module_batch512_bf16x3": {"images_per_s": n / (t_x3 * 1e-3), "ms_per_batch": t_x3,

@@ -47,5 +47,12 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_m
     python3 scripts/bench_module.py 512 x3only > $OUT/module_x3.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_cal -o cal -- \
     ./scripts/ubench/mfma_bench > $OUT/mfma_cal.log 2>&1
-ls -R $OUT | head -60
+# 5. summaries are made HERE (the raw kernel traces of the recogniser / the driver's command are tens of MB each and
+#    gpurun copies back at most 64 MiB): gpurun_out/prof_summary/* is what gets committed under profiles/
+TAG=${TAG:-r04}
+TPSPP_PROFILE_DST=gpurun_out/prof_summary python3 scripts/summarize_profiles.py $TAG > $OUT/summarize.log 2>&1
+find $OUT -name "*_kernel_trace.csv" -size +3M -delete
+find $OUT -name "*counter_collection.csv" -size +3M -delete
+du -sh $OUT gpurun_out/prof_summary
+tail -3 $OUT/summarize.log
 tail -2 $OUT/bench_trace.log

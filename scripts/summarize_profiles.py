@@ -19,7 +19,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("TPSPP_PROFILE_DST") or os.path.join(ROOT, "profiles")   # (the GPU box writes to gpurun_out/prof_summary)
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 KERNEL = os.environ.get("TPSPP_PROFILE_KERNEL", "tps_warp_pair_kernel")
 COPY_BYTES = 512 * 3 * 32 * 100 * 4          # scripts/ubench/copy_bench.hip: bytes read = bytes written
@@ -151,7 +151,10 @@ bench.py times two launch protocols, each over `repeats` regions of exactly `ste
 (S = `config.streams_tried[-1]`; launches on different streams overlap) and all steps on one stream.  Two different numbers
 describe a region: a kernel's own start-to-end DURATION (what `--stats` averages) and the PERIOD between launches,
 (last end - first start) / launches, which is what `ms_per_step` / `roofline.*.regions_us` of the bench line measure.  On
-one stream the two coincide up to the launch gap.  Computed by scripts/summarize_profiles.py from the
+one stream the two coincide up to the launch gap.  The bench's HIP events bracket a region from the host's first enqueue:
+the few microseconds between the start event and the first kernel's start are in the line's figure and not in the trace's
+period -- at K = 20 launches per region that is ~0.5 us per launch (5-6 %), at K = 400 the two agree within 1 %.
+Computed by scripts/summarize_profiles.py from the
 `*_kernel_trace.csv` of each run (the dispatches of `{KERNEL}` in dispatch order: warm-up, the S-stream regions, the
 one-stream regions).  Profiled runs are slower than un-profiled ones (rocprofv3 adds per-dispatch work), so the trace's
 period is compared with the bench line of THE SAME run.

@@ -727,6 +727,17 @@ dec_gemm_x3_kernel(const DGemm P)
         xa[j][0] = xp[4 * j]; xa[j][1] = xp[4 * j + 1];
         ah[j] = wp[(size_t)j * 128]; al[j] = wp[(size_t)j * 128 + 64];
     }
+    // ... and the epilogue's operands with them (round 4): behind the reduction they were one more dependent round trip
+    // to memory per launch, in a loop of ~2000 dependent launches
+    const int c = co0 + 8 * wv + 4 * half;
+    const bool mine = m < P.M && c < P.Co;                 // (Co is a multiple of 4: a whole piece is in or out)
+    const size_t o = (size_t)mc * P.Co + (c < P.Co ? c : 0);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), b4 = cs, r4 = cs;
+    if (mine) {
+        if (LN) cs = *reinterpret_cast<const float4*>(P.colsum + c);
+        if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + c);
+        if (P.res) r4 = *reinterpret_cast<const float4*>(P.res + o);
+    }
     f32x16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -758,8 +769,7 @@ dec_gemm_x3_kernel(const DGemm P)
     if (LN) { sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2; }
     __syncthreads();
     // wavefront w finishes accumulator registers 4 w .. 4 w + 3: outputs co0 + 8 w + 4 half + (0 .. 3) of token l31
-    const int c = co0 + 8 * wv + 4 * half;
-    if (m >= P.M || c >= P.Co) return;                     // (Co is a multiple of 4: a whole piece is in or out)
+    if (!mine) return;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -770,23 +780,15 @@ dec_gemm_x3_kernel(const DGemm P)
         for (int j = 0; j < 8; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
         const float mean = t1 / (float)P.K;
         const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
-        const float4 cs = *reinterpret_cast<const float4*>(P.colsum + c);
         v[0] = rstd * (v[0] - mean * cs.x); v[1] = rstd * (v[1] - mean * cs.y);
         v[2] = rstd * (v[2] - mean * cs.z); v[3] = rstd * (v[3] - mean * cs.w);
     }
-    if (P.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + c);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-    }
+    if (P.bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
     if (P.act == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
     }
-    const size_t o = (size_t)m * P.Co + c;
-    if (P.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(P.res + o);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-    }
+    if (P.res) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
     *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -815,6 +817,16 @@ dec_gemm_f32_kernel(const DGemmF P)
     float4 xa[KUW], wa[KUW];
 #pragma unroll
     for (int j = 0; j < KUW; ++j) { xa[j] = xp[2 * j]; wa[j] = wp[(size_t)j * 64]; }
+    // the epilogue's operands ride with them (wavefronts 0 - 3 finish the tile; see dec_gemm_x3_kernel)
+    const int c = co0 + 8 * (wv & 3) + 4 * half;
+    const bool mine = wv < 4 && m < P.M && c < P.Co;
+    const size_t o = (size_t)mc * P.Co + (c < P.Co ? c : 0);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), b4 = cs, r4 = cs;
+    if (mine) {
+        if (LN) cs = *reinterpret_cast<const float4*>(P.colsum + c);
+        if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + c);
+        if (P.res) r4 = *reinterpret_cast<const float4*>(P.res + o);
+    }
     f32x16_t acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -834,9 +846,7 @@ dec_gemm_f32_kernel(const DGemmF P)
     if (LN) { sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2; }
     __syncthreads();
     // wavefronts 0 - 3 finish accumulator registers 4 w .. 4 w + 3: outputs co0 + 8 w + 4 half + (0 .. 3) of token l31
-    if (wv >= 4) return;
-    const int c = co0 + 8 * wv + 4 * half;
-    if (m >= P.M || c >= P.Co) return;
+    if (!mine) return;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -851,23 +861,15 @@ dec_gemm_f32_kernel(const DGemmF P)
         for (int j = 0; j < 16; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
         const float mean = t1 / (float)P.K;
         const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
-        const float4 cs = *reinterpret_cast<const float4*>(P.colsum + c);
         v[0] = rstd * (v[0] - mean * cs.x); v[1] = rstd * (v[1] - mean * cs.y);
         v[2] = rstd * (v[2] - mean * cs.z); v[3] = rstd * (v[3] - mean * cs.w);
     }
-    if (P.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(P.bias + c);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-    }
+    if (P.bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
     if (P.act == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
     }
-    const size_t o = (size_t)m * P.Co + c;
-    if (P.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(P.res + o);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-    }
+    if (P.res) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
     *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
