@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TPSPP_ABI_VERSION 1
+#define TPSPP_ABI_VERSION 2   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
