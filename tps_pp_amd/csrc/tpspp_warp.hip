@@ -1042,7 +1042,10 @@ bool launch_img_geo(int C, int H, int W, const float* in, const float* ctrl, con
     TPSPP_IMG_GEO(1, 32, 128, 1, 2, 1, 2)
     TPSPP_IMG_GEO(3, 48, 160, 1, 3, 3, 1)
     TPSPP_IMG_GEO(1, 48, 160, 1, 3, 3, 1)
-    TPSPP_IMG_GEO(3, 32, 160, 1, 2, 2, 1)      // the reference's recog-config test shape (tests/test_models/test_recog_config.py:103-157)
+    // the reference's recog-config test shape (tests/test_models/test_recog_config.py:103-157): an image pair per
+    // workgroup, two quadrant pixels per thread (12 + 3 wavefronts, 123 KB): 15.1 us per 512 images on one stream against
+    // 17.9 with one image per workgroup and 18.7 with two such workgroups per CU (scripts/debug/bench_32x160_variants.py)
+    TPSPP_IMG_GEO(3, 32, 160, 2, 2, 3, 1)
     TPSPP_IMG_GEO(1, 32, 160, 1, 2, 1, 2)
     TPSPP_IMG_GEO(3, 32, 64, 2, 1, 3, 1)
     TPSPP_IMG_GEO(1, 32, 64, 2, 1, 1, 1)
