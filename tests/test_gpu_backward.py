@@ -342,3 +342,32 @@ def test_input_gradients_mixed_magnitudes(cuda, geometry):
     r = ops.warp_backward(g1, inp, grid, ctrl, inv, ph, hw, **kw)[0]
     bad = ~torch.isfinite(r)
     assert 1 <= int(bad.sum()) <= 4 and bool(bad[0, 1].any()) and int(bad.sum()) == int(bad[0, 1].sum())
+
+
+def test_backward_workspace_size_is_checked(cuda):
+    """The C entry point refuses a workspace smaller than tpspp_warp_bwd_workspace_floats() (round 3 grew it silently;
+    since ABI version 2 the size travels with the pointer)."""
+    import ctypes
+    from tps_pp_amd import _lib
+    L = _lib.lib()
+    n, hw = 2, (32, 100)
+    c = O.classic_constants(20, hw)
+    inv, ph = dev(c["inv_delta_C"], cuda), dev(c["P_hat"], cuda)
+    img = torch.rand((n, 3, 32, 100), device=cuda)
+    ctrl = dev(c["C"].astype("float32"), cuda)[None].repeat(n, 1, 1).contiguous()
+    _, _, grid, _ = ops.warp(img, ctrl, inv, ph, hw, want_grid=True)
+    T = ops.solve_T(inv, ctrl)
+    g0 = torch.rand_like(img)
+    g_in, g_ctrl = torch.empty_like(img), torch.empty((n, 20, 2), device=cuda)
+    need = int(L.tpspp_warp_bwd_workspace_floats(n, 32, 100))
+    ws = torch.empty((need,), device=cuda)
+    P = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())   # noqa: E731
+
+    def call(floats):
+        return L.tpspp_warp_bwd(P(g0), P(img), 3, 32, 100, P(None), P(None), 0, 0, 0, P(grid), P(T), P(inv), P(ph), 23,
+                                P(None), P(None), P(None), 0, n, 20, 32, 100, P(g_in), P(None), P(g_ctrl), P(None),
+                                P(ws), floats, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert call(n * 3200 * 2) == -22            # the documented size of rounds 1-2: refused, nothing launched
+    assert call(need) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(g_ctrl).all() and torch.isfinite(g_in).all()

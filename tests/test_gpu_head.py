@@ -311,3 +311,15 @@ def test_head_argument_errors(cuda):
             enc(torch.zeros(1, 64, 2, 4, device=cuda))                                # wrong width
         with pytest.raises(ValueError):
             enc(torch.zeros(2, cases.HD_SMALL["d_model"], 2, 4, device=cuda), [dict(valid_ratio=1.0)])
+        # the decoder's pointer table travels with its length (ABI version 2): a table in an earlier round's 18-pointer-
+        # per-layer layout is refused with TPSPP_EINVAL instead of being read out of bounds
+        feat = torch.zeros(2, cases.HD_SMALL["d_model"], 2, 4, device=cuda)
+        out_enc = enc(feat, None)
+        table = dec._weights()[0]
+        good = len(table)
+        try:
+            table.keep = table.keep[:good - 6]          # what len(table) reports to the C entry point
+            with pytest.raises(_lib.TpsppError, match="layer_ptrs_len"):
+                dec(feat, out_enc, None, None, train_mode=False)
+        finally:
+            dec._w_cache = None                          # rebuild the table for whoever uses the module next

@@ -481,3 +481,39 @@ def test_runtime_geometry_kernel_forced(cuda, oracle, N, C, H, W):
                 assert_biteq(idx, ref["idx"], "corner indices")
     finally:
         ops.set_warp_tuning()
+
+
+def test_runtime_geometry_kernel_geometry_sweep(cuda, oracle):
+    """Every (H, W) of a grid of sizes the kernel's planner accepts (H % 16 == 0, W % 4 == 0, image fits the LDS), C in
+    {1, 3, 4}, odd and even batches: forced run-time-geometry kernel, bit for bit the oracle.  Covers every pixel-block
+    shape (4 x 8, 8 x 4, 16 x 2, 32 x 1), QP 1-4 and workgroups ("bands") per image 1, 2 and 4."""
+    F = 20
+    shapes = [(16, 32), (16, 36), (16, 200), (32, 40), (32, 48), (32, 72), (32, 96), (32, 224), (48, 64), (48, 100),
+              (64, 64), (64, 128), (64, 160), (96, 128), (128, 64)]
+    checked = 0
+    for i, (H, W) in enumerate(shapes):
+        C = (1, 3, 4)[i % 3]
+        if C * H * W * 4 > 150 * 1024:
+            C = 1
+        N = 2 + (i % 3)
+        Kc = oracle.classic_constants(F, (H, W))
+        P_hat = dev(Kc["P_hat"], cuda)
+        prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
+        assert packed == ops.TABLE_PACKED, (H, W)
+        ctrl = oracle.classic_initial_ctrl(F)[None] + 0.3 * synth.dyadic((N, F, 2), "sw.ctrl", i)
+        img = synth.dyadic((N, C, H, W), "sw.img", i)
+        ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
+        ops.set_warp_tuning(kernel_choice=7)
+        try:
+            out, _, grid, idx = ops.warp(dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), P_hat, (H, W),
+                                         want_grid=True, want_idx=True, P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+            out2 = ops.warp(dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), P_hat, (H, W), P_hat_t=prep,
+                            table_flags=ops.TABLE_MIRROR4 | packed)[0]
+        finally:
+            ops.set_warp_tuning()
+        assert_biteq(grid, ref["grid"], f"grid {H}x{W}")
+        assert_biteq(idx, ref["idx"], f"corner indices {H}x{W}")
+        assert_biteq(out, ref["out0"], f"warped {H}x{W} C={C}")
+        assert_biteq(out2, ref["out0"], f"warped (no optional outputs) {H}x{W} C={C}")
+        checked += 1
+    assert checked == len(shapes)
