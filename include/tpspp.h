@@ -376,7 +376,8 @@ int tpspp_conv_set_tuning(int flags);
  * 4 = require the plane-streaming kernel, 5 = require the image-pair kernel (classic 32x100 geometry with a
  * tpspp_prepare_mirror_table buffer), 6 = require the in-place kernel (32x100, 32x128, 48x160, 32x64 with C = 1 or 3,
  * same buffer), 7 = require the in-place kernel with run-time geometry (any size that fits the LDS, C = 1, 3 or 4, F = 20,
- * same buffer); bands = workgroups per image pair in the LDS-staged kernel (0 = heuristic).
+ * same buffer); bands = workgroups per image pair in the LDS-staged kernel (0 = heuristic); with kernel_choice 7: bits 0-2 =
+ * workgroups per image (0 = heuristic), bit 3 = never an image pair per workgroup.
  */
 int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);
 

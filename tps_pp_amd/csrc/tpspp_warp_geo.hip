@@ -35,8 +35,9 @@ int geo_nthr(int Ho, int Wo, int QP)
 
 namespace {
 
-struct Plan { int QP, BW, CG, RGB, bands, nthr, NW, nload; size_t lds; };
+struct Plan { int QP, BW, CG, RGB, bands, nthr, NW, nload, imgs; size_t lds; };
 
+int g_geo_pair = 1;          // lab knob: 0 = never an image pair per workgroup
 int g_geo_force_bands = 0;   // lab knob (tpspp_warp_set_tuning's `bands` with kernel_choice 7): 0 = heuristic
 
 bool plan_geo(int C, int H, int W, int F, Plan* p)
@@ -49,55 +50,70 @@ bool plan_geo(int C, int H, int W, int F, Plan* p)
     const int BH = 32 / p->BW;
     p->CG = ((W / 2) + p->BW - 1) / p->BW;
     p->RGB = ((H / 2) / BH) / QP;
-    p->lds = tpspp_geo::geo_lds_bytes(F + 3, C, H, W);
+    p->imgs = 1;
+    p->lds = tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 1);
     if (p->lds > 160 * 1024) return false;
     // loaders: one per ~40 KB of image; workgroup size: <= 16 wavefronts, <= 12 from QP = 3 on (register budget)
     p->nload = (int)((size_t)C * H * W * 4 / (40 * 1024)) + 1;
     if (p->nload > 3) p->nload = 3;
     const int max_waves = QP >= 3 ? 12 : 16;
-    for (int B = 1; B <= p->RGB; ++B) {
+    bool found = false;
+    for (int B = 1; B <= p->RGB && !found; ++B) {
         if (p->RGB % B) continue;
         if (g_geo_force_bands > 0 && B != g_geo_force_bands && B < p->RGB) continue;
         const int nthr = p->CG * (p->RGB / B) * 32;
         const int NW = (nthr + kWave - 1) / kWave;
-        if (NW + p->nload <= max_waves && NW <= 13) { p->bands = B; p->nthr = nthr; p->NW = NW; return true; }
+        if (NW + p->nload <= max_waves && NW <= 13) { p->bands = B; p->nthr = nthr; p->NW = NW; found = true; }
     }
-    return false;
+    if (!found) return false;
+    // image pair per workgroup: one workgroup covers the quadrant, QP x C <= 6 results per mirror pixel (registers),
+    // two images fit the LDS, and every loader has >= kGeoKB pieces of image B to issue behind image A's
+    const int pieces1 = (C * H * W * 4) / 1024;
+    int nload2 = p->nload < 3 && pieces1 / (p->nload + 1) >= tpspp_geo::kGeoKB ? p->nload + 1 : p->nload;
+    if (g_geo_pair && p->bands == 1 && QP * C <= 6 && pieces1 / nload2 >= tpspp_geo::kGeoKB && p->NW + nload2 <= 16 &&
+        tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 2) <= 160 * 1024) {
+        p->imgs = 2; p->nload = nload2;
+        p->lds = tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 2);
+    }
+    return true;
 }
 
-template <int C, int QP, bool AUX>
+template <int C, int QP, int IMGS, bool AUX>
 void launch_one(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
 {
-    auto kern = tpspp_geo::tps_warp_geo_kernel<20, C, QP, AUX>;
+    auto kern = tpspp_geo::tps_warp_geo_kernel<20, C, QP, IMGS, AUX>;
     static bool attr_done[kMaxDevices] = {};
     if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(P.N * pl.bands)), dim3((unsigned)((pl.NW + pl.nload) * kWave)), pl.lds, st, P);
+    const unsigned groups = (unsigned)((P.N + IMGS - 1) / IMGS);
+    hipLaunchKernelGGL(kern, dim3(groups * (unsigned)pl.bands), dim3((unsigned)((pl.NW + pl.nload) * kWave)), pl.lds, st, P);
 }
 
-template <int C, int QP>
+template <int C, int QP, int IMGS>
 void launch_aux(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
 {
-    if (P.grid || P.idx) launch_one<C, QP, true>(P, pl, st);
-    else launch_one<C, QP, false>(P, pl, st);
+    if (P.grid || P.idx) launch_one<C, QP, IMGS, true>(P, pl, st);
+    else launch_one<C, QP, IMGS, false>(P, pl, st);
 }
 
 template <int C>
 void launch_qp(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
 {
     switch (pl.QP) {
-    case 1: launch_aux<C, 1>(P, pl, st); break;
-    case 2: launch_aux<C, 2>(P, pl, st); break;
-    case 3: launch_aux<C, 3>(P, pl, st); break;
-    default: launch_aux<C, 4>(P, pl, st); break;
+    case 1: if (pl.imgs == 2) launch_aux<C, 1, 2>(P, pl, st); else launch_aux<C, 1, 1>(P, pl, st); break;
+    case 2:
+        if constexpr (2 * C <= 6) { if (pl.imgs == 2) { launch_aux<C, 2, 2>(P, pl, st); break; } }
+        launch_aux<C, 2, 1>(P, pl, st); break;
+    case 3: launch_aux<C, 3, 1>(P, pl, st); break;
+    default: launch_aux<C, 4, 1>(P, pl, st); break;
     }
 }
 
 }  // namespace
 
-void geo_set_bands(int bands) { g_geo_force_bands = bands; }
+void geo_set_bands(int bands) { g_geo_force_bands = bands & 7; g_geo_pair = (bands & 8) ? 0 : 1; }
 
 bool geo_kernel_applicable(int C, int H, int W, int F)
 {
@@ -114,7 +130,7 @@ bool launch_geo_kernel(int C, int H, int W, int F, const float* in, const float*
     P.in = in; P.ctrl = ctrl; P.inv_delta_c = inv_delta_c; P.packed = packed; P.N = N;
     P.out = out; P.grid = grid; P.idx = idx;
     P.H = H; P.W = W; P.BW = pl.BW; P.CG = pl.CG; P.RGB = pl.RGB; P.bands = pl.bands; P.nthr = pl.nthr; P.NW = pl.NW;
-    P.img_off = tpspp_geo::geo_img_off(F + 3);
+    P.img_off = tpspp_geo::geo_img_off(F + 3, pl.imgs);
     if (C == 1) launch_qp<1>(P, pl, st);
     else if (C == 3) launch_qp<3>(P, pl, st);
     else launch_qp<4>(P, pl, st);
