@@ -94,9 +94,10 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
  * The prepared form of a mirror-symmetric classic table that the image-pair and in-place kernels read: the (F+3, n)
  * transposed table of tpspp_transpose_p_hat followed by a packed copy in those kernels' thread order (a thread's F+3
  * values per quadrant pixel as 16-byte pieces, [wavefront][quadrant pixels per thread][(F+3+3)/4][lane][4]; thread ->
- * pixel: a half-wavefront owns 4 columns x 8 rows of the left half of the upper half-image, a thread 1 - 3 such rows
- * groups depending on the geometry).  tpspp_prepared_table_floats: buffer size in floats, 0 when the geometry has no
- * prepared form (needs Ho % 16 == 0, Wo % 4 == 0, at most 13 wavefronts of quadrant pixels).  One-off preparation, like the transposition.  Pass the buffer
+ * pixel: a half-wavefront owns a block of 32 pixels -- 4 columns x 8 rows, 8 x 4 or 32 x 1 by the row pitch -- of the left
+ * half of the upper half-image, a thread 1 - 4 such row groups depending on the geometry).  tpspp_prepared_table_floats:
+ * buffer size in floats, 0 when the geometry has no prepared form (needs Ho % 16 == 0, Wo % 4 == 0).  One-off
+ * preparation, like the transposition.  Pass the buffer
  * as p_hat_t together with TPSPP_TABLE_PACKED (and TPSPP_TABLE_MIRROR4 once the symmetry has been verified).
  * replaces nothing in the reference (its table is a module buffer, tps_preprocessor.py:187-188); see tpspp_warp_fwd.
  */

@@ -892,8 +892,8 @@ TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, in
 {
     TPSPP_REQUIRE(p_hat && prepared, "tpspp_prepare_mirror_table: null pointer");
     TPSPP_REQUIRE(tpspp_prepared_table_floats(Ho, Wo, F) != 0,
-                  "tpspp_prepare_mirror_table: needs Ho %% 16 == 0, Wo %% 4 == 0, at most 13 wavefronts of quadrant "
-                  "pixels, 0 < F <= %d", kMaxK - 3);
+                  "tpspp_prepare_mirror_table: needs Ho %% 16 == 0, Wo %% 4 == 0 (whole 32-pixel blocks of quadrant "
+                  "pixels), 0 < F <= %d", kMaxK - 3);
     TPSPP_REQUIRE(p_hat_ld >= F + 3, "tpspp_prepare_mirror_table: p_hat_ld too small (classic layout: F + 3 columns)");
     const int K = F + 3, KG = (K + 3) / 4, n = Ho * Wo;
     const int rc = tpspp_transpose_p_hat(p_hat, p_hat_ld, n, K, prepared, stream);

@@ -1,5 +1,6 @@
-// Classic-geometry warp with results staged in place of the consumed input planes (round 3; the kernel
-// BASELINE.json configs[1] / bench.py measure).
+// Classic-geometry warp with results staged in place of the consumed input planes (round 3), instantiated per
+// geometry: 32x128, 32x160, 48x160, 32x64 (and 32x100, where the image-pair kernel of tpspp_warp_pair.h -- the one
+// bench.py measures -- is the production path).  tpspp_warp_geo.h is the same kernel with run-time geometry.
 //
 // Replaces, bit for bit: preprocessor/tps_preprocessor.py:71-83 + 270-282 (GridGenerator.build_P_prime: two bmm,
 // then F.grid_sample bilinear / border / align_corners) for a mirror-symmetric RBF table (see tpspp_warp.hip).
