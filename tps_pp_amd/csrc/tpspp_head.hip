@@ -26,6 +26,9 @@
 #include <cmath>
 
 #include "tpspp_common.h"
+#include "tpspp_tokgemm.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -924,6 +927,9 @@ transpose2d_b16_kernel(const unsigned short* __restrict__ in, int rows, int cols
     }
 }
 
+// lab switch (TPSPP_HEAD_NO_TOKGEMM=1 in the environment): the wide projections through the convolution kernel as before
+const bool g_head_no_tokgemm = getenv("TPSPP_HEAD_NO_TOKGEMM") != nullptr;
+
 struct Gemm {
     hipStream_t st;
     int rc = 0;
@@ -934,6 +940,15 @@ struct Gemm {
               const float* res, int split3 = 0)
     {
         if (rc) return;
+        // the token GEMM (tpspp_tokgemm.hip) where the shape qualifies, else the product as a 1x1 convolution
+        tpspp::TokGemmArgs ta;
+        ta.X = X; ta.W = W16; ta.bias = bias; ta.res = res; ta.out = out; ta.out_f32 = out_f32;
+        ta.K = K; ta.Co = Co; ta.M = M; ta.act = act; ta.x3 = split3; ta.kgc = tpspp_conv_bf16_chunk_channels(1) / 8;
+        if (!g_head_no_tokgemm && tpspp::tok_gemm_applicable(ta)) {
+            tpspp::launch_tok_gemm(ta, st);
+            rc = tpspp::check_launch("token GEMM");
+            return;
+        }
         const void* src[1] = {X};
         const int dims[6] = {K, 1, M, 1, 1, 1};
         rc = tpspp_conv2d_bf16_fwd(src, dims, 1, W16, bias, res, 1, nullptr, nullptr, res ? 1 : 0, act, 1, Co, 1, 1, 1, 1,
