@@ -330,6 +330,21 @@ int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
                          int N, int H, int W, int split3, tpspp_stream_t stream);
 
 /*
+ * down0 + down0_1 (or down1 + down1_1) of the ResNet45v2 wiring in one kernel (bf16 configuration):
+ *     out = bf16(relu(conv3x3 stride 2 pad 1 (bf16(relu(W0 in + b0))) + bd))
+ * without the intermediate (N, 64, H, W) map in HBM; bit for bit what tpspp_front_bf16_fwd's feat0 / feat1 followed by
+ * tpspp_conv2d_bf16_fwd (3x3, stride 2, blocked output) give.
+ *   in (N, 32, H, W) bf16, W = 128, H even;  w0 / b0 as tpspp_front_bf16_fwd takes them;  wd = the (64, 64, 3, 3) weight
+ *   arranged as tpspp_conv2d_bf16_fwd takes it ([4 chunks][9 taps][2][64 cout][8] bf16), bd (64) fp32;
+ *   out: the blocked layout (N, 8, H/2, 64, 8) bf16 (tpspp_conv2d_bf16_fwd's layout code 2).
+ * tpspp_front_bf16_fwd may then be called with feat0 = feat1 = NULL (blocked mode): it keeps computing them as operands of
+ * feat_grid and stores neither.
+ * replaces: backbones/tps_pp/tps_pp.py:560-563 (self.down0_1(self.down0(outs[0])), self.down1_1(self.down1(outs[1])))
+ */
+int tpspp_down_fused_bf16_fwd(const void* in, const void* w0, const float* b0, const void* wd, const float* bd,
+                              void* out, int N, int H, int W, int relu, tpspp_stream_t stream);
+
+/*
  * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32
  * accumulation; bias / residual / activation / affine in fp32) for the bf16 configurations
  * (BASELINE.json configs[2], configs[4]).  Every tensor is independently bf16 NCHW (layout code 0), fp32 NCHW (1) or

@@ -369,3 +369,56 @@ def test_front_bf16x3_blocked_outputs(cuda):
     for i in range(3):
         assert isinstance(b[i], ops.Blocked32) and torch.equal(b[i].nchw().view(torch.int32), a[i].view(torch.int32)), i
     assert torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("N,H", [(1, 32), (3, 32), (5, 8), (2, 2), (37, 32), (530, 32)])
+def test_down_fused_is_front_then_stride2_conv_bit_for_bit(cuda, N, H):
+    """tpspp_down_fused_bf16_fwd (down0 + down0_1 in one kernel, the 1x1 result only in LDS) against the two-kernel route:
+    the front's blocked feat0 / feat1 followed by the 3x3 stride-2 convolution.  Whole images per workgroup (N = 530),
+    strips of output rows with the row above recomputed (small N), a single output row (H = 2); signed inputs so that
+    ReLU and the zero padding of the intermediate map (not of the input) both matter."""
+    from tps_pp_amd import TPS_PP
+    torch.manual_seed(11)
+    m = TPS_PP().eval().to(cuda)
+    with torch.no_grad():
+        for c in (m.down0, m.down1, m.down0_1, m.down1_1):
+            c.conv.bias.uniform_(-0.5, 0.5)                 # relu(b0) != 0: padding must be applied to feat, not to `in`
+    fw = ops.FrontWeightsBf16(m)
+    cw0 = ops.prep_conv_weight_bf16(m.down0_1.conv.weight, conv_bias=m.down0_1.conv.bias)
+    cw1 = ops.prep_conv_weight_bf16(m.down1_1.conv.weight, conv_bias=m.down1_1.conv.bias)
+    g = torch.Generator(device=cuda).manual_seed(N * 100 + H)
+    o0 = torch.randn((N, 32, H, 128), generator=g, device=cuda).bfloat16()
+    o1 = torch.randn((N, 32, H, 128), generator=g, device=cuda).bfloat16()
+    x = torch.randn((N, 64, H // 2, 64), generator=g, device=cuda).bfloat16()
+    f0, f1, f2, fg = ops.front_bf16(o0, o1, x, fw, torch.bfloat16, blocked=True)
+    want0 = ops.conv2d_bf16([f0], cw0, 2, out_blocked=True)
+    want1 = ops.conv2d_bf16([f1], cw1, 2, out_blocked=True)
+    got0 = ops.down_fused_bf16(o0, fw.w0, fw.b0, cw0)
+    got1 = ops.down_fused_bf16(o1, fw.w1, fw.b1, cw1)
+    assert isinstance(got0, ops.Blocked) and got0.shape == want0.shape
+    assert torch.equal(got0.t.view(torch.int16), want0.t.view(torch.int16))
+    assert torch.equal(got1.t.view(torch.int16), want1.t.view(torch.int16))
+    assert float(got0.t.float().abs().max()) > 0
+    # the front without the feat0 / feat1 stores: same feat2 and feat_grid
+    n0, n1, g2, gg = ops.front_bf16(o0, o1, x, fw, torch.bfloat16, blocked=True, store01=False)
+    assert n0 is None and n1 is None
+    assert torch.equal(g2.t.view(torch.int16), f2.t.view(torch.int16)) and torch.equal(gg.view(torch.int16), fg.view(torch.int16))
+    gg32 = ops.front_bf16(o0, o1, x, fw, torch.float32, blocked=True, store01=False)[3]
+    assert torch.equal(gg32, ops.front_bf16(o0, o1, x, fw, torch.float32, blocked=True)[3])
+
+
+def test_down_fused_argument_errors(cuda):
+    from tps_pp_amd import TPS_PP
+    m = TPS_PP().eval().to(cuda)
+    fw = ops.FrontWeightsBf16(m)
+    cw = ops.prep_conv_weight_bf16(m.down0_1.conv.weight, conv_bias=m.down0_1.conv.bias)
+    with pytest.raises(ValueError):
+        ops.down_fused_bf16(torch.zeros((1, 32, 32, 96), device=cuda).bfloat16(), fw.w0, fw.b0, cw)      # width
+    with pytest.raises(ValueError):
+        ops.down_fused_bf16(torch.zeros((1, 32, 31, 128), device=cuda).bfloat16(), fw.w0, fw.b0, cw)     # odd height
+    with pytest.raises(ValueError):
+        ops.down_fused_bf16(torch.zeros((1, 32, 32, 128), device=cuda), fw.w0, fw.b0, cw)                # fp32 map
+    with pytest.raises(ValueError):
+        ops.front_bf16(torch.zeros((1, 32, 32, 128), device=cuda).bfloat16(), torch.zeros((1, 32, 32, 128), device=cuda).bfloat16(),
+                       torch.zeros((1, 64, 16, 64), device=cuda).bfloat16(), fw, store01=False)          # NCHW form
+    assert ops.down_fused_bf16(torch.zeros((0, 32, 32, 128), device=cuda).bfloat16(), fw.w0, fw.b0, cw).shape == (0, 64, 16, 64)

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "tpspp_score_x3_fwd": ([_f, _f, _f, _f, _f, _f, ctypes.c_float, _f, _i, _i, _f], _i),
     "tpspp_front_fwd": ([_f] * 15 + [_i, _i, _i, _f], _i),
     "tpspp_front_bf16_fwd": ([_f] * 15 + [_i, _i, _i, _i, _i, _f], _i),
+    "tpspp_down_fused_bf16_fwd": ([_f] * 6 + [_i, _i, _i, _i, _f], _i),
     "tpspp_cbam_fwd": ([_f, _f, _f, _f, _f, _f, _i, _f], _i),
     "tpspp_tpe_points_fwd": ([_f] * 13 + [_i, _f], _i),
     "tpspp_maxpool2x2_fwd": ([_f, _i, _i, _i, _i, _f, _f], _i),

@@ -1,0 +1,288 @@
+// down0 + down0_1 (and down1 + down1_1) of the TPS++ regressor, ResNet45v2 wiring, as ONE kernel on the bf16 matrix cores:
+//
+//     feat = bf16(relu(W0 in[p] + b0))                        1x1, 32 -> 64 at full resolution (32 x 128)
+//     out  = bf16(relu(conv3x3, stride 2, pad 1 (feat) + bd)) 64 -> 64 at half resolution (16 x 64), blocked layout
+//
+// Reference: TPS_PP.forward, mmocr/models/textrecog/backbones/tps_pp/tps_pp.py:560-563 (`self.down0_1(self.down0(outs[0]))`,
+// `self.down1_1(self.down1(outs[1]))`).
+//
+// Why: as separate launches feat0 / feat1 (0.54 GB per 512 images) are written by the fused front (tpspp_front_bf16.hip,
+// a third of its time) only to be read once, by the two stride-2 convolutions (which are bound by those reads).  The front
+// still needs them as operands of its 192-deep product and keeps computing them in registers; here they are computed a
+// second time (2 of 38 matrix instructions per output fragment), straight into the LDS patch the 3x3 product reads, and
+// never exist in HBM: this kernel reads 0.13 GB instead of 0.27 GB and the front writes 0.33 GB instead of 0.87 GB.
+//
+// Same arithmetic as the unfused composition, bit for bit: the 1x1 product is the front's (two k-steps of
+// v_mfma_f32_32x32x16_bf16 in channel order, + bias, ReLU, one rounding to bf16), the 3x3 product is
+// conv_tiled_bf16_kernel's / conv3_blk_persist_kernel's (chunks of 16 channels ascending, taps row-major inside a chunk,
+// one accumulator), zero padding applied to feat (not to `in`).
+//
+// Organisation (a workgroup = 4 wavefronts walks down an image, one output row of 64 pixels per step):
+//   * the 3x3 weight never touches LDS: wavefront (f, h2) owns output pixels 32 f .. 32 f + 31 and output channels
+//     32 h2 .. 32 h2 + 31 for the life of the workgroup, i.e. 36 A fragments = 144 registers loaded once;
+//   * feat rows live in a ring of 3 LDS rows in the patch layout of the stride-2 kernels: [channel group][parity][pad |
+//     64 columns] 16-byte units, so the 32 pixels of a fragment read 32 consecutive units for every tap and the left
+//     padding column is a zero unit; a step adds input rows 2 oy and 2 oy + 1 (row 2 oy - 1 is the previous step's);
+//   * producer: every wavefront takes one 32-pixel segment of each new row exactly as the front does -- 16-byte pieces of
+//     the NCHW rows into a private [channel][32 pixels] tile, ds_read_b64_tr_b16 for the B operand, 4 matrix
+//     instructions, the C/D registers paired into 16-byte units with v_permlane32_swap -- and writes the units into the
+//     ring; the next step's pieces are already in flight (registers);
+//   * two barriers per step (ring written / ring read); two workgroups per CU cover each other's.
+// Bound: HBM (0.13 GB in, 0.07 GB out per 512 images = 33 us at 6 TB/s).
+#include "tpspp_common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct DownFParams {
+    const unsigned short* in;       // (N, 32, H, W) bf16
+    const u32x4* w0;                // [2 k-steps][2][64][8]
+    const float* b0;
+    const u32x4* wd;                // [4 chunks][9 taps][2][64][8]
+    const float* bd;
+    unsigned short* out;            // (N, 8, H / 2, 64, 8) bf16
+    int N, H, W;                    // W == 128
+    int rows_per_unit;              // output rows per work unit (divides H / 2)
+    int relu;
+};
+
+constexpr int kW = 128, kWo = 64;
+constexpr int RP = 72;                           // units per (channel group, parity) run: pad | 64 columns | 7 unused
+                                                 // (72: the even and the odd run of a producer's 16-lane write group are
+                                                 // 32 banks apart)
+constexpr int kRowUnits = 8 * 2 * RP;            // a feature row: 1152 units = 18 KB
+constexpr int kRing = 3;
+constexpr int kW0Units = 256;
+constexpr int kTileBytes = 2048;                 // a wavefront's input tile [32 channels][32 pixels]
+constexpr int kSmemBytes = kW0Units * 16 + 128 * 4 + 4 * kTileBytes + kRing * kRowUnits * 16;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    f32x2 v; v[0] = lo; v[1] = hi;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ u32x2 read_tr(const unsigned short* p)
+{
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+
+__global__ void __launch_bounds__(256, 2)
+down_fused_kernel(const DownFParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* const sW0 = reinterpret_cast<u32x4*>(smem);
+    float* const sBias = reinterpret_cast<float*>(smem + kW0Units * 16);               // b0 | bd
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned short* const tile = reinterpret_cast<unsigned short*>(smem + kW0Units * 16 + 512 + wv * kTileBytes);
+    u32x4* const ring = reinterpret_cast<u32x4*>(smem + kW0Units * 16 + 512 + 4 * kTileBytes);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    sW0[tid] = P.w0[tid];
+    if (tid < 128) sBias[tid] = tid < 64 ? P.b0[tid] : P.bd[tid - 64];
+    if (tid < kRing * 16) {                                   // the padding column of every run, zero for good
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        ring[(tid >> 4) * kRowUnits + (tid & 15) * RP] = z;
+    }
+    // this wavefront's 3x3 weight: output channels 32 h2 + l31, k group `half` of every (chunk, tap)
+    const int f = wv >> 1, h2 = wv & 1;
+    bf16x8 wa[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wa[c][t] = __builtin_bit_cast(bf16x8, P.wd[((c * 9 + t) * 2 + half) * 64 + 32 * h2 + l31]);
+    __syncthreads();
+
+    const int H = P.H, Ho = H >> 1, plane = H * kW;
+    const int RS = P.rows_per_unit, upi = Ho / RS, nunits = P.N * upi;
+    const int lb = (((lane & 15) >> 2) + 8 * half) * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int px = 32 * wv + l31;                             // the producer's pixel: segment = wavefront
+    const int punit = (px & 1) * RP + 1 + (px >> 1);          // its unit inside a (channel group) pair of runs
+
+    // 16-byte pieces of the wavefront's segment of input row iy: piece p = lane + 64 i -> channel p >> 2, pixels 8 (p & 3) ..
+    auto fetch = [&](int n, int iy, u32x4 (&r)[2]) {
+        const unsigned short* src = P.in + (size_t)n * 32 * plane + (size_t)iy * kW + 32 * wv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = lane + 64 * i;
+            r[i] = *reinterpret_cast<const u32x4*>(src + (size_t)(p >> 2) * plane + (p & 3) * 8);
+        }
+    };
+    // feat of the wavefront's segment of input row iy -> ring
+    auto produce = [&](int iy, const u32x4 (&r)[2]) {
+        reinterpret_cast<u32x4*>(tile)[lane] = r[0];
+        reinterpret_cast<u32x4*>(tile)[lane + 64] = r[1];
+        asm volatile("" ::: "memory");
+        u32x4 b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x2 k0 = read_tr(tile + lb + (16 * j) * 32), k1 = read_tr(tile + lb + (16 * j + 4) * 32);
+            b[j][0] = k0[0]; b[j][1] = k0[1]; b[j][2] = k1[0]; b[j][3] = k1[1];
+        }
+        asm volatile("" ::: "memory");                        // ... before the next segment overwrites the tile
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, sW0[(2 * j + half) * 64 + l31]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, sW0[(2 * j + half) * 64 + 32 + l31]);
+            const bf16x8 bb = __builtin_bit_cast(bf16x8, b[j]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1], 0, 0, 0);
+        }
+        u32x4* const row = ring + ((iy + 1) % kRing) * kRowUnits + punit;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = acc[t][4 * g + e] + sBias[32 * t + 8 * g + 4 * half + e];
+                    v[e] = s > 0.0f ? s : 0.0f;
+                }
+                pk[g][0] = pack_bf16(v[0], v[1]); pk[g][1] = pack_bf16(v[2], v[3]);
+            }
+            // the two half-wavefronts hold the two 8-byte halves of every unit: after the swap the lower one owns the
+            // unit of channel group 4 t + g, the upper one that of 4 t + g + 1
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const u32x2 d0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const u32x2 d1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                row[(4 * t + g + half) * (2 * RP)] = unit;
+            }
+        }
+    };
+
+    u32x4 pa[2], pb[2];                                       // the pieces of the next step's two rows
+    int u = blockIdx.x;
+    if (u < nunits) {
+        const int n = u / upi, oy = (u - n * upi) * RS;
+        fetch(n, 2 * oy, pa);
+        fetch(n, 2 * oy + 1, pb);
+    }
+    for (; u < nunits; u += gridDim.x) {
+        const int n = u / upi, oy_s = (u - n * upi) * RS;
+        __syncthreads();                                      // the previous unit's last row has been read
+        if (oy_s == 0) {
+            // input row -1: zero padding (slot 0)
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int i = tid; i < kRowUnits; i += 256) ring[i] = z;
+        } else {
+            u32x4 pc[2];
+            fetch(n, 2 * oy_s - 1, pc);
+            produce(2 * oy_s - 1, pc);
+        }
+        for (int oy = oy_s; oy < oy_s + RS; ++oy) {
+            if (oy > oy_s) __syncthreads();                   // the rows this step overwrites have been read
+            produce(2 * oy, pa);
+            produce(2 * oy + 1, pb);
+            {
+                // the next step's pieces: in flight under this step's products
+                int nn = n, noy = oy + 1;
+                bool more = true;
+                if (noy == oy_s + RS) {
+                    const int nu = u + (int)gridDim.x;
+                    more = nu < nunits;
+                    nn = nu / upi;
+                    noy = (nu - nn * upi) * RS;
+                }
+                if (more) { fetch(nn, 2 * noy, pa); fetch(nn, 2 * noy + 1, pb); }
+            }
+            __syncthreads();                                  // the three rows of this step are in the ring
+            // ---- 3x3, stride 2: input rows 2 oy - 1 + ky in ring slots (2 oy + ky) % 3 ----
+            const u32x4* rows[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rows[ky] = ring + ((2 * oy + ky) % kRing) * kRowUnits + half * (2 * RP) + 32 * f + l31;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int ky = t / 3, kx = t - 3 * ky;
+                    // kx = 0: odd column 2 ox - 1 (run 1, slot ox); kx = 1: even column 2 ox (run 0, slot ox + 1);
+                    // kx = 2: odd column 2 ox + 1 (run 1, slot ox + 1)
+                    const int off = (2 * c) * (2 * RP) + (kx == 1 ? 0 : RP) + (kx == 0 ? 0 : 1);
+                    const bf16x8 bb = __builtin_bit_cast(bf16x8, rows[ky][off]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[c][t], bb, acc, 0, 0, 0);
+                }
+            // ---- bias, ReLU, rounding; 16-byte units of the blocked output ----
+            u32x2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = acc[4 * g + e] + sBias[64 + 32 * h2 + 8 * g + 4 * half + e];
+                    v[e] = (P.relu && !(s > 0.0f)) ? 0.0f : s;
+                }
+                pk[g][0] = pack_bf16(v[0], v[1]); pk[g][1] = pack_bf16(v[2], v[3]);
+            }
+            unsigned short* const ob = P.out + (((size_t)n * 8 * Ho + oy) * kWo + 32 * f + l31) * 8;
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const u32x2 d0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const u32x2 d1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                *reinterpret_cast<u32x4*>(ob + (size_t)(4 * h2 + g + half) * Ho * kWo * 8) = unit;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+TPSPP_EXPORT int tpspp_down_fused_bf16_fwd(const void* in, const void* w0, const float* b0, const void* wd, const float* bd,
+                                           void* out, int N, int H, int W, int relu, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(in && w0 && b0 && wd && bd && out, "tpspp_down_fused_bf16_fwd: null pointer");
+    TPSPP_REQUIRE(N >= 0 && H > 0 && (H % 2) == 0 && W == kW,
+                  "tpspp_down_fused_bf16_fwd: needs an even height and a width of 128 (got %d x %d)", H, W);
+    TPSPP_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(w0) |
+                    reinterpret_cast<size_t>(wd)) & 15) == 0, "tpspp_down_fused_bf16_fwd: tensors must be 16-byte aligned");
+    if (N == 0) return TPSPP_OK;
+    TPSPP_REQUIRE((long)N * (H / 2) < 0x7fffffffL, "tpspp_down_fused_bf16_fwd: batch too large");
+    DownFParams P;
+    P.in = static_cast<const unsigned short*>(in);
+    P.w0 = static_cast<const u32x4*>(w0); P.b0 = b0;
+    P.wd = static_cast<const u32x4*>(wd); P.bd = bd;
+    P.out = static_cast<unsigned short*>(out);
+    P.N = N; P.H = H; P.W = W; P.relu = relu ? 1 : 0;
+    // work units: whole images when there are enough of them for two workgroups per CU, else strips of output rows (a
+    // strip below the top of an image computes the feature row above it once more)
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+        (void)hipGetLastError();
+        ncu = 256;
+    }
+    const int Ho = H / 2, slots = 2 * ncu;
+    int rs = Ho;
+    while (rs > 1 && (rs % 2) == 0 && (long)N * (Ho / rs) < slots) rs /= 2;
+    P.rows_per_unit = rs;
+    const long nunits = (long)N * (Ho / rs);
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&down_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kSmemBytes);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(down_fused_kernel, dim3((unsigned)(nunits < slots ? nunits : slots)), dim3(256), kSmemBytes,
+                       tpspp::as_stream(stream), P);
+    return tpspp::check_launch("tpspp_down_fused_bf16_fwd");
+}

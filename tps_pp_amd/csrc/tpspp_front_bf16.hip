@@ -233,7 +233,9 @@ __device__ __forceinline__ void flush_tile(const unsigned short* tile, char* __r
 constexpr int kSlabUnits = (2 + 2 + 4 + 12) * 128;      // 16-byte units: w0 | w1 | w2 | wg
 constexpr int kSlabBytes = kSlabUnits * 16 + 4 * 64 * 4;  // + the four bias vectors
 
-template <bool FG32, int NW, bool BLK>
+// ST01: feat0 / feat1 are stored (false: operands of feat_grid only -- tpspp_down_fused_bf16_fwd recomputes them where
+// they are consumed; blocked form only)
+template <bool FG32, int NW, bool BLK, bool ST01 = true>
 __global__ void __launch_bounds__(NW * 64)
 front_bf16_kernel(const FrontBParams P)
 {
@@ -317,10 +319,13 @@ front_bf16_kernel(const FrontBParams P)
         if constexpr (BLK) {
             // blocked feat0 / feat1 / feat2: 8-byte pieces straight from the result registers
             const size_t bbase = ((size_t)n * 8 * plane + seg0 + l31) * 8;
-            finish(acc, bias, half, to, l31, true, f, P.feat0 + bbase, (size_t)plane * 8);
+            // ST01 = false: the stores are skipped by a run-time (uniform) test of the pointer, not compiled out -- as a
+            // compile-time variant the kernel spills (260 bytes of scratch per lane at 168 registers, 455 us instead of 250)
+            const bool st01 = ST01 || P.feat0 != nullptr;
+            finish(acc, bias, half, to, l31, st01, f, P.feat0 + bbase, (size_t)plane * 8);
             zero();
             gemm<2>(w1, in1, half, l31, acc);
-            finish(acc, bias + 64, half, to, l31, true, f + 4, P.feat1 + bbase, (size_t)plane * 8);
+            finish(acc, bias + 64, half, to, l31, st01, f + 4, P.feat1 + bbase, (size_t)plane * 8);
         } else {
             finish(acc, bias, half, to, l31, true, f);
             flush_tile<32>(to, reinterpret_cast<char*>(P.feat0 + obase), pb, lane);
@@ -372,7 +377,7 @@ front_bf16_kernel(const FrontBParams P)
         // stores issued since the fetch: feat0 4, feat1 4, feat2 2 (even rows), feat_grid 4 (bf16) or 8 (fp32);
         // blocked: feat0 4, feat1 4, feat2 4 (even rows)
         if (more) {
-            constexpr int NS = (FG32 ? 8 : 4) + 8;
+            constexpr int NS = (FG32 ? 8 : 4) + (ST01 ? 8 : 0);
             constexpr int N2 = BLK ? 4 : 2;
             if (row2) wait_fetched<NS + N2>(pf0, pf1, pf2);
             else wait_fetched<NS>(pf0, pf1, pf2);
@@ -576,8 +581,11 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
                                       void* feat0, void* feat1, void* feat2, void* feat_grid, int feat_grid_f32,
                                       int N, int H, int W, int split3, tpspp_stream_t stream)
 {
-    TPSPP_REQUIRE(outs0 && outs1 && x && w0 && w1 && w2 && wg && b0 && b1 && b2 && bg && feat0 && feat1 && feat2 &&
-                  feat_grid, "tpspp_front_bf16_fwd: null pointer");
+    TPSPP_REQUIRE(outs0 && outs1 && x && w0 && w1 && w2 && wg && b0 && b1 && b2 && bg && feat2 && feat_grid,
+                  "tpspp_front_bf16_fwd: null pointer");
+    // feat0 = feat1 = NULL: not stored (their consumers recompute them: tpspp_down_fused_bf16_fwd); plain bf16, blocked only
+    TPSPP_REQUIRE((feat0 && feat1) || (!feat0 && !feat1 && !split3 && (feat_grid_f32 & 2)),
+                  "tpspp_front_bf16_fwd: feat0 / feat1 may only be omitted together, in the blocked bf16 form");
     TPSPP_REQUIRE(N >= 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 32) == 0,
                   "tpspp_front_bf16_fwd: needs an even height and a width that is a multiple of 32");
     if (N == 0) return TPSPP_OK;
@@ -637,6 +645,15 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
     auto go = [&](auto kern, int nwv) {
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nwv * 64), kSlabBytes + nwv * kTileBytes, tpspp::as_stream(stream), P);
     };
+    if (!feat0) {
+        static bool attr2_done[tpspp::kMaxDevices] = {};
+        if (tpspp::first_use_on_device(attr2_done)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<true, 8, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&front_bf16_kernel<false, 12, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipGetLastError();
+        }
+        if (P.fg_f32) go(front_bf16_kernel<true, 8, true, false>, 8); else go(front_bf16_kernel<false, 12, true, false>, 12);
+    } else
     if (P.fg_f32) { if (P.blk) go(front_bf16_kernel<true, 8, true>, 8); else go(front_bf16_kernel<true, 8, false>, 8); }
     else          { if (P.blk) go(front_bf16_kernel<false, 12, true>, 12); else go(front_bf16_kernel<false, 4, false>, 4); }
     return tpspp::check_launch("tpspp_front_bf16_fwd");

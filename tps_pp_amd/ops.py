@@ -787,9 +787,10 @@ def front_bf16_applicable(o0, o1, x, x3=False):
     return all(t.dtype == dt for t in (o0, o1, x)) and o0.shape[2] % 2 == 0 and o0.shape[3] % 32 == 0
 
 
-def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False):
+def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False, store01=True):
     """`front` on the bf16 matrix cores: bf16 in, bf16 feat0 / feat1 / feat2, feat_grid bf16 or fp32; with x3 weights
-    (`FrontWeightsBf16(m, x3=True)`) fp32 in and out, three-term split."""
+    (`FrontWeightsBf16(m, x3=True)`) fp32 in and out, three-term split.  `store01=False` (blocked bf16 only): feat0 / feat1
+    stay operands of feat_grid and are returned as None -- `down_fused_bf16` recomputes them where they are consumed."""
     o0, o1, x = _chk16("outs[0]", o0, 4), _chk16("outs[1]", o1, 4), _chk16("x", x, 4)
     N, c0, H, W = o0.shape
     if c0 != 32 or tuple(o1.shape) != (N, 32, H, W) or tuple(x.shape) != (N, 64, H // 2, W // 2):
@@ -809,18 +810,49 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False):
         feat0 = torch.empty((N, 64, H, W), device=dev, dtype=bf)
         feat2 = torch.empty((N, 64, H // 2, W // 2), device=dev, dtype=bf)
     feat1 = torch.empty_like(feat0)
+    if not store01:
+        if not blocked or fw.x3:
+            raise ValueError("front_bf16: store01=False goes with the blocked bf16 form")
+        feat0 = feat1 = None
     feat_grid = torch.empty((N, 64, H, W), device=dev, dtype=feat_grid_dtype)
     with torch.cuda.device(dev):
         rc = _lib.lib().tpspp_front_bf16_fwd(_ptr(o0), _ptr(o1), _ptr(x), _ptr(fw.w0), _ptr(fw.b0), _ptr(fw.w1),
                                              _ptr(fw.b1), _ptr(fw.w2), _ptr(fw.b2), _ptr(fw.wg), _ptr(fw.bg),
-                                             _ptr(feat0), _ptr(feat1), _ptr(feat2), _ptr(feat_grid),
+                                             _ptr(feat0) if store01 else None, _ptr(feat1) if store01 else None,
+                                             _ptr(feat2), _ptr(feat_grid),
                                              int(feat_grid_dtype == torch.float32) | (2 if blocked else 0), N, H, W,
                                              int(fw.x3), _stream(o0))
     _lib.check(rc, "tpspp_front_bf16_fwd")
     if blocked:
         B = Blocked32 if fw.x3 else Blocked
-        return B(feat0), B(feat1), B(feat2), feat_grid
+        return (B(feat0), B(feat1), B(feat2), feat_grid) if store01 else (None, None, B(feat2), feat_grid)
     return feat0, feat1, feat2, feat_grid
+
+
+def down_fused_bf16_applicable(o, cw):
+    """`down_fused_bf16` takes a bfloat16 (N, 32, H, 128) map with an even H and a plain-bf16 64 -> 64 3x3 weight."""
+    return (o.dtype == torch.bfloat16 and o.dim() == 4 and o.shape[1] == 32 and o.shape[2] % 2 == 0 and o.shape[3] == 128
+            and not cw.x3 and cw.kernel == 3 and cw.cin == 64 and cw.cout == 64 and cw.bias is not None
+            and cw.post_scale is None)
+
+
+def down_fused_bf16(o, w0_slab, b0, cw, relu=True):
+    """`down0_1(down0(outs[0]))` / `down1_1(down1(outs[1]))` of TPS_PP.forward (tps_pp.py:560-563) in one kernel
+    (`tpspp_down_fused_bf16_fwd`): the 1x1 result never exists in HBM.  `w0_slab`, `b0`: the 1x1 layer as
+    `FrontWeightsBf16` holds it; `cw`: the 3x3 stride-2 layer (`prep_conv_weight_bf16`).  Returns a `Blocked` map."""
+    o = _chk16("outs", o, 4)
+    if not down_fused_bf16_applicable(o, cw):
+        raise ValueError("down_fused_bf16: needs a bfloat16 (N, 32, H, 128) map with an even H and a 64 -> 64 3x3 bf16 weight "
+                         "with a bias")
+    N, _, H, W = o.shape
+    out = Blocked(torch.empty((N, 8, H // 2, W // 2, 8), device=o.device, dtype=torch.bfloat16))
+    if N == 0:
+        return out
+    with torch.cuda.device(o.device):
+        rc = _lib.lib().tpspp_down_fused_bf16_fwd(_ptr(o), _ptr(w0_slab), _ptr(b0), _ptr(cw.arranged), _ptr(cw.bias),
+                                                  out.t.data_ptr(), N, H, W, int(relu), _stream(o))
+    _lib.check(rc, "tpspp_down_fused_bf16_fwd")
+    return out
 
 
 def cbam(x, atten):

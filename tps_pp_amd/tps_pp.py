@@ -22,8 +22,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from . import constants, ops
 from .registry import BACKBONES, PREPROCESSOR
+
+_NO_DOWN_FUSED = os.environ.get("TPSPP_NO_DOWN_FUSED") == "1"      # lab switch, see _regress_hip_bf16
 
 
 class ConvModule(nn.Module):
@@ -480,13 +484,22 @@ class TPS_PP(nn.Module):
                 fc = getattr(self, "_front16_cache", None)
                 if fc is None or fc[0] != fkey:
                     self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self, x3))
-                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype, blocked=True)
+                # round 4: feat0 / feat1 are not stored where the stride-2 layers can recompute them from outs[0] / outs[1]
+                # (tpspp_down_fused.hip; TPSPP_NO_DOWN_FUSED=1 keeps the two-kernel route for A/B runs)
+                fused = (not x3 and not _NO_DOWN_FUSED and ops.down_fused_bf16_applicable(o0, cw["down0_1"])
+                         and ops.down_fused_bf16_applicable(o1, cw["down1_1"]))
+                feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype, blocked=True, store01=not fused)
+                if fused:
+                    fw = fc[1]
+                    cat_srcs = [ops.down_fused_bf16(o0, fw.w0, fw.b0, cw["down0_1"]),
+                                ops.down_fused_bf16(o1, fw.w1, fw.b1, cw["down1_1"]), feat2]
             else:
                 feat0 = c16([o0], cw["down0"], 1)
                 feat1 = c16([o1], cw["down1"], 1)
                 feat2 = c16([x], cw["down2"], 1)
                 feat_grid = c16([feat0, feat1, (feat2, 2, 2)], cw["down_feat"], 1, out_dtype=fg_dtype)
-            cat_srcs = [c16([feat0], cw["down0_1"], 2, **blk), c16([feat1], cw["down1_1"], 2, **blk), feat2]
+            if feat0 is not None:
+                cat_srcs = [c16([feat0], cw["down0_1"], 2, **blk), c16([feat1], cw["down1_1"], 2, **blk), feat2]
         else:
             cat_srcs = [c16([o0], cw["down0"], 2, **blk), c16([o1], cw["down1"], 1, **blk), c16([x], cw["down2"], 1, **blk)]
             feat_grid = x
