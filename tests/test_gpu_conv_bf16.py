@@ -422,3 +422,29 @@ def test_down_fused_argument_errors(cuda):
         ops.front_bf16(torch.zeros((1, 32, 32, 128), device=cuda).bfloat16(), torch.zeros((1, 32, 32, 128), device=cuda).bfloat16(),
                        torch.zeros((1, 64, 16, 64), device=cuda).bfloat16(), fw, store01=False)          # NCHW form
     assert ops.down_fused_bf16(torch.zeros((0, 32, 32, 128), device=cuda).bfloat16(), fw.w0, fw.b0, cw).shape == (0, 64, 16, 64)
+
+
+@pytest.mark.parametrize("store01", [True, False])
+def test_front_bf16_full_machine_matches_chunked_runs(cuda, store01):
+    """The fused front waits for its prefetched pieces by COUNT (s_waitcnt vmcnt(n): all but the segment's stores): with
+    every CU busy (530 images) the result must still be what chunk-by-chunk calls give."""
+    from tps_pp_amd import TPS_PP
+    torch.manual_seed(9)
+    m = TPS_PP().eval().to(cuda)
+    fw = ops.FrontWeightsBf16(m)
+    N = 530
+    g = torch.Generator(device=cuda).manual_seed(77)
+    o0 = torch.randn((N, 32, 32, 128), generator=g, device=cuda).bfloat16()
+    o1 = torch.randn((N, 32, 32, 128), generator=g, device=cuda).bfloat16()
+    x = torch.randn((N, 64, 16, 64), generator=g, device=cuda).bfloat16()
+    for rep in range(3):
+        whole = ops.front_bf16(o0, o1, x, fw, torch.bfloat16, blocked=True, store01=store01)
+        for lo in range(0, N, 53):
+            part = ops.front_bf16(o0[lo:lo + 53].contiguous(), o1[lo:lo + 53].contiguous(), x[lo:lo + 53].contiguous(), fw,
+                                  torch.bfloat16, blocked=True, store01=store01)
+            for a, b in zip(whole, part):
+                if a is None:
+                    continue
+                a = a.t if isinstance(a, ops.Blocked) else a
+                b = b.t if isinstance(b, ops.Blocked) else b
+                assert torch.equal(a[lo:lo + 53].view(torch.int16), b.view(torch.int16)), (rep, lo)

@@ -54,6 +54,20 @@ struct DownFParams {
     int relu;
 };
 
+// -DTPSPP_DOWNF_TRACE: workgroup 0 records s_memtime at its phase boundaries (wavefront w: stamps 64 w ..), read back with
+// tpspp_debug_downf_trace (scripts/debug/trace_down_fused.py); compiled out of the product.
+#ifdef TPSPP_DOWNF_TRACE
+__device__ long long g_trace[4 * 64];
+#define TRACE_INIT() long long* trp_ = g_trace + wv * 64; int tri_ = 0; const bool tr_ = blockIdx.x == 0 && lane == 0
+#define STAMP() do { if (tr_ && tri_ < 64) trp_[tri_++] = __builtin_amdgcn_s_memtime(); } while (0)
+// a stamp taken once `v` is available
+#define STAMP2(v) do { asm volatile("s_nop 0" :: "v"(v)); STAMP(); } while (0)
+#else
+#define STAMP2(v) do {} while (0)
+#define TRACE_INIT() do {} while (0)
+#define STAMP() do {} while (0)
+#endif
+
 constexpr int kW = 128, kWo = 64;
 constexpr int RP = 72;                           // units per (channel group, parity) run: pad | 64 columns | 7 unused
                                                  // (72: the even and the odd run of a producer's 16-lane write group are
@@ -86,6 +100,8 @@ down_fused_kernel(const DownFParams P)
     u32x4* const ring = reinterpret_cast<u32x4*>(smem + kW0Units * 16 + 512 + 4 * kTileBytes);
     const int half = lane >> 5, l31 = lane & 31;
 
+    TRACE_INIT();
+    STAMP();
     sW0[tid] = P.w0[tid];
     if (tid < 128) sBias[tid] = tid < 64 ? P.b0[tid] : P.bd[tid - 64];
     if (tid < kRing * 16) {                                   // the padding column of every run, zero for good
@@ -100,6 +116,7 @@ down_fused_kernel(const DownFParams P)
 #pragma unroll
         for (int t = 0; t < 9; ++t) wa[c][t] = __builtin_bit_cast(bf16x8, P.wd[((c * 9 + t) * 2 + half) * 64 + 32 * h2 + l31]);
     __syncthreads();
+    STAMP();
 
     const int H = P.H, Ho = H >> 1, plane = H * kW;
     const int RS = P.rows_per_unit, upi = Ho / RS, nunits = P.N * upi;
@@ -128,6 +145,7 @@ down_fused_kernel(const DownFParams P)
             b[j][0] = k0[0]; b[j][1] = k0[1]; b[j][2] = k1[0]; b[j][3] = k1[1];
         }
         asm volatile("" ::: "memory");                        // ... before the next segment overwrites the tile
+        STAMP2(b[1][3]);
         f32x16 acc[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -141,6 +159,7 @@ down_fused_kernel(const DownFParams P)
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1], 0, 0, 0);
         }
+        STAMP2(acc[1][15]);
         u32x4* const row = ring + ((iy + 1) % kRing) * kRowUnits + punit;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -168,6 +187,9 @@ down_fused_kernel(const DownFParams P)
     };
 
     u32x4 pa[2], pb[2];                                       // the pieces of the next step's two rows
+    u32x4 hold[2];                                            // the last step's two result units and where they go
+    unsigned short* hold_p = nullptr;
+    bool held = false;                                        // (uniform)
     int u = blockIdx.x;
     if (u < nunits) {
         const int n = u / upi, oy = (u - n * upi) * RS;
@@ -188,8 +210,20 @@ down_fused_kernel(const DownFParams P)
         }
         for (int oy = oy_s; oy < oy_s + RS; ++oy) {
             if (oy > oy_s) __syncthreads();                   // the rows this step overwrites have been read
+            STAMP();
             produce(2 * oy, pa);
             produce(2 * oy + 1, pb);
+            STAMP();
+            // The previous step's results leave HERE, in front of the next fetch: a wavefront's vector-memory operations
+            // retire in issue order and the compiler waits for the fetched pieces with vmcnt(0) at the top of a step, so
+            // stores issued BEHIND the fetch (at the end of the step that computed them) are drained there as well --
+            // their write acknowledgements, 1100-2200 of a step's 6700 cycles (scripts/debug/trace_down_fused.py).
+            // Waiting by count instead (s_waitcnt vmcnt(2): "all but the two stores") is not safe: with the machine full
+            // (530 images) stores were seen to retire before older loads.
+            if (held) {
+                *reinterpret_cast<u32x4*>(hold_p) = hold[0];
+                *reinterpret_cast<u32x4*>(hold_p + (size_t)2 * Ho * kWo * 8) = hold[1];
+            }
             {
                 // the next step's pieces: in flight under this step's products
                 int nn = n, noy = oy + 1;
@@ -203,6 +237,7 @@ down_fused_kernel(const DownFParams P)
                 if (more) { fetch(nn, 2 * noy, pa); fetch(nn, 2 * noy + 1, pb); }
             }
             __syncthreads();                                  // the three rows of this step are in the ring
+            STAMP();
             // ---- 3x3, stride 2: input rows 2 oy - 1 + ky in ring slots (2 oy + ky) % 3 ----
             const u32x4* rows[3];
 #pragma unroll
@@ -210,17 +245,27 @@ down_fused_kernel(const DownFParams P)
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            // B fragments are requested kPD products ahead (a register ring; the scheduling barriers keep the order: left
+            // to itself the compiler issues every read right in front of its product -- 36 LDS latencies per step)
+            constexpr int kPD = 3;
+            bf16x8 fb[kPD + 1];
+            auto fetch_b = [&](int i, int slot) {
+                const int c = i / 9, t = i - 9 * c, ky = t / 3, kx = t - 3 * ky;
+                // kx = 0: odd column 2 ox - 1 (run 1, slot ox); kx = 1: even column 2 ox (run 0, slot ox + 1);
+                // kx = 2: odd column 2 ox + 1 (run 1, slot ox + 1)
+                const int off = (2 * c) * (2 * RP) + (kx == 1 ? 0 : RP) + (kx == 0 ? 0 : 1);
+                fb[slot] = __builtin_bit_cast(bf16x8, rows[ky][off]);
+            };
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int i = 0; i < kPD; ++i) fetch_b(i, i);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int ky = t / 3, kx = t - 3 * ky;
-                    // kx = 0: odd column 2 ox - 1 (run 1, slot ox); kx = 1: even column 2 ox (run 0, slot ox + 1);
-                    // kx = 2: odd column 2 ox + 1 (run 1, slot ox + 1)
-                    const int off = (2 * c) * (2 * RP) + (kx == 1 ? 0 : RP) + (kx == 0 ? 0 : 1);
-                    const bf16x8 bb = __builtin_bit_cast(bf16x8, rows[ky][off]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[c][t], bb, acc, 0, 0, 0);
-                }
+            for (int i = 0; i < 36; ++i) {
+                if (i + kPD < 36) fetch_b(i + kPD, (i + kPD) % (kPD + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i / 9][i % 9], fb[i % (kPD + 1)], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            STAMP();
             // ---- bias, ReLU, rounding; 16-byte units of the blocked output ----
             u32x2 pk[4];
 #pragma unroll
@@ -233,19 +278,32 @@ down_fused_kernel(const DownFParams P)
                 }
                 pk[g][0] = pack_bf16(v[0], v[1]); pk[g][1] = pack_bf16(v[2], v[3]);
             }
-            unsigned short* const ob = P.out + (((size_t)n * 8 * Ho + oy) * kWo + 32 * f + l31) * 8;
+            hold_p = P.out + ((((size_t)n * 8 + 4 * h2 + half) * Ho + oy) * kWo + 32 * f + l31) * 8;
 #pragma unroll
             for (int g = 0; g < 4; g += 2) {
                 const u32x2 d0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
                 const u32x2 d1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
                 u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
-                *reinterpret_cast<u32x4*>(ob + (size_t)(4 * h2 + g + half) * Ho * kWo * 8) = unit;
+                hold[g >> 1] = unit;                          // channel group 4 h2 + g + half
             }
+            held = true;
+            STAMP();
         }
+    }
+    if (held) {
+        *reinterpret_cast<u32x4*>(hold_p) = hold[0];
+        *reinterpret_cast<u32x4*>(hold_p + (size_t)2 * Ho * kWo * 8) = hold[1];
     }
 }
 
 }  // namespace
+
+#ifdef TPSPP_DOWNF_TRACE
+extern "C" __attribute__((visibility("default"))) int tpspp_debug_downf_trace(long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(long long) * n);
+}
+#endif
 
 TPSPP_EXPORT int tpspp_down_fused_bf16_fwd(const void* in, const void* w0, const float* b0, const void* wd, const float* bd,
                                            void* out, int N, int H, int W, int relu, tpspp_stream_t stream)

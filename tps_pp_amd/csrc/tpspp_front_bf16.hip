@@ -87,10 +87,14 @@ __device__ __forceinline__ u32x2 read_tr(const unsigned short* p)
 
 // one input tile of 2 KB in global memory: 128 pieces of 16 bytes, two per lane; a channel's row segment holds
 // 1 << QB pieces.  The pieces of the NEXT segment are fetched into registers while this one is computed.
-// The loads are inline asm so that their completion is waited for by COUNT (wait_fetched): the compiler's own
-// wait would be vmcnt(0) at the top of the next segment, which also drains that segment's 12-14 stores -- their
-// write acknowledgements, not the loads, are then what a wavefront spends its time on (measured: 373 us with the
-// drain; 196 us without the stores, 285 us without the loads).  vmcnt retires loads and stores in issue order.
+// The loads are inline asm so that the wait for them stands where the kernel wants it (wait_fetched, at the END of the
+// segment that was computed under them) instead of where the compiler would put it.
+// Rounds 2-3 waited by COUNT there -- s_waitcnt vmcnt(n) with n = the stores issued since the fetch, "all but the
+// segment's stores have completed" -- on the premise that a wavefront's loads and stores retire in issue order.  They do
+// not: round 4's variant without the feat0 / feat1 stores (n = 4-8 instead of 12-20) read stale pieces with every CU busy
+// (test_front_bf16_full_machine_matches_chunked_runs: 530 images against chunked runs) -- stores were acknowledged
+// before older loads had returned, which lets the count drop below n early.  The wait is vmcnt(0) in every variant now;
+// same box, same run: 281-285 us against 308-330 us counted (blocked bf16, 512 images), i.e. nothing lost.
 template <int QB>
 __device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ src, int plane, int lane, u32x4 (&r)[2])
 {
@@ -102,8 +106,8 @@ __device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ sr
     }
 }
 
-// all but the youngest NSTORES vector-memory operations of this wavefront have completed: the six fetches issued before
-// them have landed.  The registers are operands so that their uses stay behind the wait.
+// every vector-memory operation of this wavefront has completed (NSTORES = 0; a count > 0 is not a safe way to skip
+// younger stores, see above).  The registers are operands so that their uses stay behind the wait.
 template <int NSTORES>
 __device__ __forceinline__ void wait_fetched(u32x4 (&a)[2], u32x4 (&b)[2], u32x4 (&c)[2])
 {
@@ -374,14 +378,7 @@ front_bf16_kernel(const FrontBParams P)
             finish(acc, bias + 192, half, to, l31, true, unused);
             flush_tile<32>(to, reinterpret_cast<char*>(reinterpret_cast<unsigned short*>(P.feat_grid) + obase), pb, lane);
         }
-        // stores issued since the fetch: feat0 4, feat1 4, feat2 2 (even rows), feat_grid 4 (bf16) or 8 (fp32);
-        // blocked: feat0 4, feat1 4, feat2 4 (even rows)
-        if (more) {
-            constexpr int NS = (FG32 ? 8 : 4) + (ST01 ? 8 : 0);
-            constexpr int N2 = BLK ? 4 : 2;
-            if (row2) wait_fetched<NS + N2>(pf0, pf1, pf2);
-            else wait_fetched<NS>(pf0, pf1, pf2);
-        }
+        if (more) wait_fetched<0>(pf0, pf1, pf2);
     }
 }
 
