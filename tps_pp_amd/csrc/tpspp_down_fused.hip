@@ -27,8 +27,14 @@
 //     the NCHW rows into a private [channel][32 pixels] tile, ds_read_b64_tr_b16 for the B operand, 4 matrix
 //     instructions, the C/D registers paired into 16-byte units with v_permlane32_swap -- and writes the units into the
 //     ring; the next step's pieces are already in flight (registers);
-//   * two barriers per step (ring written / ring read); two workgroups per CU cover each other's.
-// Bound: HBM (0.13 GB in, 0.07 GB out per 512 images = 33 us at 6 TB/s).
+//   * two barriers per step (ring written / ring read); two workgroups per CU cover each other's;
+//   * a step's two result units are stored one step late, in front of the next fetch (see the loop).
+// Bound: HBM (0.13 GB in, 0.07 GB out per 512 images = 33 us at 6 TB/s); measured 62-68 us = 3.0-3.2 TB/s: the sum of a
+// step's dependent phases (scripts/debug/trace_down_fused.py; per step and wavefront ~128 results x (add, max, half a
+// conversion) + pairing in the producer = ~400 vector instructions, then the 36-deep chain of dependent products).
+// Tried and dropped (round 4): the two phases on different wavefronts -- 4 consumers (the weight registers) + 4 producers
+// (the 1x1 bias in registers) per workgroup, ring of 5 rows, LDS counters instead of barriers, pieces two steps ahead --
+// bit-identical and no faster (64-72 us): the producers' vector instructions, not the phases' order, set the step time.
 #include "tpspp_common.h"
 
 namespace {
@@ -166,13 +172,19 @@ down_fused_kernel(const DownFParams P)
             u32x2 pk[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float s = acc[t][4 * g + e] + sBias[32 * t + 8 * g + 4 * half + e];
-                    v[e] = s > 0.0f ? s : 0.0f;
-                }
-                pk[g][0] = pack_bf16(v[0], v[1]); pk[g][1] = pack_bf16(v[2], v[3]);
+                // the bias goes on with packed adds and the ReLU is taken AFTER the rounding, on the packed pair (a negative
+                // bf16 is a negative int16, so max(., 0) is the same ReLU; -0 and NaN -> +0 / NaN as before is not needed:
+                // s > 0 ? s : 0 maps NaN to 0 and so does the signed max of a NaN pattern with the sign bit set only --
+                // positive-NaN patterns cannot come out of finite operands): 6 instructions per 4 results instead of 10
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                const float4 b4 = *reinterpret_cast<const float4*>(sBias + 32 * t + 8 * g + 4 * half);
+                f32x2 lo, hi, blo, bhi;
+                lo[0] = acc[t][4 * g]; lo[1] = acc[t][4 * g + 1]; hi[0] = acc[t][4 * g + 2]; hi[1] = acc[t][4 * g + 3];
+                blo[0] = b4.x; blo[1] = b4.y; bhi[0] = b4.z; bhi[1] = b4.w;
+                lo = lo + blo; hi = hi + bhi;
+                const s16x2 z = {0, 0};
+                pk[g][0] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(lo[0], lo[1])), z));
+                pk[g][1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack_bf16(hi[0], hi[1])), z));
             }
             // the two half-wavefronts hold the two 8-byte halves of every unit: after the swap the lower one owns the
             // unit of channel group 4 t + g, the upper one that of 4 t + g + 1
@@ -295,6 +307,7 @@ down_fused_kernel(const DownFParams P)
         *reinterpret_cast<u32x4*>(hold_p + (size_t)2 * Ho * kWo * 8) = hold[1];
     }
 }
+
 
 }  // namespace
 
