@@ -323,3 +323,36 @@ def test_head_argument_errors(cuda):
                 dec(feat, out_enc, None, None, train_mode=False)
         finally:
             dec._w_cache = None                          # rebuild the table for whoever uses the module next
+
+
+def test_decoder_fused_q_cross_launch_is_bit_identical(cuda, tmp_path):
+    """TPSPP_HEAD_QCROSS=1 (q projection + cross-attention of a layer-step in one launch; opt-in, measured slower) must
+    give exactly the scores of the two-launch path: the switch is read when the library loads, so two processes."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "from tps_pp_amd.nrtr_head import NRTRDecoder\n"
+        "torch.manual_seed(3)\n"
+        "dec = NRTRDecoder(num_classes=93, max_seq_len=6, start_idx=91, padding_idx=92).eval().cuda()\n"
+        "enc = torch.randn(37, 64, 512, device='cuda'); feat = torch.empty(37, 512, 8, 8, device='cuda')\n"
+        "res = {}\n"
+        "for tag, cd in (('bf16x3', 'bf16x3'), ('bf16', torch.bfloat16)):\n"
+        "    dec.compute_dtype = cd\n"
+        "    with torch.no_grad():\n"
+        "        res[tag] = dec(feat, enc, None, None, train_mode=False).cpu()\n"
+        "torch.save(res, sys.argv[1])\n")
+    import os
+    outs = []
+    for val in (None, "1"):
+        env = dict(os.environ)
+        env.pop("TPSPP_HEAD_QCROSS", None)
+        if val:
+            env["TPSPP_HEAD_QCROSS"] = val
+        path = str(tmp_path / f"dec_{val}.pt")
+        subprocess.run([sys.executable, "-c", code, path], env=env, check=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(torch.load(path))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.isfinite(outs[0][k]).all()

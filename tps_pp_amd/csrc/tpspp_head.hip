@@ -418,24 +418,16 @@ template <> struct Wide<unsigned short> {
     }
 };
 
-// cross-attention: q_t (Nb, C), Kx_t / Vx_t (Nb*T, C) token-major, out (Nb, C) token-major.  One wavefront per (image, head).
+// cross-attention of one (image b, head h) by one wavefront: q (this lane's EPL features, already scaled), Kx_t / Vx_t
+// (Nb*T, C) token-major, out (Nb, C) token-major (or channel-major).
 template <typename KV>
-__global__ void __launch_bounds__(256)
-attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
-                           int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out, int out_cm)
+__device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
+                                             int C, int Nb, int T, int nvalid, int b, int h, int lane, float* __restrict__ out,
+                                             int out_cm)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;   // tokens per instruction, pieces per 64 tokens
-    const int lane = threadIdx.x & (kWave - 1);
-    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pair >= Nb * H) return;
-    const int b = pair / H, h = pair - b * H;
     const int grp = lane / GS, dl = lane % GS;             // this lane: tokens grp, grp + TPI, ...; features EPL dl ..
-    float q[EPL];
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) q[e] = q_t[(size_t)b * C + kDK * h + EPL * dl + e] * 0.125f;
-    int nvalid = valid_len ? valid_len[b] : T;
-    nvalid = nvalid < T ? nvalid : T;
     const typename Wd::raw* kb = reinterpret_cast<const typename Wd::raw*>(Kx_t + ((size_t)b * T) * C + kDK * h + EPL * dl);
     const typename Wd::raw* vb = reinterpret_cast<const typename Wd::raw*>(Vx_t + ((size_t)b * T) * C + kDK * h + EPL * dl);
     const size_t rstride = (size_t)C / EPL;                // row pitch in raw pieces
@@ -511,6 +503,26 @@ attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__
             for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
         }
     }
+}
+
+// cross-attention: q_t (Nb, C), Kx_t / Vx_t (Nb*T, C) token-major, out (Nb, C) token-major.  One wavefront per (image, head).
+template <typename KV>
+__global__ void __launch_bounds__(256)
+attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
+                           int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out, int out_cm)
+{
+    constexpr int EPL = Wide<KV>::EPL, GS = kDK / EPL;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair - b * H;
+    const int dl = lane % GS;
+    float q[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] = q_t[(size_t)b * C + kDK * h + EPL * dl + e] * 0.125f;
+    int nvalid = valid_len ? valid_len[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    cross_attend<KV>(q, Kx_t, Vx_t, C, Nb, T, nvalid, b, h, lane, out, out_cm);
 }
 
 // masked self-attention against token-major caches Kc / Vc [image][head][position][64]; qkv_t (Nb, 3C); out (Nb, C).
@@ -795,6 +807,121 @@ dec_gemm_x3_kernel(const DGemm P)
     *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- q projection + cross-attention of a layer-step in ONE launch (round 4; the review's item 3) ------------------------------
+// A workgroup owns 16 images x one head: (A) their 64 q features = LN(y) Wq + b exactly as dec_gemm_x3_kernel<8, true>
+// computes them -- the same loads, k split, products, reduction order and epilogue, for the head's two 32-output tiles, the
+// 16 tokens in the lower half of the MFMA's columns -- left in LDS; (B) each of the four wavefronts then runs cross_attend for
+// four of the sixteen (image, head) pairs.  Bit for bit the two launches it replaces.  Grid (Nb / 16, H) = 256 workgroups at
+// batch 512: the 128 KB of the head's weight slice is read once per 16 images as before (33 MB of L2 reads per launch).
+// MEASURED (batch 512, 40 steps, scripts/debug/dec_fusion_ab.py, interleaved runs on one box): the greedy decoder takes
+// 24.9 ms with it against 21.8 ms with the two launches (bf16x3 head), 18.05 against 16.65 ms (bf16 head): +13 / +6 us per
+// layer-step.  The separate attention launch runs 16 wavefronts per CU, one (image, head) each, and is bound by the keys' and
+// values' bytes; here four wavefronts per CU walk four pairs each, one after the other, behind the projection's own load ->
+// product -> reduce chain, and what the fusion removes -- one kernel boundary, ~1.5-2 us -- is less than what the lost
+// parallelism costs.  Hence opt-in only (TPSPP_HEAD_QCROSS=1), kept as the measured form of the review's proposal.
+template <typename KV>
+__global__ void __launch_bounds__(256)
+dec_q_cross_x3_kernel(const DGemm P, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t, int H, int T,
+                      const int* __restrict__ valid_len, float* __restrict__ out)
+{
+    constexpr int KSW = 8;
+    __shared__ float sRed[4][2][16][kWave];
+    __shared__ float sS1[8][32], sS2[8][32];
+    __shared__ __attribute__((aligned(16))) float sQ[16][kDK];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31, l15 = lane & 15;
+    const int m0 = blockIdx.x * 16, h = blockIdx.y;
+    const int KS = P.K >> 4;
+    const int m = m0 + l15;
+    const int mc = m < P.M ? m : P.M - 1;
+    const float4* xp = reinterpret_cast<const float4*>(P.X + (size_t)mc * P.K + 16 * (wv * KSW) + 8 * half);
+    float4 xa[KSW][2];
+    du32x4 ah[2][KSW], al[2][KSW];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) { xa[j][0] = xp[4 * j]; xa[j][1] = xp[4 * j + 1]; }
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+        const du32x4* wp = P.Wp + ((size_t)((2 * h + tl) * KS + wv * KSW) * 4 + half) * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) { ah[tl][j] = wp[(size_t)j * 128]; al[tl][j] = wp[(size_t)j * 128 + 64]; }
+    }
+    const int c = 8 * wv + 4 * half;                       // + 32 tl: this lane's four q features of the head (epilogue)
+    float4 cs[2], b4[2];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+        cs[tl] = *reinterpret_cast<const float4*>(P.colsum + kDK * h + 32 * tl + c);
+        b4[tl] = P.bias ? *reinterpret_cast<const float4*>(P.bias + kDK * h + 32 * tl + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x16_t acc[2];
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tl][i] = 0.0f;
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const float x[8] = {xa[j][0].x, xa[j][0].y, xa[j][0].z, xa[j][0].w, xa[j][1].x, xa[j][1].y, xa[j][1].z, xa[j][1].w};
+        du32x4 bh, bl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned pk = dpack2(x[2 * q], x[2 * q + 1]);
+            const float h0 = __builtin_bit_cast(float, pk << 16), h1 = __builtin_bit_cast(float, pk & 0xffff0000u);
+            bh[q] = pk;
+            bl[q] = dpack2(x[2 * q] - h0, x[2 * q + 1] - h1);
+            s1 += x[2 * q] + x[2 * q + 1];
+            s2 = fmaf(x[2 * q], x[2 * q], s2);
+            s2 = fmaf(x[2 * q + 1], x[2 * q + 1], s2);
+        }
+        const dbf16x8 Bh = __builtin_bit_cast(dbf16x8, bh), Bl = __builtin_bit_cast(dbf16x8, bl);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const dbf16x8 Ah = __builtin_bit_cast(dbf16x8, ah[tl][j]), Al = __builtin_bit_cast(dbf16x8, al[tl][j]);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[tl], 0, 0, 0);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[tl], 0, 0, 0);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[tl], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sRed[wv][tl][r][lane] = acc[tl][r];
+    sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2;
+    __syncthreads();
+    if (l31 < 16) {
+        float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
+        const float mean = t1 / (float)P.K;
+        const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[e] = (sRed[0][tl][4 * wv + e][lane] + sRed[1][tl][4 * wv + e][lane]) +
+                       (sRed[2][tl][4 * wv + e][lane] + sRed[3][tl][4 * wv + e][lane]);
+            v[0] = rstd * (v[0] - mean * cs[tl].x); v[1] = rstd * (v[1] - mean * cs[tl].y);
+            v[2] = rstd * (v[2] - mean * cs[tl].z); v[3] = rstd * (v[3] - mean * cs[tl].w);
+            if (P.bias) { v[0] += b4[tl].x; v[1] += b4[tl].y; v[2] += b4[tl].z; v[3] += b4[tl].w; }
+            *reinterpret_cast<float4*>(&sQ[l31][32 * tl + c]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    constexpr int EPL = Wide<KV>::EPL, GS = kDK / EPL;
+    const int dl = lane % GS;
+    for (int t = wv; t < 16; t += 4) {
+        const int b = m0 + t;
+        if (b >= P.M) break;                               // wave-uniform
+        float q[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = sQ[t][EPL * dl + e] * 0.125f;
+        int nvalid = valid_len ? valid_len[b] : T;
+        nvalid = nvalid < T ? nvalid : T;
+        cross_attend<KV>(q, Kx_t, Vx_t, P.Co, P.M, T, nvalid, b, h, lane, out, 0);
+    }
+}
+
 // The same GEMM with exact fp32 products (v_mfma_f32_32x32x2_f32) for the exact-fp32 configuration: the weight arrives
 // as fp32 in fragment order, [Co/32][K/8][k half][32 outputs][4 k] with k = 8 u + 4 half + e, x as 16-byte pieces of the
 // token-major row (the lane's four k of the step), four MFMAs per 16-byte pair; eight wavefronts split K.
@@ -929,6 +1056,9 @@ transpose2d_b16_kernel(const unsigned short* __restrict__ in, int rows, int cols
 
 // lab switch (TPSPP_HEAD_NO_TOKGEMM=1 in the environment): the wide projections through the convolution kernel as before
 const bool g_head_no_tokgemm = getenv("TPSPP_HEAD_NO_TOKGEMM") != nullptr;
+// TPSPP_HEAD_QCROSS=1: the q projection and the cross-attention of a decoder layer-step as ONE launch (dec_q_cross_x3_kernel).
+// Off by default: bit-identical and slower (see the kernel's header).
+const bool g_head_qcross = getenv("TPSPP_HEAD_QCROSS") != nullptr;
 
 struct Gemm {
     hipStream_t st;
@@ -1275,6 +1405,19 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                 hipLaunchKernelGGL(attn_dec_self_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, C, N, H, s, L, Kc[l],
                                    Vc[l], tokens, Lt, padding_idx, a, 0);
             dec_gemm_x3(st, a, w[D_WFC_X], w[D_BFC], nullptr, 0.0f, x, 0, N, C, C, y, gemm_f32);              // y = x + fc(a)
+            if (!gemm_f32 && C == 512 && g_head_qcross) {
+                // q projection + cross-attention in one launch (dec_q_cross_x3_kernel)
+                DGemm Q;
+                Q.X = y; Q.Wp = reinterpret_cast<const du32x4*>(w[D_Q_X]); Q.bias = w[D_Q_B]; Q.colsum = w[D_Q_CS]; Q.res = nullptr;
+                Q.out = nullptr; Q.M = N; Q.K = C; Q.Co = C; Q.eps = 1e-5f; Q.act = 0;
+                const dim3 qgrid((unsigned)((N + 15) / 16), (unsigned)H);
+                if (b16)
+                    hipLaunchKernelGGL(dec_q_cross_x3_kernel<unsigned short>, qgrid, dim3(256), 0, st, Q,
+                                       reinterpret_cast<const unsigned short*>(Kx[l]),
+                                       reinterpret_cast<const unsigned short*>(Vx[l]), H, T, valid_len, a);
+                else
+                    hipLaunchKernelGGL(dec_q_cross_x3_kernel<float>, qgrid, dim3(256), 0, st, Q, Kx[l], Vx[l], H, T, valid_len, a);
+            } else {
             dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv, gemm_f32);
             if (b16)
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
@@ -1283,6 +1426,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             else
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<float>, dim3(pair_blocks), dim3(256), 0, st, qkv, Kx[l], Vx[l], C,
                                    N, H, T, valid_len, a, 0);
+            }
             dec_gemm_x3(st, a, w[D_WFC2_X], w[D_BFC2], nullptr, 0.0f, y, 0, N, C, C, x, gemm_f32);            // x = y + fc(a)
             dec_gemm_x3(st, x, w[D_W1_X], w[D_W1_B], w[D_W1_CS], 1e-5f, nullptr, 2, N, C, d_inner, hid, gemm_f32);
             dec_gemm_x3(st, hid, w[D_W2_X], w[D_B2], nullptr, 0.0f, x, 0, N, d_inner, C, y, gemm_f32);        // y = x + w2(...)
