@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define TPSPP_ABI_VERSION 2   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table */
+#define TPSPP_ABI_VERSION 3   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
+                               3: tpspp_down_fused_bf16_fwd, tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtpspp_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _f = ctypes.c_void_p       # device pointers travel as integers
 _i = ctypes.c_int
