@@ -548,15 +548,31 @@ attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H,
     typename Wd::raw* kc = reinterpret_cast<typename Wd::raw*>(Kc + bh * Lmax * kDK + EPL * dl);
     typename Wd::raw* vc = reinterpret_cast<typename Wd::raw*>(Vc + bh * Lmax * kDK + EPL * dl);
     constexpr int rstride = GS;                            // a cached row is GS pieces
-    if (grp == 0) { kc[(size_t)step * rstride] = Wd::pack(k); vc[(size_t)step * rstride] = Wd::pack(v); }
 
+    // Every load of the wavefront is requested here, before the first use of any of them: the cached keys AND values of the
+    // earlier positions (the values do not depend on the scores) and the positions' token ids (the <PAD> mask).  Round 4: the
+    // ids used to be read inside the score loop, one 4-byte load and one s_waitcnt vmcnt(0) per piece, and the values behind
+    // the softmax -- eleven dependent round trips to memory in a kernel that moves 5-20 KB per wavefront (9-13 us per launch,
+    // 240 launches per batch); now three (four with fp32 caches).
+    // (fp32 caches: keys + values together are 128 registers of loads in flight, 140 in all -- three wavefronts per SIMD
+    // instead of four, i.e. a second, nearly empty round of the 4096 wavefronts: 16.7 us against 13.4; their values stay
+    // behind the softmax.  bf16 caches: 123 registers, 9.2 -> 8.9 us.)
+    constexpr bool kValuesEarly = sizeof(KV) == 2;
     float sc[NP];
-    typename Wd::raw kr[NP];
+    typename Wd::raw kr[NP], vr[NP];
+    int tk[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int p = TPI * i + grp;
-        if (TPI * i < step) kr[i] = kc[(size_t)(p < step ? p : 0) * rstride];      // (uniform test: whole pieces beyond `step` are skipped)
+        tk[i] = pad_idx;
+        if (TPI * i <= step) tk[i] = tokens[(size_t)b * Lt + (p <= step ? p : 0)];   // (uniform tests: whole pieces beyond `step` are skipped)
+        if (TPI * i < step) {
+            kr[i] = kc[(size_t)(p < step ? p : 0) * rstride];
+            if (kValuesEarly) vr[i] = vc[(size_t)(p < step ? p : 0) * rstride];
+        }
     }
+    // the new position's key / value join the caches (rows `step`: never among the rows read above)
+    if (grp == 0) { kc[(size_t)step * rstride] = Wd::pack(k); vc[(size_t)step * rstride] = Wd::pack(v); }
     float cur = 0.0f;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) cur = fmaf(q[e], k[e], cur);
@@ -576,7 +592,7 @@ attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H,
                 dot = group_sum<GS>(dot);
             }
             if (p == step) dot = cur;
-            const bool valid = p <= step && tokens[(size_t)b * Lt + (p <= step ? p : 0)] != pad_idx;
+            const bool valid = p <= step && tk[i] != pad_idx;
             s = valid ? dot : -INFINITY;
         }
         sc[i] = s;
@@ -591,11 +607,12 @@ attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H,
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
-    typename Wd::raw vr[NP];
+    if (!kValuesEarly) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int p = TPI * i + grp;
-        if (TPI * i < step) vr[i] = vc[(size_t)(p < step ? p : 0) * rstride];
+        for (int i = 0; i < NP; ++i) {
+            const int p = TPI * i + grp;
+            if (TPI * i < step) vr[i] = vc[(size_t)(p < step ? p : 0) * rstride];
+        }
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
