@@ -148,30 +148,40 @@ tok_gemm_kernel(const tpspp::TokGemmArgs P)
 #pragma unroll
             for (int ci = 0; ci < NCI; ++ci) { ch[ks][ci] = ah[ks][ci]; if (X3) cl[ks][ci] = al[ks][ci]; }
         if (s + 1 < nst) { load_stage(s + 1); load_a(s + 1); }     // in flight under this stage's matrix instructions
+        // the stage's eight B fragments (k-step ks, 32-token tile ti) are requested kPD fragments ahead of their products
+        // through a register ring; the scheduling barriers keep that order (left alone the compiler issues every
+        // fragment's reads right in front of its products: one LDS latency per fragment in every wavefront)
+        constexpr int kPD = 2;
+        u32x4 bh[kPD + 1], bl[kPD + 1];
+        auto fetch_b = [&](int i, int slot) {
+            const int ks = i >> 2, ti = i & 3;
+            const unsigned short* p = &sX[buf][0][0][0] + lb + (16 * ks) * PITCH + 32 * ti;
+            const u32x2 k0 = read_tr(p), k1 = read_tr(p + 4 * PITCH);
+            bh[slot][0] = k0[0]; bh[slot][1] = k0[1]; bh[slot][2] = k1[0]; bh[slot][3] = k1[1];
+            if (X3) {
+                const unsigned short* q = &sX[buf][HL - 1][0][0] + lb + (16 * ks) * PITCH + 32 * ti;
+                const u32x2 j0 = read_tr(q), j1 = read_tr(q + 4 * PITCH);
+                bl[slot][0] = j0[0]; bl[slot][1] = j0[1]; bl[slot][2] = j1[0]; bl[slot][3] = j1[1];
+            }
+        };
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int i = 0; i < kPD; ++i) fetch_b(i, i);
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                u32x4 bh, bl;
-                const unsigned short* p = &sX[buf][0][0][0] + lb + (16 * ks) * PITCH + 32 * ti;
-                const u32x2 k0 = read_tr(p), k1 = read_tr(p + 4 * PITCH);
-                bh[0] = k0[0]; bh[1] = k0[1]; bh[2] = k1[0]; bh[3] = k1[1];
+        for (int i = 0; i < 8; ++i) {
+            const int ks = i >> 2, ti = i & 3, slot = i % (kPD + 1);
+            if (i + kPD < 8) fetch_b(i + kPD, (i + kPD) % (kPD + 1));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ci = 0; ci < NCI; ++ci) {
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ch[ks][ci]), Bh = __builtin_bit_cast(bf16x8, bh[slot]);
+                acc[ci][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[ci][ti], 0, 0, 0);
                 if (X3) {
-                    const unsigned short* q = &sX[buf][HL - 1][0][0] + lb + (16 * ks) * PITCH + 32 * ti;
-                    const u32x2 j0 = read_tr(q), j1 = read_tr(q + 4 * PITCH);
-                    bl[0] = j0[0]; bl[1] = j0[1]; bl[2] = j1[0]; bl[3] = j1[1];
-                }
-#pragma unroll
-                for (int ci = 0; ci < NCI; ++ci) {
-                    const bf16x8 Ah = __builtin_bit_cast(bf16x8, ch[ks][ci]), Bh = __builtin_bit_cast(bf16x8, bh);
-                    acc[ci][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[ci][ti], 0, 0, 0);
-                    if (X3) {
-                        const bf16x8 Al = __builtin_bit_cast(bf16x8, cl[ks][ci]), Bl = __builtin_bit_cast(bf16x8, bl);
-                        acc[ci][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[ci][ti], 0, 0, 0);
-                        acc[ci][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[ci][ti], 0, 0, 0);
-                    }
+                    const bf16x8 Al = __builtin_bit_cast(bf16x8, cl[ks][ci]), Bl = __builtin_bit_cast(bf16x8, bl[slot]);
+                    acc[ci][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[ci][ti], 0, 0, 0);
+                    acc[ci][ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[ci][ti], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (s + 1 < nst) store_stage(buf ^ 1);               // (that buffer was last read before the previous barrier)
         __syncthreads();
