@@ -737,7 +737,10 @@ __device__ __forceinline__ unsigned dpack2(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dbf16x2));
 }
 
-template <int KSW, bool LN>
+// NT: 32-output tiles per workgroup (1; 3 for the 1536-wide q|k|v projection: at one tile per workgroup its 768 workgroups
+// ran as two rounds of latency-bound launches -- ~14 us against 6.5 us for the 512-wide projections -- while three tiles per
+// workgroup are one round of 256 and read X once instead of three times; every tile is computed exactly as before).
+template <int KSW, bool LN, int NT = 1>
 __global__ void __launch_bounds__(256)
 dec_gemm_x3_kernel(const DGemm P)
 {
@@ -746,33 +749,45 @@ dec_gemm_x3_kernel(const DGemm P)
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * 32, ct = blockIdx.y, co0 = ct * 32;
+    const int m0 = blockIdx.x * 32, ct0 = blockIdx.y * NT;
     const int KS = P.K >> 4;
     const int m = m0 + l31;
     const int mc = m < P.M ? m : P.M - 1;
+    const int ntiles = (P.Co + 31) >> 5;
     const float4* xp = reinterpret_cast<const float4*>(P.X + (size_t)mc * P.K + 16 * (wv * KSW) + 8 * half);
-    const du32x4* wp = P.Wp + ((size_t)(ct * KS + wv * KSW) * 4 + half) * 32 + l31;
     float4 xa[KSW][2];
-    du32x4 ah[KSW], al[KSW];
+    du32x4 ah[NT][KSW], al[NT][KSW];
 #pragma unroll
-    for (int j = 0; j < KSW; ++j) {                        // every load of the wavefront in flight together
-        xa[j][0] = xp[4 * j]; xa[j][1] = xp[4 * j + 1];
-        ah[j] = wp[(size_t)j * 128]; al[j] = wp[(size_t)j * 128 + 64];
+    for (int j = 0; j < KSW; ++j) { xa[j][0] = xp[4 * j]; xa[j][1] = xp[4 * j + 1]; }   // every load of the wavefront in flight together
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const int ct = ct0 + tl < ntiles ? ct0 + tl : ntiles - 1;     // (a tile past the last one repeats it; never finished)
+        const du32x4* wp = P.Wp + ((size_t)(ct * KS + wv * KSW) * 4 + half) * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) { ah[tl][j] = wp[(size_t)j * 128]; al[tl][j] = wp[(size_t)j * 128 + 64]; }
     }
     // ... and the epilogue's operands with them (round 4): behind the reduction they were one more dependent round trip
     // to memory per launch, in a loop of ~2000 dependent launches
-    const int c = co0 + 8 * wv + 4 * half;
-    const bool mine = m < P.M && c < P.Co;                 // (Co is a multiple of 4: a whole piece is in or out)
-    const size_t o = (size_t)mc * P.Co + (c < P.Co ? c : 0);
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), b4 = cs, r4 = cs;
-    if (mine) {
-        if (LN) cs = *reinterpret_cast<const float4*>(P.colsum + c);
-        if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + c);
-        if (P.res) r4 = *reinterpret_cast<const float4*>(P.res + o);
-    }
-    f32x16_t acc;
+    bool mine[NT];
+    size_t o[NT];
+    float4 cs[NT], b4[NT], r4[NT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int tl = 0; tl < NT; ++tl) {
+        const int c = (ct0 + tl) * 32 + 8 * wv + 4 * half;
+        mine[tl] = m < P.M && c < P.Co;                    // (Co is a multiple of 4: a whole piece is in or out)
+        o[tl] = (size_t)mc * P.Co + (c < P.Co ? c : 0);
+        cs[tl] = make_float4(0.f, 0.f, 0.f, 0.f); b4[tl] = cs[tl]; r4[tl] = cs[tl];
+        if (mine[tl]) {
+            if (LN) cs[tl] = *reinterpret_cast<const float4*>(P.colsum + c);
+            if (P.bias) b4[tl] = *reinterpret_cast<const float4*>(P.bias + c);
+            if (P.res) r4[tl] = *reinterpret_cast<const float4*>(P.res + o[tl]);
+        }
+    }
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tl][i] = 0.0f;
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < KSW; ++j) {
@@ -790,38 +805,48 @@ dec_gemm_x3_kernel(const DGemm P)
                 s2 = fmaf(x[2 * q + 1], x[2 * q + 1], s2);
             }
         }
-        const dbf16x8 Ah = __builtin_bit_cast(dbf16x8, ah[j]), Al = __builtin_bit_cast(dbf16x8, al[j]);
         const dbf16x8 Bh = __builtin_bit_cast(dbf16x8, bh), Bl = __builtin_bit_cast(dbf16x8, bl);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
+        for (int tl = 0; tl < NT; ++tl) {
+            const dbf16x8 Ah = __builtin_bit_cast(dbf16x8, ah[tl][j]), Al = __builtin_bit_cast(dbf16x8, al[tl][j]);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[tl], 0, 0, 0);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[tl], 0, 0, 0);
+            acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[tl], 0, 0, 0);
+        }
+    }
     if (LN) { sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2; }
-    __syncthreads();
-    // wavefront w finishes accumulator registers 4 w .. 4 w + 3: outputs co0 + 8 w + 4 half + (0 .. 3) of token l31
-    if (!mine) return;
-    float v[4];
+    float mean = 0.0f, rstd = 1.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        v[e] = (sRed[0][4 * wv + e][lane] + sRed[1][4 * wv + e][lane]) + (sRed[2][4 * wv + e][lane] + sRed[3][4 * wv + e][lane]);
-    if (LN) {
-        float t1 = 0.0f, t2 = 0.0f;
+    for (int tl = 0; tl < NT; ++tl) {
+        if (tl > 0) __syncthreads();                       // the previous tile's partial sums have been read
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
-        const float mean = t1 / (float)P.K;
-        const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
-        v[0] = rstd * (v[0] - mean * cs.x); v[1] = rstd * (v[1] - mean * cs.y);
-        v[2] = rstd * (v[2] - mean * cs.z); v[3] = rstd * (v[3] - mean * cs.w);
+        for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[tl][r];
+        __syncthreads();
+        // wavefront w finishes accumulator registers 4 w .. 4 w + 3: outputs 32 ct + 8 w + 4 half + (0 .. 3) of token l31
+        if (LN && tl == 0) {
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
+            mean = t1 / (float)P.K;
+            rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
+        }
+        if (!mine[tl]) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = (sRed[0][4 * wv + e][lane] + sRed[1][4 * wv + e][lane]) + (sRed[2][4 * wv + e][lane] + sRed[3][4 * wv + e][lane]);
+        if (LN) {
+            v[0] = rstd * (v[0] - mean * cs[tl].x); v[1] = rstd * (v[1] - mean * cs[tl].y);
+            v[2] = rstd * (v[2] - mean * cs[tl].z); v[3] = rstd * (v[3] - mean * cs[tl].w);
+        }
+        if (P.bias) { v[0] += b4[tl].x; v[1] += b4[tl].y; v[2] += b4[tl].z; v[3] += b4[tl].w; }
+        if (P.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        }
+        if (P.res) { v[0] += r4[tl].x; v[1] += r4[tl].y; v[2] += r4[tl].z; v[3] += r4[tl].w; }
+        *reinterpret_cast<float4*>(P.out + o[tl]) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (P.bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
-    if (P.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-    }
-    if (P.res) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-    *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // ---- q projection + cross-attention of a layer-step in ONE launch (round 4; the review's item 3) ------------------------------
@@ -946,7 +971,7 @@ struct DGemmF {
     const float* X; const float4* Wp; const float* bias; const float* colsum; const float* res; float* out;
     int M, K, Co; float eps; int act;
 };
-template <int KUW, bool LN>
+template <int KUW, bool LN, int NT = 1>
 __global__ void __launch_bounds__(512)
 dec_gemm_f32_kernel(const DGemmF P)
 {
@@ -955,70 +980,98 @@ dec_gemm_f32_kernel(const DGemmF P)
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * 32, ct = blockIdx.y, co0 = ct * 32;
+    const int m0 = blockIdx.x * 32, ct0 = blockIdx.y * NT;
     const int KU = P.K >> 3;
     const int m = m0 + l31;
     const int mc = m < P.M ? m : P.M - 1;
+    const int ntiles = (P.Co + 31) >> 5;
     const float4* xp = reinterpret_cast<const float4*>(P.X + (size_t)mc * P.K + 8 * (wv * KUW) + 4 * half);
-    const float4* wp = P.Wp + ((size_t)(ct * KU + wv * KUW) * 2 + half) * 32 + l31;
-    float4 xa[KUW], wa[KUW];
+    float4 xa[KUW], wa[NT][KUW];
 #pragma unroll
-    for (int j = 0; j < KUW; ++j) { xa[j] = xp[2 * j]; wa[j] = wp[(size_t)j * 64]; }
-    // the epilogue's operands ride with them (wavefronts 0 - 3 finish the tile; see dec_gemm_x3_kernel)
-    const int c = co0 + 8 * (wv & 3) + 4 * half;
-    const bool mine = wv < 4 && m < P.M && c < P.Co;
-    const size_t o = (size_t)mc * P.Co + (c < P.Co ? c : 0);
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), b4 = cs, r4 = cs;
-    if (mine) {
-        if (LN) cs = *reinterpret_cast<const float4*>(P.colsum + c);
-        if (P.bias) b4 = *reinterpret_cast<const float4*>(P.bias + c);
-        if (P.res) r4 = *reinterpret_cast<const float4*>(P.res + o);
+    for (int j = 0; j < KUW; ++j) xa[j] = xp[2 * j];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const int ct = ct0 + tl < ntiles ? ct0 + tl : ntiles - 1;
+        const float4* wp = P.Wp + ((size_t)(ct * KU + wv * KUW) * 2 + half) * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < KUW; ++j) wa[tl][j] = wp[(size_t)j * 64];
     }
-    f32x16_t acc;
+    // the epilogue's operands ride with them (wavefronts 0 - 3 finish the tile; see dec_gemm_x3_kernel)
+    bool mine[NT];
+    size_t o[NT];
+    float4 cs[NT], b4[NT], r4[NT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int tl = 0; tl < NT; ++tl) {
+        const int c = (ct0 + tl) * 32 + 8 * (wv & 3) + 4 * half;
+        mine[tl] = wv < 4 && m < P.M && c < P.Co;
+        o[tl] = (size_t)mc * P.Co + (c < P.Co ? c : 0);
+        cs[tl] = make_float4(0.f, 0.f, 0.f, 0.f); b4[tl] = cs[tl]; r4[tl] = cs[tl];
+        if (mine[tl]) {
+            if (LN) cs[tl] = *reinterpret_cast<const float4*>(P.colsum + c);
+            if (P.bias) b4[tl] = *reinterpret_cast<const float4*>(P.bias + c);
+            if (P.res) r4[tl] = *reinterpret_cast<const float4*>(P.res + o[tl]);
+        }
+    }
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tl][i] = 0.0f;
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < KUW; ++j) {
         const float x[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
-        const float w[4] = {wa[j].x, wa[j].y, wa[j].z, wa[j].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (LN) { s1 += x[e]; s2 = fmaf(x[e], x[e], s2); }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+#pragma unroll
+            for (int tl = 0; tl < NT; ++tl) {
+                const float w = e == 0 ? wa[tl][j].x : e == 1 ? wa[tl][j].y : e == 2 ? wa[tl][j].z : wa[tl][j].w;
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x[e], acc[tl], 0, 0, 0);
+            }
         }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[r];
     if (LN) { sS1[wv * 2 + half][l31] = s1; sS2[wv * 2 + half][l31] = s2; }
-    __syncthreads();
-    // wavefronts 0 - 3 finish accumulator registers 4 w .. 4 w + 3: outputs co0 + 8 w + 4 half + (0 .. 3) of token l31
-    if (!mine) return;
-    float v[4];
+    float mean = 0.0f, rstd = 1.0f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float t = 0.0f;
+    for (int tl = 0; tl < NT; ++tl) {
+        if (tl > 0) __syncthreads();                       // the previous tile's partial sums have been read
 #pragma unroll
-        for (int pz = 0; pz < 8; pz += 2) t += sRed[pz][4 * wv + e][lane] + sRed[pz + 1][4 * wv + e][lane];
-        v[e] = t;
+        for (int r = 0; r < 16; ++r) sRed[wv][r][lane] = acc[tl][r];
+        __syncthreads();
+        // wavefronts 0 - 3 finish accumulator registers 4 w .. 4 w + 3: outputs 32 ct + 8 w + 4 half + (0 .. 3) of token l31
+        if (LN && tl == 0) {
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
+            mean = t1 / (float)P.K;
+            rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
+        }
+        if (!mine[tl]) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = 0.0f;
+#pragma unroll
+            for (int pz = 0; pz < 8; pz += 2) t += sRed[pz][4 * wv + e][lane] + sRed[pz + 1][4 * wv + e][lane];
+            v[e] = t;
+        }
+        if (LN) {
+            v[0] = rstd * (v[0] - mean * cs[tl].x); v[1] = rstd * (v[1] - mean * cs[tl].y);
+            v[2] = rstd * (v[2] - mean * cs[tl].z); v[3] = rstd * (v[3] - mean * cs[tl].w);
+        }
+        if (P.bias) { v[0] += b4[tl].x; v[1] += b4[tl].y; v[2] += b4[tl].z; v[3] += b4[tl].w; }
+        if (P.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        }
+        if (P.res) { v[0] += r4[tl].x; v[1] += r4[tl].y; v[2] += r4[tl].z; v[3] += r4[tl].w; }
+        *reinterpret_cast<float4*>(P.out + o[tl]) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (LN) {
-        float t1 = 0.0f, t2 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { t1 += sS1[j][l31]; t2 += sS2[j][l31]; }
-        const float mean = t1 / (float)P.K;
-        const float rstd = 1.0f / sqrtf(fmaxf(t2 / (float)P.K - mean * mean, 0.0f) + P.eps);
-        v[0] = rstd * (v[0] - mean * cs.x); v[1] = rstd * (v[1] - mean * cs.y);
-        v[2] = rstd * (v[2] - mean * cs.z); v[3] = rstd * (v[3] - mean * cs.w);
-    }
-    if (P.bias) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
-    if (P.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
-    }
-    if (P.res) { v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-    *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
+
+// (TPSPP_HEAD_NARROW_QKV=1: one 32-output tile per workgroup for the q|k|v projection as well, as before round 4)
+const bool g_head_narrow_qkv = getenv("TPSPP_HEAD_NARROW_QKV") != nullptr;
 
 // launches the step GEMM; false when the shape has no instantiation (K must be 256 or 512, Co a multiple of 4)
 bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bias, const float* colsum, float eps,
@@ -1026,6 +1079,18 @@ bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bi
 {
     if ((K != 256 && K != 512) || (Co & 3) || M <= 0) return false;
     const dim3 grid((unsigned)((M + 31) / 32), (unsigned)((Co + 31) / 32));
+    // the q|k|v projection (1536 outputs, folded LayerNorm) of the three-term form: three tiles per workgroup, one round of
+    // 256 workgroups instead of 768 in two (bf16x3 decoder 20.85 -> 20.45 ms, bf16 15.68 -> 15.33, bit-identical scores,
+    // scripts/debug/dec_fusion_ab.py TPSPP_HEAD_NARROW_QKV).  Not the exact-fp32 form: its 96 fp32 matrix instructions per
+    // wavefront are the launch's time either way (23.40 -> 23.72 ms with three tiles).
+    if (!f32 && K == 512 && colsum && Co >= 1024 && !g_head_narrow_qkv) {
+        const dim3 grid3((unsigned)((M + 31) / 32), (unsigned)(((Co + 31) / 32 + 2) / 3));
+        DGemm P;
+        P.X = X; P.Wp = reinterpret_cast<const du32x4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
+        P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
+        hipLaunchKernelGGL((dec_gemm_x3_kernel<8, true, 3>), grid3, dim3(256), 0, st, P);
+        return true;
+    }
     if (f32) {
         DGemmF P;
         P.X = X; P.Wp = reinterpret_cast<const float4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
