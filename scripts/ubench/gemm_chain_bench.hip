@@ -12,12 +12,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
+// MAP: 0 launch order; 1 each XCD (workgroup id % 8) an 8 x 4 sub-grid of (token blocks, output tiles); 2 a 4 x 8 sub-grid;
+// 3 a 16 x 2 strip (all of X, an eighth of W)
+template <int MODE, int MAP = 0>
 __global__ void __launch_bounds__(256) k(const float* __restrict__ X, const u32x4* __restrict__ W, float* __restrict__ out)
 {
     __shared__ float sRed[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int tb = blockIdx.x, ct = blockIdx.y;
+    int tb = blockIdx.x, ct = blockIdx.y;
+    if (MAP) {
+        const int lin = blockIdx.x + 16 * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+        if (MAP == 1) { tb = (xcd & 1) * 8 + (slot & 7); ct = (xcd >> 1) * 4 + (slot >> 3); }
+        if (MAP == 2) { tb = (xcd & 3) * 4 + (slot & 3); ct = (xcd >> 2) * 8 + (slot >> 2); }
+        if (MAP == 3) { tb = slot & 15; ct = xcd * 2 + (slot >> 4); }
+    }
     if (MODE == 0) { if (tid == 9999) out[0] = 1.0f; return; }
     float v[4] = {1.f, 2.f, 3.f, 4.f};
     if (MODE >= 2) {
@@ -59,18 +67,39 @@ __global__ void __launch_bounds__(256) k(const float* __restrict__ X, const u32x
         make_float4(v[0] * 1e-9f, v[1] * 1e-9f, v[2] * 1e-9f, v[3] * 1e-9f);
 }
 
-template <int MODE> void run(const char* name, float* a, float* b, u32x4* w)
+template <int MODE, int MAP = 0> void run(const char* name, float* a, float* b, u32x4* w)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int n = 2000;
     for (int rep = 0; rep < 3; ++rep) {
-        for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(k<MODE>, dim3(16, 16), dim3(256), 0, 0, (i & 1) ? b : a, w, (i & 1) ? a : b);
+        for (int i = 0; i < 100; ++i) hipLaunchKernelGGL((k<MODE, MAP>), dim3(16, 16), dim3(256), 0, 0, (i & 1) ? b : a, w, (i & 1) ? a : b);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k<MODE>, dim3(16, 16), dim3(256), 0, 0, (i & 1) ? b : a, w + (size_t)(i % 36) * 65536, (i & 1) ? a : b);
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL((k<MODE, MAP>), dim3(16, 16), dim3(256), 0, 0, (i & 1) ? b : a, w + (size_t)(i % 36) * 65536, (i & 1) ? a : b);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-10s %6.2f us per launch\n", name, ms * 1e3f / n);
+    }
+}
+
+// the same chain captured once into a hipGraph and replayed
+template <int MODE> void run_graph(const char* name, float* a, float* b, u32x4* w)
+{
+    hipStream_t st; hipStreamCreate(&st);
+    hipGraph_t g; hipGraphExec_t ge;
+    const int n = 2000;
+    hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k<MODE>, dim3(16, 16), dim3(256), 0, st, (i & 1) ? b : a, w + (size_t)(i % 36) * 65536, (i & 1) ? a : b);
+    hipStreamEndCapture(st, &g);
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("%s: graph instantiate failed\n", name); return; }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, st);
+        hipGraphLaunch(ge, st);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-10s %6.2f us per launch (hipGraph of %d kernel nodes)\n", name, ms * 1e3f / n, n);
     }
 }
 
@@ -84,5 +113,10 @@ int main()
     run<1>("store", a, b, w);
     run<2>("load", a, b, w);
     run<3>("load+mfma", a, b, w);
+    run<2, 1>("load 8x4", a, b, w);
+    run<2, 2>("load 4x8", a, b, w);
+    run<2, 3>("load 16x2", a, b, w);
+    run_graph<1>("store", a, b, w);
+    run_graph<3>("load+mfma", a, b, w);
     return 0;
 }

@@ -729,12 +729,31 @@ struct DGemm {
     const float* X; const du32x4* Wp; const float* bias; const float* colsum; const float* res; float* out;
     int M, K, Co;            // Co: valid outputs (the arranged weight is padded to a multiple of 32)
     float eps; int act;      // act: 0 none, 2 GELU (erf)
+    int remap = 0;           // dec_gemm_tile
 };
 
 __device__ __forceinline__ unsigned dpack2(float lo, float hi)
 {
     df32x2 v; v[0] = lo; v[1] = hi;
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dbf16x2));
+}
+
+// Workgroup -> (token block, output tile) for the step GEMMs.  Workgroups go to the 8 XCDs round-robin in launch order and
+// every XCD has its own L2, which each launch fills with the X rows (the previous launch's output) and the W tiles its
+// workgroups touch.  In launch order an XCD gets 2 of the 16 token blocks and ALL output tiles; scripts/ubench/gemm_chain_bench
+// (the projection's loads alone, 2000 dependent launches): launch order 5.03 us, 4 token blocks x half the tiles 4.77 us,
+// 8 x a quarter 5.30 us, all 16 x an eighth 5.56 us -- X, freshly written elsewhere, costs more per byte than W.
+// In the decoder (same box, interleaved): bf16 15.36 -> 15.19 ms, bf16x3 20.49 -> 20.42 ms, exact fp32 23.24 -> 23.30 (left
+// in launch order).  Only the 16-token-block grids of batch 512 with an even number of tile rows are remapped
+// (TPSPP_HEAD_PLAIN_ORDER=1: never).
+__device__ __forceinline__ void dec_gemm_tile(int& bx, int& by, bool remap)
+{
+    bx = blockIdx.x; by = blockIdx.y;
+    if (remap && gridDim.x == 16 && (gridDim.y & 1) == 0) {
+        const int lin = blockIdx.x + 16 * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+        bx = (xcd & 3) * 4 + (slot & 3);
+        by = (xcd >> 2) * (gridDim.y >> 1) + (slot >> 2);
+    }
 }
 
 // NT: 32-output tiles per workgroup (1; 3 for the 1536-wide q|k|v projection: at one tile per workgroup its 768 workgroups
@@ -749,7 +768,9 @@ dec_gemm_x3_kernel(const DGemm P)
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * 32, ct0 = blockIdx.y * NT;
+    int bx, by;
+    dec_gemm_tile(bx, by, P.remap != 0);
+    const int m0 = bx * 32, ct0 = by * NT;
     const int KS = P.K >> 4;
     const int m = m0 + l31;
     const int mc = m < P.M ? m : P.M - 1;
@@ -970,6 +991,7 @@ dec_q_cross_x3_kernel(const DGemm P, const KV* __restrict__ Kx_t, const KV* __re
 struct DGemmF {
     const float* X; const float4* Wp; const float* bias; const float* colsum; const float* res; float* out;
     int M, K, Co; float eps; int act;
+    int remap = 0;
 };
 template <int KUW, bool LN, int NT = 1>
 __global__ void __launch_bounds__(512)
@@ -980,7 +1002,9 @@ dec_gemm_f32_kernel(const DGemmF P)
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.x * 32, ct0 = blockIdx.y * NT;
+    int bx, by;
+    dec_gemm_tile(bx, by, P.remap != 0);
+    const int m0 = bx * 32, ct0 = by * NT;
     const int KU = P.K >> 3;
     const int m = m0 + l31;
     const int mc = m < P.M ? m : P.M - 1;
@@ -1072,6 +1096,7 @@ dec_gemm_f32_kernel(const DGemmF P)
 
 // (TPSPP_HEAD_NARROW_QKV=1: one 32-output tile per workgroup for the q|k|v projection as well, as before round 4)
 const bool g_head_narrow_qkv = getenv("TPSPP_HEAD_NARROW_QKV") != nullptr;
+const bool g_head_plain_order = getenv("TPSPP_HEAD_PLAIN_ORDER") != nullptr;
 
 // launches the step GEMM; false when the shape has no instantiation (K must be 256 or 512, Co a multiple of 4)
 bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bias, const float* colsum, float eps,
@@ -1087,14 +1112,14 @@ bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bi
         const dim3 grid3((unsigned)((M + 31) / 32), (unsigned)(((Co + 31) / 32 + 2) / 3));
         DGemm P;
         P.X = X; P.Wp = reinterpret_cast<const du32x4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
-        P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
+        P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act; P.remap = g_head_plain_order ? 0 : 1;
         hipLaunchKernelGGL((dec_gemm_x3_kernel<8, true, 3>), grid3, dim3(256), 0, st, P);
         return true;
     }
     if (f32) {
         DGemmF P;
         P.X = X; P.Wp = reinterpret_cast<const float4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
-        P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
+        P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act; P.remap = 0;      // (measured: nothing for the exact-fp32 form)
         if (K == 512) {
             if (colsum) hipLaunchKernelGGL((dec_gemm_f32_kernel<8, true>), grid, dim3(512), 0, st, P);
             else        hipLaunchKernelGGL((dec_gemm_f32_kernel<8, false>), grid, dim3(512), 0, st, P);
@@ -1106,7 +1131,7 @@ bool dec_gemm_x3(hipStream_t st, const float* X, const void* Wp, const float* bi
     }
     DGemm P;
     P.X = X; P.Wp = reinterpret_cast<const du32x4*>(Wp); P.bias = bias; P.colsum = colsum; P.res = res; P.out = out;
-    P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act;
+    P.M = M; P.K = K; P.Co = Co; P.eps = eps; P.act = act; P.remap = g_head_plain_order ? 0 : 1;
     if (K == 512) {
         if (colsum) hipLaunchKernelGGL((dec_gemm_x3_kernel<8, true>), grid, dim3(256), 0, st, P);
         else        hipLaunchKernelGGL((dec_gemm_x3_kernel<8, false>), grid, dim3(256), 0, st, P);
