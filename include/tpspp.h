@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define TPSPP_ABI_VERSION 3   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
-                               3: tpspp_down_fused_bf16_fwd, tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
+                               3: tpspp_down_fused_bf16_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -329,6 +329,20 @@ int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,
                          const void* w2, const float* b2, const void* wg, const float* bg,
                          void* feat0, void* feat1, void* feat2, void* feat_grid, int feat_grid_f32,
                          int N, int H, int W, int split3, tpspp_stream_t stream);
+
+/*
+ * A Linear layer over channel-major tokens on the bf16 matrix cores:  out (Co, M) = act(W^T X + bias) [+ res]
+ *   X (K, M) fp32 (rounded to bf16 -- split3: split into hi + lo -- as it is staged), M = images x tokens;
+ *   w_arranged: the (Co, K, 1, 1) weight arranged as tpspp_conv2d_bf16_fwd takes a 1x1 kernel (split3: with hi and lo slabs);
+ *   bias (Co) or NULL; res (Co, M) fp32 or NULL (added after the activation); act 0 none, 2 GELU (erf);
+ *   out (Co, M) fp32 (out_f32 != 0) or bf16.  K % 32 == 0, Co % 128 == 0, M % 4 == 0; fp32 accumulation over k ascending.
+ * The recogniser head's encoder projections and the decoder's one-off key / value projections in the bf16 / bf16x3
+ * configurations go through this kernel (tpspp_nrtr_encoder_fwd / tpspp_nrtr_decoder_fwd with TPSPP_HEAD_BF16 / _BF16X3).
+ * replaces: nn.Linear inside MultiHeadAttention / PositionwiseFeedForward, common/layers/transformer_layers.py:36-75
+ */
+int tpspp_token_gemm_bf16_fwd(const float* X, const void* w_arranged, const float* bias, const float* res,
+                              void* out, int out_f32, int K, int Co, int M, int act, int split3,
+                              tpspp_stream_t stream);
 
 /*
  * down0 + down0_1 (or down1 + down1_1) of the ResNet45v2 wiring in one kernel (bf16 configuration):

@@ -356,3 +356,54 @@ def test_decoder_fused_q_cross_launch_is_bit_identical(cuda, tmp_path):
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
         assert torch.isfinite(outs[0][k]).all()
+
+
+TOKGEMM_CASES = [
+    # name, K, Co, M, act, residual, out dtype, x3
+    ("qkv_wide", 512, 1536, 32768, None, False, torch.float32, False),          # 256-output workgroups
+    ("qkv_wide_x3", 512, 1536, 32768, None, False, torch.float32, True),
+    ("fc_res", 512, 512, 4096, None, True, torch.float32, False),
+    ("w1_gelu", 512, 256, 4096, "gelu", False, torch.float32, False),
+    ("w2_res_tail", 256, 512, 1000, None, True, torch.float32, False),          # M not a multiple of the 128-token tile
+    ("kv_bf16_out", 512, 512, 2052, None, False, torch.bfloat16, False),
+    ("x3_gelu_res_tail", 256, 128, 516, "gelu", True, torch.float32, True),
+]
+
+
+@pytest.mark.parametrize("name,K,Co,M,act,res,odt,x3", TOKGEMM_CASES, ids=[c[0] for c in TOKGEMM_CASES])
+def test_token_gemm_against_float64(cuda, name, K, Co, M, act, res, odt, x3):
+    """tpspp_token_gemm_bf16_fwd (the head's channel-major Linear on the bf16 matrix cores): against float64 on operands
+    rounded the way the kernel rounds them (bf16; x3: fp32 operands, ~5e-6 of the scale); wide and narrow workgroups, a
+    tail tile, GELU, residual, bf16 output."""
+    g = torch.Generator(device="cpu").manual_seed(K * 7 + Co + M)
+    w = (torch.randn((Co, K, 1, 1), generator=g) * 0.05)
+    b = torch.randn(Co, generator=g) * 0.1
+    x = torch.randn((K, M), generator=g)
+    r = torch.randn((Co, M), generator=g) if res else None
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda), x3=x3)
+    got = ops.token_gemm_bf16(x.to(cuda), cw, act=act, residual=None if r is None else r.to(cuda), out_dtype=odt)
+    assert got.shape == (Co, M) and got.dtype == odt
+    if x3:
+        wq, xq = w.view(Co, K).double(), x.double()
+    else:
+        wq, xq = w.view(Co, K).bfloat16().double(), x.bfloat16().double()
+    want = wq @ xq + b.double()[:, None]
+    if act == "gelu":
+        want = torch.nn.functional.gelu(want)
+    if r is not None:
+        want = want + r.double()
+    scale = float(want.abs().max())
+    err = float((got.double().cpu() - want).abs().max()) / scale
+    tol = 2e-5 if x3 else (6e-3 if odt == torch.bfloat16 else 2e-6)
+    assert err < tol, (name, err)
+
+
+def test_token_gemm_argument_errors(cuda):
+    cw = ops.prep_conv_weight_bf16(torch.zeros((128, 64, 1, 1), device=cuda), conv_bias=torch.zeros(128, device=cuda))
+    with pytest.raises(Exception):
+        ops.token_gemm_bf16(torch.zeros((64, 6), device=cuda), cw)                 # M not a multiple of 4
+    with pytest.raises(ValueError):
+        ops.token_gemm_bf16(torch.zeros((32, 8), device=cuda), cw)                 # K != Cin
+    cw96 = ops.prep_conv_weight_bf16(torch.zeros((96, 64, 1, 1), device=cuda), conv_bias=torch.zeros(96, device=cuda))
+    with pytest.raises(Exception):
+        ops.token_gemm_bf16(torch.zeros((64, 8), device=cuda), cw96)               # Co not a multiple of 128

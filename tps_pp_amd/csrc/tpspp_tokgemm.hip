@@ -265,3 +265,19 @@ void launch_tok_gemm(const TokGemmArgs& a, hipStream_t st)
 }
 
 }  // namespace tpspp
+
+// out (Co, M) = act(W^T X + bias) [+ res] on channel-major tokens: the C-ABI face of the kernel above (include/tpspp.h)
+TPSPP_EXPORT int tpspp_token_gemm_bf16_fwd(const float* X, const void* w_arranged, const float* bias, const float* res,
+                                           void* out, int out_f32, int K, int Co, int M, int act, int split3,
+                                           tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(X && w_arranged && out, "tpspp_token_gemm_bf16_fwd: null pointer");
+    tpspp::TokGemmArgs a;
+    a.X = X; a.W = w_arranged; a.bias = bias; a.res = res; a.out = out; a.out_f32 = out_f32 ? 1 : 0;
+    a.K = K; a.Co = Co; a.M = M; a.act = act; a.x3 = split3 ? 1 : 0; a.kgc = tpspp_conv_bf16_chunk_channels(1) / 8;
+    TPSPP_REQUIRE(tpspp::tok_gemm_applicable(a),
+                  "tpspp_token_gemm_bf16_fwd: needs K a multiple of 32, Co a multiple of 128, M a multiple of 4 (>= 4), act 0 or 2 "
+                  "and 16-byte aligned tensors (got K = %d, Co = %d, M = %d, act = %d)", K, Co, M, act);
+    tpspp::launch_tok_gemm(a, tpspp::as_stream(stream));
+    return tpspp::check_launch("tpspp_token_gemm_bf16_fwd");
+}

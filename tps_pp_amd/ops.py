@@ -829,6 +829,28 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False, sto
     return feat0, feat1, feat2, feat_grid
 
 
+def token_gemm_bf16(x_cm, cw, act=None, residual=None, out_dtype=torch.float32):
+    """`out (Co, M) = act(W^T x + bias) [+ residual]` for channel-major tokens `x_cm` (K, M) float32 on the bf16 matrix cores
+    (`tpspp_token_gemm_bf16_fwd`); `cw`: a 1x1 `prep_conv_weight_bf16` weight (x3: the three-term split); act None | "gelu"."""
+    x_cm = _chk("x_cm", x_cm, 2)
+    K, M = x_cm.shape
+    if cw.kernel != 1 or cw.cin != K or cw.post_scale is not None:
+        raise ValueError("token_gemm_bf16: needs a 1x1 weight with Cin = x_cm.shape[0] and no post-affine")
+    if residual is not None:
+        residual = _chk("residual", residual, 2)
+        if tuple(residual.shape) != (cw.cout, M):
+            raise ValueError("token_gemm_bf16: residual must be (Co, M)")
+    if out_dtype not in (torch.float32, torch.bfloat16) or act not in (None, "gelu"):
+        raise ValueError("token_gemm_bf16: out_dtype float32 | bfloat16, act None | 'gelu'")
+    out = torch.empty((cw.cout, M), device=x_cm.device, dtype=out_dtype)
+    with torch.cuda.device(x_cm.device):
+        rc = _lib.lib().tpspp_token_gemm_bf16_fwd(_ptr(x_cm), _ptr(cw.arranged), _ptr(cw.bias), _ptr(residual), out.data_ptr(),
+                                                  int(out_dtype == torch.float32), K, cw.cout, M, 2 if act == "gelu" else 0,
+                                                  int(cw.x3), _stream(x_cm))
+    _lib.check(rc, "tpspp_token_gemm_bf16_fwd")
+    return out
+
+
 def down_fused_bf16_applicable(o, cw):
     """`down_fused_bf16` takes a bfloat16 (N, 32, H, 128) map with an even H and a plain-bf16 64 -> 64 3x3 weight."""
     return (o.dtype == torch.bfloat16 and o.dim() == 4 and o.shape[1] == 32 and o.shape[2] % 2 == 0 and o.shape[3] == 128
