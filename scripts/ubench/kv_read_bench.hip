@@ -1,0 +1,55 @@
+// How fast can 4096 wavefronts (one per (image, head), 4 per workgroup) stream the cross-attention's keys + values?
+//   token-major:  K / V (image, token, 512 features): a wavefront reads 64 rows of 256 B (its head's 64 features), 2 KB apart
+//   head-major:   K / V (image, head, token, 64 features): a wavefront reads 16 KB contiguous
+// fp32 (EPL 4: 16 lanes per row, 4 rows per load instruction, 16 instructions per tensor) and bf16 (8 lanes per row, 8 rows per
+// instruction, 8 instructions).  Each wavefront reduces what it read to one float (so that nothing is optimised away).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+template <int BYTES_PER_FEATURE, bool HEADMAJOR>
+__global__ void __launch_bounds__(256) k(const uint4* __restrict__ K, const uint4* __restrict__ V, float* __restrict__ out, int Nb)
+{
+    constexpr int EPL = 16 / BYTES_PER_FEATURE, GS = 64 / EPL, TPI = 64 / GS, NP = 64 / TPI, H = 8, T = 64, C = 512;
+    const int lane = threadIdx.x & 63, pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair % H, grp = lane / GS, dl = lane % GS;
+    const size_t rstride = HEADMAJOR ? GS : C / EPL;
+    const size_t base = HEADMAJOR ? ((size_t)(b * H + h) * T) * GS + dl : ((size_t)b * T) * (C / EPL) + h * GS + dl;
+    uint4 kr[NP], vr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) kr[i] = K[base + (size_t)(TPI * i + grp) * rstride];
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s += kr[i].x ^ kr[i].y ^ kr[i].z ^ kr[i].w;
+    // (the values are requested after the keys have been used, as in the attention kernel)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) vr[i] = V[base + (size_t)(TPI * i + grp) * rstride + (s == 0x12345678u)];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s += vr[i].x ^ vr[i].y ^ vr[i].z ^ vr[i].w;
+    if (s == 0xdeadbeefu) out[pair] = 1.0f;
+}
+template <int B, bool HM> void run(const char* name, uint4* Kb, uint4* Vb, float* out, size_t layer_units)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const int n = 600;
+    for (int rep = 0; rep < 2; ++rep) {
+        hipEventRecord(e0);
+        for (int i = 0; i < n; ++i)      // six layers' worth of different tensors in turn, as in the decoder
+            hipLaunchKernelGGL((k<B, HM>), dim3(1024), dim3(256), 0, 0, Kb + (i % 6) * layer_units, Vb + (i % 6) * layer_units, out, 512);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double bytes = 2.0 * 512 * 64 * 512 * B;
+        printf("%-22s %6.2f us per launch = %.2f TB/s\n", name, ms * 1e3 / n, bytes / (ms * 1e-3 / n) / 1e12);
+    }
+}
+int main()
+{
+    const size_t layer_units = (size_t)512 * 64 * 512 * 4 / 16;
+    uint4 *Kb, *Vb; float* out;
+    hipMalloc(&Kb, 6 * layer_units * 16); hipMalloc(&Vb, 6 * layer_units * 16); hipMalloc(&out, 4096 * 4);
+    hipMemset(Kb, 1, 6 * layer_units * 16); hipMemset(Vb, 1, 6 * layer_units * 16);
+    run<4, false>("fp32 token-major", Kb, Vb, out, layer_units);
+    run<4, true>("fp32 head-major", Kb, Vb, out, layer_units);
+    run<2, false>("bf16 token-major", Kb, Vb, out, layer_units / 2);
+    run<2, true>("bf16 head-major", Kb, Vb, out, layer_units / 2);
+    return 0;
+}
