@@ -448,3 +448,41 @@ def test_front_bf16_full_machine_matches_chunked_runs(cuda, store01):
                 a = a.t if isinstance(a, ops.Blocked) else a
                 b = b.t if isinstance(b, ops.Blocked) else b
                 assert torch.equal(a[lo:lo + 53].view(torch.int16), b.view(torch.int16)), (rep, lo)
+
+
+C1X1_CASES = [
+    # name, Cin, Cout, H, W, relu, N          (256-pixel tiles: 1 per 8x32 image, 4 per 16x64 image; 256 persistent workgroups)
+    ("layer4 256->256 @8x32, 2-3 trips", 256, 256, 8, 32, True, 530),
+    ("layer4 first 128->256 @8x32", 128, 256, 8, 32, True, 37),
+    ("layer3 128->128 @8x32, no relu", 128, 128, 8, 32, False, 300),
+    ("layer2 64->64 @16x64, ragged trips", 64, 64, 16, 64, True, 129),
+    ("layer3 first 64->128 @16x64, one image", 64, 128, 16, 64, True, 1),
+]
+
+
+@pytest.mark.parametrize("name,cin,cout,H,W,relu,N", C1X1_CASES, ids=[c[0] for c in C1X1_CASES])
+def test_conv1x1_blocked_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, cin, cout, H, W, relu, N):
+    """tpspp_conv1x1_blk.hip (1x1 layers between blocked maps: every activation read once, the weight in LDS) against the
+    tiled kernel on the same tensors (tpspp_conv_set_tuning bit 1 switches it off), and against float64 on bf16-rounded
+    operands."""
+    from tps_pp_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + N)
+    x = torch.randn((N, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 1, 1), generator=g) / np.sqrt(cin)
+    b = torch.randn((cout,), generator=g) * 0.2
+    xb = ops.Blocked.from_nchw(x.to(cuda))
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    try:
+        _lib.lib().tpspp_conv_set_tuning(2)
+        want = ops.conv2d_bf16([xb], cw, 1, relu=relu, out_blocked=True).t.view(torch.int16).clone()
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
+    for _ in range(2):
+        got = ops.conv2d_bf16([xb], cw, 1, relu=relu, out_blocked=True)
+        assert torch.equal(got.t.view(torch.int16), want)
+    n = min(N, 3)
+    ref = torch.einsum("oc,nchw->nohw", w.view(cout, cin).bfloat16().double(), x[:n].bfloat16().double()) + b.double().view(1, -1, 1, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    err = (got.nchw()[:n].double().cpu() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 6e-3                                # one bf16 rounding of the result

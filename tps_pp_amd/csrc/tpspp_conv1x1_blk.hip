@@ -1,0 +1,166 @@
+// 1x1 convolution (stride 1) between maps in the BLOCKED bf16 layout (N, C/8, H, W, 8): the first convolution of the
+// backbone's BasicBlocks on the 16x64 and 8x32 levels in the bf16 configuration (64 -> 64, 128 -> 128, 256 -> 256, ...).
+// Replaces (when the module runs bf16): conv1x1 + BN + ReLU of BasicBlock.forward,
+// mmocr/models/textrecog/layers/conv_layer.py as used by backbones/resnet_v2_large.py (ResNetABI_v2_large).
+//
+// Same arithmetic as conv_tiled_bf16_kernel (channels ascending through v_mfma_f32_32x32x16_bf16, one accumulator per
+// 32 x 32 tile, bias + ReLU in fp32, one rounding), so the two agree bit for bit; what changes is the data movement.  The
+// tiled kernel is built for 3x3 patches: 64 output channels per workgroup (a 256-wide layer stages every activation four
+// times), patch staging through LDS, and it took 54 us for the 134 MB of a 256 -> 256 layer at batch 512 (22 us at 6 TB/s).
+// For a 1x1 kernel on a blocked map nothing needs staging:
+//   * a 16-byte unit of the map (8 channels of a pixel) IS the B operand's lane image: lane (pixel, k half) loads the unit of
+//     channel group 2 ks + half straight from global memory, 512 contiguous bytes per half-wavefront; all of a wavefront's
+//     Cin / 16 loads are in flight together;
+//   * a wavefront owns 32 pixels and ALL output channels (up to 8 accumulators), so every activation is read once;
+//   * the whole weight (<= 128 KB, the convolution's arranged copy) sits in LDS for the life of the persistent workgroup:
+//     an A fragment is one ds_read_b128;
+//   * results leave as 16-byte units of the blocked output (v_permlane32_swap pairs the two half-wavefronts' halves).
+// Bound: HBM.
+#include "tpspp_conv_bf16_impl.h"
+
+namespace {
+
+constexpr int kMaxLds = 160 * 1024;
+
+// NT: 32-output tiles (Cout / 32); NKS: 16-channel k-steps (Cin / 16); NW: wavefronts per workgroup = 32-pixel fragments per tile.
+// NW = 8 (256 registers per wavefront): the next tile's units are requested once this tile's products are issued.
+// NW = 4 (512 registers; the 256 -> 256 layer, whose 128 accumulator + 64 operand registers do not leave room at 256): the
+// next tile's units are requested BEFORE this tile's products and land under them.
+template <int NT, int NKS, int NW>
+__global__ void __launch_bounds__(NW * 64, 1)
+conv1x1_blk_kernel(const BParams P, int ntiles)
+{
+    extern __shared__ u32x4 sAll[];
+    constexpr int WUNITS = NT * 32 * NKS * 2;               // Cout * Cin / 8 units of 16 bytes
+    u32x4* const sW = sAll;
+    float* const sBias = reinterpret_cast<float*>(sAll + WUNITS);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int i = tid; i < WUNITS; i += NW * 64) sW[i] = P.wt[i];
+    for (int i = tid; i < NT * 32; i += NW * 64) sBias[i] = P.bias ? P.bias[i] : 0.0f;
+    __syncthreads();
+
+    const int HW = P.Ho * P.Wo;
+    constexpr int TPX = NW * 32;                             // pixels per tile
+    constexpr bool EARLY = NW == 4;
+    const int tpi = HW / TPX;                                // tiles per image
+    const u32x4* const src = reinterpret_cast<const u32x4*>(P.src[0].p);
+    constexpr int nch = NKS / 2;                             // 32-channel chunks of the arranged weight
+    const bool relu1 = P.relu == 1;
+
+    u32x4 b[NKS], bn[EARLY ? NKS : 1];
+    auto fetch = [&](int tile, u32x4* dst) {
+        const int n = tile / tpi, px = (tile - n * tpi) * TPX + 32 * wv + l31;
+        const u32x4* s = src + ((size_t)n * (2 * NKS) + half) * HW + px;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) dst[ks] = s[(size_t)(2 * ks) * HW];
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile, b);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tpi, px = (tile - n * tpi) * TPX + 32 * wv + l31;
+        const int next = tile + (int)gridDim.x;
+        if (EARLY && next < ntiles) fetch(next, bn);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        // the weight does not change from tile to tile; the optimiser must not see that (it would hoist NT x NKS fragments --
+        // up to 512 registers -- out of this loop and spill them), nor read more than one k-step's fragments ahead
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        const u32x4* const w = sW + opaque;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bf16x8 B = __builtin_bit_cast(bf16x8, b[ks]);
+            bf16x8 A[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                // arranged weight: [64-output tile][32-channel chunk][k group of the chunk (4)][64 outputs][8]
+                A[t] = __builtin_bit_cast(bf16x8, w[(((t >> 1) * nch + (ks >> 1)) * 4 + 2 * (ks & 1) + half) * 64 + 32 * (t & 1) + l31]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t], B, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (EARLY) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) b[ks] = bn[ks];
+        } else if (next < ntiles) {
+            fetch(next, b);                                  // in flight under the epilogue and the other wavefronts' products
+        }
+        unsigned short* const ob = reinterpret_cast<unsigned short*>(P.out) + ((size_t)n * (4 * NT) * HW + px) * 8;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            tpspp_u32x2 pk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[t][4 * g + e] + sBias[32 * t + 8 * g + 4 * half + e];
+                    if (relu1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                }
+                pk[g][0] = pack2_bf16(v[0], v[1]); pk[g][1] = pack2_bf16(v[2], v[3]);
+            }
+            // the two half-wavefronts hold the two halves of a 16-byte unit: after the swap the lower one owns the unit of
+            // channel group 4 t + g, the upper one that of 4 t + g + 1
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const tpspp_u32x2 d0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                const tpspp_u32x2 d1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                *reinterpret_cast<u32x4*>(ob + (size_t)(4 * t + g + half) * HW * 8) = unit;
+            }
+        }
+    }
+}
+
+template <int NT, int NKS>
+bool launch(const BParams& P, hipStream_t st)
+{
+    constexpr int NW = (NT * 16 + NKS * 4 > 160) ? 4 : 8;      // accumulators + operands per lane
+    const size_t lds = (size_t)NT * 32 * NKS * 2 * 16 + (size_t)NT * 32 * 4;
+    if (lds > (size_t)kMaxLds) return false;
+    const int HW = P.Ho * P.Wo;
+    const long nt = (long)P.N * (HW / (NW * 32));
+    if (nt <= 0 || nt > 0x3fffffffL) return false;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+        (void)hipGetLastError();
+        return false;
+    }
+    static bool attr[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_blk_kernel<NT, NKS, NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    hipLaunchKernelGGL((conv1x1_blk_kernel<NT, NKS, NW>), dim3((unsigned)(nt < ncu ? nt : ncu)), dim3(NW * 64), lds, st, P, (int)nt);
+    return true;
+}
+
+}  // namespace
+
+namespace tpspp {
+
+// true when the kernel took the layer: 1x1, stride 1, one blocked bf16 source at its own resolution, blocked bf16 output,
+// bias / ReLU only, Cin and Cout in {64, 128, 256}, whole 256-pixel tiles
+bool conv1x1_blk_launch(const BParams& P, hipStream_t st)
+{
+    if (P.nsrc != 1 || P.src[0].f32 != 2 || P.out_f32 != 2 || P.res || P.res_mode || P.post_scale || P.relu > 1) return false;
+    if (P.src[0].lh || P.src[0].lw || P.src[0].H != P.Ho || P.src[0].W != P.Wo || P.src[0].C != P.Cin) return false;
+    if ((P.Ho * P.Wo) % 256) return false;
+    if ((reinterpret_cast<size_t>(P.src[0].p) | reinterpret_cast<size_t>(P.out) | reinterpret_cast<size_t>(P.wt)) & 15) return false;
+#define TPSPP_C1(CI, CO) if (P.Cin == CI && P.Cout == CO) return launch<CO / 32, CI / 16>(P, st);
+    TPSPP_C1(64, 64) TPSPP_C1(64, 128) TPSPP_C1(128, 128) TPSPP_C1(128, 256) TPSPP_C1(256, 256)
+#undef TPSPP_C1
+    return false;
+}
+
+}  // namespace tpspp

@@ -637,5 +637,7 @@ namespace tpspp {
 bool conv_bf16x3_launch(const BParams& P, int KH, int sh, int sw, hipStream_t st);
 // defined in tpspp_conv_bf16_persist.hip: the persistent kernel for blocked 3x3 layers; false when it does not apply
 bool conv_bf16_persist_launch(const BParams& P, int sh, int sw, hipStream_t st);
+// defined in tpspp_conv1x1_blk.hip: 1x1 layers between blocked maps; false when it does not apply
+bool conv1x1_blk_launch(const BParams& P, hipStream_t st);
 extern int g_conv_bf16_no_persist;           // tpspp_conv_set_tuning bit 1
 }  // namespace tpspp

@@ -211,10 +211,13 @@ class ResNetABI_v2_large(nn.Module):
                     x = outputs["output"]
             outs.append(x)
             blocks = list(getattr(self, name))
+            # the results of stages 0 / 1 are handed to `tpsnet` (with `outs`) and the last stage's to the caller: those stay
+            # NCHW; the others only feed the next stage's first block, whose convolutions take the blocked layout as well
+            # (its two 1x1 layers then run on tpspp_conv1x1_blk.hip)
+            hidden = 2 <= i < len(self.res_layers) - 1
             for j, blk in enumerate(blocks):
-                # `inner`: the result only feeds the next block of this stage (a stage's last result is seen by `tpsnet` /
-                # the caller and stays NCHW)
-                x = apply_block(blk, x, j + 1 < len(blocks))
+                # `inner`: nobody but this backbone's next block reads the result
+                x = apply_block(blk, x, j + 1 < len(blocks) or hidden)
         return {"output": x, "img_ref": outputs.get("output", None) if outputs is not None else None}
 
     def _forward_torch(self, x, tpsnet=None, **kwargs):
