@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define TPSPP_ABI_VERSION 3   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
-                               3: tpspp_down_fused_bf16_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
+                               3: tpspp_down_fused_bf16_fwd / _x3_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -358,6 +358,16 @@ int tpspp_token_gemm_bf16_fwd(const float* X, const void* w_arranged, const floa
  */
 int tpspp_down_fused_bf16_fwd(const void* in, const void* w0, const float* b0, const void* wd, const float* bd,
                               void* out, int N, int H, int W, int relu, tpspp_stream_t stream);
+
+/*
+ * The same for the three-term "bf16x3" split: in (N, 32, H, 128) fp32, w0 / wd with their hi and lo slabs (as
+ * tpspp_front_bf16_fwd / tpspp_conv2d_bf16_fwd take them with split3), out the fp32 blocked layout (N, 8, H/2, 64, 8)
+ * (layout code 3); bit for bit tpspp_front_bf16_fwd(split3)'s feat0 / feat1 followed by the three-term 3x3 stride-2
+ * convolution.  tpspp_front_bf16_fwd(split3, blocked) accepts feat0 = feat1 = NULL as well.
+ * replaces: backbones/tps_pp/tps_pp.py:560-563
+ */
+int tpspp_down_fused_x3_fwd(const float* in, const void* w0, const float* b0, const void* wd, const float* bd,
+                            float* out, int N, int H, int W, int relu, tpspp_stream_t stream);
 
 /*
  * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32

@@ -486,3 +486,34 @@ def test_conv1x1_blocked_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, cin,
         ref = ref.clamp_min(0)
     err = (got.nchw()[:n].double().cpu() - ref).abs().max() / ref.abs().max()
     assert float(err) < 6e-3                                # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("N,H", [(1, 32), (3, 32), (5, 8), (2, 2), (270, 32)])
+def test_down_fused_x3_is_front_then_stride2_conv_bit_for_bit(cuda, N, H):
+    """tpspp_down_fused_x3_fwd (the three-term split form: fp32 maps) against front_x3's blocked feat0 / feat1 followed by the
+    three-term 3x3 stride-2 convolution; whole images per workgroup (N = 270: some workgroups take two), strips, one row."""
+    from tps_pp_amd import TPS_PP
+    torch.manual_seed(12)
+    m = TPS_PP().eval().to(cuda)
+    with torch.no_grad():
+        for c in (m.down0, m.down1, m.down0_1, m.down1_1):
+            c.conv.bias.uniform_(-0.5, 0.5)
+    fw = ops.FrontWeightsBf16(m, True)
+    cw0 = ops.prep_conv_weight_bf16(m.down0_1.conv.weight, conv_bias=m.down0_1.conv.bias, x3=True)
+    cw1 = ops.prep_conv_weight_bf16(m.down1_1.conv.weight, conv_bias=m.down1_1.conv.bias, x3=True)
+    g = torch.Generator(device=cuda).manual_seed(N * 100 + H + 1)
+    o0 = torch.randn((N, 32, H, 128), generator=g, device=cuda)
+    o1 = torch.randn((N, 32, H, 128), generator=g, device=cuda)
+    x = torch.randn((N, 64, H // 2, 64), generator=g, device=cuda)
+    f0, f1, f2, fg = ops.front_bf16(o0, o1, x, fw, blocked=True)
+    want0 = ops.conv2d_bf16([f0], cw0, 2, out_dtype=torch.float32, out_blocked=True)
+    want1 = ops.conv2d_bf16([f1], cw1, 2, out_dtype=torch.float32, out_blocked=True)
+    got0 = ops.down_fused_bf16(o0, fw.w0, fw.b0, cw0)
+    got1 = ops.down_fused_bf16(o1, fw.w1, fw.b1, cw1)
+    assert isinstance(got0, ops.Blocked32) and got0.shape == want0.shape
+    assert torch.equal(got0.t.view(torch.int32), want0.t.view(torch.int32))
+    assert torch.equal(got1.t.view(torch.int32), want1.t.view(torch.int32))
+    assert float(got0.t.abs().max()) > 0
+    n0, n1, g2, gg = ops.front_bf16(o0, o1, x, fw, blocked=True, store01=False)
+    assert n0 is None and n1 is None
+    assert torch.equal(g2.t.view(torch.int32), f2.t.view(torch.int32)) and torch.equal(gg.view(torch.int32), fg.view(torch.int32))

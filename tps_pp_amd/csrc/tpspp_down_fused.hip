@@ -309,6 +309,228 @@ down_fused_kernel(const DownFParams P)
 }
 
 
+
+// ---- the same kernel for the three-term split ("bf16x3": fp32 tensors, products hi*hi + hi*lo + lo*hi) ----------------------
+// in (N, 32, H, 128) fp32, out (N, 8, H/2, 64, 8) fp32 (the blocked fp32 layout of tpspp_conv2d_bf16_fwd, code 3).  Bit for bit
+// front_x3_kernel's feat0 / feat1 followed by the three-term 3x3 stride-2 convolution: the producer is front_x3's arithmetic
+// (fp32 inputs split in registers, six matrix instructions per k-step in its order, bias + ReLU in fp32, the fp32 result
+// split into hi and lo -- never rounded as a whole), the ring holds a hi and a lo row image, the consumer adds
+// Ah Bh, Ah Bl, Al Bh per (chunk, tap) in the convolution kernel's order.  The 36 hi and 36 lo weight fragments of a
+// wavefront are 288 registers: one workgroup of four wavefronts per CU (512 registers each).
+constexpr int kSmemX3 = 2 * kW0Units * 16 + 128 * 4 + 2 * kRing * kRowUnits * 16;
+
+__device__ __forceinline__ void split2(float v0, float v1, unsigned& hi, unsigned& lo)
+{
+    hi = pack_bf16(v0, v1);
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pack_bf16(v0 - h0, v1 - h1);
+}
+
+struct DownXParams {
+    const float* in;                // (N, 32, H, W) fp32
+    const u32x4* w0;                // [hi|lo][2 k-steps][2][64][8]
+    const float* b0;
+    const u32x4* wd;                // [4 chunks][hi|lo][9 taps][2][64][8]
+    const float* bd;
+    float* out;                     // (N, 8, H / 2, 64, 8) fp32
+    int N, H, W;
+    int rows_per_unit;
+    int relu;
+};
+
+__global__ void __launch_bounds__(256, 1)
+down_fused_x3_kernel(const DownXParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* const sW0 = reinterpret_cast<u32x4*>(smem);                                   // hi slab | lo slab
+    float* const sBias = reinterpret_cast<float*>(smem + 2 * kW0Units * 16);           // b0 | bd
+    u32x4* const ringH = reinterpret_cast<u32x4*>(smem + 2 * kW0Units * 16 + 512);
+    u32x4* const ringL = ringH + kRing * kRowUnits;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    for (int i = tid; i < 2 * kW0Units; i += 256) sW0[i] = P.w0[i];
+    if (tid < 128) sBias[tid] = tid < 64 ? P.b0[tid] : P.bd[tid - 64];
+    if (tid < kRing * 16) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        ringH[(tid >> 4) * kRowUnits + (tid & 15) * RP] = z;
+        ringL[(tid >> 4) * kRowUnits + (tid & 15) * RP] = z;
+    }
+    const int f = wv >> 1, h2 = wv & 1;
+    bf16x8 wah[4][9], wal[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            wah[c][t] = __builtin_bit_cast(bf16x8, P.wd[(((c * 2 + 0) * 9 + t) * 2 + half) * 64 + 32 * h2 + l31]);
+            wal[c][t] = __builtin_bit_cast(bf16x8, P.wd[(((c * 2 + 1) * 9 + t) * 2 + half) * 64 + 32 * h2 + l31]);
+        }
+    __syncthreads();
+
+    const int H = P.H, Ho = H >> 1, plane = H * kW;
+    const int RS = P.rows_per_unit, upi = Ho / RS, nunits = P.N * upi;
+    const int px = 32 * wv + l31;
+    const int punit = (px & 1) * RP + 1 + (px >> 1);
+    const unsigned lo = (unsigned)(l31 + 8 * half * plane);
+
+    // the 16 fp32 inputs of this lane for a segment: channels 16 j + 8 half + e of pixel 32 wv + l31 of row iy
+    auto fetch = [&](int n, int iy, float (&v)[2][8]) {
+        const float* base = P.in + (size_t)n * 32 * plane + (size_t)iy * kW + 32 * wv;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = (base + (size_t)(16 * j + e) * plane)[lo];
+    };
+    auto produce = [&](int iy, const float (&v)[2][8]) {
+        u32x4 ih[2], il[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h, l;
+                split2(v[j][2 * q], v[j][2 * q + 1], h, l);
+                ih[j][q] = h; il[j][q] = l;
+            }
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        constexpr int LO = kW0Units;                          // 16-byte units between the hi and the lo slab
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, sW0[(2 * j + half) * 64 + l31]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, sW0[(2 * j + half) * 64 + 32 + l31]);
+            const bf16x8 a0l = __builtin_bit_cast(bf16x8, sW0[LO + (2 * j + half) * 64 + l31]);
+            const bf16x8 a1l = __builtin_bit_cast(bf16x8, sW0[LO + (2 * j + half) * 64 + 32 + l31]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, ih[j]), bl = __builtin_bit_cast(bf16x8, il[j]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bl, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bl, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh, acc[1], 0, 0, 0);
+        }
+        const int ro = ((iy + 1) % kRing) * kRowUnits + punit;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x2 ph[4], pl[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sum = acc[t][4 * g + e] + sBias[32 * t + 8 * g + 4 * half + e];
+                    r[e] = sum > 0.0f ? sum : 0.0f;
+                }
+                unsigned h01, l01, h23, l23;
+                split2(r[0], r[1], h01, l01);
+                split2(r[2], r[3], h23, l23);
+                ph[g][0] = h01; ph[g][1] = h23; pl[g][0] = l01; pl[g][1] = l23;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const u32x2 d0 = __builtin_amdgcn_permlane32_swap(ph[g][0], ph[g + 1][0], false, false);
+                const u32x2 d1 = __builtin_amdgcn_permlane32_swap(ph[g][1], ph[g + 1][1], false, false);
+                u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                ringH[ro + (4 * t + g + half) * (2 * RP)] = unit;
+                const u32x2 e0 = __builtin_amdgcn_permlane32_swap(pl[g][0], pl[g + 1][0], false, false);
+                const u32x2 e1 = __builtin_amdgcn_permlane32_swap(pl[g][1], pl[g + 1][1], false, false);
+                u32x4 ul; ul[0] = e0[0]; ul[1] = e1[0]; ul[2] = e0[1]; ul[3] = e1[1];
+                ringL[ro + (4 * t + g + half) * (2 * RP)] = ul;
+            }
+        }
+    };
+
+    float pa[2][8], pb[2][8];
+    float4 hold[4];
+    float* hold_p = nullptr;
+    bool held = false;
+    int u = blockIdx.x;
+    if (u < nunits) {
+        const int n = u / upi, oy = (u - n * upi) * RS;
+        fetch(n, 2 * oy, pa);
+        fetch(n, 2 * oy + 1, pb);
+    }
+    for (; u < nunits; u += gridDim.x) {
+        const int n = u / upi, oy_s = (u - n * upi) * RS;
+        __syncthreads();
+        if (oy_s == 0) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (int i = tid; i < kRowUnits; i += 256) { ringH[i] = z; ringL[i] = z; }
+        } else {
+            float pc[2][8];
+            fetch(n, 2 * oy_s - 1, pc);
+            produce(2 * oy_s - 1, pc);
+        }
+        for (int oy = oy_s; oy < oy_s + RS; ++oy) {
+            if (oy > oy_s) __syncthreads();
+            produce(2 * oy, pa);
+            produce(2 * oy + 1, pb);
+            if (held) {                                       // the previous step's results leave in front of the next fetch
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(hold_p + (size_t)g * Ho * kWo * 8) = hold[g];
+            }
+            {
+                int nn = n, noy = oy + 1;
+                bool more = true;
+                if (noy == oy_s + RS) {
+                    const int nu = u + (int)gridDim.x;
+                    more = nu < nunits;
+                    nn = nu / upi;
+                    noy = (nu - nn * upi) * RS;
+                }
+                if (more) { fetch(nn, 2 * noy, pa); fetch(nn, 2 * noy + 1, pb); }
+            }
+            __syncthreads();
+            const int rbase = half * (2 * RP) + 32 * f + l31;
+            int rows[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rows[ky] = ((2 * oy + ky) % kRing) * kRowUnits + rbase;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            constexpr int kPD = 2;
+            bf16x8 fbh[kPD + 1], fbl[kPD + 1];
+            auto fetch_b = [&](int i, int slot) {
+                const int c = i / 9, t = i - 9 * c, ky = t / 3, kx = t - 3 * ky;
+                const int off = (2 * c) * (2 * RP) + (kx == 1 ? 0 : RP) + (kx == 0 ? 0 : 1);
+                fbh[slot] = __builtin_bit_cast(bf16x8, ringH[rows[ky] + off]);
+                fbl[slot] = __builtin_bit_cast(bf16x8, ringL[rows[ky] + off]);
+            };
+#pragma unroll
+            for (int i = 0; i < kPD; ++i) fetch_b(i, i);
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                if (i + kPD < 36) fetch_b(i + kPD, (i + kPD) % (kPD + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wah[i / 9][i % 9], fbh[i % (kPD + 1)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wah[i / 9][i % 9], fbl[i % (kPD + 1)], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wal[i / 9][i % 9], fbh[i % (kPD + 1)], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // bias, ReLU; this lane's four channels of channel group 4 h2 + g are 16 bytes of that group's 32-byte unit
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float sum = acc[4 * g + e] + sBias[64 + 32 * h2 + 8 * g + 4 * half + e];
+                    r[e] = (P.relu && !(sum > 0.0f)) ? 0.0f : sum;
+                }
+                hold[g] = make_float4(r[0], r[1], r[2], r[3]);
+            }
+            hold_p = P.out + ((((size_t)n * 8 + 4 * h2) * Ho + oy) * kWo + 32 * f + l31) * 8 + 4 * half;
+            held = true;
+        }
+    }
+    if (held) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(hold_p + (size_t)g * Ho * kWo * 8) = hold[g];
+    }
+}
+
 }  // namespace
 
 #ifdef TPSPP_DOWNF_TRACE
@@ -356,4 +578,39 @@ TPSPP_EXPORT int tpspp_down_fused_bf16_fwd(const void* in, const void* w0, const
     hipLaunchKernelGGL(down_fused_kernel, dim3((unsigned)(nunits < slots ? nunits : slots)), dim3(256), kSmemBytes,
                        tpspp::as_stream(stream), P);
     return tpspp::check_launch("tpspp_down_fused_bf16_fwd");
+}
+
+TPSPP_EXPORT int tpspp_down_fused_x3_fwd(const float* in, const void* w0, const float* b0, const void* wd, const float* bd,
+                                         float* out, int N, int H, int W, int relu, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(in && w0 && b0 && wd && bd && out, "tpspp_down_fused_x3_fwd: null pointer");
+    TPSPP_REQUIRE(N >= 0 && H > 0 && (H % 2) == 0 && W == kW,
+                  "tpspp_down_fused_x3_fwd: needs an even height and a width of 128 (got %d x %d)", H, W);
+    TPSPP_REQUIRE(((reinterpret_cast<size_t>(in) | reinterpret_cast<size_t>(out) | reinterpret_cast<size_t>(w0) |
+                    reinterpret_cast<size_t>(wd)) & 15) == 0, "tpspp_down_fused_x3_fwd: tensors must be 16-byte aligned");
+    if (N == 0) return TPSPP_OK;
+    TPSPP_REQUIRE((long)N * (H / 2) < 0x7fffffffL, "tpspp_down_fused_x3_fwd: batch too large");
+    DownXParams P;
+    P.in = in; P.w0 = static_cast<const u32x4*>(w0); P.b0 = b0; P.wd = static_cast<const u32x4*>(wd); P.bd = bd; P.out = out;
+    P.N = N; P.H = H; P.W = W; P.relu = relu ? 1 : 0;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+        (void)hipGetLastError();
+        ncu = 256;
+    }
+    const int Ho = H / 2, slots = ncu;                      // one workgroup per CU
+    int rs = Ho;
+    while (rs > 1 && (rs % 2) == 0 && (long)N * (Ho / rs) < 2 * slots) rs /= 2;
+    P.rows_per_unit = rs;
+    const long nunits = (long)N * (Ho / rs);
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&down_fused_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kSmemX3);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(down_fused_x3_kernel, dim3((unsigned)(nunits < slots ? nunits : slots)), dim3(256), kSmemX3,
+                       tpspp::as_stream(stream), P);
+    return tpspp::check_launch("tpspp_down_fused_x3_fwd");
 }

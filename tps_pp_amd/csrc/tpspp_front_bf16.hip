@@ -528,6 +528,7 @@ front_x3_kernel(const FrontXParams P)
         const u32x4* wg = w0 + 2048;
         const float* bias = sBias + opaque;
 
+        const bool st01 = P.feat0 != nullptr;               // (uniform) feat0 / feat1 wanted in HBM at all: tpspp_down_fused_x3_fwd
         u32x4 fh[12], fl[12];
         f32x16 acc[2];
         auto zero = [&]() {
@@ -541,7 +542,7 @@ front_x3_kernel(const FrontXParams P)
             load_b3<2>(P.o0 + (size_t)n * 32 * plane + seg0, lo, plane, ih, il);
             zero();
             gemm3<2>(w0, ih, il, half, l31, acc);
-            finish3(acc, bias, half, P.feat0 + obase, so, plane, true, fh, fl,
+            finish3(acc, bias, half, P.feat0 + obase, so, plane, st01, fh, fl,
                     P.blk ? P.feat0 + ((size_t)n * 8 * plane + seg0 + l31) * 8 + 4 * half : nullptr, (size_t)plane * 8);
         }
         {
@@ -549,7 +550,7 @@ front_x3_kernel(const FrontXParams P)
             load_b3<2>(P.o1 + (size_t)n * 32 * plane + seg0, lo, plane, ih, il);
             zero();
             gemm3<2>(w1, ih, il, half, l31, acc);
-            finish3(acc, bias + 64, half, P.feat1 + obase, so, plane, true, fh + 4, fl + 4,
+            finish3(acc, bias + 64, half, P.feat1 + obase, so, plane, st01, fh + 4, fl + 4,
                     P.blk ? P.feat1 + ((size_t)n * 8 * plane + seg0 + l31) * 8 + 4 * half : nullptr, (size_t)plane * 8);
         }
         {
@@ -586,9 +587,9 @@ TPSPP_EXPORT int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, cons
 {
     TPSPP_REQUIRE(outs0 && outs1 && x && w0 && w1 && w2 && wg && b0 && b1 && b2 && bg && feat2 && feat_grid,
                   "tpspp_front_bf16_fwd: null pointer");
-    // feat0 = feat1 = NULL: not stored (their consumers recompute them: tpspp_down_fused_bf16_fwd); plain bf16, blocked only
-    TPSPP_REQUIRE((feat0 && feat1) || (!feat0 && !feat1 && !split3 && (feat_grid_f32 & 2)),
-                  "tpspp_front_bf16_fwd: feat0 / feat1 may only be omitted together, in the blocked bf16 form");
+    // feat0 = feat1 = NULL: not stored (their consumers recompute them: tpspp_down_fused_bf16_fwd / _x3_fwd); blocked form only
+    TPSPP_REQUIRE((feat0 && feat1) || (!feat0 && !feat1 && (feat_grid_f32 & 2)),
+                  "tpspp_front_bf16_fwd: feat0 / feat1 may only be omitted together, in the blocked form");
     TPSPP_REQUIRE(N >= 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 32) == 0,
                   "tpspp_front_bf16_fwd: needs an even height and a width that is a multiple of 32");
     if (N == 0) return TPSPP_OK;

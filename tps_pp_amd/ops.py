@@ -811,8 +811,8 @@ def front_bf16(o0, o1, x, fw, feat_grid_dtype=torch.bfloat16, blocked=False, sto
         feat2 = torch.empty((N, 64, H // 2, W // 2), device=dev, dtype=bf)
     feat1 = torch.empty_like(feat0)
     if not store01:
-        if not blocked or fw.x3:
-            raise ValueError("front_bf16: store01=False goes with the blocked bf16 form")
+        if not blocked:
+            raise ValueError("front_bf16: store01=False goes with the blocked form")
         feat0 = feat1 = None
     feat_grid = torch.empty((N, 64, H, W), device=dev, dtype=feat_grid_dtype)
     with torch.cuda.device(dev):
@@ -852,10 +852,11 @@ def token_gemm_bf16(x_cm, cw, act=None, residual=None, out_dtype=torch.float32):
 
 
 def down_fused_bf16_applicable(o, cw):
-    """`down_fused_bf16` takes a bfloat16 (N, 32, H, 128) map with an even H and a plain-bf16 64 -> 64 3x3 weight."""
-    return (o.dtype == torch.bfloat16 and o.dim() == 4 and o.shape[1] == 32 and o.shape[2] % 2 == 0 and o.shape[3] == 128
-            and not cw.x3 and cw.kernel == 3 and cw.cin == 64 and cw.cout == 64 and cw.bias is not None
-            and cw.post_scale is None)
+    """`down_fused_bf16` takes a (N, 32, H, 128) map with an even H -- bfloat16 with a plain-bf16 64 -> 64 3x3 weight, float32
+    with an x3 (three-term split) weight."""
+    return (o.dtype == (torch.float32 if cw.x3 else torch.bfloat16) and o.dim() == 4 and o.shape[1] == 32
+            and o.shape[2] % 2 == 0 and o.shape[3] == 128
+            and cw.kernel == 3 and cw.cin == 64 and cw.cout == 64 and cw.bias is not None and cw.post_scale is None)
 
 
 def down_fused_bf16(o, w0_slab, b0, cw, relu=True):
@@ -864,16 +865,21 @@ def down_fused_bf16(o, w0_slab, b0, cw, relu=True):
     `FrontWeightsBf16` holds it; `cw`: the 3x3 stride-2 layer (`prep_conv_weight_bf16`).  Returns a `Blocked` map."""
     o = _chk16("outs", o, 4)
     if not down_fused_bf16_applicable(o, cw):
-        raise ValueError("down_fused_bf16: needs a bfloat16 (N, 32, H, 128) map with an even H and a 64 -> 64 3x3 bf16 weight "
-                         "with a bias")
+        raise ValueError("down_fused_bf16: needs a (N, 32, H, 128) map with an even H -- bfloat16 with a 64 -> 64 3x3 bf16 weight, "
+                         "float32 with an x3 weight -- and a bias")
     N, _, H, W = o.shape
-    out = Blocked(torch.empty((N, 8, H // 2, W // 2, 8), device=o.device, dtype=torch.bfloat16))
+    if cw.x3:                                           # three-term split: fp32 maps, `w0_slab` with its hi and lo halves
+        out = Blocked32(torch.empty((N, 8, H // 2, W // 2, 8), device=o.device, dtype=torch.float32))
+        fn, name = _lib.lib().tpspp_down_fused_x3_fwd, "tpspp_down_fused_x3_fwd"
+    else:
+        out = Blocked(torch.empty((N, 8, H // 2, W // 2, 8), device=o.device, dtype=torch.bfloat16))
+        fn, name = _lib.lib().tpspp_down_fused_bf16_fwd, "tpspp_down_fused_bf16_fwd"
     if N == 0:
         return out
     with torch.cuda.device(o.device):
-        rc = _lib.lib().tpspp_down_fused_bf16_fwd(_ptr(o), _ptr(w0_slab), _ptr(b0), _ptr(cw.arranged), _ptr(cw.bias),
-                                                  out.t.data_ptr(), N, H, W, int(relu), _stream(o))
-    _lib.check(rc, "tpspp_down_fused_bf16_fwd")
+        rc = fn(_ptr(o), _ptr(w0_slab), _ptr(b0), _ptr(cw.arranged), _ptr(cw.bias), out.t.data_ptr(), N, H, W, int(relu),
+                _stream(o))
+    _lib.check(rc, name)
     return out
 
 

@@ -486,7 +486,7 @@ class TPS_PP(nn.Module):
                     self._front16_cache = fc = (fkey, ops.FrontWeightsBf16(self, x3))
                 # round 4: feat0 / feat1 are not stored where the stride-2 layers can recompute them from outs[0] / outs[1]
                 # (tpspp_down_fused.hip; TPSPP_NO_DOWN_FUSED=1 keeps the two-kernel route for A/B runs)
-                fused = (not x3 and not _NO_DOWN_FUSED and ops.down_fused_bf16_applicable(o0, cw["down0_1"])
+                fused = (not _NO_DOWN_FUSED and ops.down_fused_bf16_applicable(o0, cw["down0_1"])
                          and ops.down_fused_bf16_applicable(o1, cw["down1_1"]))
                 feat0, feat1, feat2, feat_grid = ops.front_bf16(o0, o1, x, fc[1], fg_dtype, blocked=True, store01=not fused)
                 if fused:
