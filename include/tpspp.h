@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define TPSPP_ABI_VERSION 3   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
-                               3: tpspp_down_fused_bf16_fwd / _x3_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
+                               3: tpspp_down_fused_bf16_fwd / _x3_fwd / _f32_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_fwd and tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -368,6 +368,16 @@ int tpspp_down_fused_bf16_fwd(const void* in, const void* w0, const float* b0, c
  */
 int tpspp_down_fused_x3_fwd(const float* in, const void* w0, const float* b0, const void* wd, const float* bd,
                             float* out, int N, int H, int W, int relu, tpspp_stream_t stream);
+
+/*
+ * The same for the exact-fp32 configuration: in (N, 32, H, 128) fp32, w0_slab [32][64] (tpspp_front_fwd's), wd_tiled the
+ * (64, 64, 3, 3) weight as tpspp_conv2d_fwd's weight_tiled ([16 chunks][9 taps][4][64]), out (N, 64, H/2, 64) fp32 NCHW; bit for
+ * bit tpspp_front_fwd's feat0 / feat1 followed by tpspp_conv2d_fwd (3x3, stride 2).  tpspp_front_fwd accepts
+ * feat0 = feat1 = NULL.
+ * replaces: backbones/tps_pp/tps_pp.py:560-563
+ */
+int tpspp_down_fused_f32_fwd(const float* in, const float* w0_slab, const float* b0, const float* wd_tiled,
+                             const float* bd, float* out, int N, int H, int W, int relu, tpspp_stream_t stream);
 
 /*
  * The same fused convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: bf16 operands, fp32

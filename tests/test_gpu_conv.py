@@ -96,3 +96,35 @@ def test_folded_batchnorm(cuda):
     cw = ops.prep_conv_weight(w.to(cuda), bn=tuple(v.to(cuda) for v in (gamma, beta, mean, var)))
     got = ops.conv2d([x.to(cuda)], cw, 1, True)
     assert (got.cpu() - ref).abs().max().item() <= 3e-5
+
+
+@pytest.mark.parametrize("N,H", [(1, 32), (3, 32), (5, 8), (2, 2), (270, 32)])
+def test_down_fused_f32_is_front_then_stride2_conv_bit_for_bit(cuda, N, H):
+    """tpspp_down_fused_f32_fwd (exact fp32: down0 + down0_1 in one kernel, the 1x1 result only in LDS) against tpspp_front_fwd's
+    feat0 / feat1 followed by the 3x3 stride-2 tpspp_conv2d_fwd; whole images per workgroup (N = 270: some workgroups take
+    two), strips with a recomputed halo row, a single output row; signed inputs and non-zero biases (the padding applies to
+    the intermediate map)."""
+    from tps_pp_amd import TPS_PP
+    torch.manual_seed(13)
+    m = TPS_PP().eval().to(cuda)
+    with torch.no_grad():
+        for c in (m.down0, m.down1, m.down0_1, m.down1_1):
+            c.conv.bias.uniform_(-0.5, 0.5)
+    fw = ops.FrontWeights(m)
+    cw0 = ops.prep_conv_weight(m.down0_1.conv.weight, conv_bias=m.down0_1.conv.bias)
+    cw1 = ops.prep_conv_weight(m.down1_1.conv.weight, conv_bias=m.down1_1.conv.bias)
+    g = torch.Generator(device=cuda).manual_seed(N * 100 + H + 2)
+    o0 = torch.randn((N, 32, H, 128), generator=g, device=cuda)
+    o1 = torch.randn((N, 32, H, 128), generator=g, device=cuda)
+    x = torch.randn((N, 64, H // 2, 64), generator=g, device=cuda)
+    f0, f1, f2, fg = ops.front(o0, o1, x, fw)
+    want0 = ops.conv2d([f0], cw0, 2)
+    want1 = ops.conv2d([f1], cw1, 2)
+    got0 = ops.down_fused_f32(o0, fw.w0, fw.b0, cw0)
+    got1 = ops.down_fused_f32(o1, fw.w1, fw.b1, cw1)
+    assert got0.shape == want0.shape
+    assert torch.equal(got0.view(torch.int32), want0.view(torch.int32))
+    assert torch.equal(got1.view(torch.int32), want1.view(torch.int32))
+    assert float(got0.abs().max()) > 0
+    n0, n1, g2, gg = ops.front(o0, o1, x, fw, store01=False)
+    assert n0 is None and n1 is None and torch.equal(g2, f2) and torch.equal(gg, fg)

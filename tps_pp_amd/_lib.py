@@ -36,6 +36,7 @@ _SIGNATURES = {
     "tpspp_front_bf16_fwd": ([_f] * 15 + [_i, _i, _i, _i, _i, _f], _i),
     "tpspp_down_fused_bf16_fwd": ([_f] * 6 + [_i, _i, _i, _i, _f], _i),
     "tpspp_down_fused_x3_fwd": ([_f] * 6 + [_i, _i, _i, _i, _f], _i),
+    "tpspp_down_fused_f32_fwd": ([_f] * 6 + [_i, _i, _i, _i, _f], _i),
     "tpspp_token_gemm_bf16_fwd": ([_f] * 5 + [_i, _i, _i, _i, _i, _i, _f], _i),
     "tpspp_cbam_fwd": ([_f, _f, _f, _f, _f, _f, _i, _f], _i),
     "tpspp_tpe_points_fwd": ([_f] * 13 + [_i, _f], _i),

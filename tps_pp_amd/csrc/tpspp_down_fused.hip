@@ -531,6 +531,155 @@ down_fused_x3_kernel(const DownXParams P)
     }
 }
 
+
+// ---- the same kernel for the exact-fp32 configuration (v_mfma_f32_32x32x2_f32) ------------------------------------------------
+// in (N, 32, H, 128) fp32, out (N, 64, H/2, 64) fp32 NCHW.  Bit for bit front_kernel's feat0 / feat1 (tpspp_front.hip: channel
+// pairs ascending, two accumulators, bias + ReLU) followed by conv_tiled_f32_kernel<3, 2, 2, ...> (tpspp_conv.hip: chunks of
+// 4 channels ascending, taps row-major inside a chunk, the chunk's two channel pairs inside a tap, one accumulator).  A
+// wavefront's weight is 16 chunks x 9 taps x 2 pairs = 288 one-register A fragments; the ring holds fp32 rows
+// [channel][parity][pad | 64 columns] (a fragment's 32 pixels read 32 consecutive floats); one workgroup per CU.
+constexpr int RPF = 80;                          // floats per (channel, parity) run (80: the even and the odd run of a
+                                                 // producer's write are 16 banks apart)
+constexpr int kRowF = 64 * 2 * RPF;              // floats per feature row
+constexpr int kSmemF32 = (32 * 64 + 128 + kRing * kRowF) * 4;
+
+__device__ __forceinline__ constexpr int feat_of(int ks, int half)
+{
+    return 32 * (ks >> 4) + (ks & 3) + 8 * ((ks & 15) >> 2) + 4 * half;      // the channel of result register ks (C/D layout)
+}
+
+struct DownFP32Params {
+    const float* in;                // (N, 32, H, W)
+    const float* w0;                // [32 k][64]
+    const float* b0;
+    const float* wd;                // [16 chunks][9 taps][4][64]
+    const float* bd;
+    float* out;                     // (N, 64, H / 2, 64)
+    int N, H, W;
+    int rows_per_unit;
+    int relu;
+};
+
+__global__ void __launch_bounds__(256, 1)
+down_fused_f32_kernel(const DownFP32Params P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* const sW0 = reinterpret_cast<float*>(smem);
+    float* const sBias = sW0 + 32 * 64;                                                 // b0 | bd
+    float* const ring = sBias + 128;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    for (int i = tid; i < 32 * 64; i += 256) sW0[i] = P.w0[i];
+    if (tid < 128) sBias[tid] = tid < 64 ? P.b0[tid] : P.bd[tid - 64];
+    for (int i = tid; i < kRing * 128; i += 256) ring[(i >> 7) * kRowF + (i & 127) * RPF] = 0.0f;     // the padding columns
+    const int f = wv >> 1, h2 = wv & 1;
+    float wr[16][9][2];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) wr[c][t][c2] = P.wd[((c * 9 + t) * 4 + 2 * c2 + half) * 64 + 32 * h2 + l31];
+    __syncthreads();
+
+    const int H = P.H, Ho = H >> 1, plane = H * kW;
+    const int RS = P.rows_per_unit, upi = Ho / RS, nunits = P.N * upi;
+    const int px = 32 * wv + l31;
+    const int pidx = (px & 1) * RPF + 1 + (px >> 1);
+
+    // the lane's 16 inputs of a segment: channels 2 ks + half of pixel 32 wv + l31 of row iy
+    auto fetch = [&](int n, int iy, float (&v)[16]) {
+        const float* base = P.in + ((size_t)n * 32 + half) * plane + (size_t)iy * kW + px;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) v[ks] = base[(size_t)(2 * ks) * plane];
+    };
+    auto produce = [&](int iy, const float (&v)[16]) {
+        f32x16 a0, a1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a0[i] = 0.0f; a1[i] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW0[(2 * ks + half) * 64 + l31], v[ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sW0[(2 * ks + half) * 64 + 32 + l31], v[ks], a1, 0, 0, 0);
+        }
+        float* const row = ring + ((iy + 1) % kRing) * kRowF + pidx;
+#pragma unroll
+        for (int ks = 0; ks < 32; ++ks) {
+            const float r = (ks < 16 ? a0[ks & 15] : a1[ks & 15]) + sBias[feat_of(ks, half)];
+            row[feat_of(ks, half) * (2 * RPF)] = r > 0.0f ? r : 0.0f;
+        }
+    };
+
+    float pa[16], pb[16];
+    int u = blockIdx.x;
+    if (u < nunits) {
+        const int n = u / upi, oy = (u - n * upi) * RS;
+        fetch(n, 2 * oy, pa);
+        fetch(n, 2 * oy + 1, pb);
+    }
+    for (; u < nunits; u += gridDim.x) {
+        const int n = u / upi, oy_s = (u - n * upi) * RS;
+        __syncthreads();
+        if (oy_s == 0) {
+            for (int i = tid; i < kRowF; i += 256) ring[i] = 0.0f;
+        } else {
+            float pc[16];
+            fetch(n, 2 * oy_s - 1, pc);
+            produce(2 * oy_s - 1, pc);
+        }
+        for (int oy = oy_s; oy < oy_s + RS; ++oy) {
+            if (oy > oy_s) __syncthreads();
+            produce(2 * oy, pa);
+            produce(2 * oy + 1, pb);
+            {
+                int nn = n, noy = oy + 1;
+                bool more = true;
+                if (noy == oy_s + RS) {
+                    const int nu = u + (int)gridDim.x;
+                    more = nu < nunits;
+                    nn = nu / upi;
+                    noy = (nu - nn * upi) * RS;
+                }
+                if (more) { fetch(nn, 2 * noy, pa); fetch(nn, 2 * noy + 1, pb); }
+            }
+            __syncthreads();
+            const int rbase = half * (2 * RPF) + 32 * f + l31;
+            int rows[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) rows[ky] = ((2 * oy + ky) % kRing) * kRowF + rbase;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            // (chunk c of 4 channels, tap t, pair c2): channel 4 c + 2 c2 + half at the tap's column
+            constexpr int kPD = 6;
+            float fb[kPD + 1];
+            auto fetch_b = [&](int i, int slot) {
+                const int c = i / 18, r = i - 18 * c, t = r >> 1, c2 = r & 1, ky = t / 3, kx = t - 3 * ky;
+                const int off = (4 * c + 2 * c2) * (2 * RPF) + (kx == 1 ? 0 : RPF) + (kx == 0 ? 0 : 1);
+                fb[slot] = ring[rows[ky] + off];
+            };
+#pragma unroll
+            for (int i = 0; i < kPD; ++i) fetch_b(i, i);
+#pragma clang loop unroll(full)
+            for (int i = 0; i < 288; ++i) {
+                if (i + kPD < 288) fetch_b(i + kPD, (i + kPD) % (kPD + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[i / 18][(i % 18) >> 1][i & 1], fb[i % (kPD + 1)], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float* const ob = P.out + (((size_t)n * 64 + 32 * h2 + 4 * half) * Ho + oy) * kWo + 32 * f + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 8 * (r >> 2) + (r & 3);          // + 32 h2 + 4 half
+                const float sum = acc[r] + sBias[64 + 32 * h2 + 4 * half + co];
+                ob[(size_t)co * Ho * kWo] = (P.relu && !(sum > 0.0f)) ? 0.0f : sum;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef TPSPP_DOWNF_TRACE
@@ -613,4 +762,37 @@ TPSPP_EXPORT int tpspp_down_fused_x3_fwd(const float* in, const void* w0, const 
     hipLaunchKernelGGL(down_fused_x3_kernel, dim3((unsigned)(nunits < slots ? nunits : slots)), dim3(256), kSmemX3,
                        tpspp::as_stream(stream), P);
     return tpspp::check_launch("tpspp_down_fused_x3_fwd");
+}
+
+TPSPP_EXPORT int tpspp_down_fused_f32_fwd(const float* in, const float* w0_slab, const float* b0, const float* wd_tiled,
+                                          const float* bd, float* out, int N, int H, int W, int relu, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(in && w0_slab && b0 && wd_tiled && bd && out, "tpspp_down_fused_f32_fwd: null pointer");
+    TPSPP_REQUIRE(N >= 0 && H > 0 && (H % 2) == 0 && W == kW,
+                  "tpspp_down_fused_f32_fwd: needs an even height and a width of 128 (got %d x %d)", H, W);
+    if (N == 0) return TPSPP_OK;
+    TPSPP_REQUIRE((long)N * (H / 2) < 0x7fffffffL, "tpspp_down_fused_f32_fwd: batch too large");
+    DownFP32Params P;
+    P.in = in; P.w0 = w0_slab; P.b0 = b0; P.wd = wd_tiled; P.bd = bd; P.out = out;
+    P.N = N; P.H = H; P.W = W; P.relu = relu ? 1 : 0;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+        (void)hipGetLastError();
+        ncu = 256;
+    }
+    const int Ho = H / 2, slots = ncu;                      // one workgroup per CU
+    int rs = Ho;
+    while (rs > 1 && (rs % 2) == 0 && (long)N * (Ho / rs) < 2 * slots) rs /= 2;
+    P.rows_per_unit = rs;
+    const long nunits = (long)N * (Ho / rs);
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&down_fused_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kSmemF32);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(down_fused_f32_kernel, dim3((unsigned)(nunits < slots ? nunits : slots)), dim3(256), kSmemF32,
+                       tpspp::as_stream(stream), P);
+    return tpspp::check_launch("tpspp_down_fused_f32_fwd");
 }

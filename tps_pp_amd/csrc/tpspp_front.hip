@@ -142,14 +142,14 @@ front_kernel(const FrontParams P)
         float f[32];
         // feat0: compute, store, fold into feat_grid; then feat1, feat2 -- one feature set live at a time
         dense_relu<16>(tW0, tB, i0, half, l31, f);
-        if (live) {
+        if (live && P.feat0) {                              // (feat0 = feat1 = NULL: tpspp_down_fused_f32_fwd recomputes them)
             char* q = reinterpret_cast<char*>(P.feat0 + (size_t)n * 64 * HW);
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) *reinterpret_cast<float*>(q + feat(ks, 0) * cstride + out_off) = f[ks];
         }
         accumulate_block(tWg, f, half, l31, g0, g1);
         dense_relu<16>(tW1, tB + 64, i1, half, l31, f);
-        if (live) {
+        if (live && P.feat1) {
             char* q = reinterpret_cast<char*>(P.feat1 + (size_t)n * 64 * HW);
 #pragma unroll
             for (int ks = 0; ks < 32; ++ks) *reinterpret_cast<float*>(q + feat(ks, 0) * cstride + out_off) = f[ks];
@@ -182,7 +182,7 @@ TPSPP_EXPORT int tpspp_front_fwd(const float* outs0, const float* outs1, const f
                                  int N, int H, int W, tpspp_stream_t stream)
 {
     TPSPP_REQUIRE(outs0 && outs1 && x && w0_slab && b0 && w1_slab && b1 && w2_slab && b2 && wg_slab && bg &&
-                  feat0 && feat1 && feat2 && feat_grid, "tpspp_front_fwd: null pointer");
+                  feat2 && feat_grid && (feat0 != nullptr) == (feat1 != nullptr), "tpspp_front_fwd: null pointer");
     TPSPP_REQUIRE(N >= 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && N <= 65535,
                   "tpspp_front_fwd: need even H, W");
     if (N == 0) return TPSPP_OK;

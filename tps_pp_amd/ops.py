@@ -749,17 +749,18 @@ class FrontWeights:
         self.b0, self.b1, self.b2, self.bg = (f(c.conv.bias) for c in (m.down0, m.down1, m.down2, m.down_feat))
 
 
-def front(o0, o1, x, fw):
+def front(o0, o1, x, fw, store01=True):
     """down0/down1/down2 + grid() of TPS_PP.forward (tps_pp.py:560-562,581-585) in one kernel.
-    Returns (feat0, feat1, feat2, feat_grid)."""
+    Returns (feat0, feat1, feat2, feat_grid); `store01=False`: feat0 / feat1 stay operands of feat_grid and are returned as
+    None (`down_fused_f32` recomputes them where they are consumed)."""
     o0, o1, x = _chk("outs[0]", o0, 4), _chk("outs[1]", o1, 4), _chk("x", x, 4)
     N, c0, H, W = o0.shape
     if c0 != 32 or tuple(o1.shape) != (N, 32, H, W) or tuple(x.shape) != (N, 64, H // 2, W // 2):
         raise ValueError("front: needs outs (N,32,H,W) x2 and x (N,64,H/2,W/2)")
     dev = o0.device
-    feat0 = torch.empty((N, 64, H, W), device=dev, dtype=torch.float32)
-    feat1 = torch.empty_like(feat0)
-    feat_grid = torch.empty_like(feat0)
+    feat_grid = torch.empty((N, 64, H, W), device=dev, dtype=torch.float32)
+    feat0 = torch.empty_like(feat_grid) if store01 else None
+    feat1 = torch.empty_like(feat_grid) if store01 else None
     feat2 = torch.empty((N, 64, H // 2, W // 2), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
         rc = _lib.lib().tpspp_front_fwd(_ptr(o0), _ptr(o1), _ptr(x), _ptr(fw.w0), _ptr(fw.b0), _ptr(fw.w1),
@@ -768,6 +769,31 @@ def front(o0, o1, x, fw):
                                         _stream(o0))
     _lib.check(rc, "tpspp_front_fwd")
     return feat0, feat1, feat2, feat_grid
+
+
+def down_fused_f32_applicable(o, cw):
+    """`down_fused_f32` takes a float32 (N, 32, H, 128) map with an even H and a 64 -> 64 3x3 fp32 weight with a bias."""
+    return (o.dtype == torch.float32 and o.dim() == 4 and o.shape[1] == 32 and o.shape[2] % 2 == 0 and o.shape[3] == 128
+            and cw.kernel == 3 and cw.tiled is not None and tuple(cw.tiled.shape) == (16, 3, 3, 4, 64) and cw.bias is not None
+            and cw.post_scale is None)
+
+
+def down_fused_f32(o, w0_slab, b0, cw, relu=True):
+    """`down0_1(down0(outs[0]))` / `down1_1(down1(outs[1]))` of TPS_PP.forward (tps_pp.py:560-563) in one exact-fp32 kernel
+    (`tpspp_down_fused_f32_fwd`); `w0_slab`, `b0`: the 1x1 layer as `FrontWeights` holds it; `cw`: the 3x3 stride-2 layer
+    (`prep_conv_weight`).  Returns (N, 64, H/2, 64) float32."""
+    o = _chk("outs", o, 4)
+    if not down_fused_f32_applicable(o, cw):
+        raise ValueError("down_fused_f32: needs a float32 (N, 32, H, 128) map with an even H and a 64 -> 64 3x3 weight with a bias")
+    N, _, H, W = o.shape
+    out = torch.empty((N, 64, H // 2, W // 2), device=o.device, dtype=torch.float32)
+    if N == 0:
+        return out
+    with torch.cuda.device(o.device):
+        rc = _lib.lib().tpspp_down_fused_f32_fwd(_ptr(o), _ptr(w0_slab), _ptr(b0), _ptr(cw.tiled), _ptr(cw.bias), _ptr(out),
+                                                 N, H, W, int(relu), _stream(o))
+    _lib.check(rc, "tpspp_down_fused_f32_fwd")
+    return out
 
 
 class FrontWeightsBf16:

@@ -594,9 +594,16 @@ class TPS_PP(nn.Module):
             fc = getattr(self, "_front_cache", None)
             if fc is None or fc[0] != fkey:
                 self._front_cache = fc = (fkey, ops.FrontWeights(self))
-            feat0, feat1, feat2, feat_grid = ops.front(o0, o1, x, fc[1])
-            d0 = ops.conv2d([feat0], cw["down0_1"], 2)
-            d1 = ops.conv2d([feat1], cw["down1_1"], 2)
+            fw = fc[1]
+            fused = (not _NO_DOWN_FUSED and ops.down_fused_f32_applicable(o0, cw["down0_1"])
+                     and ops.down_fused_f32_applicable(o1, cw["down1_1"]))
+            feat0, feat1, feat2, feat_grid = ops.front(o0, o1, x, fw, store01=not fused)
+            if fused:           # round 4: feat0 / feat1 never reach HBM (tpspp_down_fused.hip, exact-fp32 form)
+                d0 = ops.down_fused_f32(o0, fw.w0, fw.b0, cw["down0_1"])
+                d1 = ops.down_fused_f32(o1, fw.w1, fw.b1, cw["down1_1"])
+            else:
+                d0 = ops.conv2d([feat0], cw["down0_1"], 2)
+                d1 = ops.conv2d([feat1], cw["down1_1"], 2)
             cat_srcs = [d0, d1, feat2]
         else:
             cat_srcs = [ops.conv2d([o0], cw["down0"], 2), ops.conv2d([o1], cw["down1"], 1),
