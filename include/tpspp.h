@@ -112,6 +112,8 @@ int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo,
 #define TPSPP_SCORE_TRANSPOSED 2   /* table_flags bit: `score` is laid out (N, F, n) instead of the
                                       reference's (N, n, F): lanes that own consecutive pixels then read
                                       it coalesced.  Same values, same results. */
+#define TPSPP_BWD_FIXED_POINT 16   /* table_flags bit of tpspp_warp_bwd only: accumulate dL/d input in 64-bit fixed point (bitwise
+                                    * reproducible from run to run) instead of the default fp64 LDS atomics; per call, any stream */
 #define TPSPP_IO_BF16 4            /* table_flags bit: in0 / in1 / out0 / out1 hold bfloat16 (the pointers are
                                       reinterpreted; everything else stays fp32).  The bf16 configuration
                                       (BASELINE.json configs[2]): T, grid and interpolation in fp32 exactly as
@@ -158,10 +160,15 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *           preprocessor/tps_preprocessor.py:71-83,270-282
  */
 size_t tpspp_warp_bwd_workspace_floats(int N, int Ho, int Wo);
-/* How dL/d input is accumulated in LDS when whole planes fit: 0 (default) = fp64 atomics (every term's fp32 bits kept
- * whatever the spread of magnitudes; a non-finite gradient poisons the four taps it touches, as ATen does), 1 = round 3's
- * 64-bit fixed point (exact and order-independent within 2^-50 of a pass's largest |g|; a non-finite gradient turns the
- * whole plane NaN).  Process-wide; for measurements (scripts/bench_backward.py). */
+/* How dL/d input is accumulated in LDS when whole planes fit.  Default = fp64 LDS atomics: every term's fp32 bits are kept
+ * whatever the spread of magnitudes (a non-finite gradient poisons the four taps it touches, as ATen does), but the fp64 sum
+ * depends on the order in which the atomics arrive (2^-53 relative per add), so g_in0 / g_in1 are NOT bitwise reproducible
+ * from run to run: after the rounding to fp32 two runs differ by at most one fp32 ulp, and only where the fp64 sum lies
+ * within ~2^-50 of an fp32 rounding tie (tests/test_gpu_backward.py bounds it).  TPSPP_BWD_FIXED_POINT in `table_flags`
+ * selects, for that call only, round 3's 64-bit fixed point: order-independent, hence bitwise reproducible, exact within
+ * 2^-50 of a pass's largest |g| (a non-finite gradient turns the whole plane NaN).  g_ctrl / g_score are computed in a fixed
+ * order in either mode.  tpspp_warp_bwd_set_accumulator(1) makes the fixed point the process-wide default of calls that do
+ * not pass the flag (kept for scripts/bench_backward.py; prefer the flag: it is per call and per stream). */
 int tpspp_warp_bwd_set_accumulator(int fixed_point);
 int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
                    const float* g_out1, const float* in1, int C1, int H1, int W1,
@@ -322,6 +329,10 @@ int tpspp_conv_chunk_channels(int kernel_size);
  *   split3: the three-term "bf16x3" split on fp32 tensors -- inputs and all four outputs fp32, every slab holds its hi
  *   and lo halves ([hi|lo][k-steps][2][64][8]), feat0 / feat1 / feat2 are chained without an intermediate rounding;
  *   feat_grid_f32 bit 1 then means the fp32 blocked layout (N, 8, H, W, 8) (tpspp_conv2d_bf16_fwd's code 3).
+ * Non-finite values: the ReLU of the bf16 form is a signed 16-bit max on the rounded pair (identical bits for every finite
+ * value and for +-inf; a NaN with the sign bit clear propagates like torch.relu's, a NaN with the sign bit set becomes +0);
+ * the fp32 / three-term forms and tpspp_down_fused_* use fmaxf(x, 0), which sends every NaN to 0.  NaN inputs are outside
+ * the parity contract of all of them (tests/test_gpu_conv_bf16.py pins this behaviour so that a change is noticed).
  * replaces: backbones/tps_pp/tps_pp.py:560-562,581-585
  */
 int tpspp_front_bf16_fwd(const void* outs0, const void* outs1, const void* x,

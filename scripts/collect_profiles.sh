@@ -49,7 +49,7 @@ timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-tr
     ./scripts/ubench/mfma_bench > $OUT/mfma_cal.log 2>&1
 # 5. summaries are made HERE (the raw kernel traces of the recogniser / the driver's command are tens of MB each and
 #    gpurun copies back at most 64 MiB): gpurun_out/prof_summary/* is what gets committed under profiles/
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 TPSPP_PROFILE_DST=gpurun_out/prof_summary python3 scripts/summarize_profiles.py $TAG > $OUT/summarize.log 2>&1
 find $OUT -name "*_kernel_trace.csv" -size +3M -delete
 find $OUT -name "*counter_collection.csv" -size +3M -delete

@@ -101,6 +101,62 @@ def timeline(trace_csv, kernel_substr, steps):
     return rows
 
 
+def line_regions(bench):
+    """(S, regions_us on S streams, regions_us on one stream) of a bench line; round 5 made them flat strings of
+    `roofline` (the driver's parser drops nested objects), earlier lines carry nested lists."""
+    rf = bench["roofline"]
+    if "multi_stream_streams" in rf:
+        S = int(rf["multi_stream_streams"])
+        f = lambda k: [float(x) for x in str(rf.get(k, "")).split()] or None       # noqa: E731
+        return S, f("regions_us_multi_stream"), f("regions_us_one_stream")
+    tried = bench["config"].get("streams_tried", [bench["config"]["streams"]])
+    return max(tried), rf.get("multi_stream", {}).get("regions_us"), rf.get("one_stream", {}).get("regions_us")
+
+
+def protocol_tables():
+    """The driver's command in the kernel trace, reduced so that the timeline can be recomputed from profiles/ alone:
+    rNN_bench_dispatches.csv  -- every dispatch of the warp kernel (protocol, region, queue, start, end; ns from the first)
+    and per-protocol aggregate rows for rNN_bench_kernel_stats.csv (one-stream and S-stream dispatches SEPARATED: their
+    durations differ by 2x because overlapped kernels share the memory system)."""
+    pth = os.path.join(SRC, "trace_driver", "bench_kernel_trace.csv")
+    log = os.path.join(SRC, "bench_trace_driver.log")
+    if not (os.path.exists(pth) and os.path.exists(log)):
+        return []
+    lines = [l for l in open(log) if l.startswith("{")]
+    if not lines:
+        return []
+    bench = json.loads(lines[-1])
+    steps, warm, R = bench["steps"], bench["warmup"], int(bench["config"].get("repeats", 1))
+    S, _, _ = line_regions(bench)
+    rows = timeline(pth, KERNEL, steps)
+    t0 = int(rows[0]["Start_Timestamp"])
+    lo, out, agg = warm, [], []
+    for i, r in enumerate(rows[:warm]):
+        out.append(("warmup", S, -1, i, r))
+    for streams in ([S, 1] if S > 1 else [S]):
+        durs, periods = [], []
+        for reg in range(R):
+            sel = rows[lo:lo + steps]
+            if len(sel) < steps:
+                break
+            for i, r in enumerate(sel):
+                out.append(("timed", streams, reg, lo + i, r))
+            lo += steps
+            durs += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
+            periods.append((max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)) / len(sel))
+        if durs:
+            agg.append((streams, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs), sorted(periods)))
+    for i, r in enumerate(rows[lo:]):
+        out.append(("after", 1, -1, lo + i, r))
+    with open(os.path.join(DST, f"{TAG}_bench_dispatches.csv"), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["phase", "streams_of_protocol", "region", "dispatch", "queue_id", "start_ns", "end_ns", "duration_ns"])
+        for ph, st, reg, i, r in out:
+            a, b = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+            wr.writerow([ph, st, reg, i, r.get("Queue_Id", "?"), a, b, b - a])
+    return agg
+
+
 def timeline_summary():
     """Per traced run of bench.py: the dispatch order is warm-up, `repeats` regions of `steps` launches on S streams,
     `repeats` regions on one stream (when S > 1), then the parity step / extras.  For every region: the kernels' average
@@ -121,12 +177,11 @@ def timeline_summary():
         bench = json.loads(lines[-1])
         steps, warm = bench["steps"], bench["warmup"]
         R = int(bench["config"].get("repeats", 1))
-        tried = bench["config"].get("streams_tried", [bench["config"]["streams"]])
-        S = max(tried)
+        S, reg_m, reg_1 = line_regions(bench)
         rows = timeline(pth, KERNEL, steps)
-        protos = [(S, bench["roofline"].get("multi_stream", {}).get("regions_us"))]
+        protos = [(S, reg_m)]
         if S > 1:
-            protos.append((1, bench["roofline"].get("one_stream", {}).get("regions_us")))
+            protos.append((1, reg_1))
         lo = warm
         out = []
         for streams, line_regions in protos:
@@ -162,9 +217,11 @@ period is compared with the bench line of THE SAME run.
 """)
         for tag, bench, out in blocks:
             rf = bench["roofline"]
+            one_us = rf.get("one_stream_launch_us", rf.get("one_stream", {}).get("launch_us", float("nan")))
             f.write(f"## {tag}\n\nbench line of this (profiled) run: streams = {bench['config']['streams']}, launch_us = "
-                    f"{rf['launch_us']:.2f} (min), median {rf.get('launch_us_median', float('nan')):.2f}, frac = {rf['frac']:.3f}; "
-                    f"one stream {rf['one_stream']['launch_us']:.2f} us.\n\n"
+                    f"{rf['launch_us']:.2f} (median region), frac = {rf['frac']:.3f}; "
+                    f"one stream (median) {one_us:.2f} us = {rf.get('one_stream_frac', float('nan')):.3f}; "
+                    f"{rf.get('multi_stream_streams', '?')} streams (median) {rf.get('multi_stream_launch_us_median', float('nan')):.2f} us.\n\n"
                     "| streams | region | launches | average duration, us | period, us | HIP queues | launches that start before the previous one ends | bench line, same region, us |\n"
                     "|---|---|---|---|---|---|---|---|\n")
             for streams, r, n, d, pd, q, ov, lr in out:
@@ -180,15 +237,24 @@ period is compared with the bench line of THE SAME run.
 def main():
     os.makedirs(DST, exist_ok=True)
     timeline_summary()
-    # rocprofv3's own summary, kernel names cut to 200 characters (PyTorch's RNG kernels have 5-KB names)
+    # the warp kernel per launch protocol (from the driver-command trace), then rocprofv3's own --stats rows of the long
+    # 3-stream run with kernel names cut to 200 characters (PyTorch's RNG kernels have 5-KB names)
+    agg = protocol_tables()
     with open(os.path.join(SRC, "trace", "bench_kernel_stats.csv")) as fin, \
             open(os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"), "w", newline="") as fout:
         rd = csv.reader(fin)
         wr = csv.writer(fout, quoting=csv.QUOTE_NONNUMERIC)
+        wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "PeriodNs_per_region", "Source"])
+        for streams, n, tot, avg, mn, mx, periods in agg:
+            wr.writerow([f"{KERNEL} | timed regions on {streams} stream(s)", n, tot, round(avg, 1), "", mn, mx,
+                         " ".join(f"{x:.0f}" for x in periods),
+                         "python3 bench.py --gpus 1 --steps 20 --warmup 5 (trace_driver; dispatches in " + f"{TAG}_bench_dispatches.csv)"])
         for i, row in enumerate(rd):
-            if i and len(row[0]) > 200:
+            if i == 0:
+                continue
+            if len(row[0]) > 200:
                 row[0] = row[0][:200] + "..."
-            wr.writerow(row if i == 0 else [row[0]] + [float(x) if "." in x else int(x) for x in row[1:]])
+            wr.writerow([row[0]] + [float(x) if "." in x else int(x) for x in row[1:7]] + ["", "python3 bench.py --steps 400 --warmup 50 (3 streams + 1 stream mixed: see the rows above for the split)"])
     stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_stats.csv")))}
     krow = next(v for k, v in stats.items() if KERNEL in k)
     bench_line = [l for l in open(os.path.join(SRC, "bench_trace.log")) if l.startswith("{")][-1]

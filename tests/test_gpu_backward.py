@@ -195,7 +195,7 @@ def test_backward_full_size_properties(cuda):
 
 
 def test_fixed_point_input_gradients_are_exact_and_reproducible(cuda, request):
-    """(The fixed-point accumulator of round 3, selected with `ops.set_warp_bwd_accumulator(True)`.)  TPS_PP geometry (<= 1024 output pixels): dL/d input is summed as round(w * g * 2^s) in 64-bit LDS integers.
+    """(The fixed-point accumulator of round 3, selected per call with `ops.warp_backward(..., fixed_point=True)` = TPSPP_BWD_FIXED_POINT.)  TPS_PP geometry (<= 1024 output pixels): dL/d input is summed as round(w * g * 2^s) in 64-bit LDS integers.
     (i) two runs agree bit for bit (float atomics would not); (ii) against float64 autograd of the reference's
     sampler on the same fp32 grid the error is that of the fp32 tap weights (the coordinates are fp32 in the reference
     as well), not of the accumulation; (iii) the scale follows the data: gradients of magnitude 1e-30 and 1e+30 keep that
@@ -211,13 +211,11 @@ def test_fixed_point_input_gradients_are_exact_and_reproducible(cuda, request):
     ctrl = dev(constants.tpspp_initial_ctrl((2, 16)), cuda)[None].repeat(n, 1, 1) + \
         0.3 * (torch.rand((n, 32, 2), generator=g, device=cuda) - 0.5)          # folds and clamps: many taps share pixels
     _, _, grid, _ = ops.warp(fg, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, want_grid=True)
-    ops.set_warp_bwd_accumulator(fixed_point=True)
-    request.addfinalizer(lambda: ops.set_warp_bwd_accumulator(fixed_point=False))
     for mag in (1.0, 1e-30, 1e30):
         g0 = (torch.rand((n, 5, 16, 64), generator=g, device=cuda) - 0.5) * mag
         g1 = (torch.rand((n, 3, 16, 64), generator=g, device=cuda) - 0.5) * mag
-        a = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
-        b = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
+        a = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1, fixed_point=True)
+        b = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1, fixed_point=True)
         assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1].view(torch.int32), b[1].view(torch.int32))
         with torch.enable_grad():
             fd, xd = fg.cpu().double().requires_grad_(True), x.cpu().double().requires_grad_(True)
@@ -231,7 +229,7 @@ def test_fixed_point_input_gradients_are_exact_and_reproducible(cuda, request):
     g0 = torch.rand((n, 5, 16, 64), generator=g, device=cuda)
     g1 = torch.rand((n, 3, 16, 64), generator=g, device=cuda)
     g0[2, 3, 5, 7] = float("inf")
-    r = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1)
+    r = ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, in1=x, g_out1=g1, fixed_point=True)
     assert torch.isnan(r[0][2, 3]).all() and torch.isfinite(r[0][2, :3]).all() and torch.isfinite(r[0][[0, 1, 3, 4, 5]]).all()
     assert torch.isfinite(r[1]).all()
 
@@ -249,10 +247,8 @@ def test_fixed_point_input_gradients_classic_geometry(cuda, request):
     ctrl = dev(c["C"].astype("float32"), cuda)[None].repeat(n, 1, 1) + 0.2 * (torch.rand((n, 20, 2), generator=g, device=cuda) - 0.5)
     _, _, grid, _ = ops.warp(img, ctrl, inv, ph, hw, want_grid=True)
     g0 = torch.rand((n, 3, 32, 100), generator=g, device=cuda) - 0.5
-    ops.set_warp_bwd_accumulator(fixed_point=True)
-    request.addfinalizer(lambda: ops.set_warp_bwd_accumulator(fixed_point=False))
-    a = ops.warp_backward(g0, img, grid, ctrl, inv, ph, hw)
-    b = ops.warp_backward(g0, img, grid, ctrl, inv, ph, hw)
+    a = ops.warp_backward(g0, img, grid, ctrl, inv, ph, hw, fixed_point=True)
+    b = ops.warp_backward(g0, img, grid, ctrl, inv, ph, hw, fixed_point=True)
     assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
     with torch.enable_grad():
         fd = img.cpu().double().requires_grad_(True)
@@ -260,6 +256,53 @@ def test_fixed_point_input_gradients_classic_geometry(cuda, request):
          g0.cpu().double()).sum().backward()
     err = (a[0].cpu().double() - fd.grad).abs().max()
     assert err <= 2e-5 * fd.grad.abs().max(), float(err)
+
+
+def test_default_accumulator_run_to_run_difference_is_bounded(cuda):
+    """The default dL/d input accumulator is an fp64 LDS atomic sum: its value depends on the order in which the atomics
+    arrive (2^-53 relative per add), so after the rounding to fp32 two runs may differ -- by at most ONE fp32 ulp and only at
+    rounding ties (include/tpspp.h says so).  Six runs on a fold-heavy grid (many taps share a pixel), the per-call
+    fixed-point mode beside them as the reproducible alternative: (i) every run within one ulp of the first, element by
+    element; (ii) the fixed-point call bit-identical twice, and within the documented accuracy of the default;
+    (iii) dL/d control points and dL/d score identical in every run (fixed summation order in either mode)."""
+    n = 8
+    g = torch.Generator(device=cuda).manual_seed(21)
+    c = O.tpspp_constants(cases.PP_HW, cases.PP_POINT)
+    inv, ph, pxy = dev(c["hat_C"], cuda), dev(c["P_hat"], cuda), dev(c["P_xy"], cuda)
+    from tps_pp_amd import constants
+    fg = torch.rand((n, 6, 32, 128), generator=g, device=cuda)
+    x = torch.rand((n, 4, 16, 64), generator=g, device=cuda)
+    ctrl = dev(constants.tpspp_initial_ctrl((2, 16)), cuda)[None].repeat(n, 1, 1) + \
+        0.3 * (torch.rand((n, 32, 2), generator=g, device=cuda) - 0.5)
+    sc = torch.tanh(torch.randn((n, 1024, 32), generator=g, device=cuda))
+    _, _, grid, _ = ops.warp(fg, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, score=sc, in1=x, want_grid=True)
+    g0 = torch.randn((n, 6, 16, 64), generator=g, device=cuda)
+    g1 = torch.randn((n, 4, 16, 64), generator=g, device=cuda)
+
+    def run(**kw):
+        return ops.warp_backward(g0, fg, grid, ctrl, inv, ph, cases.PP_HW, P_xy=pxy, score=sc, in1=x, g_out1=g1, **kw)
+
+    def ulps(a, b):
+        """Distance in units of the last place (both finite, same sign or zero)."""
+        ia, ib = a.contiguous().view(torch.int32).long(), b.contiguous().view(torch.int32).long()
+        ia = torch.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+        ib = torch.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+        return (ia - ib).abs()
+
+    first = run()
+    worst = 0
+    for _ in range(5):
+        r = run()
+        for k in (0, 1):
+            worst = max(worst, int(ulps(first[k], r[k]).max()))
+        assert torch.equal(first[2], r[2]) and torch.equal(first[3], r[3])
+    assert worst <= 1, f"default accumulator: runs differ by {worst} ulp"
+    fa, fb = run(fixed_point=True), run(fixed_point=True)
+    for k in (0, 1):
+        assert torch.equal(fa[k].view(torch.int32), fb[k].view(torch.int32))
+        tol = 4e-7 * float(first[k].abs().max())                    # fixed point: exact within 2^-50 of the pass's largest |g|
+        assert float((fa[k] - first[k]).abs().max()) <= tol
+    assert torch.equal(fa[2], first[2]) and torch.equal(fa[3], first[3])
 
 
 def _scatter_reference(grid, g_out, H, W):

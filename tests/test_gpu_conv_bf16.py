@@ -407,6 +407,46 @@ def test_down_fused_is_front_then_stride2_conv_bit_for_bit(cuda, N, H):
     assert torch.equal(gg32, ops.front_bf16(o0, o1, x, fw, torch.float32, blocked=True)[3])
 
 
+def test_front_bf16_nan_input_stays_in_its_pixel(cuda):
+    """NaN inputs are outside the parity contract (include/tpspp.h, tpspp_front_bf16_fwd: the bf16 form's ReLU is a signed
+    16-bit max after the rounding -- a NaN with the sign bit clear propagates as torch.relu's does, one with the sign bit
+    set becomes +0).  What IS pinned: a NaN in one input pixel makes that pixel's feat0 channels NaN or +0 and nothing
+    else -- every other element of all four outputs is bit for bit what the clean input gives (1x1 convolutions: no
+    neighbour may see it), in the bf16 form and in the fused down kernel's 3x3 neighbourhood."""
+    from tps_pp_amd import TPS_PP
+    torch.manual_seed(13)
+    m = TPS_PP().eval().to(cuda)
+    fw = ops.FrontWeightsBf16(m)
+    N, H, W = 2, 8, 128
+    g = torch.Generator(device=cuda).manual_seed(5)
+    o0 = torch.randn((N, 32, H, W), generator=g, device=cuda).bfloat16()
+    o1 = torch.randn((N, 32, H, W), generator=g, device=cuda).bfloat16()
+    x = torch.randn((N, 64, H // 2, W // 2), generator=g, device=cuda).bfloat16()
+    clean = ops.front_bf16(o0, o1, x, fw, torch.bfloat16)
+    for nan_bits in (0x7FC0, 0xFFC0):                       # quiet NaN, sign clear / set
+        bad = o0.clone()
+        bad.view(torch.int16)[1, 7, 3, 77] = nan_bits - (1 << 16) if nan_bits & 0x8000 else nan_bits
+        got = ops.front_bf16(bad, o1, x, fw, torch.bfloat16)
+        hit = torch.zeros((N, 1, H, W), dtype=torch.bool, device=cuda)
+        hit[1, 0, 3, 77] = True
+        f0 = got[0].float()
+        at = f0[1, :, 3, 77]
+        assert bool((torch.isnan(at) | (at == 0)).all())
+        for k in (0, 3):                                    # feat0 and feat_grid: only the pixel itself may differ
+            same = (got[k].view(torch.int16) == clean[k].view(torch.int16)) | hit
+            assert bool(same.all()), (hex(nan_bits), k)
+        assert torch.equal(got[1].view(torch.int16), clean[1].view(torch.int16))
+        assert torch.equal(got[2].view(torch.int16), clean[2].view(torch.int16))
+        # the fused down0 + down0_1 kernel: the 3x3 stride-2 neighbourhood of the pixel, nothing further
+        cw0 = ops.prep_conv_weight_bf16(m.down0_1.conv.weight, conv_bias=m.down0_1.conv.bias)
+        d_clean = ops.down_fused_bf16(o0, fw.w0, fw.b0, cw0).t
+        d_bad = ops.down_fused_bf16(bad, fw.w0, fw.b0, cw0).t             # blocked (N, 8, H/2, W/2, 8)
+        diff = (d_clean.view(torch.int16) != d_bad.view(torch.int16)).any(dim=4).any(dim=1)     # (N, H/2, W/2)
+        ys, xs = torch.nonzero(diff[1], as_tuple=True)
+        assert not bool(diff[0].any())
+        assert all(abs(2 * int(y) - 3) <= 1 and abs(2 * int(xx) - 77) <= 1 for y, xx in zip(ys, xs)), (ys, xs)
+
+
 def test_down_fused_argument_errors(cuda):
     from tps_pp_amd import TPS_PP
     m = TPS_PP().eval().to(cuda)
@@ -426,8 +466,10 @@ def test_down_fused_argument_errors(cuda):
 
 @pytest.mark.parametrize("store01", [True, False])
 def test_front_bf16_full_machine_matches_chunked_runs(cuda, store01):
-    """The fused front waits for its prefetched pieces by COUNT (s_waitcnt vmcnt(n): all but the segment's stores): with
-    every CU busy (530 images) the result must still be what chunk-by-chunk calls give."""
+    """The fused front prefetches the next segment's pieces under the current segment's matrix work and stores; since the
+    round-4 fix it drains every request (`s_waitcnt vmcnt(0)`) before a segment's operands are used -- a counted wait does
+    not skip younger stores safely.  With every CU busy (530 images) the result must still be what chunk-by-chunk calls
+    give, run after run."""
     from tps_pp_amd import TPS_PP
     torch.manual_seed(9)
     m = TPS_PP().eval().to(cuda)

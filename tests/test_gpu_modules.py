@@ -86,6 +86,71 @@ def test_tpspp_module_against_reference(cuda, variant, fname):
     assert res["output"].shape == torch.Size([cases.G4_N, 64, 16, 64])
 
 
+STAGE_ORDER = ["feat_cat", "enc0", "enc1", "enc2", "enc3", "cbam", "dec0_sum", "dec1_sum", "dec2_sum", "dec3", "dgab"]
+
+
+def _stage_errors(st, G):
+    """max |HIP stage - reference intermediate| per stage, in the order of the forward pass.  The goldens are the
+    reference's own forward-hook outputs (tests/golden/make_golden.py:140-180; `*_sub` = every 8th channel);
+    k_decoder.i's hook fires before the skip addition (`tps_pp.py:165-167`), which the HIP convolution has fused in, so
+    `dec{i}_sum` is compared with golden conv output + golden skip map (the fp32 addition the reference performs)."""
+    sub = cases.sub
+    want = {"feat_cat": G["feat_cat_sub"], "cbam": G["cbam"], "dgab": G["dgab_sub"], "dec3": G["dec3_conv_sub"]}
+    for i in range(4):
+        want[f"enc{i}"] = G[f"enc{i}_sub"]
+    for i in range(3):
+        want[f"dec{i}_sum"] = G[f"dec{i}_conv_sub"] + G[f"enc{2 - i}_sub"]
+    errs = {}
+    for name in STAGE_ORDER:
+        got = st[name].cpu().numpy()
+        got = got if name == "cbam" else sub(got)
+        assert got.shape == want[name].shape, (name, got.shape, want[name].shape)
+        errs[name] = float(np.abs(got - want[name]).max())
+    return errs
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16x3", 1e-4)])
+def test_tpspp_stages_against_reference_intermediates(cuda, mode, tol):
+    """Every stage of the regressor ON THE GPU against the reference's own intermediates (golden G4: forward hooks on
+    `tps_pp.py:156-169` k_encoder / atten / k_decoder and `DGAB.py:58-77`), not only end to end: the exact-fp32 kernels
+    within 2e-5, the three-term split within 1e-4.  Then one weight of one layer is perturbed: every stage before that layer
+    still passes and the layer's own stage is the first to fail."""
+    G = cases.load("tpspp_module_v2")
+    m = build_backbone(dict(type="TPS_PP", variant="ResNet45v2")).eval()
+    sd = cases.synth_state(m.state_dict(), 4, cases.tpspp_state_rule, cases.TPSPP_KEEP)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m.to(cuda)
+    if mode == "bf16x3":
+        m.compute_dtype = "bf16x3"
+    inp = cases.g4_inputs("ResNet45v2")
+    x, outs = dev(inp["x"], cuda), [dev(o, cuda) for o in inp["outs"]]
+    with torch.no_grad():
+        ctrl, score, _, st = m.regress_stages(x, outs)
+    assert set(st) == set(STAGE_ORDER)
+    errs = _stage_errors(st, G)
+    assert all(e <= tol for e in errs.values()), errs
+    assert np.abs(ctrl.cpu().numpy() - G["ctrl"]).max() < 2e-5
+    # the hook leaves no state behind: a plain regress() afterwards records nothing
+    with torch.no_grad():
+        m.regress(x, outs)
+    assert m._stage_tap is None
+    # one perturbed weight per probe: the stage of that layer is the first that fails
+    for layer, stage in ((m.MSFA.conv.k_encoder[2].conv, "enc2"), (m.MSFA.conv.k_decoder[1][1].conv, "dec1_sum"),
+                         (m.down1_1.conv, "feat_cat")):
+        with torch.no_grad():
+            w = layer.weight
+            old = float(w[8, 5, 1, 1])  # output channel 8: the goldens keep every 8th channel
+            w[8, 5, 1, 1] = old + 0.25
+            _, _, _, st2 = m.regress_stages(x, outs)
+            w[8, 5, 1, 1] = old
+        e2 = _stage_errors(st2, G)
+        failing = [n for n in STAGE_ORDER if e2[n] > tol]
+        assert failing and failing[0] == stage, (stage, e2)
+    with torch.no_grad():
+        _, _, _, st3 = m.regress_stages(x, outs)
+    assert all(e <= tol for e in _stage_errors(st3, G).values())
+
+
 @pytest.mark.parametrize("variant,fname", [("ResNet45v2", "tpspp_module_v2"), ("ResNet45", "tpspp_module_v1")])
 def test_tpspp_module_bf16x3_meets_the_fp32_bar(cuda, variant, fname):
     """`compute_dtype = "bf16x3"` (fp32 tensors, three-term bf16 split in the convolutions) against the reference's

@@ -773,7 +773,10 @@ TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_gro
                                        int bands)
 {
     TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 7, "kernel_choice must be 0..7");
-    TPSPP_REQUIRE(bands >= 0 && bands <= 15, "bands must be in [0, 15]");   // (kernel_choice 7: bit 3 = never an image pair)
+    // kernel_choice 7 (run-time-geometry kernel): bits 0-2 = workgroups per image, bit 3 = never an image pair; every other
+    // choice: workgroups per image (pair) of the LDS-staged / mirror kernels, built and tested for 0..8
+    TPSPP_REQUIRE(bands >= 0 && bands <= (kernel_choice == 7 ? 15 : 8),
+                  "bands must be in [0, 8] (kernel_choice 7: [0, 15], bit 3 = never an image pair)");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
     tpspp::geo_set_bands(kernel_choice == 7 ? bands : 0);

@@ -592,7 +592,7 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
             else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
             else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024, F64>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part);
         };
-        if (g_bwd_fixed_point) go(std::false_type{});
+        if (g_bwd_fixed_point || (table_flags & TPSPP_BWD_FIXED_POINT)) go(std::false_type{});
         else go(std::true_type{});
     } else {
     if (hipMemsetAsync(g_grid_ws, 0, (size_t)N * P.n * 2 * sizeof(float), st) != hipSuccess)

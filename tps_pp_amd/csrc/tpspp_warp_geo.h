@@ -87,6 +87,7 @@ tps_warp_geo_kernel(const GeoParams P)
     const int b0 = grp * IMGS;
     const bool hasB = IMGS == 2 && (b0 + 1) < P.N;
     const int NLOAD = (int)(blockDim.x / kWave) - NW;
+    if (NW < IMGS) __builtin_trap();                         // wavefront g < IMGS publishes image g's T: the launcher guarantees NW >= IMGS
 
     // T-solve inputs first (wavefront g -> image b0 + g; lane i keeps control point i and row i of inv_delta_C, 16 bytes
     // at a time: the last piece starts at column K - 4 so that the last row does not read past the matrix)

@@ -70,7 +70,9 @@ bool plan_geo(int C, int H, int W, int F, Plan* p)
     // two images fit the LDS, and every loader has >= kGeoKB pieces of image B to issue behind image A's
     const int pieces1 = (C * H * W * 4) / 1024;
     int nload2 = p->nload < 3 && pieces1 / (p->nload + 1) >= tpspp_geo::kGeoKB ? p->nload + 1 : p->nload;
-    if (g_geo_pair && p->bands == 1 && QP * C <= 6 && pieces1 / nload2 >= tpspp_geo::kGeoKB && p->NW + nload2 <= 16 &&
+    // (NW >= 2: compute wavefront g solves image g's T -- with a single compute wavefront, wavefront 1 is a loader and image
+    // B's T would never be published)
+    if (g_geo_pair && p->bands == 1 && p->NW >= 2 && QP * C <= 6 && pieces1 / nload2 >= tpspp_geo::kGeoKB && p->NW + nload2 <= 16 &&
         tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 2) <= 160 * 1024) {
         p->imgs = 2; p->nload = nload2;
         p->lds = tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 2);

@@ -29,19 +29,19 @@ def shard_batch(t: torch.Tensor, rank: int, world_size: int):
 
 
 def _fused_gather(local: torch.Tensor, group) -> bool:
-    """True when this tensor's collective runs on RCCL (backend "nccl"): only then is the fused
-    `all_gather_into_tensor` taken -- some gloo builds lack it, also for CUDA tensors on a gloo-only group.  The
-    answer depends on the tensor's device and the group's (possibly per-device) backend, both the same on every rank."""
+    """True when this tensor's collective runs on RCCL: only then is the fused `all_gather_into_tensor` taken -- some gloo
+    builds lack it, also for CUDA tensors on a gloo-only group.  The answer depends only on the tensor's device type and the
+    group's (possibly per-device) backend string, both the same on every rank, so every rank takes the same branch; a failing
+    backend query PROPAGATES (a rank that silently fell back to the list-based all_gather while its peers issue
+    all_gather_into_tensor would desynchronise the communicator)."""
     if not local.is_cuda:
         return False
-    try:
-        backend = str(dist.get_backend(group)).lower()
-    except Exception:
-        return False
-    # "nccl", or a per-device map such as "cpu:gloo,cuda:nccl"
+    backend = str(dist.get_backend(group)).lower()
+    # "nccl" (RCCL registers under that name on ROCm; "rccl" accepted as well), or a per-device map such as
+    # "cpu:gloo,cuda:nccl"
     for part in backend.split(","):
         dev, _, name = part.rpartition(":")
-        if name == "nccl" and dev in ("", "cuda"):
+        if name in ("nccl", "rccl") and dev in ("", "cuda"):
             return True
     return False
 

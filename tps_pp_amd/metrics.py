@@ -73,7 +73,9 @@ def precision_agreement(model, img, img_metas, mode):
       * teacher forcing: the reduced-precision model is fed the fp32 run's greedy tokens; fraction of positions (up to and
         including the fp32 run's <EOS>) whose arg-max is the fp32 one -- every position is an independent decision;
       * greedy: word agreement (identical strings) and character agreement (difflib matching blocks over the fp32
-        strings' characters) -- on random-init weights one flipped near-tie rewrites the rest of a string.
+        strings' characters) -- on random-init weights one flipped near-tie rewrites the rest of a string;
+      * the same two restricted to decisions the fp32 run is sure of (top-1 minus top-2 score >= 0.05): positions for the
+        teacher-forced figure, words all of whose positions are confident for the greedy one.
     Returns a dict of floats; `model` is left in the exact-fp32 configuration."""
     import torch
     conv, dec = model.label_convertor, model.decoder
@@ -123,7 +125,19 @@ def precision_agreement(model, img, img_metas, mode):
     first_end = torch.where(is_end.any(1), is_end.float().argmax(1), torch.full((n,), L - 1, device=ref_tok.device))
     valid = torch.arange(L, device=ref_tok.device)[None, :] <= first_end[:, None]
     m = count_matches(low_txt, ref_txt)
+    # decisions the fp32 run itself is sure of: top-1 minus top-2 softmax score >= 0.05.  Random-init weights put many
+    # positions on near-ties, where ANY rounding flips the arg-max; restricted to confident positions / words the figure
+    # says something about the arithmetic without a trained checkpoint
+    top2 = ref.topk(2, dim=-1).values
+    confident = ((top2[..., 0] - top2[..., 1]) >= 0.05) & valid
+    conf_words = [i for i in range(n) if bool((confident | ~valid)[i].all())]
     return {"images": n, "positions": int(valid.sum()),
+            "positions_margin_ge_0.05": int(confident.sum()),
+            "teacher_forced_agreement_margin_ge_0.05":
+                float((low_tf == ref_tok)[confident].float().mean()) if bool(confident.any()) else float("nan"),
+            "words_all_positions_margin_ge_0.05": len(conf_words),
+            "greedy_word_agreement_margin_ge_0.05":
+                (sum(low_txt[i] == ref_txt[i] for i in conf_words) / len(conf_words)) if conf_words else float("nan"),
             "teacher_forced_argmax_agreement": float((low_tf == ref_tok)[valid].float().mean()),
             "teacher_forced_self_check_fp32": float((self_tf == ref_tok)[valid].float().mean()),
             "greedy_word_agreement": sum(a == b for a, b in zip(low_txt, ref_txt)) / max(1, n),

@@ -107,6 +107,7 @@ def transpose_p_hat(P_hat):
 TABLE_MIRROR4 = 1
 SCORE_TRANSPOSED = 2
 IO_BF16 = 4              # TPSPP_IO_BF16: in0 / in1 / out0 / out1 are bfloat16
+BWD_FIXED_POINT = 16     # TPSPP_BWD_FIXED_POINT: tpspp_warp_bwd accumulates dL/d input in 64-bit fixed point (this call only)
 TABLE_PACKED = 8         # TPSPP_TABLE_PACKED: P_hat_t is the head of a prepare_mirror_table() buffer
 
 
@@ -980,15 +981,20 @@ def linear(x, cw, relu=False):
 
 
 def set_warp_bwd_accumulator(fixed_point: bool = False):
-    """`tpspp_warp_bwd_set_accumulator`: how dL/d input is accumulated in LDS (default: fp64 atomics; True: round 3's
-    64-bit fixed point, bitwise reproducible but with a per-pass scale).  Process-wide; tests and measurements only."""
+    """`tpspp_warp_bwd_set_accumulator`: the process-wide default of how dL/d input is accumulated in LDS (fp64 atomics;
+    True: round 3's 64-bit fixed point, bitwise reproducible but with a per-pass scale).  Measurement scripts only: prefer
+    `warp_backward(..., fixed_point=True)`, which is per call and per stream."""
     _lib.check(_lib.lib().tpspp_warp_bwd_set_accumulator(1 if fixed_point else 0), "tpspp_warp_bwd_set_accumulator")
 
 
 def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
-    """kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel, 3 the same without the mirror trick, 4 plane-streaming
-    kernel, 5 image-pair kernel (2..5: error if not applicable);
-    bands: workgroups per image pair in the LDS-staged kernel (0 = heuristic)."""
+    """`tpspp_warp_set_tuning` (process-wide lab knobs; 0 everywhere = the automatic choice).
+    kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel, 3 the same without the mirror trick, 4 plane-streaming
+    kernel, 5 image-pair kernel, 6 instantiated in-place kernel (tpspp_warp_img.h), 7 run-time-geometry in-place kernel
+    (tpspp_warp_geo.h) (2..7: error if not applicable to the call's shapes);
+    bands: kernel_choice 0 / 2 / 3: workgroups per image (pair) in the LDS-staged kernels, 0..8 (0 = heuristic);
+    kernel_choice 7: bits 0-2 = workgroups per image (0 = heuristic), bit 3 (value 8) = never an image pair per
+    workgroup, so 0..15; values above 8 are rejected for every other choice."""
     _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group),
                                                 int(kernel_choice), int(bands)),
                "tpspp_warp_set_tuning")
@@ -1191,9 +1197,12 @@ def resize_normalize(packed, offsets, src_h, src_w, resize_w, lut, pad_value, N,
 
 # ---- backward of the fused warp ------------------------------------------------
 def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
-                  g_out1=None, P_hat_t=None, need_in0=True, need_in1=True, need_score=True):
+                  g_out1=None, P_hat_t=None, need_in0=True, need_in1=True, need_score=True, fixed_point=False):
     """`tpspp_warp_bwd`: (g_in0 | None, g_in1 | None, g_ctrl, g_score | None) for the call
-    `warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1)`; `grid` is that call's grid output."""
+    `warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1)`; `grid` is that call's grid output.
+    `fixed_point=True` (TPSPP_BWD_FIXED_POINT, this call only): dL/d input accumulated in 64-bit fixed point -- bitwise
+    reproducible from run to run; the default fp64 LDS atomics keep every term's bits but their sum depends on arrival
+    order, so two runs may differ by one fp32 ulp at rounding ties (include/tpspp.h)."""
     g_out0, in0 = _chk("g_out0", g_out0, 4), _chk("in0", in0, 4)
     grid, ctrl = _chk("grid", grid, 3), _chk("ctrl", ctrl, 3)
     inv_delta_C, P_hat = _chk("inv_delta_C", inv_delta_C, 2), _chk("P_hat", P_hat, 2)
@@ -1203,7 +1212,7 @@ def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None
     n = Ho * Wo
     if tuple(g_out0.shape) != (N, C0, Ho, Wo) or tuple(grid.shape) != (N, n, 2):
         raise ValueError("warp_backward: g_out0 / grid shape")
-    flags = 0
+    flags = BWD_FIXED_POINT if fixed_point else 0
     g_score = None
     if score is not None:
         if tuple(score.shape) != (N, n, F):

@@ -403,6 +403,31 @@ class TPS_PP(nn.Module):
     def init_weights(self):
         pass
 
+    # ---- debug hook: the regressor's named stages, as the reference's forward hooks see them ----------------
+    def regress_stages(self, batch_img, outs):
+        """DEBUG / TEST HOOK: `regress()` on the HIP kernels (whatever configuration `compute_dtype` / the input dtype
+        select) plus a dict of its intermediate maps as fp32 NCHW tensors, named after the reference modules whose
+        forward hooks produce the goldens (`tps_pp.py:156-169`, `DGAB.py:58-77`): `feat_cat` (input of MSFA), `enc0..3`
+        (k_encoder.i), `cbam` (atten), `dec0..2_sum` (k_decoder.i output PLUS the skip map -- the upsample and the skip
+        addition are fused into the convolution here, so the sum is what exists), `dec3` (= de_feat), `dgab`.  Not used by
+        forward(); costs a layout conversion per stage."""
+        self._stage_tap = {}
+        try:
+            cp, sc, fg = self.regress(batch_img, outs)
+            st = self._stage_tap
+        finally:
+            self._stage_tap = None
+        return cp, sc, fg, st
+
+    def _tap(self, name, t):
+        tap = getattr(self, "_stage_tap", None)
+        if tap is None:
+            return
+        if isinstance(t, (list, tuple)):                     # the concat that feeds k_encoder.0
+            tap[name] = torch.cat([(x.nchw() if isinstance(x, ops.Blocked) else x).float() for x in t], dim=1)
+        else:
+            tap[name] = (t.nchw() if isinstance(t, ops.Blocked) else t).float().clone()
+
     # ---- hand-written conv path (fp32 MFMA kernels, tps_pp_amd/csrc/tpspp_conv.hip) -------------
     def _conv_weights(self):
         """ConvWeight per conv layer, rebuilt when a parameter changes (version counters)."""
@@ -427,15 +452,17 @@ class TPS_PP(nn.Module):
         the concat feeding k_encoder.0, every nn.Upsample and every skip addition are folded into
         the convolutions that consume / produce them."""
         p = self.MSFA.conv.stride
-        e0 = ops.conv2d(feat_srcs, cw["enc0"], 1)
-        e1 = ops.conv2d([e0], cw["enc1"], 2)
-        e2 = ops.conv2d([e1], cw["enc2"], p)
-        e3 = ops.conv2d([e2], cw["enc3"], (2, 1))
-        k = ops.cbam(e3, self.MSFA.conv.atten)
-        k = ops.conv2d([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1)
-        k = ops.conv2d([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1)
-        k = ops.conv2d([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1)
-        k = ops.conv2d([k], cw["dec3"], 1)
+        tap = self._tap
+        tap("feat_cat", feat_srcs)
+        e0 = ops.conv2d(feat_srcs, cw["enc0"], 1); tap("enc0", e0)
+        e1 = ops.conv2d([e0], cw["enc1"], 2); tap("enc1", e1)
+        e2 = ops.conv2d([e1], cw["enc2"], p); tap("enc2", e2)
+        e3 = ops.conv2d([e2], cw["enc3"], (2, 1)); tap("enc3", e3)
+        k = ops.cbam(e3, self.MSFA.conv.atten); tap("cbam", k)
+        k = ops.conv2d([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1); tap("dec0_sum", k)
+        k = ops.conv2d([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1); tap("dec1_sum", k)
+        k = ops.conv2d([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1); tap("dec2_sum", k)
+        k = ops.conv2d([k], cw["dec3"], 1); tap("dec3", k)
         return e3, k
 
     # ---- bf16 path (BASELINE.json configs[2]): bf16 MFMA convolutions, tpspp_conv_bf16.hip ------------
@@ -504,15 +531,17 @@ class TPS_PP(nn.Module):
             cat_srcs = [c16([o0], cw["down0"], 2, **blk), c16([o1], cw["down1"], 1, **blk), c16([x], cw["down2"], 1, **blk)]
             feat_grid = x
         p = self.MSFA.conv.stride
-        e0 = c16(cat_srcs, cw["enc0"], 1, **blk)
-        e1 = c16([e0], cw["enc1"], 2, **blk)
-        e2 = c16([e1], cw["enc2"], p, **blk)
-        e3 = c16([e2], cw["enc3"], (2, 1), out_dtype=f32)
-        k = ops.cbam(e3, self.MSFA.conv.atten)
-        k = c16([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1, **blk)
-        k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1, **blk)
-        k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1, **blk)
-        de_feat = c16([k], cw["dec3"], 1, out_dtype=f32)
+        tap = self._tap
+        tap("feat_cat", cat_srcs)
+        e0 = c16(cat_srcs, cw["enc0"], 1, **blk); tap("enc0", e0)
+        e1 = c16([e0], cw["enc1"], 2, **blk); tap("enc1", e1)
+        e2 = c16([e1], cw["enc2"], p, **blk); tap("enc2", e2)
+        e3 = c16([e2], cw["enc3"], (2, 1), out_dtype=f32); tap("enc3", e3)
+        k = ops.cbam(e3, self.MSFA.conv.atten); tap("cbam", k)
+        k = c16([(k, 2, 1)], cw["dec0"], 1, residual=e2, res_mode=1, **blk); tap("dec0_sum", k)
+        k = c16([(k, p, p)], cw["dec1"], 1, residual=e1, res_mode=1, **blk); tap("dec1_sum", k)
+        k = c16([(k, 2, 2)], cw["dec2"], 1, residual=e0, res_mode=1, **blk); tap("dec2_sum", k)
+        de_feat = c16([k], cw["dec3"], 1, out_dtype=f32); tap("dec3", de_feat)
         control_point, atten_score = self._tpe_hip(e3, de_feat, bf16=True, x3=x3)
         return control_point, atten_score, feat_grid
 
@@ -632,6 +661,7 @@ class TPS_PP(nn.Module):
             de = ops.dgab_bf16(de_feat, en_feat.reshape(n, en_feat.size(1), -1), c16[1])
         else:
             de = ops.dgab(de_feat, en_feat.reshape(n, en_feat.size(1), -1), cache[1])
+        self._tap("dgab", de)
         control_point, p1 = ops.tpe_points(en_feat, T)
         if T.without_as:
             return control_point, torch.zeros((n, de.shape[2] * de.shape[3], T.num_fiducial), device=de.device)
