@@ -231,11 +231,17 @@ def extra_measurements(dev):
                                                "kernel": "tps_warp_stream_kernel<32,true,true,2>"}}
 
 
-def classic_warp_extra(dev, hw, nstreams):
+def classic_warp_extra(dev, hw, nstreams, kernel_choice=0):
     """The classic warp at another geometry (configs/textrecog/nrtr/nrtr_tps++.py:28-33: img_size 32x128, 3 channels,
     20 fiducials), batch 512, same protocol as the headline: rotating buffer sets > 2x the Infinity Cache, one
     pre-marshalled call per step, HIP events; on one stream and on `nstreams`."""
     Hh, Ww = hw
+    if kernel_choice:
+        ops.set_warp_tuning(0, 0, kernel_choice, 0)
+        try:
+            return classic_warp_extra(dev, hw, nstreams)
+        finally:
+            ops.set_warp_tuning(0, 0, 0, 0)
     mod = TPSPreprocessor(num_fiducial=F, img_size=hw, rectified_img_size=hw, num_img_channel=C).eval().to(dev)
     gg = mod.GridGenerator
     p_hat_t, flags = gg.prepared_table()
@@ -286,9 +292,9 @@ def classic_warp_extra(dev, hw, nstreams):
     return {"launch_us": usn, "streams": nstreams, "frac_of_hbm_peak": bytes_launch / (usn * 1e-6) / 1e9 / HBM_PEAK_GBS,
             "one_stream": {"launch_us": us1, "frac_of_hbm_peak": bytes_launch / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS},
             "algorithmic_bytes_per_launch": bytes_launch, "max_abs_err_vs_oracle": err,
-            "kernel": ("tps_warp_img_kernel<20,{},{},{},...> (in-place staging)".format(C, Hh, Ww)
-                       if (Hh, Ww) in ((32, 100), (32, 128), (48, 160), (32, 64), (32, 160))
-                       else "tps_warp_geo_kernel<20,{},QP,...> (in-place staging, run-time geometry)".format(C))
+            "kernel": "automatic choice of tpspp_warp_fwd: tps_warp_img_kernel (instantiated in-place staging) for 32x100, "
+                      "32x128, 48x160, 32x64, 32x160; else tps_warp_geo_kernel (one workgroup per image, run-time geometry) or, "
+                      "for larger images, tps_warp_span_kernel (row bands, span staging)"
             if bool(flags & ops.TABLE_PACKED) else "LDS-staged kernel", "rotating_buffer_sets": int(nbuf)}
 
 
@@ -356,7 +362,7 @@ def recognizer_measurement(dev, timeit):
                      ("bf16_backbone__bf16x3_head", dict(backbone=bf, encoder="bf16x3", decoder="bf16x3"))):
         r = metrics.precision_agreement(m, img[:256], metas[:256], md)
         stages[name] = {k: r[k] for k in ("teacher_forced_argmax_agreement", "greedy_word_agreement", "greedy_char_agreement",
-                                          "teacher_forced_agreement_margin_ge_0.05", "greedy_word_agreement_margin_ge_0.05")}
+                                          "teacher_forced_agreement_margin_ge_0.05", "greedy_agreement_up_to_first_margin_lt_0.05")}
     return {"images_per_s": n / (t_all * 1e-3), "ms_per_batch": t_all,
             "ms_backbone_tpspp": t_feat, "ms_encoder": t_enc, "ms_greedy_decoder_40_steps": t_dec,
             "strings_equal_to_cpu_oracle": f"{sum(a == b for a, b in zip(got, want))}/{k}",
@@ -767,6 +773,10 @@ def main():
             # that only the run-time-geometry in-place kernel takes (tpspp_warp_geo.h)
             rec["extra"]["classic_warp_32x160_batch512_fp32"] = classic_warp_extra(dev, (32, 160), S)
             rec["extra"]["classic_warp_64x200_batch512_fp32"] = classic_warp_extra(dev, (64, 200), S)
+            # round 5: an image that fits no LDS as a whole (196 KB; round 4: gather kernel, 0.25), and 48x160 with the
+            # run-time-geometry kernels REQUIRED (kernel_choice 7) instead of its instantiated kernel
+            rec["extra"]["classic_warp_64x256_batch512_fp32"] = classic_warp_extra(dev, (64, 256), S)
+            rec["extra"]["classic_warp_48x160_runtime_geometry_batch512_fp32"] = classic_warp_extra(dev, (48, 160), S, kernel_choice=7)
         if sharded is not None:
             rec.setdefault("extra", {})["recognizer_sharded"] = sharded
         if world == 1 and not a.no_cpu_baseline:

@@ -96,7 +96,9 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
  * transposed table of tpspp_transpose_p_hat followed by a packed copy in those kernels' thread order (a thread's F+3
  * values per quadrant pixel as 16-byte pieces, [wavefront][quadrant pixels per thread][(F+3+3)/4][lane][4]; thread ->
  * pixel: a half-wavefront owns a block of 32 pixels -- 4 columns x 8 rows, 8 x 4 or 32 x 1 by the row pitch -- of the left
- * half of the upper half-image, a thread 1 - 4 such row groups depending on the geometry).  tpspp_prepared_table_floats:
+ * half of the upper half-image, a thread 1 - 4 such row groups depending on the geometry); for the large geometries (more
+ * than two row groups per thread in that copy) a third section follows: the same packing with ONE row group per thread,
+ * read by the span-staging kernel (tpspp_warp_span.h).  tpspp_prepared_table_floats:
  * buffer size in floats, 0 when the geometry has no prepared form (needs Ho % 16 == 0, Wo % 4 == 0).  One-off
  * preparation, like the transposition.  Pass the buffer
  * as p_hat_t together with TPSPP_TABLE_PACKED (and TPSPP_TABLE_MIRROR4 once the symmetry has been verified).
@@ -437,9 +439,14 @@ int tpspp_conv_set_tuning(int flags);
  * (TPSPP_EINVAL if the shape does not qualify), 3 = as 2 but ignore TPSPP_TABLE_MIRROR4,
  * 4 = require the plane-streaming kernel, 5 = require the image-pair kernel (classic 32x100 geometry with a
  * tpspp_prepare_mirror_table buffer), 6 = require the in-place kernel (32x100, 32x128, 48x160, 32x64 with C = 1 or 3,
- * same buffer), 7 = require the in-place kernel with run-time geometry (any size that fits the LDS, C = 1, 3 or 4, F = 20,
- * same buffer); bands = workgroups per image pair in the LDS-staged kernel (0 = heuristic); with kernel_choice 7: bits 0-2 =
- * workgroups per image (0 = heuristic), bit 3 = never an image pair per workgroup.
+ * same buffer), 7 = require a run-time-geometry kernel (C = 1, 3 or 4, F = 20, same buffer): the in-place kernel where one
+ * workgroup covers the image, else row bands with span staging, 8 = require the span-staging kernel (geometries whose
+ * prepared table has the third section: tpspp_prepared_table_floats), 9 = require the in-place kernel with run-time
+ * geometry in its banded form as well (every band stages the whole image: round 4's kernel, kept for comparisons);
+ * bands = workgroups per image pair in the LDS-staged kernel, 0..8 (0 = heuristic); with kernel_choice 7 / 9: bits 0-2 =
+ * workgroups per image (0 = heuristic), bit 3 = never an image pair per workgroup; with kernel_choice 8: bits 0-5 =
+ * workgroups per image (0 = heuristic), bit 6 = every workgroup on its global-memory path, bits 8-15 = LDS budget per
+ * workgroup in KB (0 = 38: four workgroups per CU).
  */
 int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);
 

@@ -71,17 +71,21 @@ def test_prepared_table_geometry_planner(lib):
     """Host-side planning of the packed table (no GPU): which output geometries have a prepared form and how large it is.
     F + 3 transposed rows of Ho * Wo floats, then the packed copy: ceil(threads / 64) wavefronts x QP x 6 pieces x 64 lanes x
     4 floats, with QP = the smallest divisor of the quadrant's row groups that leaves <= 13 wavefronts, else the largest
-    <= 4 (tpspp_warp_geo.hip: geo_qp)."""
+    <= 4 (tpspp_warp_geo.hip: geo_qp); geometries with QP >= 3 carry a third section, the same packing with QP = 1 (every
+    quadrant pixel: the span-staging kernel's copy, tpspp_warp_span.h)."""
     K = 23
     want = {(32, 100): (1, 13 * 2 * 32), (32, 128): (2, 2 * 8 * 32), (48, 160): (3, 3 * 8 * 32), (32, 64): (1, 1 * 16 * 32),
-            (32, 160): (2, 3 * 8 * 32), (64, 256): (4, 4 * 8 * 32), (64, 200): (2, 13 * 4 * 32), (16, 64): (1, 1 * 8 * 32)}
+            (32, 160): (2, 3 * 8 * 32), (64, 256): (4, 4 * 8 * 32), (64, 200): (4, 13 * 2 * 32), (16, 64): (1, 1 * 8 * 32)}
     for (Ho, Wo), (qp, nthr) in want.items():
         nw = (nthr + 63) // 64
-        assert lib.tpspp_prepared_table_floats(Ho, Wo, 20) == K * Ho * Wo + nw * qp * 6 * 64 * 4, (Ho, Wo)
+        span = ((nthr * qp + 63) // 64) * 6 * 64 * 4 if qp >= 3 else 0
+        assert lib.tpspp_prepared_table_floats(Ho, Wo, 20) == K * Ho * Wo + nw * qp * 6 * 64 * 4 + span, (Ho, Wo)
     for Ho, Wo in ((31, 100), (32, 99), (32, 102), (24, 100), (0, 100)):
         assert lib.tpspp_prepared_table_floats(Ho, Wo, 20) == 0, (Ho, Wo)   # Ho % 16 != 0 or Wo % 4 != 0: no packed form
     assert lib.tpspp_prepared_table_floats(32, 100, 62) == 0                 # F + 3 > 64
-    assert lib.tpspp_warp_set_tuning(0, 0, 7, 9) == 0 and lib.tpspp_warp_set_tuning(0, 0, 8, 0) == -22
+    assert lib.tpspp_warp_set_tuning(0, 0, 7, 9) == 0 and lib.tpspp_warp_set_tuning(0, 0, 10, 0) == -22
+    assert lib.tpspp_warp_set_tuning(0, 0, 0, 9) == -22 and lib.tpspp_warp_set_tuning(0, 0, 2, 9) == -22   # 9..15 only with 7 / 9
+    assert lib.tpspp_warp_set_tuning(0, 0, 8, 4 | 64 | (100 << 8)) == 0 and lib.tpspp_warp_set_tuning(0, 0, 9, 15) == 0
     assert lib.tpspp_warp_set_tuning(0, 0, 0, 0) == 0
     assert lib.tpspp_warp_bwd_set_accumulator(1) == 0 and lib.tpspp_warp_bwd_set_accumulator(0) == 0
     assert lib.tpspp_warp_bwd_workspace_floats(2, 32, 100) > 2 * 3200 * 2

@@ -517,3 +517,87 @@ def test_runtime_geometry_kernel_geometry_sweep(cuda, oracle):
         assert_biteq(out2, ref["out0"], f"warped (no optional outputs) {H}x{W} C={C}")
         checked += 1
     assert checked == len(shapes)
+
+
+SPAN_CASES = [(5, 3, 64, 200), (2, 1, 64, 256), (3, 3, 64, 256), (3, 4, 48, 160), (9, 3, 96, 128), (17, 3, 128, 64),
+              (1, 3, 48, 160)]
+
+
+@pytest.mark.parametrize("N,C,H,W", SPAN_CASES)
+def test_span_staging_kernel_forced(cuda, oracle, N, C, H, W):
+    """`kernel_choice` 8 = REQUIRE the row-band kernel with span staging (tpspp_warp_span.h; an error if the geometry has no
+    third table section, so a pass proves which kernel ran).  Bit for bit the oracle -- grid, tap indices, warped values
+    -- for a near-identity transformation (every band's span fits its buffer: the LDS-DMA path), for a violent one (0.45
+    noise: bands fold far more rows than the buffer holds and take their taps from global memory, others still stage), with
+    every workgroup forced onto the global-memory path (bit 6), with another band count and a small buffer; specials in
+    the image (a NaN / inf tap must poison exactly the outputs the oracle's taps reach); batches that are no multiple of
+    the 8 XCDs the block -> image mapping interleaves; 64x256x3 does not fit the LDS as a whole image at all."""
+    F = 20
+    Kc = oracle.classic_constants(F, (H, W))
+    img = synth.dyadic((N, C, H, W), "sp.img", N + 3).copy()
+    flat = img.reshape(-1)
+    flat[5::1013] = np.inf
+    flat[7::2027] = -np.inf
+    flat[11::3001] = np.nan
+    flat[13::997] = -0.0
+    P_hat = dev(Kc["P_hat"], cuda)
+    prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
+    assert packed == ops.TABLE_PACKED
+    inv = dev(Kc["inv_delta_C"], cuda)
+    try:
+        for noise, knob in ((0.03, 0), (0.45, 0), (0.1, 64), (0.1, 2 | (40 << 8)), (0.03, 0 | (150 << 8))):
+            ctrl = oracle.classic_initial_ctrl(F)[None] + noise * synth.dyadic((N, F, 2), "sp.ctrl", N + int(100 * noise))
+            ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
+            try:
+                ops.set_warp_tuning(kernel_choice=8, bands=knob)
+                out, _, grid, idx = ops.warp(dev(img, cuda), dev(ctrl, cuda), inv, P_hat, (H, W), want_grid=True, want_idx=True,
+                                             P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+                out2 = ops.warp(dev(img, cuda), dev(ctrl, cuda), inv, P_hat, (H, W), P_hat_t=prep,
+                                table_flags=ops.TABLE_MIRROR4 | packed)[0]
+            except Exception as e:                       # a band count / budget the planner rejects for this geometry
+                if knob & 63 and "do not qualify" in str(e):
+                    continue
+                raise
+            tag = f"{H}x{W} C={C} noise {noise} knob {knob}"
+            assert_biteq(grid, ref["grid"], "grid " + tag)
+            assert_biteq(idx, ref["idx"], "corner indices " + tag)
+            assert_biteq(out, ref["out0"], "warped " + tag)
+            assert_biteq(out2, ref["out0"], "warped (no optional outputs) " + tag)
+    finally:
+        ops.set_warp_tuning()
+
+
+def test_span_staging_kernel_is_the_default_for_large_geometries(cuda, oracle):
+    """Without any tuning a 64x200 / 64x256 image takes the span-staging kernel (the banded in-place kernel staged the whole
+    image per band; 64x256x3 fits no LDS and went to the gather kernel) and stays bit for bit the oracle; the banded form is
+    still reachable (kernel_choice 9) and gives the same bits; a geometry without the third table section is refused by
+    kernel_choice 8."""
+    F = 20
+    for (N, C, H, W) in ((6, 3, 64, 200), (3, 3, 64, 256)):
+        Kc = oracle.classic_constants(F, (H, W))
+        P_hat = dev(Kc["P_hat"], cuda)
+        prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
+        ctrl = oracle.classic_initial_ctrl(F)[None] + 0.2 * synth.dyadic((N, F, 2), "spd.ctrl", H)
+        img = synth.dyadic((N, C, H, W), "spd.img", W)
+        ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W))
+        args = (dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), P_hat, (H, W))
+        kw = dict(P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+        assert_biteq(ops.warp(*args, **kw)[0], ref["out0"], f"default {H}x{W}")
+        try:
+            ops.set_warp_tuning(kernel_choice=7)
+            assert_biteq(ops.warp(*args, **kw)[0], ref["out0"], f"kernel_choice 7 {H}x{W}")
+            if C * H * W * 4 <= 150 * 1024:
+                ops.set_warp_tuning(kernel_choice=9)
+                assert_biteq(ops.warp(*args, **kw)[0], ref["out0"], f"kernel_choice 9 {H}x{W}")
+        finally:
+            ops.set_warp_tuning()
+    Kc = oracle.classic_constants(F, (32, 100))
+    P_hat = dev(Kc["P_hat"], cuda)
+    prep, packed = ops.prepare_mirror_table(P_hat, (32, 100))
+    try:
+        ops.set_warp_tuning(kernel_choice=8)
+        with pytest.raises(Exception, match="do not qualify"):
+            ops.warp(torch.zeros((2, 3, 32, 100), device=cuda), dev(oracle.classic_initial_ctrl(F)[None].repeat(2, 0), cuda),
+                     dev(Kc["inv_delta_C"], cuda), P_hat, (32, 100), P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
+    finally:
+        ops.set_warp_tuning()

@@ -772,14 +772,18 @@ void launch_warp(const WarpParams& P, dim3 grid, dim3 block, size_t lds, hipStre
 TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice,
                                        int bands)
 {
-    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 7, "kernel_choice must be 0..7");
+    TPSPP_REQUIRE(kernel_choice >= 0 && kernel_choice <= 9, "kernel_choice must be 0..9");
     // kernel_choice 7 (run-time-geometry kernel): bits 0-2 = workgroups per image, bit 3 = never an image pair; every other
     // choice: workgroups per image (pair) of the LDS-staged / mirror kernels, built and tested for 0..8
-    TPSPP_REQUIRE(bands >= 0 && bands <= (kernel_choice == 7 ? 15 : 8),
-                  "bands must be in [0, 8] (kernel_choice 7: [0, 15], bit 3 = never an image pair)");
+    // kernel_choice 8 (row bands with span staging): bits 0-5 = workgroups per image (0 = heuristic), bit 6 (64) = every
+    // workgroup on its global-memory path, bits 8-15 = LDS budget per workgroup in KB (0 = 38)
+    TPSPP_REQUIRE(bands >= 0 && bands <= (kernel_choice == 8 ? 0xffff : (kernel_choice == 7 || kernel_choice == 9) ? 15 : 8),
+                  "bands must be in [0, 8] (kernel_choice 7 / 9: [0, 15], bit 3 = never an image pair; 8: see tpspp.h)");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
-    tpspp::geo_set_bands(kernel_choice == 7 ? bands : 0);
+    tpspp::geo_set_bands((kernel_choice == 7 || kernel_choice == 9) ? bands : 0);
+    tpspp::span_set_tuning(kernel_choice == 8 ? (bands & 63) : 0, kernel_choice == 8 ? ((bands >> 6) & 1) : 0,
+                           kernel_choice == 8 ? ((bands >> 8) & 255) : 0);
     g_tune_bands = bands;
     TPSPP_REQUIRE(images_per_group >= 0 && images_per_group <= 64, "images_per_group out of range");
     TPSPP_REQUIRE(threads_per_group == 0 || (threads_per_group % 64 == 0 && threads_per_group >= 64 &&
@@ -887,7 +891,8 @@ TPSPP_EXPORT size_t tpspp_prepared_table_floats(int Ho, int Wo, int F)
     if (QP == 0 || F <= 0 || F + 3 > kMaxK) return 0;
     const int K = F + 3, KG = (K + 3) / 4;
     const int NW = (img_nthr(Ho, Wo, QP) + kWave - 1) / kWave;
-    return (size_t)K * Ho * Wo + (size_t)NW * QP * KG * kWave * 4;
+    // + the span kernel's copy (one quadrant pixel per thread) for the large geometries (tpspp_warp_span.h)
+    return (size_t)K * Ho * Wo + (size_t)NW * QP * KG * kWave * 4 + (size_t)tpspp::span_table_waves(Ho, Wo) * KG * kWave * 4;
 }
 
 TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo, int F,
@@ -907,6 +912,13 @@ TPSPP_EXPORT int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, in
     const int total = NW * QP * KG * kWave * 4;
     hipLaunchKernelGGL(tpspp_img::pack_img_table_kernel, dim3((total + 255) / 256), dim3(256), 0,
                        tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, CG, QP, BW, nthr, K, prepared + (size_t)K * n);
+    const int sw = tpspp::span_table_waves(Ho, Wo);
+    if (sw > 0) {                                            // third section: QP = 1, every quadrant pixel
+        const int nthr1 = img_nthr(Ho, Wo, 1), total1 = sw * KG * kWave * 4;
+        hipLaunchKernelGGL(tpspp_img::pack_img_table_kernel, dim3((total1 + 255) / 256), dim3(256), 0,
+                           tpspp::as_stream(stream), p_hat, p_hat_ld, Wo, CG, 1, BW, nthr1, K,
+                           prepared + (size_t)K * n + (size_t)total);
+    }
     return tpspp::check_launch("tpspp_prepare_mirror_table");
 }
 
@@ -1112,12 +1124,31 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
             return tpspp::check_launch("tpspp_warp_fwd(in-place)");
         if (g_tune_kernel == 6)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the in-place kernel");
-        // every other geometry that fits the LDS: the in-place kernel with run-time geometry (tpspp_warp_geo.h)
-        if (packed_ok && (g_tune_kernel == 0 || g_tune_kernel == 7) &&
+        // every other geometry: the in-place kernel with run-time geometry where ONE workgroup covers the image
+        // (tpspp_warp_geo.h), else row bands with span staging (tpspp_warp_span.h; round 5 -- the in-place kernel's banded
+        // form, every band staging the whole image, is kept for comparisons: kernel_choice 9)
+        const bool want_geo = g_tune_kernel == 0 || g_tune_kernel == 7;
+        if (packed_ok && (g_tune_kernel == 9 || (want_geo && tpspp::geo_kernel_single_workgroup(C0, Ho, Wo, F))) &&
             tpspp::launch_geo_kernel(C0, Ho, Wo, F, in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st))
             return tpspp::check_launch("tpspp_warp_fwd(in-place, run-time geometry)");
-        if (g_tune_kernel == 7)
+        if (g_tune_kernel == 9)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the run-time-geometry in-place kernel");
+        if (packed_ok && (want_geo || g_tune_kernel == 8) && tpspp::span_table_waves(Ho, Wo) > 0) {
+            const int QPg = tpspp::geo_qp(Ho, Wo);
+            const int KGs = (F + 3 + 3) / 4;
+            const int NWg = (tpspp::geo_nthr(Ho, Wo, QPg) + kWave - 1) / kWave;
+            const float* span_packed = packed + (size_t)NWg * QPg * KGs * kWave * 4;      // third section of the prepared table
+            if (tpspp::launch_span_kernel(C0, Ho, Wo, F, in0, ctrl, inv_delta_c, span_packed, N, out0, grid_or_null, idx_or_null, st))
+                return tpspp::check_launch("tpspp_warp_fwd(row bands, span staging)");
+        }
+        if (g_tune_kernel == 8)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the span-staging kernel");
+        // (a geometry the span kernel does not take but whose image fits the LDS: the banded in-place kernel)
+        if (packed_ok && want_geo &&
+            tpspp::launch_geo_kernel(C0, Ho, Wo, F, in0, ctrl, inv_delta_c, packed, N, out0, grid_or_null, idx_or_null, st))
+            return tpspp::check_launch("tpspp_warp_fwd(in-place, run-time geometry, bands)");
+        if (g_tune_kernel == 7)
+            return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the run-time-geometry kernels");
     }
 
     // ---- LDS-staged kernel: single small input, classic layout, transposed table available ----

@@ -4,6 +4,7 @@
 // packed FMA occupies the SIMD for two passes and the kernel is bound by VALU time, not by issue slots).
 #include "tpspp_common.h"
 #include "tpspp_warp_geo.h"
+#include "tpspp_warp_span.h"
 #include "tpspp_warp_geo_launch.h"
 
 namespace tpspp {
@@ -33,9 +34,88 @@ int geo_nthr(int Ho, int Wo, int QP)
     return (((Wo / 2) + BW - 1) / BW) * (((Ho / 2) / BH) / QP) * 32;
 }
 
+// the span kernel's own packed copy (QP = 1: one quadrant pixel per thread) exists for the geometries whose quadrant one
+// workgroup of the in-place kernels cannot cover with <= 2 pixels per thread: wavefronts of that copy, 0 = none
+int span_table_waves(int Ho, int Wo)
+{
+    if (geo_qp(Ho, Wo) < 3) return 0;
+    const int BW = tpspp_img::img_block_w(Wo), BH = 32 / BW;
+    const int CG = ((Wo / 2) + BW - 1) / BW, RG = (Ho / 2) / BH;
+    return (CG * RG * 32 + kWave - 1) / kWave;
+}
+
 namespace {
 
 struct Plan { int QP, BW, CG, RGB, bands, nthr, NW, nload, imgs; size_t lds; };
+struct SpanPlan { int BW, CG, RG, bands, nthr, NWv, span_rows, chunk_floats; size_t lds; };
+
+int g_span_bands = 0;        // lab knobs (tpspp_warp_set_tuning with kernel_choice 8): workgroups per image, 0 = heuristic;
+int g_span_gather = 0;       // every workgroup on the global-memory path;
+int g_span_lds_kb = 0;       // LDS budget per workgroup in KB, 0 = 38 (four workgroups per CU)
+
+// Row bands with span staging (tpspp_warp_span.h): workgroups per image (a divisor of the quadrant's row groups) and the
+// staging buffer's size; the buffer then takes whatever span fits (the rows the band's taps reach, per region).
+bool plan_span(int C, int H, int W, int F, SpanPlan* p)
+{
+    if (!(C == 1 || C == 3 || C == 4) || F != 20 || span_table_waves(H, W) == 0 || (H * W) % 4 != 0) return false;
+    p->BW = tpspp_img::img_block_w(W);
+    const int BH = 32 / p->BW;
+    p->CG = ((W / 2) + p->BW - 1) / p->BW;
+    p->RG = (H / 2) / BH;
+    const int K = F + 3;
+    // Measured at batch 512 (scripts/debug/bench_span_knobs.py): the kernel is bound by vector-ALU time per SIMD, so (a) a
+    // workgroup whose wavefronts spread evenly over the four SIMDs wins (48x160: 12 wavefronts 32.8 us, 9 wavefronts 39.4),
+    // (b) small workgroups with a small buffer -- four per CU -- beat two large ones (64x200: 7 wavefronts / 38 KB 48.7 us,
+    // 7 / 78 KB 59.4, 13 / any 64.3).  Preference: whole multiples of four wavefronts (the most, <= 12), else the most
+    // wavefronts <= 8, else anything <= 13; buffer 38 KB, more only when the band's own rows + 3 do not fit.
+    const size_t kb = (size_t)(g_span_lds_kb > 0 ? g_span_lds_kb : 38);
+    const size_t budgets[3] = {kb * 1024, (size_t)78 * 1024, (size_t)158 * 1024};
+    for (size_t budget : budgets)
+        for (int cls = 0; cls < 3; ++cls) {
+            int bestB = 0, bestNW = 0;
+            for (int B = 1; B <= p->RG; ++B) {
+                if (p->RG % B) continue;
+                if (g_span_bands > 0 && B != g_span_bands) continue;
+                const int nthr = p->CG * (p->RG / B) * 32, NWv = (nthr + kWave - 1) / kWave;
+                const bool ok = cls == 0 ? (nthr % 256 == 0 && NWv <= 12) : cls == 1 ? NWv <= 8 : NWv <= 13;
+                if (!ok || NWv <= bestNW) continue;
+                const int rows = (p->RG / B) * BH;
+                const size_t fixed = (size_t)(tpspp_span::span_stage_off(K) + W + 4) * 4;
+                if (budget <= fixed) continue;
+                // the largest span whose chunks (whole 1-KB pieces per channel) fit the budget
+                int span_rows = (int)(((budget - fixed) / C / 1024) * 1024 / ((size_t)W * 4));
+                if (span_rows > H) span_rows = H;
+                if (span_rows < rows + 3 && span_rows < H) continue;
+                if (tpspp_span::span_lds_bytes(K, C, W, span_rows, rows) > 160 * 1024) continue;
+                bestB = B; bestNW = NWv;
+                p->bands = B; p->nthr = nthr; p->NWv = NWv; p->span_rows = span_rows;
+                p->chunk_floats = tpspp_span::span_chunk_floats(span_rows, W);
+                p->lds = tpspp_span::span_lds_bytes(K, C, W, span_rows, rows);
+            }
+            if (bestB) return true;
+        }
+    return false;
+}
+
+template <int C, bool AUX>
+void launch_span_one(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStream_t st)
+{
+    auto kern = tpspp_span::tps_warp_span_kernel<20, C, AUX>;
+    static bool attr_done[kMaxDevices] = {};
+    if (first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    const unsigned blocks = (unsigned)((P.N + 7) / 8) * 8u * (unsigned)pl.bands;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3((unsigned)(pl.NWv * kWave)), pl.lds, st, P);
+}
+
+template <int C>
+void launch_span_aux(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStream_t st)
+{
+    if (P.grid || P.idx) launch_span_one<C, true>(P, pl, st);
+    else launch_span_one<C, false>(P, pl, st);
+}
 
 int g_geo_pair = 1;          // lab knob: 0 = never an image pair per workgroup
 int g_geo_force_bands = 0;   // lab knob (tpspp_warp_set_tuning's `bands` with kernel_choice 7): 0 = heuristic
@@ -116,6 +196,37 @@ void launch_qp(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
 }  // namespace
 
 void geo_set_bands(int bands) { g_geo_force_bands = bands & 7; g_geo_pair = (bands & 8) ? 0 : 1; }
+void span_set_tuning(int bands, int gather, int lds_kb) { g_span_bands = bands; g_span_gather = gather; g_span_lds_kb = lds_kb; }
+
+bool geo_kernel_single_workgroup(int C, int H, int W, int F)
+{
+    Plan pl;
+    return plan_geo(C, H, W, F, &pl) && pl.bands == 1;
+}
+
+bool span_kernel_applicable(int C, int H, int W, int F)
+{
+    SpanPlan pl;
+    return plan_span(C, H, W, F, &pl);
+}
+
+bool launch_span_kernel(int C, int H, int W, int F, const float* in, const float* ctrl, const float* inv_delta_c,
+                        const float* span_packed, int N, float* out, float* grid, int32_t* idx, hipStream_t st)
+{
+    SpanPlan pl;
+    if (!plan_span(C, H, W, F, &pl)) return false;
+    tpspp_span::SpanParams P;
+    P.in = in; P.ctrl = ctrl; P.inv_delta_c = inv_delta_c; P.packed = span_packed; P.N = N;
+    P.out = out; P.grid = grid; P.idx = idx;
+    P.H = H; P.W = W; P.BW = pl.BW; P.CG = pl.CG; P.RG = pl.RG; P.bands = pl.bands; P.nthr = pl.nthr;
+    P.lg_bw = __builtin_ctz((unsigned)pl.BW);
+    P.span_rows = pl.span_rows; P.chunk_floats = pl.chunk_floats; P.stage_off = tpspp_span::span_stage_off(F + 3);
+    P.force_gather = g_span_gather;
+    if (C == 1) launch_span_aux<1>(P, pl, st);
+    else if (C == 3) launch_span_aux<3>(P, pl, st);
+    else launch_span_aux<4>(P, pl, st);
+    return true;
+}
 
 bool geo_kernel_applicable(int C, int H, int W, int F)
 {

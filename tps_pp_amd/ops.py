@@ -990,11 +990,14 @@ def set_warp_bwd_accumulator(fixed_point: bool = False):
 def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, bands=0):
     """`tpspp_warp_set_tuning` (process-wide lab knobs; 0 everywhere = the automatic choice).
     kernel_choice: 0 automatic, 1 gather kernel, 2 LDS-staged kernel, 3 the same without the mirror trick, 4 plane-streaming
-    kernel, 5 image-pair kernel, 6 instantiated in-place kernel (tpspp_warp_img.h), 7 run-time-geometry in-place kernel
-    (tpspp_warp_geo.h) (2..7: error if not applicable to the call's shapes);
+    kernel, 5 image-pair kernel, 6 instantiated in-place kernel (tpspp_warp_img.h), 7 a run-time-geometry kernel (the
+    in-place kernel of tpspp_warp_geo.h where one workgroup covers the image, else the span-staging kernel), 8 span-staging
+    kernel (tpspp_warp_span.h), 9 the in-place kernel of tpspp_warp_geo.h in its banded form as well (2..9: error if not
+    applicable to the call's shapes);
     bands: kernel_choice 0 / 2 / 3: workgroups per image (pair) in the LDS-staged kernels, 0..8 (0 = heuristic);
-    kernel_choice 7: bits 0-2 = workgroups per image (0 = heuristic), bit 3 (value 8) = never an image pair per
-    workgroup, so 0..15; values above 8 are rejected for every other choice."""
+    kernel_choice 7 / 9: bits 0-2 = workgroups per image (0 = heuristic), bit 3 (value 8) = never an image pair per
+    workgroup, so 0..15; kernel_choice 8: bits 0-5 = workgroups per image, bit 6 (64) = every workgroup on the
+    global-memory path, bits 8-15 = LDS budget in KB; values above 8 are rejected for every other choice."""
     _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group),
                                                 int(kernel_choice), int(bands)),
                "tpspp_warp_set_tuning")
