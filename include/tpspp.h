@@ -155,7 +155,8 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  *                                                  otherwise; the size grew in round 3); on return its first
  *                                                  N * Ho*Wo * 2 floats hold dL/d grid
  * grid (N, Ho*Wo, 2) is the sampling grid the forward produced (its grid_or_null output) and
- * T (N, F+3, 2) = tpspp_solve_T(inv_delta_c, ctrl); the tables are the forward's.  Gradients follow
+ * T (N, F+3, 2) = tpspp_solve_T(inv_delta_c, ctrl) (only dL/d score reads it: may be NULL when score is NULL); the tables
+ * are the forward's.  Gradients follow
  * ATen's CPU grid_sampler_2d_backward (bilinear, border, align_corners=True: zero coordinate gradient
  * where the coordinate was clamped) and the transposes of the two products of build_P_prime.
  * replaces: autograd through backbones/tps_pp/tps_pp.py:467-496,597-615;

@@ -407,3 +407,56 @@ def test_token_gemm_argument_errors(cuda):
     cw96 = ops.prep_conv_weight_bf16(torch.zeros((96, 64, 1, 1), device=cuda), conv_bias=torch.zeros(96, device=cuda))
     with pytest.raises(Exception):
         ops.token_gemm_bf16(torch.zeros((64, 8), device=cuda), cw96)               # Co not a multiple of 128
+
+
+def test_recognizer_training_steps_through_the_hip_warp(cuda):
+    """Round 5 (README.md:60-64 of the reference trains nrtr_tps++.py through mmocr/apis/train.py:56-70):
+    the recogniser built from the config's model dict, `.train()`, `forward(img, metas, return_loss=True)` -> the loss dict
+    of TFLoss.  Every stage is the PyTorch composition of its own layers; the TPS++ transformation stage inside the
+    backbone runs on the HIP kernels in both directions (ops.warp_autograd).  Gradients reach the parameters of all four
+    modules -- those of the TPS++ regressor only THROUGH tpspp_warp_bwd -- and a few SGD steps lower the loss."""
+    torch.manual_seed(3)
+    m = build_recognizer(cuda).train()
+    m.encoder.dropout_p = m.decoder.dropout_p = 0.0                # deterministic steps
+    n = len(cases.G12_WIDTHS)
+    img = dev(cases.g12_inputs()["img"], cuda)
+    texts = ["hello", "W0rld!", "tps++", "a"][:n] + ["x"] * max(0, n - 4)
+    metas = [dict(resize_shape=(32, w, 3), text=t) for w, t in zip(cases.G12_WIDTHS, texts)]
+    calls = []
+    orig = ops.warp_backward
+
+    def spy(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+    ops.warp_backward = spy
+    try:
+        out = m(img, [dict(mm) for mm in metas], return_loss=True)
+        assert set(out) == {"loss_ce"} and out["loss_ce"].shape == (n * 39,)
+        first = out["loss_ce"].sum() / max(1, int((out["loss_ce"] != 0).sum()))
+        first.backward()
+    finally:
+        ops.warp_backward = orig
+    assert calls, "the transformation stage's backward did not run on the HIP kernel"
+    probes = {"backbone stem": m.backbone.conv1.weight, "backbone layer5": m.backbone.layer5[0].conv2.weight,
+              "TPS++ control points (only reachable through the warp's backward)": m.tpsnet.TPE.localization_fc2.bias,
+              "TPS++ score": m.tpsnet.TPE.feat_linear[0].weight, "TPS++ down2": m.tpsnet.down2.conv.weight,
+              "encoder": m.encoder.layer_stack[0].attn.linear_q.weight, "decoder": m.decoder.layer_stack[5].mlp.w_2.weight,
+              "classifier": m.decoder.classifier.weight}
+    for name, prm in probes.items():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all() and float(prm.grad.abs().max()) > 0, name
+    opt = torch.optim.SGD(m.parameters(), lr=0.02)
+    opt.step()
+    losses_seen = [float(first)]
+    for _ in range(3):
+        opt.zero_grad()
+        o = m(img, [dict(mm) for mm in metas], return_loss=True)["loss_ce"]
+        l = o.sum() / max(1, int((o != 0).sum()))
+        l.backward()
+        opt.step()
+        losses_seen.append(float(l))
+    assert all(np.isfinite(losses_seen)) and losses_seen[-1] < losses_seen[0], losses_seen
+    # and inference still runs on the HIP kernels afterwards
+    m.eval()
+    with torch.no_grad():
+        res = m(img, [dict(mm) for mm in metas], return_loss=False)
+    assert len(res) == n and all(isinstance(r["text"], str) for r in res)

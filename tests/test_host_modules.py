@@ -268,8 +268,11 @@ def test_head_state_dict_layout_and_registries():
     assert m.decoder.classifier.out_features == 92 and m.decoder.trg_word_emb.num_embeddings == 93
     with pytest.raises(Exception, match="GPU"):
         m.simple_test(torch.zeros(1, 3, 32, 128), [dict(resize_shape=(32, 128, 3))])
-    with pytest.raises(NotImplementedError):
-        m.forward_train(torch.zeros(1, 3, 32, 128), [dict()])
+    # the training graph (round 5) needs the GPU as well: its transformation stage is the HIP warp, forward and backward
+    with pytest.raises(Exception, match="GPU"):
+        m.train().forward_train(torch.zeros(1, 3, 32, 128), [dict(resize_shape=(32, 128, 3), text="ab")])
+    from tps_pp_amd import losses
+    assert isinstance(m.loss, losses.TFLoss) and m.loss.ignore_index == 92 and m.loss.shift and m.loss.flatten
 
 
 def test_attn_convertor_matches_the_reference():
@@ -369,3 +372,61 @@ def test_attn_convertor_tensor2idx_scan_matches_the_reference_loop():
         want_s.append(ss)
     got_i, got_s = c.tensor2idx(out)
     assert got_i == want_i and got_s == want_s
+
+
+def test_head_training_graphs_reproduce_the_reference():
+    """Round 5: under `.train()` NRTREncoder / NRTRDecoder run as PyTorch compositions of their own layers
+    (`_forward_graph`, `_forward_train_graph`) so that autograd reaches the parameters.  Pinned here, on the CPU, to the
+    reference's own outputs (goldens G9 / G10: nrtr_encoder.py:66-87 with and without the valid-ratio mask;
+    nrtr_decoder.py:95-151 teacher-forced logits) in eval mode (dropout off); then in train mode with dropout 0 the same
+    numbers, and gradients reach every parameter."""
+    import tps_pp_amd as P
+    cfg = dict(cases.HD_SMALL)
+
+    def load(m, seed):
+        sd = cases.synth_state(m.state_dict(), seed, cases.head_state_rule, cases.HD_KEEP)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return m
+    enc = load(P.NRTREncoder(**cfg).eval(), 9)
+    dec = load(P.NRTRDecoder(d_embedding=cfg["d_model"], num_classes=cases.NUM_CLASSES, start_idx=cases.START_IDX,
+                             padding_idx=cases.PAD_IDX, max_seq_len=cases.HD_MAXLEN, **cfg).eval(), 10)
+    GE, GD = cases.load("nrtr_encoder"), cases.load("nrtr_decoder")
+    feat = torch.from_numpy(cases.g9_inputs()["feat"])
+    metas = [dict(valid_ratio=r) for r in cases.HD_RATIOS]
+    inp = cases.g10_inputs()
+    out_enc, tgt = torch.from_numpy(inp["out_enc"]), torch.from_numpy(inp["padded_targets"])
+    with torch.no_grad():
+        assert np.abs(enc._forward_graph(feat, metas).numpy() - GE["out_masked"]).max() <= 2e-6
+        assert np.abs(enc._forward_graph(feat, None).numpy() - GE["out_nomask"]).max() <= 2e-6
+        assert np.abs(dec._forward_train_graph(out_enc, tgt, metas).numpy() - GD["logits"]).max() <= 2e-5
+    # train mode, dropout rate 0: same arithmetic, and a loss reaches every parameter of both modules
+    enc.train(), dec.train()
+    enc.dropout_p = dec.dropout_p = 0.0
+    f = feat.clone().requires_grad_(True)
+    e = enc._forward_graph(f, metas)
+    logits = dec._forward_train_graph(e, tgt, metas)
+    assert np.abs(logits.detach().numpy() - dec._forward_train_graph(enc._forward_graph(feat, metas), tgt, metas).detach().numpy()).max() == 0
+    from tps_pp_amd import losses
+    loss = losses.TFLoss(ignore_index=cases.PAD_IDX)(logits, dict(padded_targets=tgt))["loss_ce"]
+    assert loss.shape == (cases.HD_N * (cases.HD_MAXLEN - 1),) and bool((loss[tgt[:, 1:].reshape(-1) == cases.PAD_IDX] == 0).all())
+    loss.sum().backward()
+    assert f.grad is not None and float(f.grad.abs().max()) > 0
+    for name, prm in list(enc.named_parameters()) + list(dec.named_parameters()):
+        assert prm.grad is not None, name
+        if "trg_word_emb" not in name:
+            assert float(prm.grad.abs().max()) > 0, name
+    # dropout on: outputs differ from run to run (the graph really applies it where the reference does)
+    enc.dropout_p = 0.5
+    with torch.no_grad():
+        a, b = enc._forward_graph(feat, metas), enc._forward_graph(feat, metas)
+    assert not torch.equal(a, b)
+    # losses: CELoss / TFLoss against a direct F.cross_entropy
+    import torch.nn.functional as Fn
+    lg = torch.randn(2, 5, 7)
+    tg = torch.tensor([[6, 1, 2, 3, 0], [6, 4, 0, 0, 0]])
+    want = Fn.cross_entropy(lg[:, :-1].reshape(-1, 7), tg[:, 1:].reshape(-1), ignore_index=0, reduction="none")
+    assert torch.equal(losses.build_loss(dict(type="TFLoss", ignore_index=0))(lg, dict(padded_targets=tg))["loss_ce"], want)
+    ce = losses.build_loss(dict(type="CELoss", ignore_index=0, reduction="mean"))(lg, dict(padded_targets=tg))["loss_ce"]
+    assert abs(float(ce) - float(Fn.cross_entropy(lg.permute(0, 2, 1), tg, ignore_index=0))) < 1e-6
+    with pytest.raises(AssertionError):
+        losses.CELoss(reduction="avg")

@@ -221,7 +221,8 @@ warp_bwd_sample_lds_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* 
 // correctly rounded sum except for ties broken by the order of arrival.
 template <int PPT, int NT, bool F64>
 __global__ void __launch_bounds__(NT, NT == 256 ? 2 : 1)
-warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* __restrict__ g_grid_part)
+warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float* __restrict__ g_grid_part,
+                            int* __restrict__ arrivals)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // [cpt][H*W] fixed point
     __shared__ float sMax[2][NT / 64];
@@ -234,6 +235,7 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
     const int chunks = (C + cpt - 1) / cpt;
     const bool want = P.g_in[i] != nullptr;
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) arrivals[b] = 0;      // the parameter kernel's arrival counter of this image (next launch)
 
     // this thread's pixels: taps once
     int o00[PPT]; float fw[PPT], fn[PPT], mx[PPT], my[PPT]; bool inx[PPT], iny[PPT], livep[PPT];
@@ -379,7 +381,8 @@ warp_bwd_sample_lds2_kernel(const BwdParams P, int G, int cpt0, int cpt1, float*
             }
         }
     }
-    float2* part = reinterpret_cast<float2*>(g_grid_part) + ((size_t)b * (2 * G) + blockIdx.x) * P.n;
+    // (slice stride = the G * nin workgroups of this image: with one input no slice stays empty, nothing to zero)
+    float2* part = reinterpret_cast<float2*>(g_grid_part) + ((size_t)b * gridDim.x + blockIdx.x) * P.n;
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (livep[k]) part[tid + k * NT] = make_float2(gx[k] * mx[k], gy[k] * my[k]);
@@ -404,7 +407,7 @@ constexpr int kBwdMaxS = 8;
 template <int KMAX, int TABLE, bool TRANSPOSED, int SCORE, bool GSCORE>
 __global__ void __launch_bounds__(256)
 warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const float* __restrict__ g_grid_part, int slots,
-                       int S, double* __restrict__ gT_part)
+                       int S, double* __restrict__ gT_part, int* __restrict__ arrivals)
 {
     constexpr int KPW = KMAX / 4;                              // table columns per wavefront
     __shared__ float sT[kMaxK * 2];
@@ -413,7 +416,7 @@ warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const floa
     const int b = blockIdx.x / S, sl_ = blockIdx.x - b * S;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid >> 6;
     const int K = P.F + 3, F = P.F, n = P.n;
-    for (int i = tid; i < 2 * K; i += blockDim.x) sT[i] = P.T[(size_t)b * K * 2 + i];
+    if (SCORE != 0) for (int i = tid; i < 2 * K; i += blockDim.x) sT[i] = P.T[(size_t)b * K * 2 + i];   // (only dL/d score reads T)
 
     float aT[KPW][2];
 #pragma unroll
@@ -492,29 +495,38 @@ warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const floa
         if (k < K) {
             double a = 0.0;
             for (int j = 0; j < kWave; ++j) a += (double)sPart[wv][lane][j];
-            gT_part[((size_t)b * S + sl_) * (2 * kMaxK) + 2 * k + (lane & 1)] = a;
+            // write-through (sc0 sc1) store: the partial is read by another workgroup of this launch, maybe on another XCD
+            __hip_atomic_store(gT_part + ((size_t)b * S + sl_) * (2 * kMaxK) + 2 * k + (lane & 1), a, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-}
-
-// B2: dL/dT = sum of the S partials (ascending), dL/dC'[f] = sum_k inv_delta_C[k][f] dL/dT[k], in fp64, rounded once
-__global__ void __launch_bounds__(128)
-warp_bwd_ctrl_kernel(const BwdParams P, int S, const double* __restrict__ gT_part)
-{
+    // ---- B2 (round 5: was its own launch, warp_bwd_ctrl_kernel): the LAST of the image's S workgroups to arrive sums
+    // the S partials in ascending order and applies inv_delta_C^T, in fp64, rounded once -- the same arithmetic in the
+    // same order whoever is last.  Hand-off (MI355X_MICROARCH.md, "sc0 sc1 stores and loads both sides"): the 2 K partial
+    // sums leave as write-through stores, drained (vmcnt(0)) before the barrier; one lane then takes a ticket with a
+    // relaxed agent-scope atomic; the last arriver reads every partial with sc0 sc1 loads (they bypass its L1 and L2).
+    // No release / acquire fence: a fence writes back / invalidates whole caches, which cost 15-20 us per backward when
+    // every one of the 2048 workgroups issued one.  `arrivals` was zeroed by the launch before this one.
+    __shared__ int sLast;
     __shared__ double sGT[kMaxK * 2];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int K = P.F + 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+        sLast = S == 1 || __hip_atomic_fetch_add(arrivals + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+    __syncthreads();
+    if (!sLast) return;
     for (int i = tid; i < 2 * K; i += blockDim.x) {
         double a = 0.0;
-        for (int sl = 0; sl < S; ++sl) a += gT_part[((size_t)b * S + sl) * (2 * kMaxK) + i];
+        for (int sl = 0; sl < S; ++sl)
+            a += __hip_atomic_load(gT_part + ((size_t)b * S + sl) * (2 * kMaxK) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         sGT[i] = a;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * P.F; i += blockDim.x) {
+    for (int i = tid; i < 2 * F; i += blockDim.x) {
         const int f = i >> 1, xy = i & 1;
         double a = 0.0;
         for (int k = 0; k < K; ++k) a = fma((double)P.inv_delta_c[(size_t)k * K + f], sGT[2 * k + xy], a);
-        P.g_ctrl[(size_t)b * P.F * 2 + i] = (float)a;
+        P.g_ctrl[(size_t)b * F * 2 + i] = (float)a;
     }
 }
 
@@ -532,7 +544,8 @@ TPSPP_EXPORT size_t tpspp_warp_bwd_workspace_floats(int N, int Ho, int Wo)
 {
     if (N <= 0 || Ho <= 0 || Wo <= 0) return 0;
     return (size_t)N * Ho * Wo * 2 * (1 + 2 * kBwdMaxG)       // dL/d grid + the sampling workgroups' slices
-         + (size_t)N * kBwdMaxS * 2 * kMaxK * 2 + 2;           // + the parameter kernel's partial dL/dT (fp64) per workgroup
+         + (size_t)N * kBwdMaxS * 2 * kMaxK * 2 + 2            // + the parameter kernel's partial dL/dT (fp64) per workgroup
+         + (size_t)N + 2;                                      // + its arrival counters (one int per image)
 }
 
 TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, int H0, int W0,
@@ -545,7 +558,8 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
 {
     TPSPP_REQUIRE(g_grid_ws_floats >= tpspp_warp_bwd_workspace_floats(N, Ho, Wo),
                   "tpspp_warp_bwd: g_grid_ws too small (needs tpspp_warp_bwd_workspace_floats(N, Ho, Wo) floats)");
-    TPSPP_REQUIRE(g_out0 && in0 && grid && T && inv_delta_c && p_hat && g_ctrl && g_grid_ws, "tpspp_warp_bwd: null pointer");
+    TPSPP_REQUIRE(g_out0 && in0 && grid && inv_delta_c && p_hat && g_ctrl && g_grid_ws, "tpspp_warp_bwd: null pointer");
+    TPSPP_REQUIRE(T || !score, "tpspp_warp_bwd: T is needed with a score (dL/d score = 0.5 rbf (T . dL/d grid))");
     TPSPP_REQUIRE((g_out1 == nullptr) == (in1 == nullptr), "tpspp_warp_bwd: g_out1 and in1 come together");
     TPSPP_REQUIRE(N >= 0 && F > 0 && F + 3 <= kMaxK && Ho > 0 && Wo > 0, "tpspp_warp_bwd: bad sizes (F <= %d)", kMaxK - 3);
     TPSPP_REQUIRE(C0 > 0 && H0 > 0 && W0 > 0 && (!in1 || (C1 > 0 && H1 > 0 && W1 > 0)), "tpspp_warp_bwd: bad input sizes");
@@ -567,6 +581,11 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     const size_t plane0 = (size_t)H0 * W0 * sizeof(float), plane1 = in1 ? (size_t)H1 * W1 * sizeof(float) : 0;
     int slots = 0;
     float* part = g_grid_ws + (size_t)N * P.n * 2;          // behind dL/d grid: the sampling workgroups' slices
+    // the parameter kernel's partial dL/dT (fp64, behind the slices, at an 8-byte boundary) and arrival counters
+    double* gT_part = reinterpret_cast<double*>(
+        (reinterpret_cast<uintptr_t>(g_grid_ws + (size_t)N * P.n * 2 * (1 + 2 * kBwdMaxG)) + 7) & ~(uintptr_t)7);
+    int* arrivals = reinterpret_cast<int*>(gT_part + (size_t)N * kBwdMaxS * 2 * kMaxK);
+    bool arrivals_zeroed = false;                           // (the LDS-accumulating sampling kernel zeroes them itself)
     // kernel A'': two fixed-point planes (8 bytes per element) of a pass in <= 64 KB of LDS, <= 4096 output pixels
     // (1024-thread workgroups above 1024: the classic 32x100 geometry), planes of whole 16-byte pieces
     const size_t kLds2 = 16 * 1024;
@@ -580,20 +599,20 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
         int G = ((big ? 1024 : 4096) + N * P.nin - 1) / (N * P.nin);      // ~16 (4) workgroups of 256 (1024) threads per CU
         G = G < 1 ? 1 : (G > most ? most : G);
         G = G > kBwdMaxG ? kBwdMaxG : G;
-        slots = 2 * G;
+        slots = G * P.nin;                                  // every slice is written by its workgroup (round 5: was 2 G with a
+                                                            // 26-MB memset of the unused half for single-input calls)
         const size_t accb = 2 * 2 * (plane0 > plane1 ? plane0 : plane1);      // two planes x 8 bytes per element
-        if (P.nin == 1 && hipMemsetAsync(part, 0, (size_t)N * slots * P.n * 2 * sizeof(float), st) != hipSuccess)
-            return tpspp::check_launch("tpspp_warp_bwd(memset)");     // the second input's slices stay empty
         const dim3 g2((unsigned)(G * P.nin), (unsigned)N);
         auto go = [&](auto f64) {
             constexpr bool F64 = decltype(f64)::value;
-            if (P.n <= 256)       hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<1, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
-            else if (P.n <= 512)  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<2, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
-            else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part);
-            else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024, F64>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part);
+            if (P.n <= 256)       hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<1, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part, arrivals);
+            else if (P.n <= 512)  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<2, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part, arrivals);
+            else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part, arrivals);
+            else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024, F64>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part, arrivals);
         };
         if (g_bwd_fixed_point || (table_flags & TPSPP_BWD_FIXED_POINT)) go(std::false_type{});
         else go(std::true_type{});
+        arrivals_zeroed = true;
     } else {
     if (hipMemsetAsync(g_grid_ws, 0, (size_t)N * P.n * 2 * sizeof(float), st) != hipSuccess)
         return tpspp::check_launch("tpspp_warp_bwd(memset)");
@@ -632,14 +651,13 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     int S = (2048 + N - 1) / N;
     S = S < 1 ? 1 : (S > kBwdMaxS ? kBwdMaxS : S);
     while (S > 1 && (P.n + S - 1) / S < 256) --S;
-    // (fp64, behind the slices, at an 8-byte boundary)
-    double* gT_part = reinterpret_cast<double*>(
-        (reinterpret_cast<uintptr_t>(g_grid_ws + (size_t)N * P.n * 2 * (1 + 2 * kBwdMaxG)) + 7) & ~(uintptr_t)7);
+    if (S > 1 && !arrivals_zeroed && hipMemsetAsync(arrivals, 0, (size_t)N * sizeof(int), st) != hipSuccess)
+        return tpspp::check_launch("tpspp_warp_bwd(memset)");
     const dim3 grid_dim((unsigned)(N * S));
     auto launch_b = [&](auto kmax, auto table, auto transposed, auto scorem, auto gscore) {
         auto kern = warp_bwd_params_kernel<decltype(kmax)::value, decltype(table)::value, decltype(transposed)::value,
                                            decltype(scorem)::value, decltype(gscore)::value>;
-        hipLaunchKernelGGL(kern, grid_dim, block, 0, st, P, g_grid_ws, part, slots, S, gT_part);
+        hipLaunchKernelGGL(kern, grid_dim, block, 0, st, P, g_grid_ws, part, slots, S, gT_part, arrivals);
     };
     auto pick_score = [&](auto kmax, auto table, auto transposed) {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -655,6 +673,5 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     if (F + 3 <= 24)      pick_table(std::integral_constant<int, 24>{});
     else if (F + 3 <= 36) pick_table(std::integral_constant<int, 36>{});
     else                  pick_table(std::integral_constant<int, 64>{});
-    hipLaunchKernelGGL(warp_bwd_ctrl_kernel, dim3((unsigned)N), dim3(128), 0, st, P, S, gT_part);
     return tpspp::check_launch("tpspp_warp_bwd");
 }

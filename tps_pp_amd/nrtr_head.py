@@ -10,8 +10,9 @@ PositionwiseFeedForward, PositionalEncoding), `common/layers/transformer_layers.
 
 The sub-modules below only HOLD parameters (so `state_dict` matches); the arithmetic of a whole
 encoder / decoder call is one C-ABI call (`tpspp_nrtr_encoder_fwd` / `tpspp_nrtr_decoder_fwd`) that
-enqueues hand-written HIP kernels: there is no CPU or library-kernel path, and the modules raise on CPU
-tensors or under training.  The decoder is incremental (one position per step against cached
+enqueues hand-written HIP kernels: there is no CPU or library-kernel path for inference, and the modules raise on
+CPU tensors.  Under `.train()` (round 5) encoder and decoder run as PyTorch compositions of the same layers so that
+autograd reaches their parameters (`_forward_graph`, `_forward_train_graph`).  The decoder is incremental (one position per step against cached
 keys/values) where the reference re-runs the padded sequence every step; results agree to fp32
 rounding (see tests/test_gpu_head.py).
 """
@@ -127,6 +128,47 @@ def _arranged16(weight, x3=False):
     return ops.prep_conv_weight_bf16(w.view(w.shape[0], w.shape[1], 1, 1), x3=x3).arranged
 
 
+
+# ---- training graph ("training widening") ---------------------------------------
+# `.train()` turns every module of the recogniser into the plain PyTorch composition of its own layers, so that autograd
+# reaches the parameters (the reference trains nrtr_tps++.py through mmocr/apis/train.py:56-70); the TPS++ transformation
+# stage inside it still runs on the HIP kernels in both directions (tps_pp.TPS_PP._forward_autograd -> ops.warp_autograd).
+# Dropout sits where the reference has it (transformer_module.py:30,93,120; nrtr_decoder.py:99) with the rate the module
+# was built with; in eval mode these functions reproduce the HIP kernels' arithmetic up to summation order and are what
+# the host-side tests compare against the oracle.
+def _mha_graph(m, q_in, kv_in, mask, p_drop, training):
+    """MultiHeadAttention.forward (transformer_module.py:71-96) on the parameters `m` holds.  mask: None, (N, Lk) or
+    (N, Lq, Lk); 0 = masked."""
+    import torch.nn.functional as Fn
+    n, lq, _ = q_in.shape
+    lk = kv_in.shape[1]
+    q = Fn.linear(q_in, m.linear_q.weight, m.linear_q.bias).view(n, lq, m.n_head, m.d_k).transpose(1, 2)
+    k = Fn.linear(kv_in, m.linear_k.weight, m.linear_k.bias).view(n, lk, m.n_head, m.d_k).transpose(1, 2)
+    v = Fn.linear(kv_in, m.linear_v.weight, m.linear_v.bias).view(n, lk, m.n_head, m.d_v).transpose(1, 2)
+    att = torch.matmul(q / (m.d_k ** 0.5), k.transpose(2, 3))
+    if mask is not None:
+        mk = mask.unsqueeze(1) if mask.dim() == 3 else mask.unsqueeze(1).unsqueeze(1)
+        att = att.masked_fill(mk == 0, float("-inf"))
+    att = Fn.dropout(Fn.softmax(att, dim=-1), p_drop, training)
+    out = torch.matmul(att, v).transpose(1, 2).contiguous().view(n, lq, m.dim_v)
+    return Fn.dropout(Fn.linear(out, m.fc.weight, m.fc.bias), p_drop, training)
+
+
+def _ffn_graph(m, x, p_drop, training):
+    """PositionwiseFeedForward.forward (transformer_module.py:122-128), GELU in its erf form."""
+    import torch.nn.functional as Fn
+    h = Fn.gelu(Fn.linear(x, m.w_1.weight, m.w_1.bias))
+    return Fn.dropout(Fn.linear(h, m.w_2.weight, m.w_2.bias), p_drop, training)
+
+
+def _ratio_mask(img_metas, n, t, device):
+    """`_get_mask` of encoder / decoder as a (N, T) 0/1 tensor, None without metas."""
+    vl = _valid_len(img_metas, n, t, device)
+    if vl is None:
+        return None
+    return (torch.arange(t, device=device)[None, :] < vl[:, None]).to(torch.float32)
+
+
 def _head_flags(compute_dtype):
     return ops.HEAD_BF16 if compute_dtype == torch.bfloat16 else ops.HEAD_BF16X3 if compute_dtype == "bf16x3" else 0
 
@@ -142,6 +184,7 @@ class NRTREncoder(nn.Module):
         if d_model != n_head * d_k:
             raise ValueError("d_model must equal n_head * d_k (linear_q maps dim_k -> dim_k)")
         self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
+        self.dropout_p = float(dropout)    # (only the training graph applies it)
         self.compute_dtype = None          # torch.bfloat16: the wide projections on the bf16 matrix cores
         self.layer_stack = nn.ModuleList([
             TFEncoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout, **kwargs) for _ in range(n_layers)])
@@ -176,8 +219,25 @@ class NRTREncoder(nn.Module):
             self._w_cache = cache
         return cache[1:]
 
+    def _forward_graph(self, feat, img_metas=None):
+        """`NRTREncoder.forward` (nrtr_encoder.py:66-87) as a PyTorch composition of this module's layers: the TRAINING
+        graph (autograd reaches the parameters; dropout active under .train()) and the host-side tests' reference."""
+        import torch.nn.functional as Fn
+        n, c, h, w = feat.shape
+        x = feat.reshape(n, c, h * w).permute(0, 2, 1).contiguous()
+        mask = _ratio_mask(img_metas, n, h * w, feat.device)
+        p, tr = self.dropout_p, self.training
+        for lyr in self.layer_stack:
+            y = Fn.layer_norm(x, (c,), lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps)
+            x = x + _mha_graph(lyr.attn, y, y, mask, p, tr)
+            x = x + _ffn_graph(lyr.mlp, Fn.layer_norm(x, (c,), lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps), p, tr)
+        return Fn.layer_norm(x, (c,), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+
     def forward(self, feat, img_metas=None):
-        ops.require_gpu(feat, "NRTREncoder", self.training or torch.is_grad_enabled() and feat.requires_grad)
+        if self.training or (torch.is_grad_enabled() and feat.requires_grad):
+            ops.require_gpu(feat, "NRTREncoder")
+            return self._forward_graph(feat.float(), img_metas)
+        ops.require_gpu(feat, "NRTREncoder")
         table, g, b = self._weights()
         n, c, h, w = feat.shape
         if c != self.d_model:
@@ -205,6 +265,7 @@ class NRTRDecoder(nn.Module):
             raise ValueError("d_model must equal n_head * d_k and d_embedding")
         self.padding_idx, self.start_idx, self.max_seq_len = padding_idx, start_idx, max_seq_len
         self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
+        self.dropout_p = float(dropout)    # (only the training graph applies it)
         self.compute_dtype = None          # torch.bfloat16: encoder K/V projected on the bf16 matrix cores, kept as bf16
         self.trg_word_emb = nn.Embedding(num_classes, d_embedding, padding_idx=padding_idx)
         self.position_enc = PositionalEncoding(d_embedding, n_position=n_position)
@@ -272,7 +333,33 @@ class NRTRDecoder(nn.Module):
         self.last_tokens = tokens
         return out
 
+    def _forward_train_graph(self, out_enc, targets, img_metas):
+        """`NRTRDecoder.forward_train` (nrtr_decoder.py:95-151: embedding + position table, pad & causal self-attention
+        mask, valid-ratio cross-attention mask, six pre-norm layers, LayerNorm(eps 1e-6), classifier) as a PyTorch
+        composition of this module's layers: the TRAINING graph.  Returns raw logits (N, T, num_classes - 1)."""
+        import torch.nn.functional as Fn
+        n, t, c = out_enc.shape
+        L = targets.shape[1]
+        p, tr = self.dropout_p, self.training
+        x = Fn.embedding(targets, self.trg_word_emb.weight, padding_idx=self.padding_idx)
+        x = Fn.dropout(x + self.position_enc.position_table[:, :L], p, tr)
+        causal = torch.tril(torch.ones((L, L), device=targets.device, dtype=torch.bool))[None]
+        self_mask = ((targets != self.padding_idx)[:, None, :] & causal).to(torch.float32)       # (N, L, L)
+        src_mask = _ratio_mask(img_metas, n, t, out_enc.device)
+        for lyr in self.layer_stack:
+            y = Fn.layer_norm(x, (c,), lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps)
+            x = x + _mha_graph(lyr.self_attn, y, y, self_mask, p, tr)
+            y = Fn.layer_norm(x, (c,), lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps)
+            x = x + _mha_graph(lyr.enc_attn, y, out_enc, src_mask, p, tr)
+            x = x + _ffn_graph(lyr.mlp, Fn.layer_norm(x, (c,), lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps), p, tr)
+        x = Fn.layer_norm(x, (c,), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return Fn.linear(x, self.classifier.weight, self.classifier.bias)
+
     def forward_train(self, feat, out_enc, targets_dict, img_metas):
+        if self.training or (torch.is_grad_enabled() and out_enc.requires_grad):
+            ops.require_gpu(out_enc, "NRTRDecoder")
+            return self._forward_train_graph(out_enc.float(), targets_dict["padded_targets"].to(out_enc.device).long(),
+                                             img_metas)
         targets = targets_dict["padded_targets"].to(out_enc.device).to(torch.int32).contiguous()
         return self._run(out_enc, img_metas, targets)
 
@@ -408,7 +495,8 @@ class AttnConvertor(BaseConvertor):
 class EncodeDecodeRecognizer(nn.Module):
     """`recognizer/encode_decode_recognizer.py`: preprocessor -> backbone (with the TPS++ network called
     inside it) -> encoder -> decoder -> label convertor.  Inference (`simple_test`, `aug_test`,
-    `forward(..., return_loss=False)`) runs on the HIP kernels; training raises (row F2)."""
+    `forward(..., return_loss=False)`) runs on the HIP kernels; `forward_train` (round 5) builds the training graph:
+    PyTorch compositions of every stage's layers around the HIP transformation stage (forward and backward kernels)."""
 
     def __init__(self, preprocessor=None, backbone=None, encoder=None, decoder=None, tpsnet=None, loss=None,
                  label_convertor=None, train_cfg=None, test_cfg=None, max_seq_len=40, pretrained=None,
@@ -439,6 +527,8 @@ class EncodeDecodeRecognizer(nn.Module):
         else:
             self.decoder = None
         self.loss_cfg = None if loss is None else dict(loss, ignore_index=self.label_convertor.padding_idx)
+        from .losses import build_loss
+        self.loss = None if loss is None else build_loss(self.loss_cfg)
         self.train_cfg, self.test_cfg, self.max_seq_len = train_cfg, test_cfg, max_seq_len
 
     def set_compute_dtype(self, mode):
@@ -466,7 +556,24 @@ class EncodeDecodeRecognizer(nn.Module):
         return self.backbone(img)
 
     def forward_train(self, img, img_metas, **kwargs):
-        raise NotImplementedError("the HIP path is forward-only (SURVEY.md section 8f, row F2)")
+        """`EncodeDecodeRecognizer.forward_train` (encode_decode_recognizer.py:131-183): valid ratios, features, targets from
+        `img_meta['text']`, encoder, teacher-forced decoder, loss dict.  In `.train()` mode every stage is the PyTorch
+        composition of its layers (gradients reach all parameters) and the TPS++ transformation stage runs on the HIP
+        kernels forward and backward; the loss is the config's (`TFLoss` / `CELoss`: tps_pp_amd/losses.py)."""
+        for img_meta in img_metas:
+            img_meta["valid_ratio"] = 1.0 * img_meta["resize_shape"][1] / img.size(-1)
+        feat = self.extract_feat(img, False, **kwargs)
+        if isinstance(feat, dict):
+            feat = feat["output"]
+        targets_dict = self.label_convertor.str2tensor([img_meta["text"] for img_meta in img_metas])
+        out_enc = self.encoder(feat, img_metas) if self.encoder is not None else None
+        if self.decoder is not None:
+            out_dec = self.decoder(feat, out_enc, targets_dict, img_metas, train_mode=True)
+        else:
+            out_dec = out_enc
+        if self.loss is None:
+            raise ValueError("forward_train: the recogniser was built without a `loss` config")
+        return self.loss(out_dec, targets_dict, img_metas)
 
     @torch.no_grad()          # the callers (mmdet's single/multi_gpu_test) run it under no_grad as well
     def simple_test(self, img, img_metas, **kwargs):

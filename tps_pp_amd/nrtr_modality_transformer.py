@@ -43,7 +43,9 @@ class NRTRModalityTransform(nn.Module):
         return cache[1]
 
     def forward(self, x):
-        ops.require_gpu(x, "NRTRModalityTransform", self.training)
+        ops.require_gpu(x, "NRTRModalityTransform")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            return self._forward_torch(x.float())           # training graph (round 5): autograd, BatchNorm batch statistics
         c1, c2, lin = self._weights()
         x = ops.conv2d([x.float().contiguous()], c1, 2, True)
         x = ops.conv2d([x], c2, 2, True)
@@ -54,7 +56,7 @@ class NRTRModalityTransform(nn.Module):
         return y.view(n, w, 512).permute(0, 2, 1).contiguous().view(n, -1, 1, w)
 
     def _forward_torch(self, x):
-        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
+        """Plain PyTorch composition of the same layers: the TRAINING graph and the host-side tests' reference."""
         x = self.bn_1(self.relu_1(self.conv_1(x)))
         x = self.bn_2(self.relu_2(self.conv_2(x)))
         n, c, h, w = x.size()

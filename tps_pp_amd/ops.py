@@ -1237,7 +1237,7 @@ def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None
         _, C1, H1, W1 = in1.shape
         if tuple(g_out1.shape) != (N, C1, Ho, Wo):
             raise ValueError("warp_backward: g_out1 shape")
-    T = solve_T(inv_delta_C, ctrl)
+    T = solve_T(inv_delta_C, ctrl) if score is not None else None      # (only dL/d score reads T)
     g_in0 = torch.empty_like(in0) if need_in0 else None
     g_in1 = torch.empty_like(in1) if (in1 is not None and need_in1) else None
     g_ctrl = torch.empty((N, F, 2), device=in0.device, dtype=torch.float32)

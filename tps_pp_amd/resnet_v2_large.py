@@ -8,8 +8,10 @@ call contract `forward(x, tpsnet=None, test=False, **kw) -> dict(output, img_ref
 network invoked before stage index 2 on `(x, outs)` (`:183-191`).
 
 Every convolution runs on the hand-written fp32 MFMA kernel with its BatchNorm folded in and the
-residual add + ReLU fused into the second convolution's epilogue (eval mode, GPU tensors; anything
-else raises: there is no CPU or library-kernel path).
+residual add + ReLU fused into the second convolution's epilogue (eval mode, GPU tensors; CPU tensors
+raise: there is no CPU path).  Under `.train()` (round 5) the backbone is the PyTorch composition of its own
+layers so that autograd and BatchNorm's batch statistics work; the TPS++ network it calls keeps its
+transformation stage on the HIP kernels, forward and backward.
 """
 import torch
 import torch.nn as nn
@@ -37,11 +39,14 @@ class BasicBlock(nn.Module):
         self.use_conv1x1 = use_conv1x1
 
     def forward(self, x):
-        ops.require_gpu(x, "BasicBlock", self.training)
+        ops.require_gpu(x, "BasicBlock")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            return self._forward_torch(x)                 # training graph (round 5): autograd, BatchNorm batch statistics
         return self._forward_hip(x)
 
     def _forward_torch(self, x):
-        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
+        """Plain PyTorch composition of the same layers: the TRAINING graph (`.train()`: BatchNorm uses and updates batch
+        statistics, autograd reaches the parameters) and the host-side tests' reference; eval-mode forward() never takes it."""
         residual = x
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -172,7 +177,12 @@ class ResNetABI_v2_large(nn.Module):
     def forward(self, x, tpsnet=None, test=False, **kwargs):
         """(N, 3, H, W) -> dict(output, img_ref); `tpsnet(x, outs, **kwargs)` runs before stage 2 and
         its 'output' replaces x (`resnet_v2_large.py:183-191`)."""
-        ops.require_gpu(x, "ResNetABI_v2_large", self.training)
+        ops.require_gpu(x, "ResNetABI_v2_large")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            # training graph (round 5; the reference trains through mmocr/apis/train.py:56-70): the stem and the blocks as
+            # PyTorch compositions of their own layers; `tpsnet` (in .train() mode as well) regresses with PyTorch layers and
+            # runs the transformation stage on the HIP kernels in both directions (tps_pp.TPS_PP._forward_autograd)
+            return self._forward_torch(x.float(), tpsnet, **kwargs)
         if x.dtype == torch.bfloat16 or self.compute_dtype == torch.bfloat16:
             # bf16 configuration (BASELINE.json configs[4]): every convolution on the bf16 matrix cores, bf16
             # activations in HBM (also through `tpsnet`, which follows its input dtype); the feature map handed
@@ -221,6 +231,6 @@ class ResNetABI_v2_large(nn.Module):
         return {"output": x, "img_ref": outputs.get("output", None) if outputs is not None else None}
 
     def _forward_torch(self, x, tpsnet=None, **kwargs):
-        """TEST HOOK, never called by forward(): plain PyTorch composition of the same layers."""
+        """Plain PyTorch composition of the same layers: the TRAINING graph and the host-side tests' reference."""
         return self._run(x, tpsnet, lambda t: self.relu1(self.bn1(self.conv1(t))),
                          lambda blk, t, inner: blk._forward_torch(t), **kwargs)
