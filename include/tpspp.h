@@ -459,6 +459,11 @@ int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kerne
  * the 100 MHz wall clock at entry.  NULL (default) disables it.
  */
 int tpspp_warp_set_trace(long long* device_buf);
+/* Diagnostics of the persistent decoder step (tpspp_nrtr_decoder_fwd, reduced-precision heads): when non-NULL every workgroup
+ * writes the 100 MHz wall clock at the end of each of its phases, device_buf[(step * workgroups + workgroup) * 64 + phase]
+ * (phase 0 = entry; 8 phases per layer, then the classifier); the buffer must hold steps x workgroups x 64 int64.  NULL
+ * (default) disables it. */
+int tpspp_head_set_trace(long long* device_buf);
 
 /* ===== Recogniser head after TPS++: NRTR encoder / decoder ==========
  *

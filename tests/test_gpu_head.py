@@ -346,6 +346,7 @@ def test_decoder_fused_q_cross_launch_is_bit_identical(cuda, tmp_path):
     outs = []
     for val in (None, "1"):
         env = dict(os.environ)
+        env["TPSPP_HEAD_NO_PERSIST"] = "1"               # both on the launch-per-phase pipeline (the fused launch is one of its phases)
         env.pop("TPSPP_HEAD_QCROSS", None)
         if val:
             env["TPSPP_HEAD_QCROSS"] = val
@@ -356,6 +357,52 @@ def test_decoder_fused_q_cross_launch_is_bit_identical(cuda, tmp_path):
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
         assert torch.isfinite(outs[0][k]).all()
+
+
+@pytest.mark.parametrize("n,seq", [(37, 6), (64, 40), (557, 5)])
+def test_decoder_persistent_step_matches_the_launch_pipeline(cuda, n, seq):
+    """Round 5: a decoding step of the reduced-precision heads is ONE persistent launch (tpspp_head_persist.h: clusters of 16
+    workgroups per 32 images, cluster barriers, system-scope hand-offs) instead of ~50 dependent launches
+    (TPSPP_HEAD_NO_PERSIST=1 selects those; read per call).  Same phases, same per-element arithmetic except that a
+    projection's K is split over 8 wavefronts instead of 4: soft-max scores within 5e-5 (the classifier is spread x6 here), decided tokens IDENTICAL -- a stale or torn
+    hand-off would show as an O(1) difference.  Greedy and teacher-forced, ragged valid ratios, a batch that is not a
+    multiple of the 32-image cluster (37), one of several 512-image launches per step (557), full length (40 steps);
+    bf16x3 and bf16 heads; three repetitions (the hand-offs race differently every time)."""
+    import os
+    from tps_pp_amd.nrtr_head import NRTRDecoder
+    torch.manual_seed(5)
+    dec = NRTRDecoder(num_classes=93, max_seq_len=seq, start_idx=91, padding_idx=92).eval().to(cuda)
+    with torch.no_grad():
+        dec.classifier.weight.mul_(6.0)                   # decided tokens far from ties
+    enc = torch.randn(n, 64, 512, device=cuda)
+    metas = [dict(valid_ratio=(1.0, 0.7, 0.4)[i % 3]) for i in range(n)]
+    forced = torch.randint(0, 90, (n, seq), device=cuda)
+    forced[:, 0] = 91
+    forced[::3, seq - 1] = 92                              # a <PAD> key in some rows
+    old = os.environ.pop("TPSPP_HEAD_NO_PERSIST", None)
+    try:
+        for cd in ("bf16x3", torch.bfloat16):
+            dec.compute_dtype = cd
+            with torch.no_grad():
+                os.environ["TPSPP_HEAD_NO_PERSIST"] = "1"
+                want = dec(None, enc, None, metas, train_mode=False)
+                want_tok = dec.last_tokens.clone()
+                want_tf = dec(None, enc, dict(padded_targets=forced), metas, train_mode=True)
+                del os.environ["TPSPP_HEAD_NO_PERSIST"]
+                for rep in range(3):
+                    got = dec(None, enc, None, metas, train_mode=False)
+                    got_tok = dec.last_tokens.clone()
+                    got_tf = dec(None, enc, dict(padded_targets=forced), metas, train_mode=True)
+                    assert torch.isfinite(got).all() and torch.isfinite(got_tf).all(), (cd, rep)
+                    bad = (got_tok != want_tok)
+                    assert not bool(bad.any()), (cd, rep, int(bad.sum()), bad.nonzero()[:4].tolist(), float((got - want).abs().max()))
+                    # (bf16 head: the cached keys / values are rounded to bf16, so last-bit differences of a projection reach 2e-4)
+                    assert float((got - want).abs().max()) <= (5e-5 if cd == "bf16x3" else 5e-4), (cd, rep, float((got - want).abs().max()))
+                    assert float((got_tf - want_tf).abs().max()) <= (1e-4 if cd == "bf16x3" else 1e-3) * float(want_tf.abs().max()), (cd, rep)
+    finally:
+        os.environ.pop("TPSPP_HEAD_NO_PERSIST", None)
+        if old is not None:
+            os.environ["TPSPP_HEAD_NO_PERSIST"] = old
 
 
 TOKGEMM_CASES = [

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "tpspp_conv_set_tuning": ([_i], _i),
     "tpspp_warp_set_tuning": ([_i, _i, _i, _i], _i),
     "tpspp_warp_set_trace": ([_f], _i),
+    "tpspp_head_set_trace": ([_f], _i),
     "tpspp_warp_bwd_workspace_floats": ([_i, _i, _i], ctypes.c_size_t),
     "tpspp_warp_bwd_set_accumulator": ([_i], _i),
     "tpspp_warp_bwd": ([_f, _f, _i, _i, _i, _f, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _i,

@@ -389,6 +389,30 @@ template <int GS> __device__ __forceinline__ float across_groups_max(float v)
     return v;
 }
 
+// ---- system-scope (sc0 sc1) accesses for data exchanged between workgroups INSIDE one launch (the persistent decoder
+// step, tpspp_head_persist.h): they bypass the CU's L1 and the XCD's L2, so a value written by another CU -- maybe on
+// another XCD -- is never served from a stale line (MI355X_MICROARCH.md, "sc0 sc1 stores and loads both sides").  The loads
+// are inline asm, invisible to the compiler's wait-count tracking: every use must sit behind a wait_sys() that names the
+// loaded registers.
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ hf32x4 ld16_sys(const float* p)
+{
+    hf32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st16_sys(float* p, hf32x4 v)
+{
+    // (s_nop: the VMEM store-data hazard is invisible to the compiler inside inline asm, as in tpspp_warp_pair.h)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wait_sys(hf32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory"); }
+__device__ __forceinline__ void wait_sys(hf32x4& a, hf32x4& b, hf32x4& c)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <typename KV> struct Wide;
 template <> struct Wide<float> {
     static constexpr int EPL = 4;
@@ -420,7 +444,8 @@ template <> struct Wide<unsigned short> {
 
 // cross-attention of one (image b, head h) by one wavefront: q (this lane's EPL features, already scaled), Kx_t / Vx_t
 // (Nb*T, C) token-major, out (Nb, C) token-major (or channel-major).
-template <typename KV>
+// MAXJJ: 64-token groups the code is built for (T <= 64 MAXJJ; 1 saves 48 registers of score storage)
+template <typename KV, bool SYS = false, int MAXJJ = 4>
 __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
                                              int C, int Nb, int T, int nvalid, int b, int h, int lane, float* __restrict__ out,
                                              int out_cm)
@@ -431,10 +456,10 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
     const typename Wd::raw* kb = reinterpret_cast<const typename Wd::raw*>(Kx_t + ((size_t)b * T) * C + kDK * h + EPL * dl);
     const typename Wd::raw* vb = reinterpret_cast<const typename Wd::raw*>(Vx_t + ((size_t)b * T) * C + kDK * h + EPL * dl);
     const size_t rstride = (size_t)C / EPL;                // row pitch in raw pieces
-    float sc[4][NP];
+    float sc[MAXJJ][NP];
     float mx = -INFINITY;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < MAXJJ; ++jj) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) sc[jj][i] = -INFINITY;
         if (jj * kWave < nvalid) {                         // wave-uniform
@@ -461,7 +486,7 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
     mx = across_groups_max<GS>(mx);
     float l = 0.0f;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < MAXJJ; ++jj)
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             sc[jj][i] = sc[jj][i] == -INFINITY ? 0.0f : expf(sc[jj][i] - mx);
@@ -473,7 +498,7 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
+    for (int jj = 0; jj < MAXJJ; ++jj) {
         if (jj * kWave < nvalid) {
             typename Wd::raw vr[NP];
 #pragma unroll
@@ -500,7 +525,10 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
         } else {
             float* o = out + (size_t)b * C + kDK * h + EPL * dl;
 #pragma unroll
-            for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            for (int e = 0; e < EPL; e += 4) {
+                if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            }
         }
     }
 }
@@ -527,23 +555,31 @@ attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__
 
 // masked self-attention against token-major caches Kc / Vc [image][head][position][64]; qkv_t (Nb, 3C); out (Nb, C).
 // The new position's key / value are used from registers (fp32) and appended to the caches.
-template <typename KV>
-__global__ void __launch_bounds__(256)
-attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
-                          KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
-                          int pad_idx, float* __restrict__ out, int out_cm)
+// One (image b, head h) by one wavefront.  SYS (the persistent step kernel): this step's q | k | v row and the output
+// are exchanged with other workgroups of the same launch -- system-scope accesses; the caches belong to earlier / later
+// launches and stay plain.
+template <typename KV, bool SYS>
+__device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
+                                            KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
+                                            int pad_idx, float* __restrict__ out, int out_cm, int b, int h, int lane)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (pair >= Nb * H) return;
-    const int b = pair / H, h = pair - b * H;
     const int grp = lane / GS, dl = lane % GS;
     const float* base = qkv_t + (size_t)b * 3 * C + kDK * h + EPL * dl;
     float q[EPL], k[EPL], v[EPL];
+    if (SYS) {
+        hf32x4 rq[EPL / 4], rk[EPL / 4], rv[EPL / 4];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) { q[e] = base[e] * 0.125f; k[e] = base[C + e]; v[e] = base[2 * C + e]; }
+        for (int e = 0; e < EPL / 4; ++e) { rq[e] = ld16_sys(base + 4 * e); rk[e] = ld16_sys(base + C + 4 * e); rv[e] = ld16_sys(base + 2 * C + 4 * e); }
+#pragma unroll
+        for (int e = 0; e < EPL / 4; ++e) wait_sys(rq[e], rk[e], rv[e]);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { q[e] = rq[e >> 2][e & 3] * 0.125f; k[e] = rk[e >> 2][e & 3]; v[e] = rv[e >> 2][e & 3]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) { q[e] = base[e] * 0.125f; k[e] = base[C + e]; v[e] = base[2 * C + e]; }
+    }
     const size_t bh = (size_t)b * H + h;
     typename Wd::raw* kc = reinterpret_cast<typename Wd::raw*>(Kc + bh * Lmax * kDK + EPL * dl);
     typename Wd::raw* vc = reinterpret_cast<typename Wd::raw*>(Vc + bh * Lmax * kDK + EPL * dl);
@@ -639,9 +675,25 @@ attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H,
         } else {
             float* o = out + (size_t)b * C + kDK * h + EPL * dl;
 #pragma unroll
-            for (int e = 0; e < EPL; e += 4) *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            for (int e = 0; e < EPL; e += 4) {
+                if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            }
         }
     }
+}
+
+template <typename KV>
+__global__ void __launch_bounds__(256)
+attn_dec_self_wide_kernel(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
+                          KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
+                          int pad_idx, float* __restrict__ out, int out_cm)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (pair >= Nb * H) return;
+    const int b = pair / H, h = pair - b * H;
+    self_attend<KV, false>(qkv_t, C, Nb, H, step, Lmax, Kc, Vc, tokens, Lt, pad_idx, out, out_cm, b, h, lane);
 }
 
 // ---- decoder, one step: classifier epilogue ------------------------------------------------------------------
@@ -985,6 +1037,8 @@ dec_q_cross_x3_kernel(const DGemm P, const KV* __restrict__ Kx_t, const KV* __re
     }
 }
 
+#include "tpspp_head_persist.h"
+
 // The same GEMM with exact fp32 products (v_mfma_f32_32x32x2_f32) for the exact-fp32 configuration: the weight arrives
 // as fp32 in fragment order, [Co/32][K/8][k half][32 outputs][4 k] with k = 8 u + 4 half + e, x as 16-byte pieces of the
 // token-major row (the lane's four k of the step), four MFMAs per 16-byte pair; eight wavefronts split K.
@@ -1166,6 +1220,10 @@ const bool g_head_no_tokgemm = getenv("TPSPP_HEAD_NO_TOKGEMM") != nullptr;
 // TPSPP_HEAD_QCROSS=1: the q projection and the cross-attention of a decoder layer-step as ONE launch (dec_q_cross_x3_kernel).
 // Off by default: bit-identical and slower (see the kernel's header).
 const bool g_head_qcross = getenv("TPSPP_HEAD_QCROSS") != nullptr;
+// TPSPP_HEAD_NO_PERSIST=1: the reduced-precision step pipeline as ~50 launches per step (rounds 3-4) instead of ONE persistent
+// launch per step (tpspp_head_persist.h); bit-identical scores -- for A/B runs and the bit-identity test
+bool head_no_persist() { return getenv("TPSPP_HEAD_NO_PERSIST") != nullptr; }
+long long* g_head_trace = nullptr;     // tpspp_head_set_trace
 
 struct Gemm {
     hipStream_t st;
@@ -1246,10 +1304,17 @@ size_t dec_ws_bytes(int N, int C, int T, int Di, int n_layers, int L, int Cc)
     s += align256((size_t)Cc * N * 4);                                       // logits
     s += align256((size_t)N * (L + 1) * 4);                                  // tokens
     s += align256((size_t)C * MT * 4);                                       // keys before their transposition (token-major step pipeline)
+    s += align256(((size_t)(N + 31) / 32 * 32 + 64) * 4);                    // the persistent step kernel's cluster counters (128 B apart) + error flag
     return s;
 }
 
 }  // namespace
+
+TPSPP_EXPORT int tpspp_head_set_trace(long long* device_buf)
+{
+    g_head_trace = device_buf;
+    return TPSPP_OK;
+}
 
 TPSPP_EXPORT size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner)
 {
@@ -1451,6 +1516,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     float* logits = cv.f((size_t)num_out * N);
     int* tokens = reinterpret_cast<int*>(cv.f((size_t)N * Lt));
     float* ktmp = cv.f((size_t)C * MT);
+    int* pcounters = reinterpret_cast<int*>(cv.f((size_t)(N + 31) / 32 * 32 + 64));
     TPSPP_REQUIRE(cv.ok, "tpspp_nrtr_decoder_fwd: workspace carve failed");
 
     // Reduced-precision head (TPSPP_HEAD_BF16 / _BF16X3) with arranged per-step weights in the table: every activation of
@@ -1497,6 +1563,55 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     const int greedy = forced_tokens ? 0 : 1;
     const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
     int rc = 0;
+    // ---- the step as ONE persistent launch (tpspp_head_persist.h): three-term / bf16 head, d_model 512, 8 heads ----
+    const bool persist = fast && !gemm_f32 && C == 512 && H == 8 && num_out <= 128 && n_layers <= kPMaxLayers &&
+                         !g_head_qcross && !head_no_persist();
+    if (persist) {
+        PStep PS;
+        for (int l = 0; l < n_layers; ++l) {
+            const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
+            PLayer& q = PS.L[l];
+            q.qkv_x = reinterpret_cast<const du32x4*>(w[D_QKV_X]); q.wfc_x = reinterpret_cast<const du32x4*>(w[D_WFC_X]);
+            q.q_x = reinterpret_cast<const du32x4*>(w[D_Q_X]); q.wfc2_x = reinterpret_cast<const du32x4*>(w[D_WFC2_X]);
+            q.w1_x = reinterpret_cast<const du32x4*>(w[D_W1_X]); q.w2_x = reinterpret_cast<const du32x4*>(w[D_W2_X]);
+            q.qkv_cs = w[D_QKV_CS]; q.qkv_b = w[D_QKV_B]; q.bfc = w[D_BFC]; q.q_cs = w[D_Q_CS]; q.q_b = w[D_Q_B];
+            q.bfc2 = w[D_BFC2]; q.w1_cs = w[D_W1_CS]; q.w1_b = w[D_W1_B]; q.b2 = w[D_B2];
+            q.Kx = Kx[l]; q.Vx = Vx[l]; q.Kc = Kc[l]; q.Vc = Vc[l];
+        }
+        PS.n_layers = n_layers;
+        PS.a = a; PS.qkv = qkv; PS.hid = hid; PS.logits = logits;
+        PS.cls_x = reinterpret_cast<const du32x4*>(cls_x); PS.cls_cs = cls_colsum; PS.cls_b = b_cls; PS.num_out = num_out;
+        PS.emb = emb; PS.pos = pos_table; PS.tokens = tokens; PS.Lt = Lt; PS.out = out; PS.greedy = greedy; PS.pad_idx = padding_idx;
+        PS.valid_len = valid_len; PS.N = N; PS.C = C; PS.T = T; PS.H = H; PS.d_inner = d_inner; PS.Lsteps = L; PS.Lmax = L;
+        PS.err = pcounters + (size_t)(N + 31) / 32 * 32;
+        PS.pairs = 2;
+        PS.trace = g_head_trace;
+        if (hipMemsetAsync(pcounters, 0, ((size_t)(N + 31) / 32 * 32 + 64) * sizeof(int), st) != hipSuccess)
+            return tpspp::check_launch("tpspp_nrtr_decoder_fwd(memset)");
+        auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2> : dec_step_persist_kernel<unsigned short, 4>)
+                        : (d_inner == 256 ? dec_step_persist_kernel<float, 2> : dec_step_persist_kernel<float, 4>);
+        static bool attr_done[4][tpspp::kMaxDevices] = {};
+        if (tpspp::first_use_on_device(attr_done[(b16 ? 2 : 0) + (d_inner == 256 ? 0 : 1)])) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared));
+            (void)hipGetLastError();
+        }
+        hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table, tokens, Lt, 0, C,
+                           N, x, 1);
+        const int per_step = 8 * n_layers + 2;                 // cluster barriers of one step
+        for (int s = 0; s < L; ++s) {
+            PS.x = x; PS.y = y; PS.step = s; PS.bar_base = s * per_step;
+            for (int n0 = 0; n0 < N; n0 += 512) {              // <= 256 workgroups per launch: every cluster resident
+                const int nimg = N - n0 < 512 ? N - n0 : 512;
+                PS.n0 = n0; PS.counters = pcounters + (n0 >> 5) * 32;
+                hipLaunchKernelGGL(kern, dim3((unsigned)((nimg + 31) / 32 * 16)), dim3(512), sizeof(PShared), st, PS);
+            }
+            if (n_layers & 1) { float* t = x; x = y; y = t; }  // (the kernel swaps x / y once per layer)
+            if (s + 1 < L) { float* t = x; x = y; y = t; }     // the next step's embedding went to y
+        }
+        if (tokens_out)
+            (void)hipMemcpyAsync(tokens_out, tokens, (size_t)N * Lt * sizeof(int), hipMemcpyDeviceToDevice, st);
+        return tpspp::check_launch("tpspp_nrtr_decoder_fwd(persistent step)");
+    }
     for (int s = 0; s < L && fast; ++s) {
         if (s == 0)
             hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table,

@@ -1,0 +1,456 @@
+// The greedy decoder's STEP as one persistent launch (round 5).  Included by tpspp_head.hip
+// inside its anonymous namespace (it reuses the step kernels' device code: Wide<>, self_attend, cross_attend, DGemm).
+//
+// Replaces, per decoding step: mmocr/models/textrecog/decoders/nrtr_decoder.py:153-177 (one position through
+// `_attention` + classifier + soft-max / arg-max) = 6 x common/layers/transformer_layers.py:133-163 -- the same
+// arithmetic, in the same order, as the launch-per-phase pipeline of tpspp_nrtr_decoder_fwd (its 50 launches per step):
+// scores are BIT-IDENTICAL to that pipeline (tests/test_gpu_head.py).
+//
+// Why one launch: a step is a chain of 50 dependent phases of 4-9 us each, and every launch pays 2.8 us before its first
+// instruction plus 1.35 us of gap (scripts/ubench/gemm_chain_bench.hip: 6.35 us per dependent projection launch).  The
+// images of a batch are independent, so a phase only ever needs data of its own 32 images: the 16 workgroups that own a
+// 32-image token block ("cluster") synchronise among themselves, clusters never talk to each other, and nothing needs a
+// grid-wide barrier.  scripts/ubench/persist_chain_bench.hip (the projection chain in this form): cluster barrier 0.7 us,
+// whole phase 4.2 us against 6.35.
+//
+// Mechanics (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+//   * everything a phase hands to the next one (x, y, a, q|k|v, hidden, logits) is written with system-scope
+//     write-through stores (sc0 sc1), drained (vmcnt(0)) before the workgroup arrives at the barrier, and read with
+//     system-scope loads -- no release / acquire fences (a fence writes back / invalidates whole caches: 1.7-6.5 us each);
+//   * barrier = one relaxed agent-scope atomic on the cluster's counter (monotonic over the whole batch: target = 16 x
+//     barriers so far) + a bounded poll with s_sleep by one lane; a timeout raises *err, poisons nothing else and the
+//     workgroup leaves (no hang: the GPU box survives a protocol bug);
+//   * a projection's weight tile (64-192 KB per workgroup, read-only) is requested BEFORE the barrier, its activations
+//     after it: the 32 x K block of the cluster arrives as whole rows (1 KB per wavefront instruction) and is re-read from
+//     LDS in the matrix core's fragment order (partial-line system-scope loads cost 0.8 us more per phase);
+//   * read-only operands (weights, encoder keys / values) and the self-attention caches (written by this launch, read by
+//     LATER launches only) use plain accesses.
+// One launch per step (40 per batch), 512 threads per workgroup: wavefronts 0-3 run the projections exactly as
+// dec_gemm_x3_kernel does (4-way split K), all 8 run the attentions (two (image, head) pairs each).  Workgroup w of a
+// cluster owns output tile w of a projection (tiles 3 w .. 3 w + 2 of q|k|v) and images 2 w, 2 w + 1 in the attentions.
+// A cluster's workgroups are consecutive in launch order (complete clusters become resident together); at most 512
+// images per launch (256 workgroups, one per CU): larger batches run as several launches per step.
+#pragma once
+#ifndef PGEMM_INLINE
+#define PGEMM_INLINE __forceinline__
+#endif
+#ifndef PATTN_INLINE
+#define PATTN_INLINE __forceinline__
+#endif
+
+struct PLayer {
+    const du32x4 *qkv_x, *wfc_x, *q_x, *wfc2_x, *w1_x, *w2_x;   // arranged hi / lo weights (ops.arrange_x3)
+    const float *qkv_cs, *qkv_b, *bfc, *q_cs, *q_b, *bfc2, *w1_cs, *w1_b, *b2;
+    const void *Kx, *Vx;        // encoder keys / values of the layer, token-major (fp32 or bf16)
+    void *Kc, *Vc;              // self-attention caches
+};
+constexpr int kPMaxLayers = 8;
+
+struct PStep {
+    PLayer L[kPMaxLayers];
+    int n_layers;
+    float *x, *y, *a, *qkv, *hid, *logits;    // step buffers (token-major), exchanged inside the launch
+    const du32x4* cls_x; const float* cls_cs; const float* cls_b; int num_out;
+    const float *emb, *pos;
+    int* tokens; int Lt; float* out; int greedy; int pad_idx;
+    const int* valid_len;
+    int N, n0, C, T, H, d_inner, step, Lsteps, Lmax;   // images [n0, n0 + up to 512) of N
+    int* counters; int bar_base;              // cluster counters (128 B apart), barriers passed before this launch
+    int pairs;                                // (image, head) pairs per wavefront in the attention phases (2; a run-time value: the
+                                              // pair loop must stay a loop -- unrolled, the compiler interleaves two attentions' registers)
+    int* err;
+    long long* trace;                         // optional (tpspp_head_set_trace): 64 wall-clock stamps (100 MHz) per workgroup and step
+};
+
+constexpr int kPXPitch = 516;                 // floats per staged X row (512 + 4: fragment reads hit all banks)
+
+// ---- cluster barrier ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cluster_barrier(int* cnt, int target, int* sFlag, int* err)
+{
+    __syncthreads();                                         // every wavefront has drained its stores (drain_stores())
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 21); ++spin) {
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sFlag = ok;
+    }
+    __syncthreads();
+    return *sFlag != 0;
+}
+
+// ---- a projection phase: out (M, Co) = act(LN?(X) W + bias) [+ res] for the cluster's 32 tokens, tiles ct0 .. ct0 + NT - 1.
+// The arithmetic is dec_gemm_x3_kernel's, instruction for instruction (same fragments, k order, three-term products,
+// reduction order, LayerNorm statistics, epilogue); what differs: X arrives as rows -> LDS -> fragments, a workgroup's
+// tiles are worked off one after the other (the next tile's weights are requested under the current tile's products: two
+// tiles of weights in registers instead of three -- a 512-thread workgroup has 256 registers per lane), stores are
+// system-scope.  Called by ALL 8 wavefronts (the barriers count every wavefront); wavefronts 0 - 3 do the products.
+struct PGemm {
+    const float* X; const du32x4* Wp; const float* bias; const float* colsum; const float* res; float* out;
+    int M, Co; float eps; int act;
+    int ldo;                    // row pitch of `out` and `res` in floats (Co, except the q projection: see the step kernel)
+};
+
+// KSW = 16-wide k-steps per wavefront = K / 128: the EIGHT wavefronts of the workgroup split K (the launch-per-phase kernel
+// splits it over four: a 512-thread workgroup has 256 registers per lane, and with an eighth of K per wavefront the weights
+// of all three q|k|v tiles -- 96 registers -- can be requested before the barrier)
+template <int KSW>
+__device__ __forceinline__ void pgemm_load_w(du32x4 (&ah)[KSW], du32x4 (&al)[KSW], const PGemm& G, int ct, int wv, int half, int l31)
+{
+    constexpr int KS = 8 * KSW;                             // 16-wide k-steps of the whole K
+    const du32x4* wp = G.Wp + ((size_t)(ct * KS + wv * KSW) * 4 + half) * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) { ah[j] = wp[(size_t)j * 128]; al[j] = wp[(size_t)j * 128 + 64]; }
+}
+
+// all 8 wavefronts: the cluster's 32 x K block of X (rows m0 .. m0 + 31, clamped to M - 1) -> sX
+template <int K>
+__device__ __forceinline__ void stage_rows(const float* X, int m0, int M, float* sX, int wv8, int lane)
+{
+    // row = 4 K bytes = K / 256 wavefront instructions of 1 KB; wavefront w: rows 4 w .. 4 w + 3
+    constexpr int PPR = K / 256;                             // pieces per row
+    hf32x4 t[4 * PPR];
+#pragma unroll
+    for (int i = 0; i < 4 * PPR; ++i) {
+        const int r = 4 * wv8 + i / PPR;
+        const int m = m0 + r < M ? m0 + r : M - 1;
+        t[i] = ld16_sys(X + (size_t)m * K + 256 * (i % PPR) + 4 * lane);
+    }
+    if constexpr (PPR == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3])::"memory");
+#pragma unroll
+    for (int i = 0; i < 4 * PPR; ++i)
+        *reinterpret_cast<hf32x4*>(&sX[(4 * wv8 + i / PPR) * kPXPitch + 256 * (i % PPR) + 4 * lane]) = t[i];
+}
+
+struct PShared {
+    float sX[32 * kPXPitch];
+    float sRed[8][16][kWave];
+    float sS1[16][32], sS2[16][32];
+    int flag;
+};
+
+// One projection phase, called by all 8 wavefronts.  Returns false after a barrier timeout.
+// Differences from dec_gemm_x3_kernel in the arithmetic: K is split over 8 wavefronts instead of 4, so the 8 partial sums
+// of an output meet as ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) and the LayerNorm sums as 16 partials in ascending
+// order -- the last bits of a result may differ from the launch-per-phase pipeline's (tests: <= 2e-6 of the scores).
+template <int KSW, bool LN, int NT>
+__device__ PGEMM_INLINE bool pgemm_phase(const PGemm& G, int tb, int ct0, PShared& S, int* cnt, int target, int* err)
+{
+    constexpr int K = 128 * KSW;
+    // (opaque per phase: otherwise the compiler hoists every phase's lane-dependent addresses out of the layer loop and
+    // spills them -- 78 scratch stores in the prologue)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (G.Co + 31) >> 5;
+    const bool wg_active = ct0 < ntiles;                   // (w1: 8 tiles, classifier: 3 -- the other workgroups only pass the barrier)
+    const int m0 = tb * 32;                                 // (tb: the cluster's token block in the whole batch)
+    du32x4 ah[NT][KSW], al[NT][KSW];
+    if (wg_active) {                                        // before the barrier: the weights depend on nothing
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl)
+            pgemm_load_w<KSW>(ah[tl], al[tl], G, ct0 + tl < ntiles ? ct0 + tl : ntiles - 1, wv, half, l31);
+    }
+    if (!cluster_barrier(cnt, target, &S.flag, err)) return false;
+    if (!wg_active) return true;
+    stage_rows<K>(G.X, m0, G.M, S.sX, wv, lane);
+    __syncthreads();
+    const int m = m0 + l31;
+    const int mc = m < G.M ? m : G.M - 1;
+    float s1 = 0.0f, s2 = 0.0f, mean = 0.0f, rstd = 1.0f;
+    const float* xs = S.sX + l31 * kPXPitch + 16 * (wv * KSW) + 8 * half;
+    // the lane's B fragments (hi / lo halves of its 8 k per k-step) once, for every tile
+    du32x4 bh[KSW], bl[KSW];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + 16 * j), x1 = *reinterpret_cast<const float4*>(xs + 16 * j + 4);
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned pk = dpack2(x[2 * q], x[2 * q + 1]);
+            const float h0 = __builtin_bit_cast(float, pk << 16), h1 = __builtin_bit_cast(float, pk & 0xffff0000u);
+            bh[j][q] = pk;
+            bl[j][q] = dpack2(x[2 * q] - h0, x[2 * q + 1] - h1);
+            if (LN) {
+                s1 += x[2 * q] + x[2 * q + 1];
+                s2 = fmaf(x[2 * q], x[2 * q], s2);
+                s2 = fmaf(x[2 * q + 1], x[2 * q + 1], s2);
+            }
+        }
+    }
+    if (LN) { S.sS1[wv * 2 + half][l31] = s1; S.sS2[wv * 2 + half][l31] = s2; }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const int ct = ct0 + tl;
+        const int c = ct * 32 + 8 * (wv & 3) + 4 * half;
+        // wavefronts 0 - 3 finish the tile: accumulator registers 4 w .. 4 w + 3 = outputs 32 ct + 8 w + 4 half + (0 .. 3) of token l31
+        const bool mine = wv < 4 && ct < ntiles && m < G.M && c < G.Co;
+        const size_t o = (size_t)mc * G.ldo + (c < G.Co ? c : 0);
+        hf32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), bb = c4;
+        if (mine) {
+            // (compiler-visible system-scope loads: an inline-asm load whose wait sits far away may have its destination
+            // register copied by the compiler before the data has arrived)
+            if (G.res) {
+                const unsigned long long* rp = reinterpret_cast<const unsigned long long*>(G.res + o);
+                const unsigned long long lo = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                r4[0] = __builtin_bit_cast(float, (unsigned)lo); r4[1] = __builtin_bit_cast(float, (unsigned)(lo >> 32));
+                r4[2] = __builtin_bit_cast(float, (unsigned)hi); r4[3] = __builtin_bit_cast(float, (unsigned)(hi >> 32));
+            }
+            if (LN) c4 = *reinterpret_cast<const float4*>(G.colsum + c);
+            if (G.bias) bb = *reinterpret_cast<const float4*>(G.bias + c);
+        }
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KSW; ++j) {
+            const dbf16x8 Bh = __builtin_bit_cast(dbf16x8, bh[j]), Bl = __builtin_bit_cast(dbf16x8, bl[j]);
+            const dbf16x8 Ah = __builtin_bit_cast(dbf16x8, ah[tl][j]), Al = __builtin_bit_cast(dbf16x8, al[tl][j]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S.sRed[wv][r][lane] = acc[r];
+        __syncthreads();
+        if (LN && tl == 0) {
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { t1 += S.sS1[j][l31]; t2 += S.sS2[j][l31]; }
+            mean = t1 / (float)K;
+            rstd = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean * mean, 0.0f) + G.eps);
+        }
+        if (mine) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * wv + e;
+                v[e] = ((S.sRed[0][r][lane] + S.sRed[1][r][lane]) + (S.sRed[2][r][lane] + S.sRed[3][r][lane])) +
+                       ((S.sRed[4][r][lane] + S.sRed[5][r][lane]) + (S.sRed[6][r][lane] + S.sRed[7][r][lane]));
+            }
+            if (LN) {
+                v[0] = rstd * (v[0] - mean * c4.x); v[1] = rstd * (v[1] - mean * c4.y);
+                v[2] = rstd * (v[2] - mean * c4.z); v[3] = rstd * (v[3] - mean * c4.w);
+            }
+            if (G.bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+            if (G.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            }
+            if (G.res) { v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+            st16_sys(G.out + o, hf32x4{v[0], v[1], v[2], v[3]});
+        }
+        if (tl + 1 < NT) __syncthreads();                  // the partial sums have been read: sRed is free for the next tile
+    }
+    drain_stores();
+    return true;
+}
+
+// ---- the attention phases (their own functions: each gets its own register allocation) -------------------------------------
+template <typename KV>
+__device__ PATTN_INLINE void pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
+{
+    asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
+#pragma unroll 1
+    for (int i = 0; i < P.pairs; ++i)
+        self_attend<KV, true>(P.qkv, P.C, P.N, P.H, P.step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
+                              P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0 + i, lane);
+    drain_stores();
+}
+
+template <typename KV>
+__device__ PATTN_INLINE void pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
+{
+    asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
+    typedef Wide<KV> Wd;
+    constexpr int EPL = Wd::EPL, GS = kDK / EPL;
+    int nvalid = P.valid_len ? P.valid_len[ab] : P.T;
+    nvalid = nvalid < P.T ? nvalid : P.T;
+    const int dl = lane % GS;
+#pragma unroll 1
+    for (int i = 0; i < P.pairs; ++i) {
+        const int h = ah0 + i;
+        hf32x4 rq[EPL / 4];
+#pragma unroll
+        for (int e = 0; e < EPL / 4; ++e) rq[e] = ld16_sys(P.qkv + (size_t)ab * 3 * P.C + kDK * h + EPL * dl + 4 * e);      // (q: pitch 3 C, see the step kernel)
+#pragma unroll
+        for (int e = 0; e < EPL / 4; ++e) wait_sys(rq[e]);
+        float q[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = rq[e >> 2][e & 3] * 0.125f;
+        if (P.T <= kWave)
+            cross_attend<KV, true, 1>(q, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.N, P.T, nvalid,
+                                      ab, h, lane, P.a, 0);
+        else
+            cross_attend<KV, true, 4>(q, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.N, P.T, nvalid,
+                                      ab, h, lane, P.a, 0);
+    }
+    drain_stores();
+}
+
+// ---- the step ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ld4_sys(const float* p)
+{
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// KSW2 = d_inner / 128 (2 or 4).  grid = clusters x 16 workgroups of 512 threads; dynamic LDS = sizeof(PShared).
+template <typename KV, int KSW2>
+__global__ void __launch_bounds__(512)
+dec_step_persist_kernel(const PStep P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char p_smem[];
+    PShared& S = *reinterpret_cast<PShared*>(p_smem);
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb = blockIdx.x >> 4, ct = blockIdx.x & 15;      // cluster (32 images), workgroup within it
+    int* cnt = P.counters + tb * 32;
+    int bar = P.bar_base;
+    const int N = P.N, C = P.C, H = P.H;
+    const int tbg = (P.n0 >> 5) + tb;                         // the cluster's token block in the whole batch
+    float *x = P.x, *y = P.y;
+    // this wavefront's two (image, head) pairs in the attention phases: images 2 ct + (wv >> 2), heads 2 (wv & 3) + {0, 1}
+    const int ab = tbg * 32 + 2 * ct + (wv >> 2);
+    const int ah0 = 2 * (wv & 3);
+
+    int stamp_i = 0;
+    auto stamp = [&]() {                                       // (diagnostics: end of a phase on this workgroup, before the next barrier)
+        if (P.trace && tid == 0 && stamp_i < 64) P.trace[((size_t)P.step * gridDim.x + blockIdx.x) * 64 + stamp_i] = (long long)wall_clock64();
+        ++stamp_i;
+    };
+    stamp();
+    auto fail = [&]() {
+        // barrier timeout: make it loud -- this step's scores of the workgroup's images become NaN
+        if (wv < 2) {
+            const int b = tbg * 32 + 2 * ct + wv;
+            if (b < N) for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + P.step) * P.num_out + c] = __builtin_nanf("");
+        }
+    };
+
+    for (int l = 0; l < P.n_layers; ++l) {
+        const PLayer& W = P.L[l];
+        // 1. q | k | v = LN1(x) Wqkv                                              transformer_layers.py:150-151
+        {
+            const PGemm G{x, W.qkv_x, W.qkv_b, W.qkv_cs, nullptr, P.qkv, N, 3 * C, 1e-5f, 0, 3 * C};
+            if (!pgemm_phase<4, true, 3>(G, tbg, 3 * ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        }
+        stamp();
+        // 2. cached self-attention -> a
+        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
+#ifndef PBISECT_NO_SELF
+        if (ab < N) pself_phase<KV>(P, W, ab, ah0, lane);
+#endif
+        stamp();
+        // 3. y = x + fc(a)                                                         transformer_layers.py:152-154
+        {
+            const PGemm G{P.a, W.wfc_x, W.bfc, nullptr, x, y, N, C, 0.0f, 0, C};
+            if (!pgemm_phase<4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        }
+        stamp();
+        // 4. q = LN2(y) Wq                                                         transformer_layers.py:156-157
+        {
+            // (q goes into the first C columns of the image's OWN q|k|v row, pitch 3 C: the launch pipeline packs q rows at pitch C
+            // into the same buffer, which there is safe -- every image is past its self-attention -- and here would let one
+            // cluster's q overwrite another cluster's q|k|v rows: clusters are not synchronised with each other)
+            const PGemm G{y, W.q_x, W.q_b, W.q_cs, nullptr, P.qkv, N, C, 1e-5f, 0, 3 * C};
+            if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        }
+        stamp();
+        // 5. cross-attention against the encoder keys / values -> a
+        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
+#ifndef PBISECT_NO_CROSS
+        if (ab < N) pcross_phase<KV>(P, W, ab, ah0, lane);
+#endif
+        stamp();
+        // 6. x = y + fc(a)                                                         transformer_layers.py:158-159
+        {
+            const PGemm G{P.a, W.wfc2_x, W.bfc2, nullptr, y, x, N, C, 0.0f, 0, C};
+            if (!pgemm_phase<4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        }
+        stamp();
+        // 7. hidden = gelu(LN3(x) W1 + b1)                                         transformer_layers.py:161-162
+        {
+            const PGemm G{x, W.w1_x, W.w1_b, W.w1_cs, nullptr, P.hid, N, P.d_inner, 1e-5f, 2, P.d_inner};
+            if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        }
+        stamp();
+        // 8. y = x + W2 hidden + b2                                                transformer_layers.py:162-163
+        {
+            const PGemm G{P.hid, W.w2_x, W.b2, nullptr, x, y, N, C, 0.0f, 0, C};
+            if (!pgemm_phase<KSW2, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        }
+        stamp();
+        float* t = x; x = y; y = t;
+    }
+    // final LayerNorm (eps 1e-6) folded into the classifier                       nrtr_decoder.py:77,111 + :78
+    {
+        const PGemm G{x, P.cls_x, P.cls_b, P.cls_cs, nullptr, P.logits, N, P.num_out, 1e-6f, 0, P.num_out};
+        if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+    }
+    stamp();
+    // soft-max / arg-max of the step, the next step's embedding row (dec_classify_kernel, one wavefront per image)
+    if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
+    if (wv < 2) {
+        const int b = tbg * 32 + 2 * ct + wv;
+        if (b < N) {
+            const int Cc = P.num_out;                          // (<= 128: two classes per lane)
+            const float* lg = P.logits + (size_t)b * Cc;
+            float v0 = -INFINITY, v1 = -INFINITY;
+            if (lane < Cc) v0 = ld4_sys(lg + lane);
+            if (lane + kWave < Cc) v1 = ld4_sys(lg + lane + kWave);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+            float* o = P.out + ((size_t)b * P.Lsteps + P.step) * Cc;
+            const bool more = P.step + 1 < P.Lsteps;
+            // the next step's embedding goes to y (which becomes the next launch's x: the host swaps as the launch path does)
+            auto embed_next = [&](int tok) {
+                if (more) {
+                    const float* er = P.emb + (size_t)tok * C;
+                    const float* pr = P.pos + (size_t)(P.step + 1) * C;
+                    // (system-scope stores as well: a plain store leaves the line in this XCD's L2, and the NEXT launch's
+                    // system-scope loads of the row -- after another XCD has rewritten it -- were served from that stale line)
+                    for (int c = 4 * lane; c < C; c += 4 * kWave) {
+                        const float4 e4 = *reinterpret_cast<const float4*>(er + c), p4 = *reinterpret_cast<const float4*>(pr + c);
+                        st16_sys(y + (size_t)b * C + c, hf32x4{e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w});
+                    }
+                }
+            };
+            if (!P.greedy) {
+                if (lane < Cc) o[lane] = v0;
+                if (lane + kWave < Cc) o[lane + kWave] = v1;
+                embed_next(P.tokens[(size_t)b * P.Lt + P.step + 1]);
+            } else {
+                // first maximum: the same comparison sequence as dec_classify_kernel (ascending classes per lane, then the butterfly)
+                float mx = -INFINITY;
+                int am = 0x7fffffff;
+                if (lane < Cc && v0 > mx) { mx = v0; am = lane; }
+                if (lane + kWave < Cc && v1 > mx) { mx = v1; am = lane + kWave; }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(mx, off, kWave);
+                    const int oi = __shfl_xor(am, off, kWave);
+                    if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+                }
+                float sum = 0.0f;
+                if (lane < Cc) sum += expf(v0 - mx);
+                if (lane + kWave < Cc) sum += expf(v1 - mx);
+                sum = wave_sum(sum);
+                if (lane < Cc) o[lane] = expf(v0 - mx) / sum;
+                if (lane + kWave < Cc) o[lane + kWave] = expf(v1 - mx) / sum;
+                if (lane == 0) P.tokens[(size_t)b * P.Lt + P.step + 1] = am;
+                embed_next(am);
+            }
+        }
+    }
+}
