@@ -42,3 +42,12 @@ for k, nm in enumerate(names):
           f"{np.median(per[1, :, :, k]):.2f} / {np.median(per[20, :, :, k]):.2f} / {np.median(per[39, :, :, k]):.2f}")
 print(f"  classifier   median {np.median(d[:, :, 48]):6.2f} us")
 print(f"  sum of layer-phase medians x 6 = {6 * sum(np.median(per[:, :, :, k]) for k in range(8)):.1f} us")
+
+# sub-stamps (shader clock ticks; 100 MHz s_memtime on this chip? printed raw) of layer 2's x+fc and LN+q phases:
+# [entry (weights requested), barrier passed, X staged, epilogue stored, stores drained]
+raw = buf.cpu().numpy()
+for nm, o in (("x+fc ", 50), ("LN+q ", 56)):
+    sub = raw[:, :, o:o + 5].astype(np.float64)
+    dd = np.diff(sub, axis=2)
+    print(f"  {nm} sub-phases (s_memtime ticks): barrier {np.median(dd[:, :, 0]):.0f}  staging {np.median(dd[:, :, 1]):.0f}  "
+          f"product+epilogue {np.median(dd[:, :, 2]):.0f}  drain {np.median(dd[:, :, 3]):.0f}   total {np.median(sub[:, :, 4] - sub[:, :, 0]):.0f}")

@@ -411,6 +411,16 @@ __device__ __forceinline__ void wait_sys(hf32x4& a, hf32x4& b, hf32x4& c)
 {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)::"memory");
 }
+// the same load as two 8-byte system-scope atomic loads: VISIBLE to the compiler (it tracks their wait count itself and may
+// schedule them among other loads) -- for small operands whose latency should overlap other requests
+__device__ __forceinline__ hf32x4 ld16_sys_v(const float* p)
+{
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return hf32x4{__builtin_bit_cast(float, (unsigned)lo), __builtin_bit_cast(float, (unsigned)(lo >> 32)),
+                  __builtin_bit_cast(float, (unsigned)hi), __builtin_bit_cast(float, (unsigned)(hi >> 32))};
+}
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <typename KV> struct Wide;
@@ -533,6 +543,98 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
     }
 }
 
+// cross-attention of image b, heads h and h + 1, by one wavefront, T <= 64 encoder tokens: cross_attend's arithmetic per head
+// (same fragments, same reduction order), every stage run for BOTH heads before the next one starts -- the keys of both heads
+// are in flight together, then the values of both (8 wavefronts per CU must keep as many requests outstanding as the 16 of
+// the launch form; in the launch form itself two heads per wavefront measured 22-23 us per launch against 28.6 with one).
+// SYS: q via compiler-visible system-scope loads, output system-scope (the persistent step kernel).
+template <typename KV, bool SYS>
+__device__ __forceinline__ void cross_attend2(const float* __restrict__ qrow, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
+                                              int C, int T, int nvalid, int b, int h, int lane, float* __restrict__ out)
+{
+    typedef Wide<KV> Wd;
+    constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI, NH = 2;
+    const int grp = lane / GS, dl = lane % GS;
+    const size_t rstride = (size_t)C / EPL;                // row pitch in raw pieces
+    typename Wd::raw kr[NH][NP], vr[NH][NP];
+    float q[NH][EPL], sc[NH][NP], inv[NH];
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        const typename Wd::raw* kb = reinterpret_cast<const typename Wd::raw*>(Kx_t + ((size_t)b * T) * C + kDK * (h + n) + EPL * dl);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {                     // every key piece of both heads in flight together
+            const int t = TPI * i + grp;
+            kr[n][i] = kb[(size_t)(t < T ? t : T - 1) * rstride];
+        }
+#pragma unroll
+        for (int e = 0; e < EPL / 4; ++e) {
+            const float* qp = qrow + kDK * (h + n) + EPL * dl + 4 * e;
+            const hf32x4 rq = SYS ? ld16_sys_v(qp) : *reinterpret_cast<const hf32x4*>(qp);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[n][4 * e + i] = rq[i] * 0.125f;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float kf[EPL];
+            Wd::unpack(kr[n][i], kf);
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s = fmaf(q[n][e], kf[e], s);
+            s = group_sum<GS>(s);
+            const int t = TPI * i + grp;
+            sc[n][i] = t < nvalid ? s : -INFINITY;
+            mx = fmaxf(mx, sc[n][i]);
+        }
+        mx = across_groups_max<GS>(mx);
+        float l = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            sc[n][i] = sc[n][i] == -INFINITY ? 0.0f : expf(sc[n][i] - mx);
+            l += sc[n][i];
+        }
+        l = across_groups_sum<GS>(l);
+        inv[n] = 1.0f / l;
+    }
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        const typename Wd::raw* vb = reinterpret_cast<const typename Wd::raw*>(Vx_t + ((size_t)b * T) * C + kDK * (h + n) + EPL * dl);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int t = TPI * i + grp;
+            vr[n][i] = vb[(size_t)(t < T ? t : T - 1) * rstride];
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        float acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float vf[EPL];
+            Wd::unpack(vr[n][i], vf);
+            const float pw = sc[n][i] * inv[n];            // 0 for masked tokens
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, vf[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
+        if (grp == 0) {
+            float* o = out + (size_t)b * C + kDK * (h + n) + EPL * dl;
+#pragma unroll
+            for (int e = 0; e < EPL; e += 4) {
+                if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+            }
+        }
+    }
+}
+
+
 // cross-attention: q_t (Nb, C), Kx_t / Vx_t (Nb*T, C) token-major, out (Nb, C) token-major.  One wavefront per (image, head).
 template <typename KV>
 __global__ void __launch_bounds__(256)
@@ -553,12 +655,31 @@ attn_dec_cross_wide_kernel(const float* __restrict__ q_t, const KV* __restrict__
     cross_attend<KV>(q, Kx_t, Vx_t, C, Nb, T, nvalid, b, h, lane, out, out_cm);
 }
 
+// two heads per wavefront (T <= 64, H even, token-major output): q_t rows at pitch `ldq`
+template <typename KV>
+__global__ void __launch_bounds__(256)
+attn_dec_cross_wide2_kernel(const float* __restrict__ q_t, int ldq, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
+                            int C, int Nb, int H, int T, const int* __restrict__ valid_len, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pair2 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (image, head pair)
+    const int H2 = H >> 1;
+    if (pair2 >= Nb * H2) return;
+    const int b = pair2 / H2, h = 2 * (pair2 - b * H2);
+    int nvalid = valid_len ? valid_len[b] : T;
+    nvalid = nvalid < T ? nvalid : T;
+    cross_attend2<KV, false>(q_t + (size_t)b * ldq, Kx_t, Vx_t, C, T, nvalid, b, h, lane, out);
+}
+
+
 // masked self-attention against token-major caches Kc / Vc [image][head][position][64]; qkv_t (Nb, 3C); out (Nb, C).
 // The new position's key / value are used from registers (fp32) and appended to the caches.
-// One (image b, head h) by one wavefront.  SYS (the persistent step kernel): this step's q | k | v row and the output
-// are exchanged with other workgroups of the same launch -- system-scope accesses; the caches belong to earlier / later
-// launches and stay plain.
-template <typename KV, bool SYS>
+// NH consecutive heads h .. h + NH - 1 of image b by one wavefront (NH = 1: the launch-per-phase kernel; 2: the persistent
+// step kernel, whose 8 wavefronts per CU need both heads' requests in flight together to keep the memory system as busy as
+// the 16 wavefronts per CU of the launch form do -- every stage below runs over the NH heads before the next stage starts).
+// SYS (the persistent step kernel): this step's q | k | v row and the output are exchanged with other workgroups of the same
+// launch -- system-scope accesses; the caches belong to earlier / later launches and stay plain.
+template <typename KV, bool SYS, int NH = 1>
 __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
                                             KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
                                             int pad_idx, float* __restrict__ out, int out_cm, int b, int h, int lane)
@@ -566,23 +687,27 @@ __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;
     const int grp = lane / GS, dl = lane % GS;
-    const float* base = qkv_t + (size_t)b * 3 * C + kDK * h + EPL * dl;
-    float q[EPL], k[EPL], v[EPL];
-    if (SYS) {
-        hf32x4 rq[EPL / 4], rk[EPL / 4], rv[EPL / 4];
+    float q[NH][EPL], k[NH][EPL], v[NH][EPL];
+    typename Wd::raw *kc[NH], *vc[NH];
 #pragma unroll
-        for (int e = 0; e < EPL / 4; ++e) { rq[e] = ld16_sys(base + 4 * e); rk[e] = ld16_sys(base + C + 4 * e); rv[e] = ld16_sys(base + 2 * C + 4 * e); }
+    for (int n = 0; n < NH; ++n) {
+        const float* base = qkv_t + (size_t)b * 3 * C + kDK * (h + n) + EPL * dl;
+        if (SYS) {
+            // (compiler-visible system-scope loads: they stay in flight together with the cache rows requested below)
 #pragma unroll
-        for (int e = 0; e < EPL / 4; ++e) wait_sys(rq[e], rk[e], rv[e]);
+            for (int e = 0; e < EPL / 4; ++e) {
+                const hf32x4 rq = ld16_sys_v(base + 4 * e), rk = ld16_sys_v(base + C + 4 * e), rv = ld16_sys_v(base + 2 * C + 4 * e);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { q[e] = rq[e >> 2][e & 3] * 0.125f; k[e] = rk[e >> 2][e & 3]; v[e] = rv[e >> 2][e & 3]; }
-    } else {
+                for (int i = 0; i < 4; ++i) { q[n][4 * e + i] = rq[i] * 0.125f; k[n][4 * e + i] = rk[i]; v[n][4 * e + i] = rv[i]; }
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) { q[e] = base[e] * 0.125f; k[e] = base[C + e]; v[e] = base[2 * C + e]; }
+            for (int e = 0; e < EPL; ++e) { q[n][e] = base[e] * 0.125f; k[n][e] = base[C + e]; v[n][e] = base[2 * C + e]; }
+        }
+        const size_t bh = (size_t)b * H + h + n;
+        kc[n] = reinterpret_cast<typename Wd::raw*>(Kc + bh * Lmax * kDK + EPL * dl);
+        vc[n] = reinterpret_cast<typename Wd::raw*>(Vc + bh * Lmax * kDK + EPL * dl);
     }
-    const size_t bh = (size_t)b * H + h;
-    typename Wd::raw* kc = reinterpret_cast<typename Wd::raw*>(Kc + bh * Lmax * kDK + EPL * dl);
-    typename Wd::raw* vc = reinterpret_cast<typename Wd::raw*>(Vc + bh * Lmax * kDK + EPL * dl);
     constexpr int rstride = GS;                            // a cached row is GS pieces
 
     // Every load of the wavefront is requested here, before the first use of any of them: the cached keys AND values of the
@@ -594,8 +719,8 @@ __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int
     // instead of four, i.e. a second, nearly empty round of the 4096 wavefronts: 16.7 us against 13.4; their values stay
     // behind the softmax.  bf16 caches: 123 registers, 9.2 -> 8.9 us.)
     constexpr bool kValuesEarly = sizeof(KV) == 2;
-    float sc[NP];
-    typename Wd::raw kr[NP], vr[NP];
+    float sc[NH][NP];
+    typename Wd::raw kr[NH][NP], vr[NH][NP];
     int tk[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -603,81 +728,97 @@ __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int
         tk[i] = pad_idx;
         if (TPI * i <= step) tk[i] = tokens[(size_t)b * Lt + (p <= step ? p : 0)];   // (uniform tests: whole pieces beyond `step` are skipped)
         if (TPI * i < step) {
-            kr[i] = kc[(size_t)(p < step ? p : 0) * rstride];
-            if (kValuesEarly) vr[i] = vc[(size_t)(p < step ? p : 0) * rstride];
+#pragma unroll
+            for (int n = 0; n < NH; ++n) {
+                kr[n][i] = kc[n][(size_t)(p < step ? p : 0) * rstride];
+                if (kValuesEarly) vr[n][i] = vc[n][(size_t)(p < step ? p : 0) * rstride];
+            }
         }
     }
     // the new position's key / value join the caches (rows `step`: never among the rows read above)
-    if (grp == 0) { kc[(size_t)step * rstride] = Wd::pack(k); vc[(size_t)step * rstride] = Wd::pack(v); }
-    float cur = 0.0f;
+    if (grp == 0) {
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) cur = fmaf(q[e], k[e], cur);
-    cur = group_sum<GS>(cur);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int p = TPI * i + grp;
-        float s = -INFINITY;
-        if (TPI * i <= step) {                             // uniform
-            float dot = 0.0f;
-            if (TPI * i < step) {
-                float kf[EPL];
-                Wd::unpack(kr[i], kf);
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) dot = fmaf(q[e], kf[e], dot);
-                dot = group_sum<GS>(dot);
-            }
-            if (p == step) dot = cur;
-            const bool valid = p <= step && tk[i] != pad_idx;
-            s = valid ? dot : -INFINITY;
-        }
-        sc[i] = s;
-        mx = fmaxf(mx, s);
+        for (int n = 0; n < NH; ++n) { kc[n][(size_t)step * rstride] = Wd::pack(k[n]); vc[n][(size_t)step * rstride] = Wd::pack(v[n]); }
     }
-    mx = across_groups_max<GS>(mx);
-    float l = 0.0f;
+    float inv[NH];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { sc[i] = sc[i] == -INFINITY ? 0.0f : expf(sc[i] - mx); l += sc[i]; }
-    l = across_groups_sum<GS>(l);
-    const float inv = 1.0f / l;
-    float acc[EPL];
+    for (int n = 0; n < NH; ++n) {
+        float cur = 0.0f;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
+        for (int e = 0; e < EPL; ++e) cur = fmaf(q[n][e], k[n][e], cur);
+        cur = group_sum<GS>(cur);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int p = TPI * i + grp;
+            float s = -INFINITY;
+            if (TPI * i <= step) {                             // uniform
+                float dot = 0.0f;
+                if (TPI * i < step) {
+                    float kf[EPL];
+                    Wd::unpack(kr[n][i], kf);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) dot = fmaf(q[n][e], kf[e], dot);
+                    dot = group_sum<GS>(dot);
+                }
+                if (p == step) dot = cur;
+                const bool valid = p <= step && tk[i] != pad_idx;
+                s = valid ? dot : -INFINITY;
+            }
+            sc[n][i] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = across_groups_max<GS>(mx);
+        float l = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { sc[n][i] = sc[n][i] == -INFINITY ? 0.0f : expf(sc[n][i] - mx); l += sc[n][i]; }
+        l = across_groups_sum<GS>(l);
+        inv[n] = 1.0f / l;
+    }
     if (!kValuesEarly) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int p = TPI * i + grp;
-            if (TPI * i < step) vr[i] = vc[(size_t)(p < step ? p : 0) * rstride];
-        }
-    }
+            if (TPI * i < step) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int p = TPI * i + grp;
-        if (TPI * i <= step) {
-            const float pw = sc[i] * inv;
-            if (p == step) {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, v[e], acc[e]);
-            } else if (p < step) {
-                float vf[EPL];
-                Wd::unpack(vr[i], vf);
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, vf[e], acc[e]);
+                for (int n = 0; n < NH; ++n) vr[n][i] = vc[n][(size_t)(p < step ? p : 0) * rstride];
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
-    if (grp == 0) {
-        if (out_cm) {                                      // channel-major (C, Nb): the exact-fp32 step GEMMs' operand layout
+    for (int n = 0; n < NH; ++n) {
+        float acc[EPL];
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) out[(size_t)(kDK * h + EPL * dl + e) * Nb + b] = acc[e];
-        } else {
-            float* o = out + (size_t)b * C + kDK * h + EPL * dl;
+        for (int e = 0; e < EPL; ++e) acc[e] = 0.0f;
 #pragma unroll
-            for (int e = 0; e < EPL; e += 4) {
-                if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
-                else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+        for (int i = 0; i < NP; ++i) {
+            const int p = TPI * i + grp;
+            if (TPI * i <= step) {
+                const float pw = sc[n][i] * inv[n];
+                if (p == step) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, v[n][e], acc[e]);
+                } else if (p < step) {
+                    float vf[EPL];
+                    Wd::unpack(vr[n][i], vf);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc[e] = fmaf(pw, vf[e], acc[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = across_groups_sum<GS>(acc[e]);
+        if (grp == 0) {
+            if (out_cm) {                                      // channel-major (C, Nb): the exact-fp32 step GEMMs' operand layout
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) out[(size_t)(kDK * (h + n) + EPL * dl + e) * Nb + b] = acc[e];
+            } else {
+                float* o = out + (size_t)b * C + kDK * (h + n) + EPL * dl;
+#pragma unroll
+                for (int e = 0; e < EPL; e += 4) {
+                    if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                    else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+                }
             }
         }
     }
@@ -1222,6 +1363,8 @@ const bool g_head_no_tokgemm = getenv("TPSPP_HEAD_NO_TOKGEMM") != nullptr;
 const bool g_head_qcross = getenv("TPSPP_HEAD_QCROSS") != nullptr;
 // TPSPP_HEAD_NO_PERSIST=1: the reduced-precision step pipeline as ~50 launches per step (rounds 3-4) instead of ONE persistent
 // launch per step (tpspp_head_persist.h); bit-identical scores -- for A/B runs and the bit-identity test
+// TPSPP_HEAD_CROSS1=1: the cross-attention with one head per wavefront as before round 5 (A/B runs)
+const bool g_head_cross1 = getenv("TPSPP_HEAD_CROSS1") != nullptr;
 bool head_no_persist() { return getenv("TPSPP_HEAD_NO_PERSIST") != nullptr; }
 long long* g_head_trace = nullptr;     // tpspp_head_set_trace
 
@@ -1586,6 +1729,8 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         PS.err = pcounters + (size_t)(N + 31) / 32 * 32;
         PS.pairs = 2;
         PS.trace = g_head_trace;
+        // odd clusters start 15 us late (TPSPP_HEAD_STAGGER_US overrides; 0 = together): bf16x3 20.0 -> 19.4 ms, bf16 15.4 -> 15.0
+        { const char* sv = getenv("TPSPP_HEAD_STAGGER_US"); PS.stagger = (sv ? atoi(sv) : (N > 32 ? 15 : 0)) * 100; }
         if (hipMemsetAsync(pcounters, 0, ((size_t)(N + 31) / 32 * 32 + 64) * sizeof(int), st) != hipSuccess)
             return tpspp::check_launch("tpspp_nrtr_decoder_fwd(memset)");
         auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2> : dec_step_persist_kernel<unsigned short, 4>)
@@ -1641,7 +1786,17 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                     hipLaunchKernelGGL(dec_q_cross_x3_kernel<float>, qgrid, dim3(256), 0, st, Q, Kx[l], Vx[l], H, T, valid_len, a);
             } else {
             dec_gemm_x3(st, y, w[D_Q_X], w[D_Q_B], w[D_Q_CS], 1e-5f, nullptr, 0, N, C, C, qkv, gemm_f32);
-            if (b16)
+            if (T <= kWave && (H & 1) == 0 && !g_head_cross1) {
+                // two heads per wavefront (round 5): both heads' keys, then both heads' values in flight together
+                const unsigned blocks2 = (unsigned)((N * (H / 2) + 3) / 4);
+                if (b16)
+                    hipLaunchKernelGGL(attn_dec_cross_wide2_kernel<unsigned short>, dim3(blocks2), dim3(256), 0, st, qkv, C,
+                                       reinterpret_cast<const unsigned short*>(Kx[l]),
+                                       reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a);
+                else
+                    hipLaunchKernelGGL(attn_dec_cross_wide2_kernel<float>, dim3(blocks2), dim3(256), 0, st, qkv, C, Kx[l], Vx[l], C, N,
+                                       H, T, valid_len, a);
+            } else if (b16)
                 hipLaunchKernelGGL(attn_dec_cross_wide_kernel<unsigned short>, dim3(pair_blocks), dim3(256), 0, st, qkv,
                                    reinterpret_cast<const unsigned short*>(Kx[l]),
                                    reinterpret_cast<const unsigned short*>(Vx[l]), C, N, H, T, valid_len, a, 0);

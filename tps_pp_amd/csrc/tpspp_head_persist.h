@@ -18,25 +18,33 @@
 //     write-through stores (sc0 sc1), drained (vmcnt(0)) before the workgroup arrives at the barrier, and read with
 //     system-scope loads -- no release / acquire fences (a fence writes back / invalidates whole caches: 1.7-6.5 us each);
 //   * barrier = one relaxed agent-scope atomic on the cluster's counter (monotonic over the whole batch: target = 16 x
-//     barriers so far) + a bounded poll with s_sleep by one lane; a timeout raises *err, poisons nothing else and the
-//     workgroup leaves (no hang: the GPU box survives a protocol bug);
-//   * a projection's weight tile (64-192 KB per workgroup, read-only) is requested BEFORE the barrier, its activations
-//     after it: the 32 x K block of the cluster arrives as whole rows (1 KB per wavefront instruction) and is re-read from
-//     LDS in the matrix core's fragment order (partial-line system-scope loads cost 0.8 us more per phase);
+//     barriers so far) + a bounded poll with s_sleep by one lane; a timeout raises *err, turns the step's scores of the
+//     workgroup's images into NaN and the workgroup leaves (no hang: the GPU box survives a protocol bug);
+//   * a projection's weights (64-192 KB per workgroup, read-only), column sums, bias and residual are requested BEFORE the
+//     barrier, its activations after it: the 32 x K block of the cluster arrives as whole rows (1 KB per wavefront
+//     instruction) and is re-read from LDS in the matrix core's fragment order (partial-line system-scope loads cost 0.8 us
+//     more per phase);
+//   * buffers are indexed so that an image's data is only ever touched by its own cluster (the launch pipeline packs the
+//     cross-attention's q rows at pitch C into the q|k|v buffer -- harmless when phases are launches, a cross-cluster
+//     overwrite here: q keeps the q|k|v row pitch);
 //   * read-only operands (weights, encoder keys / values) and the self-attention caches (written by this launch, read by
 //     LATER launches only) use plain accesses.
-// One launch per step (40 per batch), 512 threads per workgroup: wavefronts 0-3 run the projections exactly as
-// dec_gemm_x3_kernel does (4-way split K), all 8 run the attentions (two (image, head) pairs each).  Workgroup w of a
-// cluster owns output tile w of a projection (tiles 3 w .. 3 w + 2 of q|k|v) and images 2 w, 2 w + 1 in the attentions.
-// A cluster's workgroups are consecutive in launch order (complete clusters become resident together); at most 512
-// images per launch (256 workgroups, one per CU): larger batches run as several launches per step.
+// One launch per step (40 per batch instead of ~2000), 512 threads per workgroup.  Projections: all 8 wavefronts split K
+// (dec_gemm_x3_kernel: 4 -- a 512-thread workgroup has 256 registers per lane; with an eighth of K per wavefront the
+// weights of all three q|k|v tiles can be requested before the barrier), so a result's last bits may differ from the
+// launch pipeline's: soft-max scores within 2e-5, decided tokens identical (tests/test_gpu_head.py).  Attentions: a
+// wavefront owns both heads of a head pair of one image and runs every stage for both before the next stage starts (8
+// wavefronts per CU must keep as many requests in flight as the launch form's 16).  Workgroup w of a cluster owns output
+// tile w of a projection (tiles 3 w .. 3 w + 2 of q|k|v) and images 2 w, 2 w + 1 in the attentions.  A cluster's
+// workgroups are consecutive in launch order (complete clusters become resident together); at most 512 images per launch
+// (256 workgroups, one per CU): larger batches run as several launches per step.
+// Odd clusters start `stagger` late: with every cluster in the same phase the memory system is saturated during the
+// attentions and idle during the latency-bound projections; half a phase apart the two halves of the chip alternate.
+// Measured (batch 512, 40 steps, MI355X): bf16x3 head 20.3 -> 19.4 ms, bf16 head 15.5 -> 15.0 ms; per layer-step
+// (scripts/debug/trace_decoder_step.py): q|k|v 9.1, self-attention 14.0, x+fc 6.6, q 5.5, cross-attention 22.4 (launch
+// form: 28.6), x+fc 6.8, w1 4.5, w2 6.5 us -- a projection phase is barrier 1.5 (incl. the cluster's skew) + rows 1.5 +
+// products / reduction / epilogue 1.2-1.6 + store drain 0.5-0.8 us.
 #pragma once
-#ifndef PGEMM_INLINE
-#define PGEMM_INLINE __forceinline__
-#endif
-#ifndef PATTN_INLINE
-#define PATTN_INLINE __forceinline__
-#endif
 
 struct PLayer {
     const du32x4 *qkv_x, *wfc_x, *q_x, *wfc2_x, *w1_x, *w2_x;   // arranged hi / lo weights (ops.arrange_x3)
@@ -59,6 +67,7 @@ struct PStep {
     int pairs;                                // (image, head) pairs per wavefront in the attention phases (2; a run-time value: the
                                               // pair loop must stay a loop -- unrolled, the compiler interleaves two attentions' registers)
     int* err;
+    int stagger;                              // odd clusters start this many 10-ns ticks late (see the kernel); 0 = together
     long long* trace;                         // optional (tpspp_head_set_trace): 64 wall-clock stamps (100 MHz) per workgroup and step
 };
 
@@ -140,7 +149,8 @@ struct PShared {
 // of an output meet as ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) and the LayerNorm sums as 16 partials in ascending
 // order -- the last bits of a result may differ from the launch-per-phase pipeline's (tests: <= 2e-6 of the scores).
 template <int KSW, bool LN, int NT>
-__device__ PGEMM_INLINE bool pgemm_phase(const PGemm& G, int tb, int ct0, PShared& S, int* cnt, int target, int* err)
+__device__ __forceinline__ bool pgemm_phase(const PGemm& G, int tb, int ct0, PShared& S, int* cnt, int target, int* err,
+                                          long long* sub = nullptr)
 {
     constexpr int K = 128 * KSW;
     // (opaque per phase: otherwise the compiler hoists every phase's lane-dependent addresses out of the layer loop and
@@ -154,17 +164,42 @@ __device__ PGEMM_INLINE bool pgemm_phase(const PGemm& G, int tb, int ct0, PShare
     const bool wg_active = ct0 < ntiles;                   // (w1: 8 tiles, classifier: 3 -- the other workgroups only pass the barrier)
     const int m0 = tb * 32;                                 // (tb: the cluster's token block in the whole batch)
     du32x4 ah[NT][KSW], al[NT][KSW];
-    if (wg_active) {                                        // before the barrier: the weights depend on nothing
+    // in front of the barrier: everything that does not depend on the previous phase -- the weights, and the epilogue's
+    // operands (column sums, bias, and the residual: it was produced at least two phases ago, i.e. behind barriers this
+    // workgroup has already passed)
+    const int m = m0 + l31;
+    const int mc = m < G.M ? m : G.M - 1;
+    float4 c4[NT], bb[NT];
+    hf32x4 r4[NT];
+    if (wg_active) {
 #pragma unroll
-        for (int tl = 0; tl < NT; ++tl)
-            pgemm_load_w<KSW>(ah[tl], al[tl], G, ct0 + tl < ntiles ? ct0 + tl : ntiles - 1, wv, half, l31);
+        for (int tl = 0; tl < NT; ++tl) {
+            const int ct = ct0 + tl;
+            pgemm_load_w<KSW>(ah[tl], al[tl], G, ct < ntiles ? ct : ntiles - 1, wv, half, l31);
+            const int c = ct * 32 + 8 * (wv & 3) + 4 * half;
+            c4[tl] = make_float4(0.f, 0.f, 0.f, 0.f); bb[tl] = c4[tl]; r4[tl] = hf32x4{0.f, 0.f, 0.f, 0.f};
+            if (wv < 4 && ct < ntiles && m < G.M && c < G.Co) {
+                if (LN) c4[tl] = *reinterpret_cast<const float4*>(G.colsum + c);
+                if (G.bias) bb[tl] = *reinterpret_cast<const float4*>(G.bias + c);
+                if (G.res) {
+                    // (compiler-visible system-scope loads: an inline-asm load whose wait sits far away may have its
+                    // destination register copied by the compiler before the data has arrived)
+                    const unsigned long long* rp = reinterpret_cast<const unsigned long long*>(G.res + (size_t)mc * G.ldo + c);
+                    const unsigned long long lo = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    r4[tl][0] = __builtin_bit_cast(float, (unsigned)lo); r4[tl][1] = __builtin_bit_cast(float, (unsigned)(lo >> 32));
+                    r4[tl][2] = __builtin_bit_cast(float, (unsigned)hi); r4[tl][3] = __builtin_bit_cast(float, (unsigned)(hi >> 32));
+                }
+            }
+        }
     }
+    if (sub && tid == 0) sub[0] = (long long)__builtin_amdgcn_s_memtime();
     if (!cluster_barrier(cnt, target, &S.flag, err)) return false;
+    if (sub && tid == 0) sub[1] = (long long)__builtin_amdgcn_s_memtime();
     if (!wg_active) return true;
     stage_rows<K>(G.X, m0, G.M, S.sX, wv, lane);
     __syncthreads();
-    const int m = m0 + l31;
-    const int mc = m < G.M ? m : G.M - 1;
+    if (sub && tid == 0) sub[2] = (long long)__builtin_amdgcn_s_memtime();
     float s1 = 0.0f, s2 = 0.0f, mean = 0.0f, rstd = 1.0f;
     const float* xs = S.sX + l31 * kPXPitch + 16 * (wv * KSW) + 8 * half;
     // the lane's B fragments (hi / lo halves of its 8 k per k-step) once, for every tile
@@ -194,21 +229,6 @@ __device__ PGEMM_INLINE bool pgemm_phase(const PGemm& G, int tb, int ct0, PShare
         // wavefronts 0 - 3 finish the tile: accumulator registers 4 w .. 4 w + 3 = outputs 32 ct + 8 w + 4 half + (0 .. 3) of token l31
         const bool mine = wv < 4 && ct < ntiles && m < G.M && c < G.Co;
         const size_t o = (size_t)mc * G.ldo + (c < G.Co ? c : 0);
-        hf32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), bb = c4;
-        if (mine) {
-            // (compiler-visible system-scope loads: an inline-asm load whose wait sits far away may have its destination
-            // register copied by the compiler before the data has arrived)
-            if (G.res) {
-                const unsigned long long* rp = reinterpret_cast<const unsigned long long*>(G.res + o);
-                const unsigned long long lo = __hip_atomic_load(rp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const unsigned long long hi = __hip_atomic_load(rp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                r4[0] = __builtin_bit_cast(float, (unsigned)lo); r4[1] = __builtin_bit_cast(float, (unsigned)(lo >> 32));
-                r4[2] = __builtin_bit_cast(float, (unsigned)hi); r4[3] = __builtin_bit_cast(float, (unsigned)(hi >> 32));
-            }
-            if (LN) c4 = *reinterpret_cast<const float4*>(G.colsum + c);
-            if (G.bias) bb = *reinterpret_cast<const float4*>(G.bias + c);
-        }
         f32x16_t acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -239,61 +259,62 @@ __device__ PGEMM_INLINE bool pgemm_phase(const PGemm& G, int tb, int ct0, PShare
                        ((S.sRed[4][r][lane] + S.sRed[5][r][lane]) + (S.sRed[6][r][lane] + S.sRed[7][r][lane]));
             }
             if (LN) {
-                v[0] = rstd * (v[0] - mean * c4.x); v[1] = rstd * (v[1] - mean * c4.y);
-                v[2] = rstd * (v[2] - mean * c4.z); v[3] = rstd * (v[3] - mean * c4.w);
+                v[0] = rstd * (v[0] - mean * c4[tl].x); v[1] = rstd * (v[1] - mean * c4[tl].y);
+                v[2] = rstd * (v[2] - mean * c4[tl].z); v[3] = rstd * (v[3] - mean * c4[tl].w);
             }
-            if (G.bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+            if (G.bias) { v[0] += bb[tl].x; v[1] += bb[tl].y; v[2] += bb[tl].z; v[3] += bb[tl].w; }
             if (G.act == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
             }
-            if (G.res) { v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3]; }
+            if (G.res) { v[0] += r4[tl][0]; v[1] += r4[tl][1]; v[2] += r4[tl][2]; v[3] += r4[tl][3]; }
             st16_sys(G.out + o, hf32x4{v[0], v[1], v[2], v[3]});
         }
         if (tl + 1 < NT) __syncthreads();                  // the partial sums have been read: sRed is free for the next tile
     }
+    if (sub && tid == 0) sub[3] = (long long)__builtin_amdgcn_s_memtime();
     drain_stores();
+    if (sub && tid == 0) sub[4] = (long long)__builtin_amdgcn_s_memtime();
     return true;
 }
 
 // ---- the attention phases (their own functions: each gets its own register allocation) -------------------------------------
 template <typename KV>
-__device__ PATTN_INLINE void pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
+__device__ __forceinline__ void pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
-#pragma unroll 1
-    for (int i = 0; i < P.pairs; ++i)
-        self_attend<KV, true>(P.qkv, P.C, P.N, P.H, P.step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
-                              P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0 + i, lane);
+    // both heads of the wavefront at once (their requests are in flight together: self_attend's NH)
+    self_attend<KV, true, 2>(P.qkv, P.C, P.N, P.H, P.step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
+                             P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0, lane);
     drain_stores();
 }
 
 template <typename KV>
-__device__ PATTN_INLINE void pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
+__device__ __forceinline__ void pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL;
     int nvalid = P.valid_len ? P.valid_len[ab] : P.T;
     nvalid = nvalid < P.T ? nvalid : P.T;
-    const int dl = lane % GS;
+    const float* qrow = P.qkv + (size_t)ab * 3 * P.C;     // (q: pitch 3 C, see the step kernel)
+    if (P.T <= kWave) {
+        cross_attend2<KV, true>(qrow, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.T, nvalid, ab, ah0, lane, P.a);
+    } else {
+        const int dl = lane % GS;
 #pragma unroll 1
-    for (int i = 0; i < P.pairs; ++i) {
-        const int h = ah0 + i;
-        hf32x4 rq[EPL / 4];
+        for (int i = 0; i < P.pairs; ++i) {
+            const int h = ah0 + i;
+            float q[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL / 4; ++e) rq[e] = ld16_sys(P.qkv + (size_t)ab * 3 * P.C + kDK * h + EPL * dl + 4 * e);      // (q: pitch 3 C, see the step kernel)
+            for (int e = 0; e < EPL / 4; ++e) {
+                const hf32x4 rq = ld16_sys_v(qrow + kDK * h + EPL * dl + 4 * e);
 #pragma unroll
-        for (int e = 0; e < EPL / 4; ++e) wait_sys(rq[e]);
-        float q[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) q[e] = rq[e >> 2][e & 3] * 0.125f;
-        if (P.T <= kWave)
-            cross_attend<KV, true, 1>(q, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.N, P.T, nvalid,
-                                      ab, h, lane, P.a, 0);
-        else
+                for (int j = 0; j < 4; ++j) q[4 * e + j] = rq[j] * 0.125f;
+            }
             cross_attend<KV, true, 4>(q, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.N, P.T, nvalid,
                                       ab, h, lane, P.a, 0);
+        }
     }
     drain_stores();
 }
@@ -325,6 +346,14 @@ dec_step_persist_kernel(const PStep P)
     const int ab = tbg * 32 + 2 * ct + (wv >> 2);
     const int ah0 = 2 * (wv & 3);
 
+    // Clusters are independent, so they need not run the same phase at the same time: with every cluster in its
+    // cross-attention at once the memory system is saturated for 28 us (134 MB of fp32 keys / values per layer-step at
+    // 4.8 TB/s) and idle during the latency-bound projections.  Odd clusters start half a layer-step late: one half of the
+    // chip streams keys / values while the other half runs its projections.
+    if (P.stagger > 0 && (tb & 1)) {
+        const long long t0 = (long long)wall_clock64();
+        while ((long long)wall_clock64() - t0 < P.stagger) __builtin_amdgcn_s_sleep(8);
+    }
     int stamp_i = 0;
     auto stamp = [&]() {                                       // (diagnostics: end of a phase on this workgroup, before the next barrier)
         if (P.trace && tid == 0 && stamp_i < 64) P.trace[((size_t)P.step * gridDim.x + blockIdx.x) * 64 + stamp_i] = (long long)wall_clock64();
@@ -349,14 +378,13 @@ dec_step_persist_kernel(const PStep P)
         stamp();
         // 2. cached self-attention -> a
         if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
-#ifndef PBISECT_NO_SELF
         if (ab < N) pself_phase<KV>(P, W, ab, ah0, lane);
-#endif
         stamp();
         // 3. y = x + fc(a)                                                         transformer_layers.py:152-154
         {
             const PGemm G{P.a, W.wfc_x, W.bfc, nullptr, x, y, N, C, 0.0f, 0, C};
-            if (!pgemm_phase<4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+            long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)P.step * gridDim.x + blockIdx.x) * 64 + 50 : nullptr;
+            if (!pgemm_phase<4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
         // 4. q = LN2(y) Wq                                                         transformer_layers.py:156-157
@@ -365,14 +393,13 @@ dec_step_persist_kernel(const PStep P)
             // into the same buffer, which there is safe -- every image is past its self-attention -- and here would let one
             // cluster's q overwrite another cluster's q|k|v rows: clusters are not synchronised with each other)
             const PGemm G{y, W.q_x, W.q_b, W.q_cs, nullptr, P.qkv, N, C, 1e-5f, 0, 3 * C};
-            if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+            long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)P.step * gridDim.x + blockIdx.x) * 64 + 56 : nullptr;
+            if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
         // 5. cross-attention against the encoder keys / values -> a
         if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
-#ifndef PBISECT_NO_CROSS
         if (ab < N) pcross_phase<KV>(P, W, ab, ah0, lane);
-#endif
         stamp();
         // 6. x = y + fc(a)                                                         transformer_layers.py:158-159
         {
