@@ -28,7 +28,7 @@ def t(reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-for mode, cd in (("bf16x3", "bf16x3"), ("bf16", torch.bfloat16)):
+for mode, cd in (("fp32", None), ("bf16x3", "bf16x3"), ("bf16", torch.bfloat16)):
     dec.compute_dtype = cd
     os.environ["TPSPP_HEAD_NO_PERSIST"] = "1"
     base = t()

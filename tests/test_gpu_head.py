@@ -361,10 +361,11 @@ def test_decoder_fused_q_cross_launch_is_bit_identical(cuda, tmp_path):
 
 @pytest.mark.parametrize("n,seq", [(37, 6), (64, 40), (557, 5)])
 def test_decoder_persistent_step_matches_the_launch_pipeline(cuda, n, seq):
-    """Round 5: a decoding step of the reduced-precision heads is ONE persistent launch (tpspp_head_persist.h: clusters of 16
+    """Round 5: a decoding step is ONE persistent launch (tpspp_head_persist.h: clusters of 16
     workgroups per 32 images, cluster barriers, system-scope hand-offs) instead of ~50 dependent launches
-    (TPSPP_HEAD_NO_PERSIST=1 selects those; read per call).  Same phases, same per-element arithmetic except that a
-    projection's K is split over 8 wavefronts instead of 4: soft-max scores within 5e-5 (the classifier is spread x6 here), decided tokens IDENTICAL -- a stale or torn
+    (TPSPP_HEAD_NO_PERSIST=1 selects those; read per call).  Exact-fp32 head: the same arithmetic in the same order, scores
+    BIT-IDENTICAL.  Reduced-precision heads: same phases, same per-element arithmetic except that a projection's K is split
+    over 8 wavefronts instead of 4: soft-max scores within 5e-5 (the classifier is spread x6 here), decided tokens IDENTICAL -- a stale or torn
     hand-off would show as an O(1) difference.  Greedy and teacher-forced, ragged valid ratios, a batch that is not a
     multiple of the 32-image cluster (37), one of several 512-image launches per step (557), full length (40 steps);
     bf16x3 and bf16 heads; three repetitions (the hand-offs race differently every time)."""
@@ -381,7 +382,7 @@ def test_decoder_persistent_step_matches_the_launch_pipeline(cuda, n, seq):
     forced[::3, seq - 1] = 92                              # a <PAD> key in some rows
     old = os.environ.pop("TPSPP_HEAD_NO_PERSIST", None)
     try:
-        for cd in ("bf16x3", torch.bfloat16):
+        for cd in (None, "bf16x3", torch.bfloat16):
             dec.compute_dtype = cd
             with torch.no_grad():
                 os.environ["TPSPP_HEAD_NO_PERSIST"] = "1"
@@ -397,8 +398,10 @@ def test_decoder_persistent_step_matches_the_launch_pipeline(cuda, n, seq):
                     bad = (got_tok != want_tok)
                     assert not bool(bad.any()), (cd, rep, int(bad.sum()), bad.nonzero()[:4].tolist(), float((got - want).abs().max()))
                     # (bf16 head: the cached keys / values are rounded to bf16, so last-bit differences of a projection reach 2e-4)
+                    if cd is None:      # exact-fp32 head: the same arithmetic in the same order -> the same bits
+                        assert torch.equal(got, want) and torch.equal(got_tf, want_tf), (cd, rep, float((got - want).abs().max()))
                     assert float((got - want).abs().max()) <= (5e-5 if cd == "bf16x3" else 5e-4), (cd, rep, float((got - want).abs().max()))
-                    assert float((got_tf - want_tf).abs().max()) <= (1e-4 if cd == "bf16x3" else 1e-3) * float(want_tf.abs().max()), (cd, rep)
+                    assert float((got_tf - want_tf).abs().max()) <= (1e-3 if cd == torch.bfloat16 else 1e-4) * float(want_tf.abs().max()), (cd, rep)
     finally:
         os.environ.pop("TPSPP_HEAD_NO_PERSIST", None)
         if old is not None:

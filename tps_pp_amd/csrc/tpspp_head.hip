@@ -1706,24 +1706,21 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     const int greedy = forced_tokens ? 0 : 1;
     const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
     int rc = 0;
-    // ---- the step as ONE persistent launch (tpspp_head_persist.h): three-term / bf16 head, d_model 512, 8 heads ----
-    const bool persist = fast && !gemm_f32 && C == 512 && H == 8 && num_out <= 128 && n_layers <= kPMaxLayers &&
-                         !g_head_qcross && !head_no_persist();
+    // ---- the step as ONE persistent launch (tpspp_head_persist.h): every head configuration, d_model 512, 8 heads ----
+    const bool persist = fast && C == 512 && H == 8 && num_out <= 128 && n_layers <= kPMaxLayers && !g_head_qcross && !head_no_persist();
     if (persist) {
         PStep PS;
         for (int l = 0; l < n_layers; ++l) {
             const float* const* w = layer_ptrs + (size_t)l * D_COUNT;
             PLayer& q = PS.L[l];
-            q.qkv_x = reinterpret_cast<const du32x4*>(w[D_QKV_X]); q.wfc_x = reinterpret_cast<const du32x4*>(w[D_WFC_X]);
-            q.q_x = reinterpret_cast<const du32x4*>(w[D_Q_X]); q.wfc2_x = reinterpret_cast<const du32x4*>(w[D_WFC2_X]);
-            q.w1_x = reinterpret_cast<const du32x4*>(w[D_W1_X]); q.w2_x = reinterpret_cast<const du32x4*>(w[D_W2_X]);
+            q.qkv_x = w[D_QKV_X]; q.wfc_x = w[D_WFC_X]; q.q_x = w[D_Q_X]; q.wfc2_x = w[D_WFC2_X]; q.w1_x = w[D_W1_X]; q.w2_x = w[D_W2_X];
             q.qkv_cs = w[D_QKV_CS]; q.qkv_b = w[D_QKV_B]; q.bfc = w[D_BFC]; q.q_cs = w[D_Q_CS]; q.q_b = w[D_Q_B];
             q.bfc2 = w[D_BFC2]; q.w1_cs = w[D_W1_CS]; q.w1_b = w[D_W1_B]; q.b2 = w[D_B2];
             q.Kx = Kx[l]; q.Vx = Vx[l]; q.Kc = Kc[l]; q.Vc = Vc[l];
         }
         PS.n_layers = n_layers;
         PS.a = a; PS.qkv = qkv; PS.hid = hid; PS.logits = logits;
-        PS.cls_x = reinterpret_cast<const du32x4*>(cls_x); PS.cls_cs = cls_colsum; PS.cls_b = b_cls; PS.num_out = num_out;
+        PS.cls_x = cls_x; PS.cls_cs = cls_colsum; PS.cls_b = b_cls; PS.num_out = num_out;
         PS.emb = emb; PS.pos = pos_table; PS.tokens = tokens; PS.Lt = Lt; PS.out = out; PS.greedy = greedy; PS.pad_idx = padding_idx;
         PS.valid_len = valid_len; PS.N = N; PS.C = C; PS.T = T; PS.H = H; PS.d_inner = d_inner; PS.Lsteps = L; PS.Lmax = L;
         PS.err = pcounters + (size_t)(N + 31) / 32 * 32;
@@ -1733,10 +1730,11 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         { const char* sv = getenv("TPSPP_HEAD_STAGGER_US"); PS.stagger = (sv ? atoi(sv) : (N > 32 ? 15 : 0)) * 100; }
         if (hipMemsetAsync(pcounters, 0, ((size_t)(N + 31) / 32 * 32 + 64) * sizeof(int), st) != hipSuccess)
             return tpspp::check_launch("tpspp_nrtr_decoder_fwd(memset)");
-        auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2> : dec_step_persist_kernel<unsigned short, 4>)
-                        : (d_inner == 256 ? dec_step_persist_kernel<float, 2> : dec_step_persist_kernel<float, 4>);
-        static bool attr_done[4][tpspp::kMaxDevices] = {};
-        if (tpspp::first_use_on_device(attr_done[(b16 ? 2 : 0) + (d_inner == 256 ? 0 : 1)])) {
+        auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2, false> : dec_step_persist_kernel<unsigned short, 4, false>)
+                  : gemm_f32 ? (d_inner == 256 ? dec_step_persist_kernel<float, 2, true> : dec_step_persist_kernel<float, 4, true>)
+                        : (d_inner == 256 ? dec_step_persist_kernel<float, 2, false> : dec_step_persist_kernel<float, 4, false>);
+        static bool attr_done[6][tpspp::kMaxDevices] = {};
+        if (tpspp::first_use_on_device(attr_done[(b16 ? 2 : gemm_f32 ? 4 : 0) + (d_inner == 256 ? 0 : 1)])) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared));
             (void)hipGetLastError();
         }

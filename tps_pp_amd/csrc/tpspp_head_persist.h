@@ -47,7 +47,7 @@
 #pragma once
 
 struct PLayer {
-    const du32x4 *qkv_x, *wfc_x, *q_x, *wfc2_x, *w1_x, *w2_x;   // arranged hi / lo weights (ops.arrange_x3)
+    const void *qkv_x, *wfc_x, *q_x, *wfc2_x, *w1_x, *w2_x;     // arranged weights: hi / lo bf16 (ops.arrange_x3) or fp32 (ops.arrange_f32)
     const float *qkv_cs, *qkv_b, *bfc, *q_cs, *q_b, *bfc2, *w1_cs, *w1_b, *b2;
     const void *Kx, *Vx;        // encoder keys / values of the layer, token-major (fp32 or bf16)
     void *Kc, *Vc;              // self-attention caches
@@ -58,7 +58,7 @@ struct PStep {
     PLayer L[kPMaxLayers];
     int n_layers;
     float *x, *y, *a, *qkv, *hid, *logits;    // step buffers (token-major), exchanged inside the launch
-    const du32x4* cls_x; const float* cls_cs; const float* cls_b; int num_out;
+    const void* cls_x; const float* cls_cs; const float* cls_b; int num_out;
     const float *emb, *pos;
     int* tokens; int Lt; float* out; int greedy; int pad_idx;
     const int* valid_len;
@@ -98,7 +98,7 @@ __device__ __forceinline__ bool cluster_barrier(int* cnt, int target, int* sFlag
 // tiles of weights in registers instead of three -- a 512-thread workgroup has 256 registers per lane), stores are
 // system-scope.  Called by ALL 8 wavefronts (the barriers count every wavefront); wavefronts 0 - 3 do the products.
 struct PGemm {
-    const float* X; const du32x4* Wp; const float* bias; const float* colsum; const float* res; float* out;
+    const float* X; const void* Wp; const float* bias; const float* colsum; const float* res; float* out;
     int M, Co; float eps; int act;
     int ldo;                    // row pitch of `out` and `res` in floats (Co, except the q projection: see the step kernel)
 };
@@ -110,7 +110,7 @@ template <int KSW>
 __device__ __forceinline__ void pgemm_load_w(du32x4 (&ah)[KSW], du32x4 (&al)[KSW], const PGemm& G, int ct, int wv, int half, int l31)
 {
     constexpr int KS = 8 * KSW;                             // 16-wide k-steps of the whole K
-    const du32x4* wp = G.Wp + ((size_t)(ct * KS + wv * KSW) * 4 + half) * 32 + l31;
+    const du32x4* wp = reinterpret_cast<const du32x4*>(G.Wp) + ((size_t)(ct * KS + wv * KSW) * 4 + half) * 32 + l31;
 #pragma unroll
     for (int j = 0; j < KSW; ++j) { ah[j] = wp[(size_t)j * 128]; al[j] = wp[(size_t)j * 128 + 64]; }
 }
@@ -278,6 +278,119 @@ __device__ __forceinline__ bool pgemm_phase(const PGemm& G, int tb, int ct0, PSh
     return true;
 }
 
+// ---- the same phase with EXACT fp32 products (the exact-fp32 head): dec_gemm_f32_kernel's arithmetic, instruction for
+// instruction -- v_mfma_f32_32x32x2_f32 on the same fragments, K split over the same 8 wavefronts, the same reduction order --
+// so the scores are bit-identical to the launch pipeline's.  KUW = 8-wide k-units per wavefront = K / 64.
+template <int KUW, bool LN, int NT>
+__device__ __forceinline__ bool pgemm_phase_f32(const PGemm& G, int tb, int ct0, PShared& S, int* cnt, int target, int* err)
+{
+    constexpr int K = 64 * KUW, KU = 8 * KUW;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                          // (opaque per phase: see pgemm_phase)
+    const int lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ntiles = (G.Co + 31) >> 5;
+    const bool wg_active = ct0 < ntiles;
+    const int m0 = tb * 32;
+    const int m = m0 + l31;
+    const int mc = m < G.M ? m : G.M - 1;
+    float4 wa[NT][KUW], c4[NT], bb[NT];
+    hf32x4 r4[NT];
+    if (wg_active) {
+#pragma unroll
+        for (int tl = 0; tl < NT; ++tl) {
+            const int ct = ct0 + tl;
+            const float4* wp = reinterpret_cast<const float4*>(G.Wp) + ((size_t)((ct < ntiles ? ct : ntiles - 1) * KU + wv * KUW) * 2 + half) * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < KUW; ++j) wa[tl][j] = wp[(size_t)j * 64];
+            const int c = ct * 32 + 8 * (wv & 3) + 4 * half;
+            c4[tl] = make_float4(0.f, 0.f, 0.f, 0.f); bb[tl] = c4[tl]; r4[tl] = hf32x4{0.f, 0.f, 0.f, 0.f};
+            if (wv < 4 && ct < ntiles && m < G.M && c < G.Co) {
+                if (LN) c4[tl] = *reinterpret_cast<const float4*>(G.colsum + c);
+                if (G.bias) bb[tl] = *reinterpret_cast<const float4*>(G.bias + c);
+                if (G.res) r4[tl] = ld16_sys_v(G.res + (size_t)mc * G.ldo + c);
+            }
+        }
+    }
+    if (!cluster_barrier(cnt, target, &S.flag, err)) return false;
+    if (!wg_active) return true;
+    stage_rows<K>(G.X, m0, G.M, S.sX, wv, lane);
+    __syncthreads();
+    float s1 = 0.0f, s2 = 0.0f, mean = 0.0f, rstd = 1.0f;
+    const float* xs = S.sX + l31 * kPXPitch + 8 * (wv * KUW) + 4 * half;
+    float4 xa[KUW];
+#pragma unroll
+    for (int j = 0; j < KUW; ++j) {
+        xa[j] = *reinterpret_cast<const float4*>(xs + 8 * j);
+        if (LN) {
+            const float x[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1 += x[e]; s2 = fmaf(x[e], x[e], s2); }
+        }
+    }
+    if (LN) { S.sS1[wv * 2 + half][l31] = s1; S.sS2[wv * 2 + half][l31] = s2; }
+#pragma unroll
+    for (int tl = 0; tl < NT; ++tl) {
+        const int ct = ct0 + tl;
+        const int c = ct * 32 + 8 * (wv & 3) + 4 * half;
+        const bool mine = wv < 4 && ct < ntiles && m < G.M && c < G.Co;
+        const size_t o = (size_t)mc * G.ldo + (c < G.Co ? c : 0);
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KUW; ++j) {
+            const float x[4] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w};
+            const float w[4] = {wa[tl][j].x, wa[tl][j].y, wa[tl][j].z, wa[tl][j].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S.sRed[wv][r][lane] = acc[r];
+        __syncthreads();
+        if (LN && tl == 0) {
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { t1 += S.sS1[j][l31]; t2 += S.sS2[j][l31]; }
+            mean = t1 / (float)K;
+            rstd = 1.0f / sqrtf(fmaxf(t2 / (float)K - mean * mean, 0.0f) + G.eps);
+        }
+        if (mine) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = 0.0f;
+#pragma unroll
+                for (int pz = 0; pz < 8; pz += 2) t += S.sRed[pz][4 * wv + e][lane] + S.sRed[pz + 1][4 * wv + e][lane];
+                v[e] = t;
+            }
+            if (LN) {
+                v[0] = rstd * (v[0] - mean * c4[tl].x); v[1] = rstd * (v[1] - mean * c4[tl].y);
+                v[2] = rstd * (v[2] - mean * c4[tl].z); v[3] = rstd * (v[3] - mean * c4[tl].w);
+            }
+            if (G.bias) { v[0] += bb[tl].x; v[1] += bb[tl].y; v[2] += bb[tl].z; v[3] += bb[tl].w; }
+            if (G.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+            }
+            if (G.res) { v[0] += r4[tl][0]; v[1] += r4[tl][1]; v[2] += r4[tl][2]; v[3] += r4[tl][3]; }
+            st16_sys(G.out + o, hf32x4{v[0], v[1], v[2], v[3]});
+        }
+        if (tl + 1 < NT) __syncthreads();
+    }
+    drain_stores();
+    return true;
+}
+
+// one entry point for both arithmetic forms (K = 128 KSW)
+template <bool F32, int KSW, bool LN, int NT>
+__device__ __forceinline__ bool pgemm(const PGemm& G, int tb, int ct0, PShared& S, int* cnt, int target, int* err, long long* sub = nullptr)
+{
+    if constexpr (F32) return pgemm_phase_f32<2 * KSW, LN, NT>(G, tb, ct0, S, cnt, target, err);
+    else return pgemm_phase<KSW, LN, NT>(G, tb, ct0, S, cnt, target, err, sub);
+}
+
 // ---- the attention phases (their own functions: each gets its own register allocation) -------------------------------------
 template <typename KV>
 __device__ __forceinline__ void pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
@@ -328,7 +441,7 @@ __device__ __forceinline__ float ld4_sys(const float* p)
 }
 
 // KSW2 = d_inner / 128 (2 or 4).  grid = clusters x 16 workgroups of 512 threads; dynamic LDS = sizeof(PShared).
-template <typename KV, int KSW2>
+template <typename KV, int KSW2, bool F32>
 __global__ void __launch_bounds__(512)
 dec_step_persist_kernel(const PStep P)
 {
@@ -373,7 +486,7 @@ dec_step_persist_kernel(const PStep P)
         // 1. q | k | v = LN1(x) Wqkv                                              transformer_layers.py:150-151
         {
             const PGemm G{x, W.qkv_x, W.qkv_b, W.qkv_cs, nullptr, P.qkv, N, 3 * C, 1e-5f, 0, 3 * C};
-            if (!pgemm_phase<4, true, 3>(G, tbg, 3 * ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+            if (!pgemm<F32, 4, true, 3>(G, tbg, 3 * ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         // 2. cached self-attention -> a
@@ -384,7 +497,7 @@ dec_step_persist_kernel(const PStep P)
         {
             const PGemm G{P.a, W.wfc_x, W.bfc, nullptr, x, y, N, C, 0.0f, 0, C};
             long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)P.step * gridDim.x + blockIdx.x) * 64 + 50 : nullptr;
-            if (!pgemm_phase<4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
+            if (!pgemm<F32, 4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
         // 4. q = LN2(y) Wq                                                         transformer_layers.py:156-157
@@ -394,7 +507,7 @@ dec_step_persist_kernel(const PStep P)
             // cluster's q overwrite another cluster's q|k|v rows: clusters are not synchronised with each other)
             const PGemm G{y, W.q_x, W.q_b, W.q_cs, nullptr, P.qkv, N, C, 1e-5f, 0, 3 * C};
             long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)P.step * gridDim.x + blockIdx.x) * 64 + 56 : nullptr;
-            if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
+            if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
         // 5. cross-attention against the encoder keys / values -> a
@@ -404,19 +517,19 @@ dec_step_persist_kernel(const PStep P)
         // 6. x = y + fc(a)                                                         transformer_layers.py:158-159
         {
             const PGemm G{P.a, W.wfc2_x, W.bfc2, nullptr, y, x, N, C, 0.0f, 0, C};
-            if (!pgemm_phase<4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+            if (!pgemm<F32, 4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         // 7. hidden = gelu(LN3(x) W1 + b1)                                         transformer_layers.py:161-162
         {
             const PGemm G{x, W.w1_x, W.w1_b, W.w1_cs, nullptr, P.hid, N, P.d_inner, 1e-5f, 2, P.d_inner};
-            if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+            if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         // 8. y = x + W2 hidden + b2                                                transformer_layers.py:162-163
         {
             const PGemm G{P.hid, W.w2_x, W.b2, nullptr, x, y, N, C, 0.0f, 0, C};
-            if (!pgemm_phase<KSW2, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+            if (!pgemm<F32, KSW2, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         float* t = x; x = y; y = t;
@@ -424,7 +537,7 @@ dec_step_persist_kernel(const PStep P)
     // final LayerNorm (eps 1e-6) folded into the classifier                       nrtr_decoder.py:77,111 + :78
     {
         const PGemm G{x, P.cls_x, P.cls_b, P.cls_cs, nullptr, P.logits, N, P.num_out, 1e-6f, 0, P.num_out};
-        if (!pgemm_phase<4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
+        if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
     }
     stamp();
     // soft-max / arg-max of the step, the next step's embedding row (dec_classify_kernel, one wavefront per image)
