@@ -263,6 +263,7 @@ int main(int argc, char** argv)
     vars.push_back({"library at argv[2] (reference for the bit-exact check)", [&](const Bufs&, int s, float* o, float* g, int32_t* ix, long long*, hipStream_t st) { pairk(s, o, g, ix, st); }, true});
     vars.push_back(pair_variant<0>("this header, as the library builds it"));
     vars.push_back(pair_variant<1>("packed chains"));
+    vars.push_back(pair_variant<2>("grid chains on the matrix pipe (4x4x1 f32)"));
     const int img1 = C * n * 4;
     CK(hipFuncSetAttribute((const void*)copy_img_k<1, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     vars.push_back({"copy, same shape: 512 x 512 thr, regs, nt ld/st", [=](const Bufs& Bf, int s, float* o, float*, int32_t*, long long*, hipStream_t st) {

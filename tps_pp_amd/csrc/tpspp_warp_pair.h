@@ -129,6 +129,15 @@ constexpr int kPairKB = 4;      // flag A is raised after 4 of them have been is
 //          the same IEEE fma per component, so bit-identical).  Measured slower (profiles/r04_warp_lab.txt): a
 //          v_pk_fma_f32 occupies the SIMD for two passes, and the kernel is bound by VALU time, not by issue slots.
 constexpr int kPairVarPacked = 1;
+//   bit 1 (round 5): the grid chains run on the MATRIX pipe.  v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4 x 4 outer
+//          products a_i * b_j added to the accumulator: one IEEE fp32 fma per element, i.e. one step of the reference's
+//          k-ascending chain (scripts/ubench/mfma_exact_probe.hip: the f32 matrix instructions are bit-identical to fmaf
+//          chains).  Block = 4 consecutive lanes; A (lane i of the block) = component i of (TxA, TyA, TxB, TyB) of step q
+//          -- one LDS word of sT --, B (lane j) = the lane's OWN table value of the mirror pixel: the accumulator of lane j
+//          is (x, y) of its pixel for both images -- exactly the 4 chains it used to run on the vector ALU.  23 x 4
+//          matrix instructions per wavefront replace 368 v_fmac (of ~850 vector instructions: the kernel is bound by vector-ALU
+//          time).
+constexpr int kPairVarMfma = 2;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Thread -> pixel, round 4.  The kernel is bound by vector-ALU time on the busiest SIMD (a wavefront's ~850 VALU
@@ -334,6 +343,34 @@ tps_warp_pair_kernel(const PairParams P)
     float gx[4][2], gy[4][2];
 #pragma unroll
     for (int m = 0; m < 4; ++m) gx[m][0] = gx[m][1] = gy[m][0] = gy[m][1] = 0.0f;
+    if constexpr ((VAR & kPairVarMfma) != 0) {
+        v4f macc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) macc[m] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* tcomp = reinterpret_cast<const float*>(sT) + (lane & 3);      // this lane's row of A: component lane % 4 of T[q]
+        static_for<K>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const float tq = tcomp[4 * q];
+            float val[4];
+            if constexpr (q == 0) {
+                val[0] = val[1] = val[2] = val[3] = v[0];
+            } else if constexpr (q == 1) {
+                val[0] = v[1]; val[1] = -v[1]; val[2] = v[1]; val[3] = -v[1];
+            } else if constexpr (q == 2) {
+                val[0] = v[2]; val[1] = v[2]; val[2] = -v[2]; val[3] = -v[2];
+            } else {
+                constexpr int k = q - 3;
+                val[0] = v[3 + k];
+                val[1] = v[3 + perm_x<F>(k)];
+                val[2] = v[3 + perm_y<F>(k)];
+                val[3] = v[3 + perm_x<F>(perm_y<F>(k))];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) macc[m] = __builtin_amdgcn_mfma_f32_4x4x1f32(tq, val[m], macc[m], 0, 0, 0);
+        });
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { gx[m][0] = macc[m][0]; gy[m][0] = macc[m][1]; gx[m][1] = macc[m][2]; gy[m][1] = macc[m][3]; }
+    } else
     static_for<K>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const float4 t = sT[q];
