@@ -423,6 +423,8 @@ __device__ __forceinline__ hf32x4 ld16_sys_v(const float* p)
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+struct NoPre { __device__ __forceinline__ bool operator()() const { return true; } };   // (see self_attend's `pre`)
+
 template <typename KV> struct Wide;
 template <> struct Wide<float> {
     static constexpr int EPL = 4;
@@ -548,9 +550,9 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
 // are in flight together, then the values of both (8 wavefronts per CU must keep as many requests outstanding as the 16 of
 // the launch form; in the launch form itself two heads per wavefront measured 22-23 us per launch against 28.6 with one).
 // SYS: q via compiler-visible system-scope loads, output system-scope (the persistent step kernel).
-template <typename KV, bool SYS>
-__device__ __forceinline__ void cross_attend2(const float* __restrict__ qrow, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
-                                              int C, int T, int nvalid, int b, int h, int lane, float* __restrict__ out)
+template <typename KV, bool SYS, typename Pre = NoPre>
+__device__ __forceinline__ bool cross_attend2(const float* __restrict__ qrow, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
+                                              int C, int T, int nvalid, int b, int h, int lane, float* __restrict__ out, Pre pre = Pre())
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI, NH = 2;
@@ -566,6 +568,11 @@ __device__ __forceinline__ void cross_attend2(const float* __restrict__ qrow, co
             const int t = TPI * i + grp;
             kr[n][i] = kb[(size_t)(t < T ? t : T - 1) * rstride];
         }
+    }
+    // (the keys do not depend on this step: they were requested in front of `pre`, the barrier behind which q is readable)
+    if (!pre()) return false;
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
 #pragma unroll
         for (int e = 0; e < EPL / 4; ++e) {
             const float* qp = qrow + kDK * (h + n) + EPL * dl + 4 * e;
@@ -632,6 +639,7 @@ __device__ __forceinline__ void cross_attend2(const float* __restrict__ qrow, co
             }
         }
     }
+    return true;
 }
 
 
@@ -679,10 +687,13 @@ attn_dec_cross_wide2_kernel(const float* __restrict__ q_t, int ldq, const KV* __
 // the 16 wavefronts per CU of the launch form do -- every stage below runs over the NH heads before the next stage starts).
 // SYS (the persistent step kernel): this step's q | k | v row and the output are exchanged with other workgroups of the same
 // launch -- system-scope accesses; the caches belong to earlier / later launches and stay plain.
-template <typename KV, bool SYS, int NH = 1>
-__device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
+// `pre` (the persistent step kernel): called once the requests that do NOT depend on this step's projections are in flight --
+// the cached keys / values and the token ids --; it is the cluster barrier behind which q | k | v become readable (false =
+// barrier timeout: give up).
+template <typename KV, bool SYS, int NH = 1, typename Pre = NoPre>
+__device__ __forceinline__ bool self_attend(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
                                             KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
-                                            int pad_idx, float* __restrict__ out, int out_cm, int b, int h, int lane)
+                                            int pad_idx, float* __restrict__ out, int out_cm, int b, int h, int lane, Pre pre = Pre())
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;
@@ -691,19 +702,6 @@ __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int
     typename Wd::raw *kc[NH], *vc[NH];
 #pragma unroll
     for (int n = 0; n < NH; ++n) {
-        const float* base = qkv_t + (size_t)b * 3 * C + kDK * (h + n) + EPL * dl;
-        if (SYS) {
-            // (compiler-visible system-scope loads: they stay in flight together with the cache rows requested below)
-#pragma unroll
-            for (int e = 0; e < EPL / 4; ++e) {
-                const hf32x4 rq = ld16_sys_v(base + 4 * e), rk = ld16_sys_v(base + C + 4 * e), rv = ld16_sys_v(base + 2 * C + 4 * e);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { q[n][4 * e + i] = rq[i] * 0.125f; k[n][4 * e + i] = rk[i]; v[n][4 * e + i] = rv[i]; }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) { q[n][e] = base[e] * 0.125f; k[n][e] = base[C + e]; v[n][e] = base[2 * C + e]; }
-        }
         const size_t bh = (size_t)b * H + h + n;
         kc[n] = reinterpret_cast<typename Wd::raw*>(Kc + bh * Lmax * kDK + EPL * dl);
         vc[n] = reinterpret_cast<typename Wd::raw*>(Vc + bh * Lmax * kDK + EPL * dl);
@@ -733,6 +731,23 @@ __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int
                 kr[n][i] = kc[n][(size_t)(p < step ? p : 0) * rstride];
                 if (kValuesEarly) vr[n][i] = vc[n][(size_t)(p < step ? p : 0) * rstride];
             }
+        }
+    }
+    if (!pre()) return false;
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        const float* base = qkv_t + (size_t)b * 3 * C + kDK * (h + n) + EPL * dl;
+        if (SYS) {
+            // (compiler-visible system-scope loads: they stay in flight together with the cache rows requested above)
+#pragma unroll
+            for (int e = 0; e < EPL / 4; ++e) {
+                const hf32x4 rq = ld16_sys_v(base + 4 * e), rk = ld16_sys_v(base + C + 4 * e), rv = ld16_sys_v(base + 2 * C + 4 * e);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { q[n][4 * e + i] = rq[i] * 0.125f; k[n][4 * e + i] = rk[i]; v[n][4 * e + i] = rv[i]; }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { q[n][e] = base[e] * 0.125f; k[n][e] = base[C + e]; v[n][e] = base[2 * C + e]; }
         }
     }
     // the new position's key / value join the caches (rows `step`: never among the rows read above)
@@ -822,6 +837,7 @@ __device__ __forceinline__ void self_attend(const float* __restrict__ qkv_t, int
             }
         }
     }
+    return true;
 }
 
 template <typename KV>

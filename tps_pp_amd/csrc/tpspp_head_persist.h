@@ -74,9 +74,13 @@ struct PStep {
 constexpr int kPXPitch = 516;                 // floats per staged X row (512 + 4: fragment reads hit all banks)
 
 // ---- cluster barrier ----------------------------------------------------------------------------------------------------
+// (workgroup barriers as raw s_barrier + lgkmcnt only: a __syncthreads() also waits for every outstanding VMEM request, i.e.
+// for exactly the prefetches -- weights, residual, cached keys -- that are meant to fly across this barrier)
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ bool cluster_barrier(int* cnt, int target, int* sFlag, int* err)
 {
-    __syncthreads();                                         // every wavefront has drained its stores (drain_stores())
+    wg_barrier_lds();                                        // every wavefront has drained its stores (drain_stores())
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
@@ -87,7 +91,7 @@ __device__ __forceinline__ bool cluster_barrier(int* cnt, int target, int* sFlag
         if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *sFlag = ok;
     }
-    __syncthreads();
+    wg_barrier_lds();
     return *sFlag != 0;
 }
 
@@ -393,30 +397,41 @@ __device__ __forceinline__ bool pgemm(const PGemm& G, int tb, int ct0, PShared& 
 
 // ---- the attention phases (their own functions: each gets its own register allocation) -------------------------------------
 template <typename KV>
-__device__ __forceinline__ void pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
+__device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane, PShared& S, int* cnt, int target)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
-    // both heads of the wavefront at once (their requests are in flight together: self_attend's NH)
-    self_attend<KV, true, 2>(P.qkv, P.C, P.N, P.H, P.step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
-                             P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0, lane);
+    auto bar = [&]() { return cluster_barrier(cnt, target, &S.flag, P.err); };
+    bool ok;
+    if (ab < P.N)
+        // both heads of the wavefront at once; the cluster barrier sits behind the cache requests (self_attend's `pre`)
+        ok = self_attend<KV, true, 2>(P.qkv, P.C, P.N, P.H, P.step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
+                                      P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0, lane, bar);
+    else
+        ok = bar();
     drain_stores();
+    return ok;
 }
 
 template <typename KV>
-__device__ __forceinline__ void pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane)
+__device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane, PShared& S, int* cnt, int target)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL;
+    auto bar = [&]() { return cluster_barrier(cnt, target, &S.flag, P.err); };
+    if (ab >= P.N) return bar();
     int nvalid = P.valid_len ? P.valid_len[ab] : P.T;
     nvalid = nvalid < P.T ? nvalid : P.T;
     const float* qrow = P.qkv + (size_t)ab * 3 * P.C;     // (q: pitch 3 C, see the step kernel)
+    bool ok = true;
     if (P.T <= kWave) {
-        cross_attend2<KV, true>(qrow, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.T, nvalid, ab, ah0, lane, P.a);
+        ok = cross_attend2<KV, true>(qrow, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.T, nvalid, ab, ah0,
+                                     lane, P.a, bar);
     } else {
+        ok = bar();
         const int dl = lane % GS;
 #pragma unroll 1
-        for (int i = 0; i < P.pairs; ++i) {
+        for (int i = 0; ok && i < P.pairs; ++i) {
             const int h = ah0 + i;
             float q[EPL];
 #pragma unroll
@@ -430,6 +445,7 @@ __device__ __forceinline__ void pcross_phase(const PStep& P, const PLayer& W, in
         }
     }
     drain_stores();
+    return ok;
 }
 
 // ---- the step ---------------------------------------------------------------------------------------------------------------
@@ -490,8 +506,7 @@ dec_step_persist_kernel(const PStep P)
         }
         stamp();
         // 2. cached self-attention -> a
-        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
-        if (ab < N) pself_phase<KV>(P, W, ab, ah0, lane);
+        if (!pself_phase<KV>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar))) { fail(); return; }
         stamp();
         // 3. y = x + fc(a)                                                         transformer_layers.py:152-154
         {
@@ -511,8 +526,7 @@ dec_step_persist_kernel(const PStep P)
         }
         stamp();
         // 5. cross-attention against the encoder keys / values -> a
-        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail(); return; }
-        if (ab < N) pcross_phase<KV>(P, W, ab, ah0, lane);
+        if (!pcross_phase<KV>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar))) { fail(); return; }
         stamp();
         // 6. x = y + fc(a)                                                         transformer_layers.py:158-159
         {
