@@ -1,4 +1,5 @@
-"""Greedy decoder (40 steps, batch 512): launch pipeline vs persistent step, with cluster stagger values.
+"""Greedy decoder (40 steps, batch 512): launch pipeline vs persistent step kernel (one launch per step / one per decode),
+with cluster stagger values.
 python scripts/debug/bench_decoder_modes.py [stagger_us ...]"""
 import os
 import sys
@@ -34,6 +35,9 @@ for mode, cd in (("fp32", None), ("bf16x3", "bf16x3"), ("bf16", torch.bfloat16))
     base = t()
     del os.environ["TPSPP_HEAD_NO_PERSIST"]
     row = [f"launch pipeline {base:.2f} ms"]
+    os.environ["TPSPP_HEAD_ONE_LAUNCH"] = "1"
+    row.append(f"one launch per decode {t():.2f}")
+    del os.environ["TPSPP_HEAD_ONE_LAUNCH"]
     for st in [int(a) for a in sys.argv[1:]] or [0, 10, 20, 30, 40, 50]:
         os.environ["TPSPP_HEAD_STAGGER_US"] = str(st)
         row.append(f"stagger {st}: {t():.2f}")

@@ -724,7 +724,11 @@ __device__ __forceinline__ bool self_attend(const float* __restrict__ qkv_t, int
     for (int i = 0; i < NP; ++i) {
         const int p = TPI * i + grp;
         tk[i] = pad_idx;
-        if (TPI * i <= step) tk[i] = tokens[(size_t)b * Lt + (p <= step ? p : 0)];   // (uniform tests: whole pieces beyond `step` are skipped)
+        if (TPI * i <= step) {                                 // (uniform tests: whole pieces beyond `step` are skipped)
+            const int* tp = tokens + (size_t)b * Lt + (p <= step ? p : 0);
+            // (SYS: the previous step of the same launch wrote the newest id)
+            tk[i] = SYS ? __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : *tp;
+        }
         if (TPI * i < step) {
 #pragma unroll
             for (int n = 0; n < NH; ++n) {
@@ -1757,15 +1761,22 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table, tokens, Lt, 0, C,
                            N, x, 1);
         const int per_step = 8 * n_layers + 2;                 // cluster barriers of one step
-        for (int s = 0; s < L; ++s) {
-            PS.x = x; PS.y = y; PS.step = s; PS.bar_base = s * per_step;
+        // one launch per step.  TPSPP_HEAD_ONE_LAUNCH=1 (lab switch): the whole decode of a chunk as ONE launch -- the kernel
+        // loops over the steps, clusters run their 40 steps independently of each other; same scores, and measured SLOWER
+        // (batch 512: fp32 23.04 -> 23.25 ms, bf16x3 20.02 -> 20.35, bf16 15.03 -> 15.20): the next step's launch is
+        // already queued behind the running one, and the launch boundary re-aligns the clusters' memory phases
+        const int per_launch = getenv("TPSPP_HEAD_ONE_LAUNCH") ? L : 1;
+        for (int s = 0; s < L; s += per_launch) {
+            PS.x = x; PS.y = y; PS.step = s; PS.nsteps = per_launch; PS.bar_base = s * per_step;
             for (int n0 = 0; n0 < N; n0 += 512) {              // <= 256 workgroups per launch: every cluster resident
                 const int nimg = N - n0 < 512 ? N - n0 : 512;
                 PS.n0 = n0; PS.counters = pcounters + (n0 >> 5) * 32;
                 hipLaunchKernelGGL(kern, dim3((unsigned)((nimg + 31) / 32 * 16)), dim3(512), sizeof(PShared), st, PS);
             }
-            if (n_layers & 1) { float* t = x; x = y; y = t; }  // (the kernel swaps x / y once per layer)
-            if (s + 1 < L) { float* t = x; x = y; y = t; }     // the next step's embedding went to y
+            if (per_launch == 1) {
+                if (n_layers & 1) { float* t = x; x = y; y = t; }  // (the kernel swaps x / y once per layer)
+                if (s + 1 < L) { float* t = x; x = y; y = t; }     // the next step's embedding went to y
+            }
         }
         if (tokens_out)
             (void)hipMemcpyAsync(tokens_out, tokens, (size_t)N * Lt * sizeof(int), hipMemcpyDeviceToDevice, st);

@@ -62,7 +62,7 @@ struct PStep {
     const float *emb, *pos;
     int* tokens; int Lt; float* out; int greedy; int pad_idx;
     const int* valid_len;
-    int N, n0, C, T, H, d_inner, step, Lsteps, Lmax;   // images [n0, n0 + up to 512) of N
+    int N, n0, C, T, H, d_inner, step, nsteps, Lsteps, Lmax;   // images [n0, n0 + up to 512) of N; steps [step, step + nsteps) in this launch
     int* counters; int bar_base;              // cluster counters (128 B apart), barriers passed before this launch
     int pairs;                                // (image, head) pairs per wavefront in the attention phases (2; a run-time value: the
                                               // pair loop must stay a loop -- unrolled, the compiler interleaves two attentions' registers)
@@ -397,14 +397,14 @@ __device__ __forceinline__ bool pgemm(const PGemm& G, int tb, int ct0, PShared& 
 
 // ---- the attention phases (their own functions: each gets its own register allocation) -------------------------------------
 template <typename KV>
-__device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane, PShared& S, int* cnt, int target)
+__device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int step, int ab, int ah0, int lane, PShared& S, int* cnt, int target)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
     auto bar = [&]() { return cluster_barrier(cnt, target, &S.flag, P.err); };
     bool ok;
     if (ab < P.N)
         // both heads of the wavefront at once; the cluster barrier sits behind the cache requests (self_attend's `pre`)
-        ok = self_attend<KV, true, 2>(P.qkv, P.C, P.N, P.H, P.step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
+        ok = self_attend<KV, true, 2>(P.qkv, P.C, P.N, P.H, step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
                                       P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0, lane, bar);
     else
         ok = bar();
@@ -483,9 +483,10 @@ dec_step_persist_kernel(const PStep P)
         const long long t0 = (long long)wall_clock64();
         while ((long long)wall_clock64() - t0 < P.stagger) __builtin_amdgcn_s_sleep(8);
     }
+    for (int step = P.step; step < P.step + P.nsteps; ++step) {
     int stamp_i = 0;
     auto stamp = [&]() {                                       // (diagnostics: end of a phase on this workgroup, before the next barrier)
-        if (P.trace && tid == 0 && stamp_i < 64) P.trace[((size_t)P.step * gridDim.x + blockIdx.x) * 64 + stamp_i] = (long long)wall_clock64();
+        if (P.trace && tid == 0 && stamp_i < 64) P.trace[((size_t)step * gridDim.x + blockIdx.x) * 64 + stamp_i] = (long long)wall_clock64();
         ++stamp_i;
     };
     stamp();
@@ -493,7 +494,7 @@ dec_step_persist_kernel(const PStep P)
         // barrier timeout: make it loud -- this step's scores of the workgroup's images become NaN
         if (wv < 2) {
             const int b = tbg * 32 + 2 * ct + wv;
-            if (b < N) for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + P.step) * P.num_out + c] = __builtin_nanf("");
+            if (b < N) for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + step) * P.num_out + c] = __builtin_nanf("");
         }
     };
 
@@ -506,12 +507,12 @@ dec_step_persist_kernel(const PStep P)
         }
         stamp();
         // 2. cached self-attention -> a
-        if (!pself_phase<KV>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar))) { fail(); return; }
+        if (!pself_phase<KV>(P, W, step, ab, ah0, lane, S, cnt, 16 * (++bar))) { fail(); return; }
         stamp();
         // 3. y = x + fc(a)                                                         transformer_layers.py:152-154
         {
             const PGemm G{P.a, W.wfc_x, W.bfc, nullptr, x, y, N, C, 0.0f, 0, C};
-            long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)P.step * gridDim.x + blockIdx.x) * 64 + 50 : nullptr;
+            long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)step * gridDim.x + blockIdx.x) * 64 + 50 : nullptr;
             if (!pgemm<F32, 4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
@@ -521,7 +522,7 @@ dec_step_persist_kernel(const PStep P)
             // into the same buffer, which there is safe -- every image is past its self-attention -- and here would let one
             // cluster's q overwrite another cluster's q|k|v rows: clusters are not synchronised with each other)
             const PGemm G{y, W.q_x, W.q_b, W.q_cs, nullptr, P.qkv, N, C, 1e-5f, 0, 3 * C};
-            long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)P.step * gridDim.x + blockIdx.x) * 64 + 56 : nullptr;
+            long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)step * gridDim.x + blockIdx.x) * 64 + 56 : nullptr;
             if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
@@ -565,13 +566,13 @@ dec_step_persist_kernel(const PStep P)
             if (lane < Cc) v0 = ld4_sys(lg + lane);
             if (lane + kWave < Cc) v1 = ld4_sys(lg + lane + kWave);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
-            float* o = P.out + ((size_t)b * P.Lsteps + P.step) * Cc;
-            const bool more = P.step + 1 < P.Lsteps;
+            float* o = P.out + ((size_t)b * P.Lsteps + step) * Cc;
+            const bool more = step + 1 < P.Lsteps;
             // the next step's embedding goes to y (which becomes the next launch's x: the host swaps as the launch path does)
             auto embed_next = [&](int tok) {
                 if (more) {
                     const float* er = P.emb + (size_t)tok * C;
-                    const float* pr = P.pos + (size_t)(P.step + 1) * C;
+                    const float* pr = P.pos + (size_t)(step + 1) * C;
                     // (system-scope stores as well: a plain store leaves the line in this XCD's L2, and the NEXT launch's
                     // system-scope loads of the row -- after another XCD has rewritten it -- were served from that stale line)
                     for (int c = 4 * lane; c < C; c += 4 * kWave) {
@@ -583,7 +584,7 @@ dec_step_persist_kernel(const PStep P)
             if (!P.greedy) {
                 if (lane < Cc) o[lane] = v0;
                 if (lane + kWave < Cc) o[lane + kWave] = v1;
-                embed_next(P.tokens[(size_t)b * P.Lt + P.step + 1]);
+                embed_next(P.tokens[(size_t)b * P.Lt + step + 1]);
             } else {
                 // first maximum: the same comparison sequence as dec_classify_kernel (ascending classes per lane, then the butterfly)
                 float mx = -INFINITY;
@@ -602,9 +603,14 @@ dec_step_persist_kernel(const PStep P)
                 sum = wave_sum(sum);
                 if (lane < Cc) o[lane] = expf(v0 - mx) / sum;
                 if (lane + kWave < Cc) o[lane + kWave] = expf(v1 - mx) / sum;
-                if (lane == 0) P.tokens[(size_t)b * P.Lt + P.step + 1] = am;
+                // (system scope: the next step of THIS launch reads it in the self-attention's <PAD> mask)
+                if (lane == 0) __hip_atomic_store(P.tokens + (size_t)b * P.Lt + step + 1, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 embed_next(am);
             }
         }
+    }
+    // the next step of this launch: its first projection stages y's rows behind its cluster barrier
+    drain_stores();
+    { float* t = x; x = y; y = t; }
     }
 }
