@@ -193,6 +193,19 @@ def extra_measurements(dev):
         t_bwd = timeit(lambda: ops.warp_backward(g0, fgc, grid, cp, at.hat_C, at.P_hat, (16, 64), P_xy=P_xy, score=sc,
                                                  in1=x, g_out1=g1, P_hat_t=P_hat_t), 10, 3)
         del g0, g1, grid, fgc
+        # the classic rectifier's backward (configs[1] geometry: 3 x 32 x 100, 20 fiducials), one launch per batch
+        from tps_pp_amd import TPSPreprocessor, constants
+        gc = TPSPreprocessor(20, (32, 100), (32, 100), 3).eval().to(dev).GridGenerator
+        tab_t, tab_flags = gc.prepared_table()
+        cimg = torch.rand((n, 3, 32, 100), generator=g, device=dev)
+        cctrl = torch.from_numpy(constants.classic_initial_ctrl(20)).to(dev)[None].repeat(n, 1, 1).contiguous()
+        cctrl = cctrl + 0.05 * (torch.rand(cctrl.shape, generator=g, device=dev) - 0.5)
+        cgo = torch.rand((n, 3, 32, 100), generator=g, device=dev)
+        _, _, cgrid, _ = ops.warp(cimg, cctrl, gc.inv_delta_C, gc.P_hat, (32, 100), want_grid=True, P_hat_t=tab_t,
+                                  table_flags=tab_flags)
+        t_cbwd = timeit(lambda: ops.warp_backward(cgo, cimg, cgrid, cctrl, gc.inv_delta_C, gc.P_hat, (32, 100),
+                                                  P_hat_t=tab_t), 30, 5)
+        del cimg, cgo, cgrid, gc
         # the same fp32 tensors with the three-term bf16 split in the convolutions ("bf16x3": within the 1e-4 bar,
         # tests/test_gpu_modules.py::test_tpspp_module_bf16x3_meets_the_fp32_bar)
         m.compute_dtype = "bf16x3"
@@ -216,7 +229,12 @@ def extra_measurements(dev):
             "tpspp_warp_backward_batch512_fp32": {"us_per_batch": t_bwd * 1e3,
                                                   "achieved_GBps": bwd_bytes_img * n / (t_bwd * 1e-3) / 1e9,
                                                   "algorithmic_bytes_per_image": bwd_bytes_img,
-                                                  "kernels": "warp_bwd_sample_lds2_kernel (fp64 LDS atomics) + warp_bwd_params_kernel<36,...> (table columns per wavefront) + warp_bwd_ctrl_kernel"},
+                                                  "kernels": "warp_bwd_sample_lds2_kernel (fp64 LDS atomics) + warp_bwd_params_kernel<36,...> (table columns per wavefront; the last workgroup of an image applies inv_delta_C^T)"},
+            # read g_out, the image and the grid; write dL/d image, dL/d grid, dL/d control points (fp32)
+            "classic_warp_backward_batch512_fp32": {"us_per_batch": t_cbwd * 1e3,
+                                                    "achieved_GBps": 4 * (3 * 3 * 3200 + 2 * 2 * 3200 + 40) * n / (t_cbwd * 1e-3) / 1e9,
+                                                    "algorithmic_bytes_per_image": 4 * (3 * 3 * 3200 + 2 * 2 * 3200 + 40),
+                                                    "kernel": "warp_bwd_classic_kernel<3>: one launch (image staged in LDS, fp64 LDS accumulators, dL/dT and inv_delta_C^T in the workgroup); host-inclusive time of ops.warp_backward (allocations + one launch)"},
             "tpspp_module_batch512_fp32": {"images_per_s": n / (t_full * 1e-3), "ms_per_batch": t_full,
                                            "gflop_per_image": 0.82},
             "tpspp_module_batch512_bf16x3": {"images_per_s": n / (t_x3 * 1e-3), "ms_per_batch": t_x3,

@@ -184,7 +184,7 @@ def timeline_summary():
             protos.append((1, reg_1))
         lo = warm
         out = []
-        for streams, line_regions in protos:
+        for streams, regs_us in protos:
             for r in range(R):
                 sel = rows[lo:lo + steps]
                 lo += steps
@@ -195,7 +195,7 @@ def timeline_summary():
                 queues = sorted({x.get("Queue_Id", "?") for x in sel})
                 overlap = sum(1 for p, q in zip(sel, sel[1:]) if int(q["Start_Timestamp"]) < int(p["End_Timestamp"]))
                 out.append((streams, r, len(sel), sum(dur) / len(dur) / 1e3, span / len(sel) / 1e3, len(queues), overlap,
-                            line_regions[r] if line_regions and r < len(line_regions) else None))
+                            regs_us[r] if regs_us and r < len(regs_us) else None))
         blocks.append((tag, bench, out))
     if not blocks:
         return

@@ -387,6 +387,64 @@ def test_input_gradients_mixed_magnitudes(cuda, geometry):
     assert 1 <= int(bad.sum()) <= 4 and bool(bad[0, 1].any()) and int(bad.sum()) == int(bad[0, 1].sum())
 
 
+@pytest.mark.parametrize("C,hw,n", [(3, (32, 100), 37), (1, (32, 100), 5), (2, (32, 64), 9), (3, (24, 132), 6), (3, (48, 64), 4)])
+def test_classic_backward_single_launch_against_the_two_kernel_route(cuda, C, hw, n):
+    """Round 5: the classic rectifier's backward (one input of <= 3 channels, no score, 1024 < pixels <= 4096, transposed
+    table) is ONE launch (warp_bwd_classic_kernel: image staged in LDS, fp64 LDS accumulators, dL/dT finished in the
+    workgroup); TPSPP_BWD_TWO_KERNELS=1 selects the sampling + parameter kernels of rounds 3-5.  Same sampling arithmetic:
+    dL/d input within one ulp (fp64 sums of the same fp32 terms -- neighbouring lanes add their shared tap in fp64 before
+    the atomic, so only the order of the fp64 additions differs); dL/dC' within 5e-5 of the largest entry of the two-kernel
+    route (which keeps fp32 partial sums of ~12 terms per lane: measured 1.8e-5 apart) and within 3e-5 of float64 on the
+    same grid (measured 1.5e-5: the fp32 coordinate gradients of the sampler, amplified by |inv_delta_C| ~ 220).  From gentle to strong deformations (folds, coordinates clamped
+    at the borders), a NaN in the incoming gradient (stays in its four taps; that image's dL/dC' is NaN in both routes)."""
+    import os
+    import torch.nn.functional as Fn
+    from tps_pp_amd import constants
+    g = torch.Generator(device=cuda).manual_seed(17 + C + hw[1])
+    p = TPSPreprocessor(20, hw, hw, C).eval().to(cuda)
+    gg = p.GridGenerator
+    P_hat_t, flags = gg.prepared_table()
+    img = torch.rand((n, C) + hw, generator=g, device=cuda)
+    ctrl = dev(constants.classic_initial_ctrl(20), cuda)[None].repeat(n, 1, 1).contiguous()
+    amp = torch.linspace(0.02, 0.9, n, device=cuda)[:, None, None]          # from gentle to folded / clamped
+    ctrl = ctrl + amp * (torch.rand(ctrl.shape, generator=g, device=cuda) - 0.5)
+    go = torch.randn((n, C) + hw, generator=g, device=cuda)
+    go[0, 0, 3, 7] = float("nan")
+    _, _, grid, _ = ops.warp(img, ctrl, gg.inv_delta_C, gg.P_hat, hw, want_grid=True, P_hat_t=P_hat_t, table_flags=flags)
+
+    def run():
+        return ops.warp_backward(go, img, grid, ctrl, gg.inv_delta_C, gg.P_hat, hw, P_hat_t=P_hat_t)
+
+    old = os.environ.pop("TPSPP_BWD_TWO_KERNELS", None)
+    try:
+        os.environ["TPSPP_BWD_TWO_KERNELS"] = "1"
+        want = run()
+        del os.environ["TPSPP_BWD_TWO_KERNELS"]
+        for rep in range(3):
+            got = run()
+            gi, wi = got[0], want[0]
+            assert torch.equal(torch.isnan(gi), torch.isnan(wi)) and int(torch.isnan(gi).sum()) in range(1, 5)
+            ok = ~torch.isnan(wi)
+            ia, ib = gi[ok].view(torch.int32).long(), wi[ok].view(torch.int32).long()
+            ia = torch.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+            ib = torch.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+            assert int((ia - ib).abs().max()) <= 1, ("dL/d input", C, hw, rep, int((ia - ib).abs().max()))
+            # image 0 carries the NaN: its dL/dC' is NaN in both routes; the others are finite
+            assert torch.isnan(got[2][0]).all() == torch.isnan(want[2][0]).all()
+            close(got[2][1:], want[2][1:].cpu().numpy(), 5e-5, "dL/d control points (single launch against two kernels)")
+    finally:
+        os.environ.pop("TPSPP_BWD_TWO_KERNELS", None)
+        if old is not None:
+            os.environ["TPSPP_BWD_TWO_KERNELS"] = old
+    # float64 on the same fp32 grid, images without the NaN
+    with torch.enable_grad():
+        gd = grid[1:].cpu().double().reshape(n - 1, hw[0], hw[1], 2).requires_grad_(True)
+        (Fn.grid_sample(img[1:].cpu().double(), gd, padding_mode="border", align_corners=True) * go[1:].cpu().double()).sum().backward()
+    gT = torch.matmul(gg.P_hat.cpu().double().t()[None], gd.grad.reshape(n - 1, -1, 2))
+    truth = torch.matmul(gg.inv_delta_C.cpu().double().t()[None], gT)[:, :20]
+    close(got[2][1:], truth.float().numpy(), 3e-5, "dL/d control points against float64 on the fp32 grid")
+
+
 def test_backward_workspace_size_is_checked(cuda):
     """The C entry point refuses a workspace smaller than tpspp_warp_bwd_workspace_floats() (round 3 grew it silently;
     since ABI version 2 the size travels with the pointer)."""

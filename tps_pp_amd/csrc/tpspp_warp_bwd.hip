@@ -4,7 +4,8 @@
 // Forward (tpspp_warp.hip):  T = inv_delta_C [C'; 0];  row(p) = [1, P.x, P.y, rbf_k (0.5 s_k + 1)];
 //                            grid(p) = row(p) T;  out_i = grid_sample(in_i, grid)  (bilinear, border,
 //                            align_corners=True), i = 0 (feature map) and optionally 1 (image).
-// Backward, two kernels:
+// Backward of the classic rectifier (one input of <= 3 channels, no score, 1024 < pixels <= 4096): ONE launch,
+// warp_bwd_classic_kernel below (round 5; 85 -> 39 us per 512 images).  Everything else, two kernels:
 //   A (thread = pixel x 8 channels of one input): dL/d(ix, iy) from the four taps (ATen's CPU formulation:
 //     gx += ((ne - nw) s + (se - sw) n) g,  gy += ((sw - nw) e + (se - ne) w) g), times (size-1)/2 and
 //     the border-clip derivative (0 where the coordinate was clamped); dL/d in_i scattered with float
@@ -530,6 +531,278 @@ warp_bwd_params_kernel(const BwdParams P, float* __restrict__ g_grid, const floa
     }
 }
 
+
+// ---- the classic rectifier's backward as ONE launch (round 5) --------------------------------------------------------------
+// One input of C <= 3 channels, table [1, x, y, rbf] without a score, 1024 < n <= 4096 output pixels, all C input-gradient
+// planes (fp64 accumulators) in <= 78 KB of LDS: the 3 x 32 x 100 geometry of BASELINE.json configs[1].  Rounds 3-5 ran it as
+// kernel A'' (one 1024-thread workgroup per image, 128 registers -> ONE workgroup per CU, two rounds of a workgroup whose
+// phases -- grid, gathers, LDS atomics, plane write-out, twice: two planes per pass -- wait for each other: 53 us per 512
+// images) + kernel B (4 workgroups per image, partial dL/dT through memory, a ticket: 30 us).  Here
+//   * the image's planes are staged in LDS (fp32, 38 KB) and the 12 taps of a pixel are LDS reads: gathering them from
+//     global memory costs ~34 cycles of the texture-address unit per 64-lane instruction -- 17 us per 512 images; the
+//     same space then becomes the fp64 accumulators of ALL planes (3 x 3200 x 8 B): phase A = dL/d grid, phase B = dL/d
+//     input with the tap offsets and weights derived again from the 4 grid points the thread keeps (same expressions,
+//     same bits);
+//   * <= 64 registers, 78 KB of LDS: TWO 1024-thread workgroups per CU, one's atomics and write-out run under the other's
+//     loads;
+//   * dL/d grid stays in the workgroup (registers -> LDS, the planes' space after their write-out) and dL/dT is finished
+//     here: wavefront w = table columns 3 (w & 7) .. + 2 over one half of the pixels (lane = pixel, an fp64 FMA chain per
+//     lane in ascending pixel order), the 64 lanes and the two halves added in fp64 in a fixed order, then
+//     dL/dC' = inv_delta_C^T dL/dT in fp64, rounded once (kernel B's arithmetic): no slices, no partials in memory, no
+//     ticket, no second launch.
+// The sampling arithmetic (taps, border-clip factors, weights, the order of the channels in the coordinate gradient, the
+// fp64 LDS accumulation of dL/d input) is that of kernel A'', expression for expression: dL/d input and dL/d grid come out
+// with the same bits; dL/dC' is the correctly rounded chain up to fp64 rounding (the two-kernel route keeps fp32 partial sums
+// of ~12 terms per lane: ~1e-5 of the largest entry).
+constexpr int kClassicNT = 1024;
+
+template <int C>
+__global__ void __launch_bounds__(kClassicNT, 8)
+warp_bwd_classic_kernel(const BwdParams P, float* __restrict__ g_grid)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];   // see the phases below
+    __shared__ double sPart[kClassicNT / kWave][6];
+    __shared__ double sGT[24 * 2];
+    constexpr int NT = kClassicNT, PPT = 4;
+    const int b = blockIdx.x;
+    const int H = P.H[0], W = P.W[0];
+    const int plane = H * W, n = P.n;
+    const bool want = P.g_in[0] != nullptr;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- requests: this thread's 4 grid points and incoming gradients, and the image's planes -> LDS ----
+    const float* in = P.in[0] + (size_t)b * C * plane;
+    const float* go = P.g_out[0] + (size_t)b * C * n;
+    float* sin_ = reinterpret_cast<float*>(acc);               // phase A: [C][plane] fp32 (+ W + 1 words that masked taps may read)
+    float2 g4[PPT];
+    float gv[PPT][C];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * NT;
+        const int pc = p < n ? p : 0;
+        g4[k] = reinterpret_cast<const float2*>(P.grid)[(size_t)b * n + pc];
+#pragma unroll
+        for (int c = 0; c < C; ++c)                            // (32-bit byte offsets from the image's uniform base)
+            gv[k][c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(go) + 4u * (unsigned)(c * n + pc));
+    }
+    for (int e = tid; e < (C * plane) >> 2; e += NT)
+        reinterpret_cast<float4*>(sin_)[e] = reinterpret_cast<const float4*>(in)[e];
+    __syncthreads();
+
+    // a pixel's taps: offset of the north-west tap + four flags in one word (east column / south row inside the image,
+    // x / y clamped at the border), the two fractions: 3 registers per pixel across both phases
+    struct Taps { int packed; float fw, fn; };
+    auto taps = [&](float2 g) {
+        Taps t;
+        float ix = ((g.x + 1.0f) * 0.5f) * (float)(W - 1);
+        float iy = ((g.y + 1.0f) * 0.5f) * (float)(H - 1);
+        // (the border-clip factors: 0 where the coordinate was clamped, else (size - 1) / 2)
+        bool clipx = false, clipy = false;
+        if (ix <= 0.0f) { ix = 0.0f; clipx = true; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); clipx = true; }
+        if (iy <= 0.0f) { iy = 0.0f; clipy = true; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); clipy = true; }
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        t.fw = ix - fx; t.fn = iy - fy;
+        t.packed = (y0 * W + x0) | ((x0 + 1) < W ? 1 << 16 : 0) | ((y0 + 1) < H ? 1 << 17 : 0) | (clipx ? 1 << 18 : 0) | (clipy ? 1 << 19 : 0);
+        return t;
+    };
+
+    // ---- phase A: dL/d grid from the staged taps ----
+    Taps tp[PPT];                                              // (kept for phase B: offset + two fractions; the flags are lane masks)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int p = tid + k * NT;
+        tp[k] = taps(g4[k]);
+        if (p < n) {
+            const Taps t = tp[k];
+            const float w = t.fw, nn = t.fn, e = 1.0f - w, s = 1.0f - nn;
+            const int o00 = t.packed & 0xffff;
+            const bool inx = t.packed & (1 << 16), iny = t.packed & (1 << 17), inxy = inx && iny;
+            float gx = 0.0f, gy = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                // (a masked tap is read anyway -- the word exists: next row, next plane or the pad -- and replaced by zero)
+                const float* q = sin_ + c * plane + o00;
+                const float v00 = q[0], r01 = q[1], r10 = q[W], r11 = q[W + 1];
+                const float g = gv[k][c];
+                const float a01 = inx ? r01 : 0.0f, a10 = iny ? r10 : 0.0f, a11 = inxy ? r11 : 0.0f;
+                gx += ((a01 - v00) * s + (a11 - a10) * nn) * g;
+                gy += ((a10 - v00) * e + (a11 - a01) * w) * g;
+            }
+            // the documented output; read back below by this same thread (8 registers less across phase B)
+            reinterpret_cast<float2*>(g_grid)[(size_t)b * n + p] =
+                make_float2(gx * ((t.packed & (1 << 18)) ? 0.0f : (float)(W - 1) * 0.5f), gy * ((t.packed & (1 << 19)) ? 0.0f : (float)(H - 1) * 0.5f));
+        }
+    }
+    __syncthreads();                                           // every tap has been read: the space becomes the accumulators
+
+    // ---- phase B: dL/d input, fp64 LDS accumulation ----
+    ulonglong2* acc2 = reinterpret_cast<ulonglong2*>(acc);
+    if (want) {
+        for (int e = tid; e < (C * plane) >> 1; e += NT) acc2[e] = make_ulonglong2(0ull, 0ull);
+        __syncthreads();
+        // What bounds this kernel is the LDS pipeline (ds_add_f64 retires 3.1 lane-operations per clock and CU: 4 per tap set and
+        // channel = 13 us per 512 images).  Neighbouring lanes are neighbouring output pixels, and for a smooth warp lane
+        // l + 1's north-west tap IS lane l's north-east tap (south-west / south-east likewise): lane l hands its two east
+        // contributions to lane l + 1 through DPP (wave_shr / wave_shl: no LDS traffic), which adds them to its own west
+        // ones in fp64 -- the sum of two fp32 products, exact unless their exponents are > 29 apart -- and issues ONE atomic
+        // per row: two per tap set instead of four wherever the pattern holds (every lane evaluates the same predicate
+        // from both sides: neighbour alive, the giver's east column inside the image, offsets one apart).
+        auto dpp_prev = [](int v) { return __builtin_amdgcn_update_dpp(-1, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
+        auto dpp_next = [](int v) { return __builtin_amdgcn_update_dpp(-1, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); };
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = tid + k * NT;
+            const bool livep = p < n;
+            const Taps t = tp[k];
+            const float w = t.fw, nn = t.fn, e = 1.0f - w, s = 1.0f - nn;
+            const float nw = s * e, ne = s * w, sw = nn * e, se = nn * w;
+            const int pk = livep ? t.packed : -1;              // (a live pixel's word has bits 20.. clear: never -1)
+            const int o00 = t.packed & 0xffff;
+            const bool inx = t.packed & (1 << 16), iny = t.packed & (1 << 17), inxy = inx && iny;
+            const int prev = dpp_prev(pk), next = dpp_next(pk);
+            const bool recv = livep && prev != -1 && (prev & (1 << 16)) && (prev & 0xffff) + 1 == o00;
+            const bool give = livep && next != -1 && inx && o00 + 1 == (next & 0xffff);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float g = gv[k][c];
+                const float t00 = nw * g, t01 = ne * g, t10 = sw * g, t11 = se * g;
+                const float p01 = __int_as_float(dpp_prev(__float_as_int(t01))), p11 = __int_as_float(dpp_prev(__float_as_int(t11)));
+                double d00 = (double)t00, d10 = (double)t10;
+                if (recv) { d00 += (double)p01; d10 += (double)p11; }     // (same row as the giver: its south row is inside iff ours is)
+                if (livep) {
+                    double* ap = reinterpret_cast<double*>(acc) + c * plane + o00;
+                    unsafeAtomicAdd(ap, d00);
+                    if (inx && !give) unsafeAtomicAdd(ap + 1, (double)t01);
+                    if (iny) unsafeAtomicAdd(ap + W, d10);
+                    if (inxy && !give) unsafeAtomicAdd(ap + W + 1, (double)t11);
+                }
+            }
+        }
+        __syncthreads();                                       // every contribution has landed
+        // (one 16-byte LDS read = two accumulators per lane: consecutive lanes on consecutive banks; two reads per lane for a
+        // 16-byte store put the lanes 32 bytes apart -- a two-way bank conflict on every read)
+        float2* gi2 = reinterpret_cast<float2*>(P.g_in[0] + (size_t)b * C * plane);
+        for (int e = tid; e < (C * plane) >> 1; e += NT) {
+            const ulonglong2 r0 = acc2[e];
+            gi2[e] = make_float2((float)__longlong_as_double((long long)r0.x), (float)__longlong_as_double((long long)r0.y));
+        }
+        __syncthreads();                                       // the planes' space is free
+    }
+    // dL/d grid into LDS for the column wavefronts below (each thread its own stores of phase A)
+    // (x and y in planes of their own: the column wavefronts read 4 consecutive pixels per lane, 16 bytes from each plane)
+    float* sgx = reinterpret_cast<float*>(acc);
+    float* sgy = sgx + n;
+    {
+        unsigned long long raw[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = tid + k * NT;
+            raw[k] = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(g_grid) + (size_t)b * n + (p < n ? p : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = tid + k * NT;
+            if (p < n) { sgx[p] = __uint_as_float((unsigned)raw[k]); sgy[p] = __uint_as_float((unsigned)(raw[k] >> 32)); }
+        }
+    }
+    __syncthreads();
+
+    // ---- dL/dT: wavefront = 3 columns of the transposed table x one half of the pixels; a lane takes 4 consecutive pixels
+    // per step (16-byte table loads), an 8-term fp32 FMA chain per two loads, the chains added in fp64 (dL/dC' = inv_delta_C^T
+    // dL/dT cancels heavily, |inv_delta_C| up to ~220: one 25-term fp32 chain per lane shows as 3e-5 of the largest entry;
+    // fp64 from the first product on costs 22 us per 512 images on the half-rate fp64 vector ALU) ----
+    const int K = P.F + 3, F = P.F;
+    const int cgp = wv & 7, half = wv >> 3;
+    constexpr int kStep = 4 * kWave, kIts = 8;                 // n <= 4096: a half is at most 8 steps of 256 pixels
+    const int hn = (((n + 1) >> 1) + kStep - 1) / kStep * kStep;
+    const int lo = half * hn, hi = min(n, lo + hn);           // (n is a multiple of 4: so is hi)
+    const char* tabc = reinterpret_cast<const char*>(P.p_hat_t);
+    double a[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[j][0] = a[j][1] = 0.0;
+#pragma unroll
+    for (int it = 0; it < kIts; it += 2) {                     // two steps per batch: 6 table loads in flight, dL/d grid read once
+        if (lo + it * kStep >= hi) break;                      // (uniform)
+        float4 tv[2][3], ga[2], gb[2];                         // (ga | gb: dL/d grid x | y of pixels p .. p + 3)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int p = lo + (it + h2) * kStep + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int col = 3 * cgp + j;
+                tv[h2][j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (p < hi && col < K) tv[h2][j] = *reinterpret_cast<const float4*>(tabc + 4u * ((unsigned)col * (unsigned)n + (unsigned)p));
+            }
+            ga[h2] = gb[h2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (p < hi) { ga[h2] = *reinterpret_cast<const float4*>(sgx + p); gb[h2] = *reinterpret_cast<const float4*>(sgy + p); }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                          // one 8-term fp32 chain per column and batch, then fp64
+            float cx = 0.0f, cy = 0.0f;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const float4 t4 = tv[h2][j];
+                cx = fmaf(t4.x, ga[h2].x, cx); cy = fmaf(t4.x, gb[h2].x, cy);
+                cx = fmaf(t4.y, ga[h2].y, cx); cy = fmaf(t4.y, gb[h2].y, cy);
+                cx = fmaf(t4.z, ga[h2].z, cx); cy = fmaf(t4.z, gb[h2].z, cy);
+                cx = fmaf(t4.w, ga[h2].w, cx); cy = fmaf(t4.w, gb[h2].w, cy);
+            }
+            a[j][0] += (double)cx;
+            a[j][1] += (double)cy;
+        }
+    }
+    // the 64 lanes in fp64, a fixed order: inside the rows of 16 lanes on the DPP path (quad swaps, half-row and row mirrors:
+    // every lane of a row ends with the row's sum), the four rows through v_readlane -- no LDS traffic (a __shfl_xor butterfly
+    // of a double is 12 ds_bpermute: 72 per wavefront, half of this kernel's non-atomic LDS instructions)
+    auto dpp_f64 = [](double v, auto ctrl) {
+        constexpr int CT = decltype(ctrl)::value;
+        const long long r = __double_as_longlong(v);
+        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)r, CT, 0xf, 0xf, false);
+        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(r >> 32), CT, 0xf, 0xf, false);
+        return __longlong_as_double(((long long)hi_ << 32) | (unsigned)lo_);
+    };
+    auto lane_f64 = [](double v, int l) {
+        const long long r = __double_as_longlong(v);
+        const int lo_ = __builtin_amdgcn_readlane((int)r, l), hi_ = __builtin_amdgcn_readlane((int)(r >> 32), l);
+        return __longlong_as_double(((long long)hi_ << 32) | (unsigned)lo_);
+    };
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int xy = 0; xy < 2; ++xy) {
+            double d = a[j][xy];
+            d += dpp_f64(d, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+            d += dpp_f64(d, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+            d += dpp_f64(d, std::integral_constant<int, 0x141>{});     // row_half_mirror
+            d += dpp_f64(d, std::integral_constant<int, 0x140>{});     // row_mirror
+            const double tot = (lane_f64(d, 0) + lane_f64(d, 16)) + (lane_f64(d, 32) + lane_f64(d, 48));
+            if (lane == 0) sPart[wv][2 * j + xy] = tot;
+        }
+    __syncthreads();
+    // this thread's row of inv_delta_C^T (requested behind the barrier -- earlier, its 24 registers would sit on top of the column loop's -- and in flight while the halves are added)
+    float idc[24];
+    {
+        const int f = (tid >> 1) < F ? (tid >> 1) : 0;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) idc[k] = (tid < 2 * F && k < K) ? P.inv_delta_c[k * K + f] : 0.0f;
+    }
+    if (tid < 2 * K) {
+        const int k = tid >> 1, xy = tid & 1;
+        const int cg_ = k / 3, j = k - 3 * cg_;
+        sGT[tid] = sPart[cg_][2 * j + xy] + sPart[8 + cg_][2 * j + xy];
+    }
+    __syncthreads();
+    if (tid < 2 * F) {
+        const int xy = tid & 1;
+        double s_ = 0.0;
+#pragma unroll
+        for (int k = 0; k < 24; ++k) if (k < K) s_ = fma((double)idc[k], sGT[2 * k + xy], s_);
+        P.g_ctrl[(size_t)b * F * 2 + tid] = (float)s_;
+    }
+}
+
 }  // namespace
 
 namespace { int g_bwd_fixed_point = 0; }
@@ -589,6 +862,29 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     // kernel A'': two fixed-point planes (8 bytes per element) of a pass in <= 64 KB of LDS, <= 4096 output pixels
     // (1024-thread workgroups above 1024: the classic 32x100 geometry), planes of whole 16-byte pieces
     const size_t kLds2 = 16 * 1024;
+    // the classic geometry: sampling + parameter gradients in one launch (warp_bwd_classic_kernel)
+    const bool fixed_point = g_bwd_fixed_point || (table_flags & TPSPP_BWD_FIXED_POINT);
+    if (!in1 && !score && !p_xy && !fixed_point && !getenv("TPSPP_BWD_TWO_KERNELS") && C0 <= 3 && F + 3 <= 24 &&
+        p_hat_t_or_null && reinterpret_cast<uintptr_t>(p_hat_t_or_null) % 16 == 0 && P.n % 4 == 0 &&
+        P.n > 1024 && P.n <= 4096 && (size_t)C0 * plane0 * 2 <= 78 * 1024 && (size_t)C0 * plane0 * 2 >= (size_t)P.n * 8 &&
+        (size_t)C0 * plane0 * 2 >= (size_t)C0 * plane0 + ((size_t)W0 + 1) * 4 &&
+        plane0 % 16 == 0 && reinterpret_cast<uintptr_t>(in0) % 16 == 0 && (!g_in0 || reinterpret_cast<uintptr_t>(g_in0) % 16 == 0)) {
+        const size_t lds = (size_t)C0 * plane0 * 2;
+        auto go = [&](auto cc) {
+            constexpr int CC = decltype(cc)::value;
+            static bool attr_done[tpspp::kMaxDevices] = {};
+            if (tpspp::first_use_on_device(attr_done)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&warp_bwd_classic_kernel<CC>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024);
+                (void)hipGetLastError();
+            }
+            hipLaunchKernelGGL(warp_bwd_classic_kernel<CC>, dim3((unsigned)N), dim3(kClassicNT), lds, st, P, g_grid_ws);
+        };
+        if (C0 == 1) go(std::integral_constant<int, 1>{});
+        else if (C0 == 2) go(std::integral_constant<int, 2>{});
+        else go(std::integral_constant<int, 3>{});
+        return tpspp::check_launch("tpspp_warp_bwd(classic)");
+    }
     if (P.n <= 4096 && plane0 <= kLds2 && plane1 <= kLds2 && plane0 % 16 == 0 && plane1 % 16 == 0 &&
         (!g_in0 || reinterpret_cast<uintptr_t>(g_in0) % 16 == 0) && (!g_in1 || reinterpret_cast<uintptr_t>(g_in1) % 16 == 0)) {
         // channels per chunk: a chunk is worked off two planes at a time, so the LDS only ever holds two
@@ -610,7 +906,7 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
             else if (P.n <= 1024) hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 256, F64>), g2, block, accb, st, P, G, cpt0, cpt1, part, arrivals);
             else                  hipLaunchKernelGGL((warp_bwd_sample_lds2_kernel<4, 1024, F64>), g2, dim3(1024), accb, st, P, G, cpt0, cpt1, part, arrivals);
         };
-        if (g_bwd_fixed_point || (table_flags & TPSPP_BWD_FIXED_POINT)) go(std::false_type{});
+        if (fixed_point) go(std::false_type{});
         else go(std::true_type{});
         arrivals_zeroed = true;
     } else {
