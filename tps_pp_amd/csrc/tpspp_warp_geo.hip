@@ -152,7 +152,9 @@ bool plan_geo(int C, int H, int W, int F, Plan* p)
     int nload2 = p->nload < 3 && pieces1 / (p->nload + 1) >= tpspp_geo::kGeoKB ? p->nload + 1 : p->nload;
     // (NW >= 2: compute wavefront g solves image g's T -- with a single compute wavefront, wavefront 1 is a loader and image
     // B's T would never be published)
-    if (g_geo_pair && p->bands == 1 && p->NW >= 2 && QP * C <= 6 && pieces1 / nload2 >= tpspp_geo::kGeoKB && p->NW + nload2 <= 16 &&
+    // (QP <= 2: launch_qp has the pair form for one and two quadrant pixels per thread only -- a plan that said "pair" for QP 3 / 4
+    // was launched as the one-image kernel with the pair's LDS layout: 64x160 C = 1 faulted once its quadrant fitted one workgroup)
+    if (g_geo_pair && p->bands == 1 && p->NW >= 2 && QP <= 2 && QP * C <= 6 && pieces1 / nload2 >= tpspp_geo::kGeoKB && p->NW + nload2 <= 16 &&
         tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 2) <= 160 * 1024) {
         p->imgs = 2; p->nload = nload2;
         p->lds = tpspp_geo::geo_lds_bytes(F + 3, C, H, W, 2);

@@ -57,7 +57,14 @@ struct ImgParams {
 // (rows 4 banks apart), 32 x 1 where OW is a multiple of 32 (every row starts on the same bank: a 4 x 8 block would
 // be an 8-way conflict on every tap read -- 32x128 measured 21 us per 512 images that way, slower than the round-1
 // kernel).  A thread owns QP of the (OH/2)/BH row groups.
-__host__ __device__ constexpr int img_block_w(int OW) { return (OW % 32) == 0 ? 32 : ((OW % 32) & -(OW % 32)); }
+// Round 5: where OW is a multiple of 32 but the half-row is not (OW = 160: 80 columns), 32-column blocks would compute
+// ceil(80 / 32) * 32 = 96 columns -- a fifth of every wavefront's lanes on pixels other lanes own; 16 x 2 blocks cover
+// the half-row exactly.  Their two rows start on the same bank (a 2-way conflict on the tap reads), which costs less
+// than the lanes: these kernels are bound by vector-ALU time, not by the LDS.
+__host__ __device__ constexpr int img_block_w(int OW)
+{
+    return (OW % 32) == 0 ? (((OW / 2) % 32) == 0 || ((OW / 2) % 16) != 0 ? 32 : 16) : ((OW % 32) & -(OW % 32));
+}
 template <int OH, int OW, int QP>
 struct ImgGeo {
     static constexpr int halfW = OW / 2;
