@@ -72,10 +72,11 @@ def test_prepared_table_geometry_planner(lib):
     F + 3 transposed rows of Ho * Wo floats, then the packed copy: ceil(threads / 64) wavefronts x QP x 6 pieces x 64 lanes x
     4 floats, with QP = the smallest divisor of the quadrant's row groups that leaves <= 13 wavefronts, else the largest
     <= 4 (tpspp_warp_geo.hip: geo_qp); geometries with QP >= 3 carry a third section, the same packing with QP = 1 (every
-    quadrant pixel: the span-staging kernel's copy, tpspp_warp_span.h)."""
+    quadrant pixel: the span-staging kernel's copy, tpspp_warp_span.h).  (Round 5: W = 160 is tiled by 16 x 2 pixel blocks,
+    5 column groups -- 32 x 1 blocks would be 3 groups = 96 columns for a half-row of 80.)"""
     K = 23
-    want = {(32, 100): (1, 13 * 2 * 32), (32, 128): (2, 2 * 8 * 32), (48, 160): (3, 3 * 8 * 32), (32, 64): (1, 1 * 16 * 32),
-            (32, 160): (2, 3 * 8 * 32), (64, 256): (4, 4 * 8 * 32), (64, 200): (4, 13 * 2 * 32), (16, 64): (1, 1 * 8 * 32)}
+    want = {(32, 100): (1, 13 * 2 * 32), (32, 128): (2, 2 * 8 * 32), (48, 160): (3, 5 * 4 * 32), (32, 64): (1, 1 * 16 * 32),
+            (32, 160): (2, 5 * 4 * 32), (64, 256): (4, 4 * 8 * 32), (64, 200): (4, 13 * 2 * 32), (16, 64): (1, 1 * 8 * 32)}
     for (Ho, Wo), (qp, nthr) in want.items():
         nw = (nthr + 63) // 64
         span = ((nthr * qp + 63) // 64) * 6 * 64 * 4 if qp >= 3 else 0
