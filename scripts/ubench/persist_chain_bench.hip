@@ -33,7 +33,7 @@ __device__ __forceinline__ void store16_sys(float* p, f32x4 v)
 // MODE 0: barrier only; 1: + X loads (sc0 sc1) and the 4 KB store; 2: + weight loads and the product
 // PRE: weights requested before the barrier (1) or behind it (0)
 // STAGE: 1 = X arrives as whole rows (1 KB per wavefront instruction, sc0 sc1) and is re-read from LDS in fragment order
-template <int MODE, int PRE, int STAGE = 0>
+template <int MODE, int PRE, int STAGE = 0, int MAP = 0, int ST = 0, int AT = 0>
 __global__ void __launch_bounds__(256) pk(float* bufA, float* bufB, const u32x4* __restrict__ W, int* counters, int phases,
                                           int* errors)
 {
@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) pk(float* bufA, float* bufB, const u32x4*
     __shared__ int sOk;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, half = lane >> 5, l31 = lane & 31;
     // cluster = token block; the 16 workgroups of a cluster sit 16 blocks apart in launch order -> on 2 XCDs (block % 8)
-    const int tb = blockIdx.x & 15, ct = blockIdx.x >> 4;
+    // MAP 0: the 16 workgroups of a cluster 16 blocks apart -> all on XCD tb % 8; MAP 1: 16 consecutive blocks -> two per XCD
+    const int tb = MAP ? blockIdx.x >> 4 : blockIdx.x & 15, ct = MAP ? blockIdx.x & 15 : blockIdx.x >> 4;
     int* cnt = counters + tb * 32;                          // one counter per cluster, 128 bytes apart
     int bad = 0;
     for (int p = 0; p < phases; ++p) {
@@ -58,7 +59,8 @@ __global__ void __launch_bounds__(256) pk(float* bufA, float* bufB, const u32x4*
         if (p > 0) {
             __syncthreads();                                // (this workgroup's stores were drained below)
             if (tid == 0) {
-                __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (AT) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (executes in this XCD's L2)
+                else __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 int ok = 0;
                 for (int spin = 0; spin < (1 << 22); ++spin) {
                     if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 16 * p) { ok = 1; break; }
@@ -140,14 +142,15 @@ __global__ void __launch_bounds__(256) pk(float* bufA, float* bufB, const u32x4*
                 v[0] = s * 0.0f;                            // (weights are zero: keeps the dependence, not the value)
             }
             const float ph = (float)p + v[0];
-            store16_sys(out + (size_t)(tb * 32 + l31) * 512 + ct * 32 + 8 * wv + 4 * half, f32x4{ph, ph, ph, ph});
+            if (ST) *reinterpret_cast<f32x4*>(out + (size_t)(tb * 32 + l31) * 512 + ct * 32 + 8 * wv + 4 * half) = f32x4{ph, ph, ph, ph};   // plain: the line stays in this XCD's L2
+            else store16_sys(out + (size_t)(tb * 32 + l31) * 512 + ct * 32 + 8 * wv + 4 * half, f32x4{ph, ph, ph, ph});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     if (bad) atomicAdd(errors, bad);
 }
 
-template <int MODE, int PRE, int STAGE = 0> void run(const char* name, float* a, float* b, u32x4* w, int* counters, int* errors)
+template <int MODE, int PRE, int STAGE = 0, int MAP = 0, int ST = 0, int AT = 0> void run(const char* name, float* a, float* b, u32x4* w, int* counters, int* errors)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int n = 2000;
@@ -156,7 +159,7 @@ template <int MODE, int PRE, int STAGE = 0> void run(const char* name, float* a,
         hipMemset(counters, 0, 16 * 32 * 4); hipMemset(errors, 0, 8);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL((pk<MODE, PRE, STAGE>), dim3(256), dim3(256), 0, 0, a, b, w, counters, n, errors);
+        hipLaunchKernelGGL((pk<MODE, PRE, STAGE, MAP, ST, AT>), dim3(256), dim3(256), 0, 0, a, b, w, counters, n, errors);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         int err[2]; hipMemcpy(err, errors, 8, hipMemcpyDeviceToHost);
@@ -177,5 +180,11 @@ int main()
     run<2, 1>("+ W before the barrier + product", a, b, w, counters, errors);
     run<1, 0, 1>("X as whole rows via LDS + store", a, b, w, counters, errors);
     run<2, 1, 1>("W before barrier, X via LDS, product", a, b, w, counters, errors);
+    // round 5: placement and store flavour (the rows above: cluster on ONE XCD, sc0 sc1 stores, agent atomics)
+    run<2, 1, 1, 1, 0, 0>("  cluster spread over 8 XCDs", a, b, w, counters, errors);
+    run<2, 1, 1, 0, 1, 0>("  one XCD, PLAIN stores", a, b, w, counters, errors);
+    run<2, 1, 1, 0, 1, 1>("  one XCD, plain stores, wg atomics", a, b, w, counters, errors);
+    run<0, 0, 0, 1, 0, 0>("barrier only, spread", a, b, w, counters, errors);
+    run<0, 0, 0, 0, 0, 1>("barrier only, one XCD, wg atomics", a, b, w, counters, errors);
     return 0;
 }
