@@ -35,9 +35,9 @@ for mode, cd in (("fp32", None), ("bf16x3", "bf16x3"), ("bf16", torch.bfloat16))
     base = t()
     del os.environ["TPSPP_HEAD_NO_PERSIST"]
     row = [f"launch pipeline {base:.2f} ms"]
-    os.environ["TPSPP_HEAD_ONE_LAUNCH"] = "1"
-    row.append(f"one launch per decode {t():.2f}")
-    del os.environ["TPSPP_HEAD_ONE_LAUNCH"]
+    os.environ["TPSPP_HEAD_STEP_LAUNCHES"] = "1"
+    row.append(f"one launch per step {t():.2f}")
+    del os.environ["TPSPP_HEAD_STEP_LAUNCHES"]
     for st in [int(a) for a in sys.argv[1:]] or [0, 10, 20, 30, 40, 50]:
         os.environ["TPSPP_HEAD_STAGGER_US"] = str(st)
         row.append(f"stagger {st}: {t():.2f}")

@@ -402,15 +402,18 @@ def test_decoder_persistent_step_matches_the_launch_pipeline(cuda, n, seq):
                         assert torch.equal(got, want) and torch.equal(got_tf, want_tf), (cd, rep, float((got - want).abs().max()))
                     assert float((got - want).abs().max()) <= (5e-5 if cd == "bf16x3" else 5e-4), (cd, rep, float((got - want).abs().max()))
                     assert float((got_tf - want_tf).abs().max()) <= (1e-3 if cd == torch.bfloat16 else 1e-4) * float(want_tf.abs().max()), (cd, rep)
-                # the lab form with the step loop INSIDE the launch (one launch per decode): the same bits as one launch per step
-                os.environ["TPSPP_HEAD_ONE_LAUNCH"] = "1"
-                one = dec(None, enc, None, metas, train_mode=False)
-                one_tf = dec(None, enc, dict(padded_targets=forced), metas, train_mode=True)
-                del os.environ["TPSPP_HEAD_ONE_LAUNCH"]
-                assert torch.equal(one, got) and torch.equal(one_tf, got_tf), (cd, float((one - got).abs().max()))
+                # the step loop is INSIDE the launch (one launch per decode); one launch per step (TPSPP_HEAD_STEP_LAUNCHES=1) and
+                # write-through stores whatever the clusters' placement (TPSPP_HEAD_WRITE_THROUGH=1): the same bits
+                for var in ("TPSPP_HEAD_STEP_LAUNCHES", "TPSPP_HEAD_WRITE_THROUGH"):
+                    os.environ[var] = "1"
+                    one = dec(None, enc, None, metas, train_mode=False)
+                    one_tf = dec(None, enc, dict(padded_targets=forced), metas, train_mode=True)
+                    del os.environ[var]
+                    assert torch.equal(one, got) and torch.equal(one_tf, got_tf), (cd, var, float((one - got).abs().max()))
     finally:
         os.environ.pop("TPSPP_HEAD_NO_PERSIST", None)
-        os.environ.pop("TPSPP_HEAD_ONE_LAUNCH", None)
+        os.environ.pop("TPSPP_HEAD_STEP_LAUNCHES", None)
+        os.environ.pop("TPSPP_HEAD_WRITE_THROUGH", None)
         if old is not None:
             os.environ["TPSPP_HEAD_NO_PERSIST"] = old
 

@@ -406,6 +406,14 @@ __device__ __forceinline__ void st16_sys(float* p, hf32x4 v)
     // (s_nop: the VMEM store-data hazard is invisible to the compiler inside inline asm, as in tpspp_warp_pair.h)
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// `plain` (the persistent step kernel, when the 16 workgroups of a cluster were verified to sit on ONE XCD): an ordinary store --
+// the line stays in that XCD's L2, where the cluster's sc0 sc1 loads (which bypass L1 only) find it at the L2's latency; a
+// write-through store drops the line and the same reader fetches it over the fabric (MI355X_MICROARCH.md, "stores of each flavour").
+__device__ __forceinline__ void st16_x(float* p, hf32x4 v, bool plain)
+{
+    if (plain) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void wait_sys(hf32x4& a) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a)::"memory"); }
 __device__ __forceinline__ void wait_sys(hf32x4& a, hf32x4& b, hf32x4& c)
 {
@@ -460,7 +468,7 @@ template <> struct Wide<unsigned short> {
 template <typename KV, bool SYS = false, int MAXJJ = 4>
 __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
                                              int C, int Nb, int T, int nvalid, int b, int h, int lane, float* __restrict__ out,
-                                             int out_cm)
+                                             int out_cm, bool plain_st = false)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;   // tokens per instruction, pieces per 64 tokens
@@ -538,7 +546,7 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
             float* o = out + (size_t)b * C + kDK * h + EPL * dl;
 #pragma unroll
             for (int e = 0; e < EPL; e += 4) {
-                if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                if (SYS) st16_x(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]}, plain_st);
                 else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
             }
         }
@@ -552,7 +560,7 @@ __device__ __forceinline__ void cross_attend(const float (&q)[Wide<KV>::EPL], co
 // SYS: q via compiler-visible system-scope loads, output system-scope (the persistent step kernel).
 template <typename KV, bool SYS, typename Pre = NoPre>
 __device__ __forceinline__ bool cross_attend2(const float* __restrict__ qrow, const KV* __restrict__ Kx_t, const KV* __restrict__ Vx_t,
-                                              int C, int T, int nvalid, int b, int h, int lane, float* __restrict__ out, Pre pre = Pre())
+                                              int C, int T, int nvalid, int b, int h, int lane, float* __restrict__ out, Pre pre = Pre(), bool plain_st = false)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI, NH = 2;
@@ -634,7 +642,7 @@ __device__ __forceinline__ bool cross_attend2(const float* __restrict__ qrow, co
             float* o = out + (size_t)b * C + kDK * (h + n) + EPL * dl;
 #pragma unroll
             for (int e = 0; e < EPL; e += 4) {
-                if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                if (SYS) st16_x(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]}, plain_st);
                 else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
             }
         }
@@ -693,7 +701,7 @@ attn_dec_cross_wide2_kernel(const float* __restrict__ q_t, int ldq, const KV* __
 template <typename KV, bool SYS, int NH = 1, typename Pre = NoPre>
 __device__ __forceinline__ bool self_attend(const float* __restrict__ qkv_t, int C, int Nb, int H, int step, int Lmax,
                                             KV* __restrict__ Kc, KV* __restrict__ Vc, const int* __restrict__ tokens, int Lt,
-                                            int pad_idx, float* __restrict__ out, int out_cm, int b, int h, int lane, Pre pre = Pre())
+                                            int pad_idx, float* __restrict__ out, int out_cm, int b, int h, int lane, Pre pre = Pre(), bool plain_st = false)
 {
     typedef Wide<KV> Wd;
     constexpr int EPL = Wd::EPL, GS = kDK / EPL, TPI = kWave / GS, NP = kWave / TPI;
@@ -835,7 +843,7 @@ __device__ __forceinline__ bool self_attend(const float* __restrict__ qkv_t, int
                 float* o = out + (size_t)b * C + kDK * (h + n) + EPL * dl;
 #pragma unroll
                 for (int e = 0; e < EPL; e += 4) {
-                    if (SYS) st16_sys(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]});
+                    if (SYS) st16_x(o + e, hf32x4{acc[e], acc[e + 1], acc[e + 2], acc[e + 3]}, plain_st);
                     else *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
                 }
             }
@@ -1746,6 +1754,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         PS.err = pcounters + (size_t)(N + 31) / 32 * 32;
         PS.pairs = 2;
         PS.trace = g_head_trace;
+        PS.no_plain = getenv("TPSPP_HEAD_WRITE_THROUGH") ? 1 : 0;
         // odd clusters start 15 us late (TPSPP_HEAD_STAGGER_US overrides; 0 = together): bf16x3 20.0 -> 19.4 ms, bf16 15.4 -> 15.0
         { const char* sv = getenv("TPSPP_HEAD_STAGGER_US"); PS.stagger = (sv ? atoi(sv) : (N > 32 ? 15 : 0)) * 100; }
         if (hipMemsetAsync(pcounters, 0, ((size_t)(N + 31) / 32 * 32 + 64) * sizeof(int), st) != hipSuccess)
@@ -1761,17 +1770,21 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table, tokens, Lt, 0, C,
                            N, x, 1);
         const int per_step = 8 * n_layers + 2;                 // cluster barriers of one step
-        // one launch per step.  TPSPP_HEAD_ONE_LAUNCH=1 (lab switch): the whole decode of a chunk as ONE launch -- the kernel
-        // loops over the steps, clusters run their 40 steps independently of each other; same scores, and measured SLOWER
-        // (batch 512: fp32 23.04 -> 23.25 ms, bf16x3 20.02 -> 20.35, bf16 15.03 -> 15.20): the next step's launch is
-        // already queued behind the running one, and the launch boundary re-aligns the clusters' memory phases
-        const int per_launch = getenv("TPSPP_HEAD_ONE_LAUNCH") ? L : 1;
+        // ONE launch per decode: the kernel loops over the steps, clusters run their 40 steps independently of each other.
+        // (With the clusters spread over the XCDs -- the first version of this kernel -- one launch per step was faster:
+        // 23.04 against 23.25 ms; with a cluster per XCD and ordinary stores the step loop inside wins: fp32 22.12 -> 21.58 ms,
+        // bf16x3 19.67 -> 19.07, bf16 14.29 -> 13.83 at batch 512.)  TPSPP_HEAD_STEP_LAUNCHES=1: one launch per step -- same
+        // scores (tests/test_gpu_head.py), for A/B runs.
+        const int per_launch = getenv("TPSPP_HEAD_STEP_LAUNCHES") ? 1 : L;
         for (int s = 0; s < L; s += per_launch) {
-            PS.x = x; PS.y = y; PS.step = s; PS.nsteps = per_launch; PS.bar_base = s * per_step;
+            // (+ one placement-check barrier per launch)
+            PS.x = x; PS.y = y; PS.step = s; PS.nsteps = per_launch; PS.bar_base = s * per_step + s / per_launch;
             for (int n0 = 0; n0 < N; n0 += 512) {              // <= 256 workgroups per launch: every cluster resident
                 const int nimg = N - n0 < 512 ? N - n0 : 512;
                 PS.n0 = n0; PS.counters = pcounters + (n0 >> 5) * 32;
-                hipLaunchKernelGGL(kern, dim3((unsigned)((nimg + 31) / 32 * 16)), dim3(512), sizeof(PShared), st, PS);
+                PS.nclusters = (nimg + 31) / 32;
+                // cluster c = 8 j + x is the 16 blocks 8 (16 j + ct) + x: one XCD per cluster (see the kernel)
+                hipLaunchKernelGGL(kern, dim3((unsigned)((PS.nclusters + 7) / 8 * 128)), dim3(512), sizeof(PShared), st, PS);
             }
             if (per_launch == 1) {
                 if (n_layers & 1) { float* t = x; x = y; y = t; }  // (the kernel swaps x / y once per layer)

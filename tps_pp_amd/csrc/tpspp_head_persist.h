@@ -14,9 +14,15 @@
 // whole phase 4.2 us against 6.35.
 //
 // Mechanics (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
-//   * everything a phase hands to the next one (x, y, a, q|k|v, hidden, logits) is written with system-scope
-//     write-through stores (sc0 sc1), drained (vmcnt(0)) before the workgroup arrives at the barrier, and read with
-//     system-scope loads -- no release / acquire fences (a fence writes back / invalidates whole caches: 1.7-6.5 us each);
+//   * everything a phase hands to the next one (x, y, a, q|k|v, hidden, logits) is stored, drained (vmcnt(0)) before the
+//     workgroup arrives at the barrier, and read with system-scope loads (sc0 sc1: they bypass the reader's L1 and are served
+//     by its XCD's L2) -- no release / acquire fences (a fence writes back / invalidates whole caches: 1.7-6.5 us each).
+//     The stores: a cluster's 16 workgroups are the blocks 8 (16 j + ct) + x -- blocks go to the XCDs round-robin, so the
+//     cluster sits on XCD x and shares ONE L2.  Each launch verifies that (every workgroup ORs its HW_REG_XCC_ID into the
+//     cluster's mask in front of an extra barrier) and, if it holds, stores with ORDINARY stores: the line stays in that L2
+//     and the cluster's reads hit it; if it does not hold (another partition mode, a different dispatcher), or with
+//     TPSPP_HEAD_WRITE_THROUGH=1, with write-through stores (sc0 sc1) as the first version did -- correct under any
+//     placement, the reader fetches over the fabric.  Same bits either way;
 //   * barrier = one relaxed agent-scope atomic on the cluster's counter (monotonic over the whole batch: target = 16 x
 //     barriers so far) + a bounded poll with s_sleep by one lane; a timeout raises *err, turns the step's scores of the
 //     workgroup's images into NaN and the workgroup leaves (no hang: the GPU box survives a protocol bug);
@@ -29,18 +35,20 @@
 //     overwrite here: q keeps the q|k|v row pitch);
 //   * read-only operands (weights, encoder keys / values) and the self-attention caches (written by this launch, read by
 //     LATER launches only) use plain accesses.
-// One launch per step (40 per batch instead of ~2000), 512 threads per workgroup.  Projections: all 8 wavefronts split K
+// One launch per DECODE (the kernel loops over the steps; ~2000 launches per batch before), 512 threads per workgroup.  Projections: all 8 wavefronts split K
 // (dec_gemm_x3_kernel: 4 -- a 512-thread workgroup has 256 registers per lane; with an eighth of K per wavefront the
 // weights of all three q|k|v tiles can be requested before the barrier), so a result's last bits may differ from the
 // launch pipeline's: soft-max scores within 2e-5, decided tokens identical (tests/test_gpu_head.py).  Attentions: a
 // wavefront owns both heads of a head pair of one image and runs every stage for both before the next stage starts (8
 // wavefronts per CU must keep as many requests in flight as the launch form's 16).  Workgroup w of a cluster owns output
-// tile w of a projection (tiles 3 w .. 3 w + 2 of q|k|v) and images 2 w, 2 w + 1 in the attentions.  A cluster's
-// workgroups are consecutive in launch order (complete clusters become resident together); at most 512 images per launch
-// (256 workgroups, one per CU): larger batches run as several launches per step.
+// tile w of a projection (tiles 3 w .. 3 w + 2 of q|k|v) and images 2 w, 2 w + 1 in the attentions.  At most 512 images
+// per launch (16 clusters = 256 workgroups, one per CU, two clusters per XCD): larger batches run as several launches.
 // Odd clusters start `stagger` late: with every cluster in the same phase the memory system is saturated during the
 // attentions and idle during the latency-bound projections; half a phase apart the two halves of the chip alternate.
-// Measured (batch 512, 40 steps, MI355X): bf16x3 head 20.3 -> 19.4 ms, bf16 head 15.5 -> 15.0 ms; per layer-step
+// (With the step loop inside the launch the clusters drift apart on their own: the stagger no longer measures.)
+// Measured (batch 512, 40 steps, MI355X; launch pipeline -> clusters spread over the XCDs, write-through stores, one launch
+// per step -> cluster per XCD, ordinary stores, one launch per decode): fp32 head 23.9 -> 22.5 -> 21.5 ms, bf16x3 head
+// 21.0 -> 19.7 -> 18.9 ms, bf16 head 15.5 -> 15.0 -> 13.5 ms; per layer-step of the first persistent version
 // (scripts/debug/trace_decoder_step.py): q|k|v 9.1, self-attention 14.0, x+fc 6.6, q 5.5, cross-attention 22.4 (launch
 // form: 28.6), x+fc 6.8, w1 4.5, w2 6.5 us -- a projection phase is barrier 1.5 (incl. the cluster's skew) + rows 1.5 +
 // products / reduction / epilogue 1.2-1.6 + store drain 0.5-0.8 us.
@@ -63,12 +71,14 @@ struct PStep {
     int* tokens; int Lt; float* out; int greedy; int pad_idx;
     const int* valid_len;
     int N, n0, C, T, H, d_inner, step, nsteps, Lsteps, Lmax;   // images [n0, n0 + up to 512) of N; steps [step, step + nsteps) in this launch
-    int* counters; int bar_base;              // cluster counters (128 B apart), barriers passed before this launch
+    int* counters; int bar_base;              // cluster counters (128 B apart; word 1: the cluster's XCD mask), barriers passed before this launch
+    int nclusters;                            // clusters of this launch (grid = ceil(nclusters / 8) x 128 workgroups: see the kernel)
     int pairs;                                // (image, head) pairs per wavefront in the attention phases (2; a run-time value: the
                                               // pair loop must stay a loop -- unrolled, the compiler interleaves two attentions' registers)
     int* err;
     int stagger;                              // odd clusters start this many 10-ns ticks late (see the kernel); 0 = together
     long long* trace;                         // optional (tpspp_head_set_trace): 64 wall-clock stamps (100 MHz) per workgroup and step
+    int no_plain;                             // lab / test switch (TPSPP_HEAD_WRITE_THROUGH=1): write-through stores whatever the placement
 };
 
 constexpr int kPXPitch = 516;                 // floats per staged X row (512 + 4: fragment reads hit all banks)
@@ -105,6 +115,7 @@ struct PGemm {
     const float* X; const void* Wp; const float* bias; const float* colsum; const float* res; float* out;
     int M, Co; float eps; int act;
     int ldo;                    // row pitch of `out` and `res` in floats (Co, except the q projection: see the step kernel)
+    bool plain;                 // the cluster sits on one XCD: ordinary stores (st16_x)
 };
 
 // KSW = 16-wide k-steps per wavefront = K / 128: the EIGHT wavefronts of the workgroup split K (the launch-per-phase kernel
@@ -272,7 +283,7 @@ __device__ __forceinline__ bool pgemm_phase(const PGemm& G, int tb, int ct0, PSh
                 for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
             }
             if (G.res) { v[0] += r4[tl][0]; v[1] += r4[tl][1]; v[2] += r4[tl][2]; v[3] += r4[tl][3]; }
-            st16_sys(G.out + o, hf32x4{v[0], v[1], v[2], v[3]});
+            st16_x(G.out + o, hf32x4{v[0], v[1], v[2], v[3]}, G.plain);
         }
         if (tl + 1 < NT) __syncthreads();                  // the partial sums have been read: sRed is free for the next tile
     }
@@ -379,7 +390,7 @@ __device__ __forceinline__ bool pgemm_phase_f32(const PGemm& G, int tb, int ct0,
                 for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
             }
             if (G.res) { v[0] += r4[tl][0]; v[1] += r4[tl][1]; v[2] += r4[tl][2]; v[3] += r4[tl][3]; }
-            st16_sys(G.out + o, hf32x4{v[0], v[1], v[2], v[3]});
+            st16_x(G.out + o, hf32x4{v[0], v[1], v[2], v[3]}, G.plain);
         }
         if (tl + 1 < NT) __syncthreads();
     }
@@ -397,7 +408,7 @@ __device__ __forceinline__ bool pgemm(const PGemm& G, int tb, int ct0, PShared& 
 
 // ---- the attention phases (their own functions: each gets its own register allocation) -------------------------------------
 template <typename KV>
-__device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int step, int ab, int ah0, int lane, PShared& S, int* cnt, int target)
+__device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int step, int ab, int ah0, int lane, PShared& S, int* cnt, int target, bool plain)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
     auto bar = [&]() { return cluster_barrier(cnt, target, &S.flag, P.err); };
@@ -405,7 +416,7 @@ __device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int
     if (ab < P.N)
         // both heads of the wavefront at once; the cluster barrier sits behind the cache requests (self_attend's `pre`)
         ok = self_attend<KV, true, 2>(P.qkv, P.C, P.N, P.H, step, P.Lmax, reinterpret_cast<KV*>(W.Kc), reinterpret_cast<KV*>(W.Vc),
-                                      P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0, lane, bar);
+                                      P.tokens, P.Lt, P.pad_idx, P.a, 0, ab, ah0, lane, bar, plain);
     else
         ok = bar();
     drain_stores();
@@ -413,7 +424,7 @@ __device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int
 }
 
 template <typename KV>
-__device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane, PShared& S, int* cnt, int target)
+__device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane, PShared& S, int* cnt, int target, bool plain)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
     typedef Wide<KV> Wd;
@@ -426,7 +437,7 @@ __device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, in
     bool ok = true;
     if (P.T <= kWave) {
         ok = cross_attend2<KV, true>(qrow, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.T, nvalid, ab, ah0,
-                                     lane, P.a, bar);
+                                     lane, P.a, bar, plain);
     } else {
         ok = bar();
         const int dl = lane % GS;
@@ -441,7 +452,7 @@ __device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, in
                 for (int j = 0; j < 4; ++j) q[4 * e + j] = rq[j] * 0.125f;
             }
             cross_attend<KV, true, 4>(q, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.N, P.T, nvalid,
-                                      ab, h, lane, P.a, 0);
+                                      ab, h, lane, P.a, 0, plain);
         }
     }
     drain_stores();
@@ -465,7 +476,12 @@ dec_step_persist_kernel(const PStep P)
     PShared& S = *reinterpret_cast<PShared*>(p_smem);
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tb = blockIdx.x >> 4, ct = blockIdx.x & 15;      // cluster (32 images), workgroup within it
+    // block -> (cluster, workgroup in it): the 16 workgroups of a cluster are 16 blocks with the SAME blockIdx.x % 8, i.e.
+    // -- as blocks are observed to be dealt to the XCDs round-robin -- on one XCD, whose L2 then carries the cluster's
+    // exchanges (verified below, per launch: nothing depends on the placement for correctness).  Cluster c = 8 j + x is
+    // blocks 8 (16 j + ct) + x; blocks of clusters >= nclusters leave.
+    const int tb = ((blockIdx.x >> 7) << 3) + (blockIdx.x & 7), ct = (blockIdx.x >> 3) & 15;   // cluster (32 images), workgroup within it
+    if (tb >= P.nclusters) return;
     int* cnt = P.counters + tb * 32;
     int bar = P.bar_base;
     const int N = P.N, C = P.C, H = P.H;
@@ -482,6 +498,29 @@ dec_step_persist_kernel(const PStep P)
     if (P.stagger > 0 && (tb & 1)) {
         const long long t0 = (long long)wall_clock64();
         while ((long long)wall_clock64() - t0 < P.stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    // ---- placement check (one extra cluster barrier per launch): every workgroup ORs the id of the XCD it runs on into the
+    // cluster's mask; one bit set = the whole cluster shares an L2 and its exchanged data goes out as ORDINARY stores (the
+    // line stays in that L2: st16_x), else as write-through stores as in the first version of this kernel.  Measured at
+    // batch 512 (scripts/debug/bench_decoder_modes.py): fp32 -8 %, bf16x3 -8 %, bf16 -10 % per decode.
+    bool plain;
+    {
+        if (tid == 0) {
+            const unsigned id = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID[3:0]
+            __hip_atomic_fetch_or(cnt + 1, 1 << id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) {
+            if (wv < 2) {                                      // (as fail() below)
+                const int b = tbg * 32 + 2 * ct + wv;
+                if (b < N) for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + P.step) * P.num_out + c] = __builtin_nanf("");
+            }
+            return;
+        }
+        if (tid == 0) S.flag = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wg_barrier_lds();
+        const int mask = S.flag;                               // (the next barrier's flag write sits behind its own workgroup barrier)
+        plain = __builtin_popcount((unsigned)mask) == 1 && !P.no_plain;
     }
     for (int step = P.step; step < P.step + P.nsteps; ++step) {
     int stamp_i = 0;
@@ -502,16 +541,16 @@ dec_step_persist_kernel(const PStep P)
         const PLayer& W = P.L[l];
         // 1. q | k | v = LN1(x) Wqkv                                              transformer_layers.py:150-151
         {
-            const PGemm G{x, W.qkv_x, W.qkv_b, W.qkv_cs, nullptr, P.qkv, N, 3 * C, 1e-5f, 0, 3 * C};
+            const PGemm G{x, W.qkv_x, W.qkv_b, W.qkv_cs, nullptr, P.qkv, N, 3 * C, 1e-5f, 0, 3 * C, plain};
             if (!pgemm<F32, 4, true, 3>(G, tbg, 3 * ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         // 2. cached self-attention -> a
-        if (!pself_phase<KV>(P, W, step, ab, ah0, lane, S, cnt, 16 * (++bar))) { fail(); return; }
+        if (!pself_phase<KV>(P, W, step, ab, ah0, lane, S, cnt, 16 * (++bar), plain)) { fail(); return; }
         stamp();
         // 3. y = x + fc(a)                                                         transformer_layers.py:152-154
         {
-            const PGemm G{P.a, W.wfc_x, W.bfc, nullptr, x, y, N, C, 0.0f, 0, C};
+            const PGemm G{P.a, W.wfc_x, W.bfc, nullptr, x, y, N, C, 0.0f, 0, C, plain};
             long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)step * gridDim.x + blockIdx.x) * 64 + 50 : nullptr;
             if (!pgemm<F32, 4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
@@ -521,29 +560,29 @@ dec_step_persist_kernel(const PStep P)
             // (q goes into the first C columns of the image's OWN q|k|v row, pitch 3 C: the launch pipeline packs q rows at pitch C
             // into the same buffer, which there is safe -- every image is past its self-attention -- and here would let one
             // cluster's q overwrite another cluster's q|k|v rows: clusters are not synchronised with each other)
-            const PGemm G{y, W.q_x, W.q_b, W.q_cs, nullptr, P.qkv, N, C, 1e-5f, 0, 3 * C};
+            const PGemm G{y, W.q_x, W.q_b, W.q_cs, nullptr, P.qkv, N, C, 1e-5f, 0, 3 * C, plain};
             long long* sub = (P.trace && l == 2) ? P.trace + ((size_t)step * gridDim.x + blockIdx.x) * 64 + 56 : nullptr;
             if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err, sub)) { fail(); return; }
         }
         stamp();
         // 5. cross-attention against the encoder keys / values -> a
-        if (!pcross_phase<KV>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar))) { fail(); return; }
+        if (!pcross_phase<KV>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar), plain)) { fail(); return; }
         stamp();
         // 6. x = y + fc(a)                                                         transformer_layers.py:158-159
         {
-            const PGemm G{P.a, W.wfc2_x, W.bfc2, nullptr, y, x, N, C, 0.0f, 0, C};
+            const PGemm G{P.a, W.wfc2_x, W.bfc2, nullptr, y, x, N, C, 0.0f, 0, C, plain};
             if (!pgemm<F32, 4, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         // 7. hidden = gelu(LN3(x) W1 + b1)                                         transformer_layers.py:161-162
         {
-            const PGemm G{x, W.w1_x, W.w1_b, W.w1_cs, nullptr, P.hid, N, P.d_inner, 1e-5f, 2, P.d_inner};
+            const PGemm G{x, W.w1_x, W.w1_b, W.w1_cs, nullptr, P.hid, N, P.d_inner, 1e-5f, 2, P.d_inner, plain};
             if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
         // 8. y = x + W2 hidden + b2                                                transformer_layers.py:162-163
         {
-            const PGemm G{P.hid, W.w2_x, W.b2, nullptr, x, y, N, C, 0.0f, 0, C};
+            const PGemm G{P.hid, W.w2_x, W.b2, nullptr, x, y, N, C, 0.0f, 0, C, plain};
             if (!pgemm<F32, KSW2, false, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
         }
         stamp();
@@ -551,7 +590,7 @@ dec_step_persist_kernel(const PStep P)
     }
     // final LayerNorm (eps 1e-6) folded into the classifier                       nrtr_decoder.py:77,111 + :78
     {
-        const PGemm G{x, P.cls_x, P.cls_b, P.cls_cs, nullptr, P.logits, N, P.num_out, 1e-6f, 0, P.num_out};
+        const PGemm G{x, P.cls_x, P.cls_b, P.cls_cs, nullptr, P.logits, N, P.num_out, 1e-6f, 0, P.num_out, plain};
         if (!pgemm<F32, 4, true, 1>(G, tbg, ct, S, cnt, 16 * (++bar), P.err)) { fail(); return; }
     }
     stamp();
@@ -577,7 +616,7 @@ dec_step_persist_kernel(const PStep P)
                     // system-scope loads of the row -- after another XCD has rewritten it -- were served from that stale line)
                     for (int c = 4 * lane; c < C; c += 4 * kWave) {
                         const float4 e4 = *reinterpret_cast<const float4*>(er + c), p4 = *reinterpret_cast<const float4*>(pr + c);
-                        st16_sys(y + (size_t)b * C + c, hf32x4{e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w});
+                        st16_x(y + (size_t)b * C + c, hf32x4{e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w}, plain);
                     }
                 }
             };
