@@ -450,8 +450,9 @@ int tpspp_conv_set_tuning(int flags);
  * geometry in its banded form as well (every band stages the whole image: round 4's kernel, kept for comparisons);
  * bands = workgroups per image pair in the LDS-staged kernel, 0..8 (0 = heuristic); with kernel_choice 7 / 9: bits 0-2 =
  * workgroups per image (0 = heuristic), bit 3 = never an image pair per workgroup; with kernel_choice 8: bits 0-5 =
- * workgroups per image (0 = heuristic), bit 6 = every workgroup on its global-memory path, bits 8-15 = LDS budget per
- * workgroup in KB (0 = 38: four workgroups per CU).
+ * workgroups per image (0 = heuristic), bit 6 = every workgroup on its global-memory path, bit 7 = measure each band's
+ * row span before staging it (the first form) instead of requesting the band's rows +- 2 at launch, bits 8-15 = LDS budget
+ * per workgroup in KB (0 = 38 / 40: four workgroups per CU).
  */
 int tpspp_warp_set_tuning(int images_per_group, int threads_per_group, int kernel_choice, int bands);
 

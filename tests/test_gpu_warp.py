@@ -531,7 +531,10 @@ def test_span_staging_kernel_forced(cuda, oracle, N, C, H, W):
     noise: bands fold far more rows than the buffer holds and take their taps from global memory, others still stage), with
     every workgroup forced onto the global-memory path (bit 6), with another band count and a small buffer; specials in
     the image (a NaN / inf tap must poison exactly the outputs the oracle's taps reach); batches that are no multiple of
-    the 8 XCDs the block -> image mapping interleaves; 64x256x3 does not fit the LDS as a whole image at all."""
+    the 8 XCDs the block -> image mapping interleaves; 64x256x3 does not fit the LDS as a whole image at all.  Round 5,
+    late: where four workgroups still fit a CU the kernel requests both regions' WINDOWS (band rows +- 2) at launch instead
+    of measuring the spans first, and a wavefront whose taps leave the window takes that mirror pixel from global memory
+    (0.45 noise: most wavefronts do); bit 7 of the knob (128) selects the measured-span form -- both forms, every case."""
     F = 20
     Kc = oracle.classic_constants(F, (H, W))
     img = synth.dyadic((N, C, H, W), "sp.img", N + 3).copy()
@@ -545,7 +548,8 @@ def test_span_staging_kernel_forced(cuda, oracle, N, C, H, W):
     assert packed == ops.TABLE_PACKED
     inv = dev(Kc["inv_delta_C"], cuda)
     try:
-        for noise, knob in ((0.03, 0), (0.45, 0), (0.1, 64), (0.1, 2 | (40 << 8)), (0.03, 0 | (150 << 8))):
+        for noise, knob in ((0.03, 0), (0.45, 0), (0.1, 64), (0.1, 2 | (40 << 8)), (0.03, 0 | (150 << 8)), (0.03, 128), (0.45, 128),
+                            (0.1, 128 | 2 | (40 << 8))):
             ctrl = oracle.classic_initial_ctrl(F)[None] + noise * synth.dyadic((N, F, 2), "sp.ctrl", N + int(100 * noise))
             ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
             try:

@@ -776,14 +776,15 @@ TPSPP_EXPORT int tpspp_warp_set_tuning(int images_per_group, int threads_per_gro
     // kernel_choice 7 (run-time-geometry kernel): bits 0-2 = workgroups per image, bit 3 = never an image pair; every other
     // choice: workgroups per image (pair) of the LDS-staged / mirror kernels, built and tested for 0..8
     // kernel_choice 8 (row bands with span staging): bits 0-5 = workgroups per image (0 = heuristic), bit 6 (64) = every
-    // workgroup on its global-memory path, bits 8-15 = LDS budget per workgroup in KB (0 = 38)
+    // workgroup on its global-memory path, bit 7 (128) = the measured-span form instead of the windows requested at launch,
+    // bits 8-15 = LDS budget per workgroup in KB (0 = 38)
     TPSPP_REQUIRE(bands >= 0 && bands <= (kernel_choice == 8 ? 0xffff : (kernel_choice == 7 || kernel_choice == 9) ? 15 : 8),
                   "bands must be in [0, 8] (kernel_choice 7 / 9: [0, 15], bit 3 = never an image pair; 8: see tpspp.h)");
     g_tune_kernel = kernel_choice % 10 == 3 ? 2 : kernel_choice;
     g_tune_mirror = kernel_choice == 3 ? 2 : 0;       // 3: LDS-staged kernel WITHOUT the mirror trick
     tpspp::geo_set_bands((kernel_choice == 7 || kernel_choice == 9) ? bands : 0);
     tpspp::span_set_tuning(kernel_choice == 8 ? (bands & 63) : 0, kernel_choice == 8 ? ((bands >> 6) & 1) : 0,
-                           kernel_choice == 8 ? ((bands >> 8) & 255) : 0);
+                           kernel_choice == 8 ? ((bands >> 8) & 255) : 0, kernel_choice == 8 ? ((bands >> 7) & 1) : 0);
     g_tune_bands = bands;
     TPSPP_REQUIRE(images_per_group >= 0 && images_per_group <= 64, "images_per_group out of range");
     TPSPP_REQUIRE(threads_per_group == 0 || (threads_per_group % 64 == 0 && threads_per_group >= 64 &&

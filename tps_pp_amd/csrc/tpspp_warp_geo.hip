@@ -47,11 +47,12 @@ int span_table_waves(int Ho, int Wo)
 namespace {
 
 struct Plan { int QP, BW, CG, RGB, bands, nthr, NW, nload, imgs; size_t lds; };
-struct SpanPlan { int BW, CG, RG, bands, nthr, NWv, span_rows, chunk_floats; size_t lds; };
+struct SpanPlan { int BW, CG, RG, bands, nthr, NWv, span_rows, chunk_floats, margin, spec; size_t lds; };
 
 int g_span_bands = 0;        // lab knobs (tpspp_warp_set_tuning with kernel_choice 8): workgroups per image, 0 = heuristic;
 int g_span_gather = 0;       // every workgroup on the global-memory path;
 int g_span_lds_kb = 0;       // LDS budget per workgroup in KB, 0 = 38 (four workgroups per CU)
+int g_span_no_spec = 0;      // the measured-span form (rounds 5's first version) instead of the windows requested at launch
 
 // Row bands with span staging (tpspp_warp_span.h): workgroups per image (a divisor of the quadrant's row groups) and the
 // staging buffer's size; the buffer then takes whatever span fits (the rows the band's taps reach, per region).
@@ -70,6 +71,7 @@ bool plan_span(int C, int H, int W, int F, SpanPlan* p)
     // wavefronts <= 8, else anything <= 13; buffer 38 KB, more only when the band's own rows + 3 do not fit.
     const size_t kb = (size_t)(g_span_lds_kb > 0 ? g_span_lds_kb : 38);
     const size_t budgets[3] = {kb * 1024, (size_t)78 * 1024, (size_t)158 * 1024};
+    p->margin = 0; p->spec = 0;
     for (size_t budget : budgets)
         for (int cls = 0; cls < 3; ++cls) {
             int bestB = 0, bestNW = 0;
@@ -92,15 +94,39 @@ bool plan_span(int C, int H, int W, int F, SpanPlan* p)
                 p->chunk_floats = tpspp_span::span_chunk_floats(span_rows, W);
                 p->lds = tpspp_span::span_lds_bytes(K, C, W, span_rows, rows);
             }
-            if (bestB) return true;
+            if (bestB) {
+                // windows requested at launch (SPEC) for the SAME decomposition: both regions' windows (band rows + 2 x margin)
+                // at once; margin 2 rows (TPSPP_SPAN_MARGIN overrides: 1 -> more wavefronts on the global-memory path at
+                // +-1.6 rows of displacement, 3 -> three workgroups per CU; both slower) -- only where four workgroups still
+                // share a CU (<= 40 KB: 64x200 45.4 against 48.8 us, 48x160 26.4 against 29.9; 64x256 would need 50 KB and
+                // measures 56.8 against 52.5 -- or fewer, smaller workgroups: worse --: it keeps the measured spans)
+                if (!g_span_no_spec) {
+                    const char* mv = getenv("TPSPP_SPAN_MARGIN");
+                    int mg = mv ? atoi(mv) : 2;
+                    if (mg < 0) mg = 0;
+                    const int rows = (p->RG / p->bands) * BH;
+                    int win = rows + 2 * mg;
+                    if (win > H) win = H;
+                    const int chunk = win * W;           // exact: no rounding to whole DMA pieces (see the kernel)
+                    size_t stage = (size_t)2 * C * chunk;
+                    const size_t outb = (size_t)2 * C * rows * W;
+                    if (outb > stage) stage = outb;
+                    const size_t lds = (size_t)(tpspp_span::span_stage_off(K) + stage + W + 4) * 4;
+                    const size_t cap = (size_t)(g_span_lds_kb > 0 ? g_span_lds_kb : 40) * 1024;
+                    if (rows * W * 4 >= 1008 && lds <= cap) {   // (a piece straddles at most two channels, also in a clipped window)
+                        p->spec = 1; p->margin = mg; p->span_rows = win; p->chunk_floats = chunk; p->lds = lds;
+                    }
+                }
+                return true;
+            }
         }
     return false;
 }
 
-template <int C, bool AUX>
+template <int C, bool AUX, bool SPEC>
 void launch_span_one(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStream_t st)
 {
-    auto kern = tpspp_span::tps_warp_span_kernel<20, C, AUX>;
+    auto kern = tpspp_span::tps_warp_span_kernel<20, C, AUX, SPEC>;
     static bool attr_done[kMaxDevices] = {};
     if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -113,8 +139,13 @@ void launch_span_one(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStr
 template <int C>
 void launch_span_aux(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStream_t st)
 {
-    if (P.grid || P.idx) launch_span_one<C, true>(P, pl, st);
-    else launch_span_one<C, false>(P, pl, st);
+    if (pl.spec) {
+        if (P.grid || P.idx) launch_span_one<C, true, true>(P, pl, st);
+        else launch_span_one<C, false, true>(P, pl, st);
+        return;
+    }
+    if (P.grid || P.idx) launch_span_one<C, true, false>(P, pl, st);
+    else launch_span_one<C, false, false>(P, pl, st);
 }
 
 int g_geo_pair = 1;          // lab knob: 0 = never an image pair per workgroup
@@ -198,7 +229,7 @@ void launch_qp(const tpspp_geo::GeoParams& P, const Plan& pl, hipStream_t st)
 }  // namespace
 
 void geo_set_bands(int bands) { g_geo_force_bands = bands & 7; g_geo_pair = (bands & 8) ? 0 : 1; }
-void span_set_tuning(int bands, int gather, int lds_kb) { g_span_bands = bands; g_span_gather = gather; g_span_lds_kb = lds_kb; }
+void span_set_tuning(int bands, int gather, int lds_kb, int no_spec) { g_span_bands = bands; g_span_gather = gather; g_span_lds_kb = lds_kb; g_span_no_spec = no_spec; }
 
 bool geo_kernel_single_workgroup(int C, int H, int W, int F)
 {
@@ -224,6 +255,7 @@ bool launch_span_kernel(int C, int H, int W, int F, const float* in, const float
     P.lg_bw = __builtin_ctz((unsigned)pl.BW);
     P.span_rows = pl.span_rows; P.chunk_floats = pl.chunk_floats; P.stage_off = tpspp_span::span_stage_off(F + 3);
     P.force_gather = g_span_gather;
+    P.margin = pl.margin;
     if (C == 1) launch_span_aux<1>(P, pl, st);
     else if (C == 3) launch_span_aux<3>(P, pl, st);
     else launch_span_aux<4>(P, pl, st);

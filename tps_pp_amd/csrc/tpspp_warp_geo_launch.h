@@ -25,7 +25,7 @@ int span_table_waves(int Ho, int Wo);
 bool geo_kernel_single_workgroup(int C, int H, int W, int F);
 bool span_kernel_applicable(int C, int H, int W, int F);
 // lab knobs: workgroups per image (0 = heuristic), every workgroup on the global-memory path, LDS budget in KB (0 = 38)
-void span_set_tuning(int bands, int gather, int lds_kb);
+void span_set_tuning(int bands, int gather, int lds_kb, int no_spec);
 bool launch_span_kernel(int C, int H, int W, int F, const float* in, const float* ctrl, const float* inv_delta_c,
                         const float* span_packed, int N, float* out, float* grid, int32_t* idx, hipStream_t st);
 

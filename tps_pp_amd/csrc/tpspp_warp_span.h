@@ -55,6 +55,7 @@ struct SpanParams {
     int chunk_floats;      // LDS floats per channel of the staging buffer (>= span_rows W, whole 1-KB DMA pieces)
     int stage_off;         // float offset of the staging buffer in LDS
     int force_gather;      // lab knob: every workgroup takes the global-memory path
+    int margin;            // SPEC: rows staged above / below the band's own rows (both regions at once, at launch)
 };
 
 // LDS floats in front of the staging buffer: T (2 K, padded to 4) + 8 words (flag, span min / max of both regions)
@@ -84,7 +85,21 @@ __device__ __forceinline__ int wave_reduce(int v)
     return op(op(a, b), op(c, d));
 }
 
-template <int F, int C, bool AUX>
+// SPEC (round 5, late): the span search serialises a workgroup -- table -> chains -> taps -> min / max -> barrier -> DMA ->
+// barrier -> reads, twice -- and with four workgroups per CU the counters still show the SIMDs issuing 62 % of the time.  A
+// rectifier's warp is mild: a band's taps land within a few rows of the band's own rows.  So both regions' WINDOWS -- the
+// band's rows +- `margin` -- are requested by LDS-DMA as the workgroup's FIRST instructions, in flight under the table
+// loads, the T solve and the chains; no span search, no atomics, three barriers instead of seven.  A wavefront in which any
+// lane's tap rows leave the window takes THAT mirror pixel's taps from global memory (same values, per wavefront and
+// uniform): exact for any warp, fast for the ones that occur.
+__device__ __forceinline__ void span_dma16(const void* g, unsigned lds_byte)
+{
+    // (inline asm: an LDS-DMA the compiler can see makes it order every later LDS access of the wavefront behind
+    // s_waitcnt vmcnt(0); s_nop: the M0 write needs a wait state the hazard recogniser does not see inside asm)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_byte), "v"(g) : "memory", "m0");
+}
+
+template <int F, int C, bool AUX, bool SPEC = false>
 __global__ void __launch_bounds__(1024, (AUX || C > 3) ? 4 : 7)        // <= 72 registers: two 13-wavefront workgroups per CU
 tps_warp_span_kernel(const SpanParams P)
 {
@@ -104,6 +119,46 @@ tps_warp_span_kernel(const SpanParams P)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = (slot / P.bands) * 8 + xcd, band = slot % P.bands;
     if (b >= P.N) return;
+
+    const unsigned row_bytes = (unsigned)HW * 4u;            // one plane
+    const unsigned chunk_bytes = (unsigned)P.chunk_floats * 4u;
+    int w0[2] = {0, 0}, wlast[2] = {0, 0};                   // SPEC: first / last staged row of each region's window
+    int wbytes0 = 0;                                         // SPEC: bytes of region 0's window = LDS offset of region 1's
+    if constexpr (SPEC) {
+        const int rows_ = (P.RG / P.bands) * BH, ra_ = band * rows_;
+        w0[0] = ra_ - P.margin > 0 ? ra_ - P.margin : 0;
+        wlast[0] = (ra_ + rows_ + P.margin < H ? ra_ + rows_ + P.margin : H) - 1;
+        w0[1] = H - ra_ - rows_ - P.margin > 0 ? H - ra_ - rows_ - P.margin : 0;
+        wlast[1] = (H - ra_ + P.margin < H ? H - ra_ + P.margin : H) - 1;
+        wbytes0 = C * (wlast[0] - w0[0] + 1) * W * 4;
+        // A region's window in LDS: the C channels' rows back to back, EXACTLY wn W 4 bytes each (no rounding to whole 1-KB
+        // pieces: with it 64x200 needs 43 KB per workgroup, three per CU; without, 39.4 KB, four).  A 1-KB piece may then
+        // straddle two channels (a lane past the first one's end takes the next channel's bytes) and the last piece of a
+        // region is partial: its lanes past the end are masked off -- LDS-DMA honours EXEC, a masked lane writes nothing.
+        const char* img0 = reinterpret_cast<const char*>(P.in) + (size_t)b * C * row_bytes;
+        const int NW_ = (int)(blockDim.x / kWave);
+        int gpiece = 0;                                      // pieces so far (region 0's count: region 1 continues the round-robin)
+#pragma unroll
+        for (int reg = 0; reg < 2; ++reg) {
+            const int nb = (wlast[reg] - w0[reg] + 1) * W * 4;               // bytes per channel (a multiple of 16)
+            const int RB = C * nb;
+            const int pieces = (RB + 1023) >> 10;
+            const char* src0 = img0 + (size_t)w0[reg] * W * 4;
+            const unsigned dst0 = (unsigned)(size_t)sStage + (reg ? (unsigned)wbytes0 : 0u);
+            // (wavefront 0 issues none when there are others: it solves T, on which every wavefront waits, and memory
+            // returns a wavefront's requests in order -- its control points would queue behind its pieces)
+            const int ND = NW_ > 1 ? NW_ - 1 : 1, wd = NW_ > 1 ? wv - 1 : 0;
+            for (int k = wd < 0 ? pieces : (wd + ND - gpiece % ND) % ND; k < pieces; k += ND) {
+                const int p0 = k * 1024;
+                const int ch0 = (p0 >= nb ? 1 : 0) + (p0 >= 2 * nb ? 1 : 0) + (p0 >= 3 * nb ? 1 : 0);   // (uniform: scalar compares)
+                int off = p0 - ch0 * nb + lane * 16;
+                int ch = ch0;
+                if (off >= nb) { off -= nb; ++ch; }          // (nb >= 1 KB - 16 is not required: a second wrap cannot occur for nb >= 1008)
+                if (p0 + lane * 16 < RB) span_dma16(src0 + (size_t)ch * row_bytes + off, dst0 + (unsigned)p0);
+            }
+            gpiece += pieces;
+        }
+    }
 
     // T-solve inputs first (wavefront 0: lane i keeps control point i and row i of inv_delta_C, 16 bytes at a time;
     // the last piece starts at column K - 4 so that the last row does not read past the matrix)
@@ -202,7 +257,6 @@ tps_warp_span_kernel(const SpanParams P)
     });
 
     // ---- taps: x0, y0 (packed), two fractions, two flags per mirror pixel; the regions' row spans ----
-    const unsigned row_bytes = (unsigned)HW * 4u;            // one plane
     int ty[4], tx[4];
     float tf[4][2];
     unsigned oob = 0;                                        // bit 2 m: east column outside, bit 2 m + 1: south row outside
@@ -227,24 +281,27 @@ tps_warp_span_kernel(const SpanParams P)
         ylo[reg] = t.y0 < ylo[reg] ? t.y0 : ylo[reg];
         yhi[reg] = y1 > yhi[reg] ? y1 : yhi[reg];
     }
+    int y0r[2] = {0, 0}, y1r[2] = {0, 0};
+    bool staged = true;
+    if constexpr (!SPEC) {
 #pragma unroll
-    for (int reg = 0; reg < 2; ++reg) {
-        const int lo = wave_reduce<false>(ylo[reg]), hi = wave_reduce<true>(yhi[reg]);
-        if (lane == 0) {
-            __hip_atomic_fetch_min(sWord + 2 + reg, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_max(sWord + 4 + reg, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int reg = 0; reg < 2; ++reg) {
+            const int lo = wave_reduce<false>(ylo[reg]), hi = wave_reduce<true>(yhi[reg]);
+            if (lane == 0) {
+                __hip_atomic_fetch_min(sWord + 2 + reg, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(sWord + 4 + reg, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
+        lds_only_barrier();                                  // both spans known to everybody
+        typedef __attribute__((address_space(3))) const volatile int lds_cvint;
+        lds_cvint* sw = (lds_cvint*)(size_t)(unsigned)(size_t)sWord;
+        y0r[0] = __builtin_amdgcn_readfirstlane(sw[2]); y0r[1] = __builtin_amdgcn_readfirstlane(sw[3]);
+        y1r[0] = __builtin_amdgcn_readfirstlane(sw[4]); y1r[1] = __builtin_amdgcn_readfirstlane(sw[5]);
+        staged = !P.force_gather && (y1r[0] - y0r[0] + 1) <= P.span_rows && (y1r[1] - y0r[1] + 1) <= P.span_rows;
     }
-    lds_only_barrier();                                      // both spans known to everybody
-    typedef __attribute__((address_space(3))) const volatile int lds_cvint;
-    lds_cvint* sw = (lds_cvint*)(size_t)(unsigned)(size_t)sWord;
-    const int y0r[2] = {__builtin_amdgcn_readfirstlane(sw[2]), __builtin_amdgcn_readfirstlane(sw[3])};
-    const int y1r[2] = {__builtin_amdgcn_readfirstlane(sw[4]), __builtin_amdgcn_readfirstlane(sw[5])};
-    const bool staged = !P.force_gather && (y1r[0] - y0r[0] + 1) <= P.span_rows && (y1r[1] - y0r[1] + 1) <= P.span_rows;
 
     typedef __attribute__((address_space(3))) const float lds_cfloat;
     const char* img = reinterpret_cast<const char*>(P.in) + (size_t)b * C * row_bytes;
-    const unsigned chunk_bytes = (unsigned)P.chunk_floats * 4u;
     float res[4][C];
 
     // the region's span of every channel -> LDS: contiguous rows [y0r, y1r] of each plane, 1 KB per wavefront instruction;
@@ -290,7 +347,43 @@ tps_warp_span_kernel(const SpanParams P)
         if (fast) go(std::false_type{}); else go(std::true_type{});
     };
 
-    if (staged) {
+    if constexpr (SPEC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's pieces of both windows have landed
+        __builtin_amdgcn_s_barrier();                        // ... and everybody's
+        asm volatile("" ::: "memory");
+        const unsigned base = (unsigned)(size_t)sStage;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int reg = m >> 1;
+            const unsigned fl = oob >> (2 * m);
+            const int y1 = (fl & 2u) ? ty[m] : ty[m] + 1;
+            const bool outw = ty[m] < w0[reg] || y1 > wlast[reg];
+            float tv[C][4];
+            if (!P.force_gather && __builtin_amdgcn_ballot_w64(outw) == 0) {
+                // an out-of-image tap is read anyway (the word exists: next row, next chunk or the pad) and replaced by zero
+                const unsigned nbr = 4u * (unsigned)((wlast[reg] - w0[reg] + 1) * W);      // bytes per channel of this window
+                unsigned a0 = base + (reg ? (unsigned)wbytes0 : 0u) + 4u * (unsigned)((ty[m] - w0[reg]) * W + tx[m]);
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    lds_cfloat* p0 = (lds_cfloat*)(size_t)a0;
+                    lds_cfloat* p1 = (lds_cfloat*)(size_t)(a0 + 4u * (unsigned)W);
+                    tv[ch][0] = p0[0]; tv[ch][1] = p0[1]; tv[ch][2] = p1[0]; tv[ch][3] = p1[1];
+                    a0 += nbr;
+                }
+                combine(m, tv, !any_oob);
+            } else {
+                // some lane's tap rows leave the window: this mirror pixel from global memory, clamped addresses
+                const int dx = (fl & 1u) ? 0 : 1, dy = (fl & 2u) ? 0 : W;
+                const float* p = reinterpret_cast<const float*>(img) + ty[m] * W + tx[m];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    tv[ch][0] = p[0]; tv[ch][1] = p[dx]; tv[ch][2] = p[dy]; tv[ch][3] = p[dy + dx];
+                    p += HW;
+                }
+                combine(m, tv, false);
+            }
+        }
+    } else if (staged) {
 #pragma unroll
         for (int reg = 0; reg < 2; ++reg) {
             if (reg == 1) lds_only_barrier();                // every tap of the upper region is in registers: the buffer is free

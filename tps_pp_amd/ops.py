@@ -997,7 +997,8 @@ def set_warp_tuning(images_per_group=0, threads_per_group=0, kernel_choice=0, ba
     bands: kernel_choice 0 / 2 / 3: workgroups per image (pair) in the LDS-staged kernels, 0..8 (0 = heuristic);
     kernel_choice 7 / 9: bits 0-2 = workgroups per image (0 = heuristic), bit 3 (value 8) = never an image pair per
     workgroup, so 0..15; kernel_choice 8: bits 0-5 = workgroups per image, bit 6 (64) = every workgroup on the
-    global-memory path, bits 8-15 = LDS budget in KB; values above 8 are rejected for every other choice."""
+    global-memory path, bit 7 (128) = measured row spans instead of the windows requested at launch, bits 8-15 = LDS budget
+    in KB; values above 8 are rejected for every other choice."""
     _lib.check(_lib.lib().tpspp_warp_set_tuning(int(images_per_group), int(threads_per_group),
                                                 int(kernel_choice), int(bands)),
                "tpspp_warp_set_tuning")
