@@ -43,9 +43,11 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libtps_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get("TPS_ORACLE_SO")            # (tests: an AddressSanitizer / UBSan build of the same source)
+        if not so:
+            so = os.path.join(_HERE, "libtps_oracle.so")
+            if not os.path.exists(so):
+                build()
         L = ctypes.CDLL(so)
         L.tps_oracle_solve_T.argtypes = [_f32p, _f32p, ctypes.c_int, ctypes.c_int, _f32p]
         L.tps_oracle_solve_T.restype = None

@@ -307,3 +307,61 @@ def test_warp_backward_oracle_against_reference(oracle):
         assert close(cases.sub(o["g_in1"]), G["pp_g_x_sub"], t_in, not chain), chain
         assert close(o["g_ctrl"], G["pp_g_ctrl"], t_par, not chain), chain
         assert close(o["g_score"], G["pp_g_score"], t_par, not chain), chain
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The C oracle (test infrastructure: the checker of every bit-exact parity claim) built with
+    -fsanitize=address,undefined and run in a child process (libasan preloaded in front of the Python interpreter) over the
+    shapes the parity tests use it on and the edge cases the sampler has: classic and TPS_PP geometry (two inputs, score),
+    C = 1, a one-pixel-high input, grids far outside [-1, 1], NaN / inf control points, optional outputs on and off.  No GPU,
+    no sanitizer on the GPU side (this pool refuses those): a heap overflow or an out-of-range index in the checker would
+    otherwise surface as a parity failure of a correct kernel -- or hide a real one."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libtps_oracle_asan.so")
+    subprocess.check_call([gcc, "-O1", "-g", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-mavx2",
+                           "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared",
+                           "-o", so, os.path.join(root, "oracle", "tps_oracle.c"), "-lm"])
+    code = """
+import numpy as np
+from oracle import tps_oracle as O
+rng = np.random.default_rng(0)
+for hw, C, N in (((32, 100), 3, 3), ((32, 100), 1, 1), ((16, 36), 4, 2), ((64, 200), 3, 1)):
+    K = O.classic_constants(20, hw)
+    img = rng.standard_normal((N, C) + hw).astype(np.float32)
+    for amp in (0.05, 0.6, 5.0):
+        ctrl = (O.classic_initial_ctrl(20)[None] + amp * rng.standard_normal((N, 20, 2))).astype(np.float32)
+        r = O.warp(img, ctrl, K["inv_delta_C"], K["P_hat"], hw, want_grid=True, want_idx=True)
+        assert r["out0"].shape == (N, C) + hw
+        O.warp(img, ctrl, K["inv_delta_C"], K["P_hat"], hw)
+    bad = O.classic_initial_ctrl(20)[None].repeat(N, 0).astype(np.float32)
+    bad[0, 3, 0] = np.nan; bad[0, 5, 1] = np.inf
+    O.warp(img, bad, K["inv_delta_C"], K["P_hat"], hw, want_grid=True, want_idx=True)
+Kp = O.tpspp_constants((16, 64), (2, 16))
+fg = rng.standard_normal((2, 5, 32, 128)).astype(np.float32)
+x = rng.standard_normal((2, 3, 16, 64)).astype(np.float32)
+thin = rng.standard_normal((2, 2, 1, 64)).astype(np.float32)          # a one-pixel-high input: no south row anywhere
+ctrl = (O.tpspp_initial_ctrl((2, 16))[None] + 0.3 * rng.standard_normal((2, 32, 2))).astype(np.float32)
+score = np.tanh(rng.standard_normal((2, 1024, 32))).astype(np.float32)
+O.warp(fg, ctrl, Kp["hat_C"], Kp["P_hat"], (16, 64), P_xy=Kp["P_xy"], score=score, in1=x, want_grid=True, want_idx=True)
+O.warp(thin, ctrl, Kp["hat_C"], Kp["P_hat"], (16, 64), P_xy=Kp["P_xy"], score=score, in1=x)
+T = O.solve_T(Kp["hat_C"], ctrl)
+g = O.build_grid(Kp["P_hat"], T, Kp["P_xy"], score)
+O.grid_sample(fg, (50.0 * g).reshape(2, 16, 64, 2), (16, 64), return_idx=True)
+O.grid_sample(thin, g, (16, 64), weight_form=1)
+print("sanitized oracle ok")
+"""
+    env = dict(os.environ, LD_PRELOAD=asan, TPS_ORACLE_SO=so, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1", PYTHONPATH=root, OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0 and "sanitized oracle ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
