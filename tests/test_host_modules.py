@@ -430,3 +430,22 @@ def test_head_training_graphs_reproduce_the_reference():
     assert abs(float(ce) - float(Fn.cross_entropy(lg.permute(0, 2, 1), tg, ignore_index=0))) < 1e-6
     with pytest.raises(AssertionError):
         losses.CELoss(reduction="avg")
+
+
+def test_default_arithmetic_configuration_follows_the_environment(monkeypatch):
+    """`TPSPP_COMPUTE_DTYPE` (tps_pp_amd/precision.py) is read when a module is constructed: unset / fp32 -> the exact fp32
+    kernels (the default: the reference's own arithmetic), bf16x3 -> every stage on the three-term split (the parity
+    configuration of configs[4], for a deployment that has checked its checkpoint), bf16 -> the throughput configuration
+    (TPS_PP then follows its input's dtype); anything else is an error, not a silent fp32."""
+    import tps_pp_amd as P
+    mk = lambda: (P.TPS_PP(), P.build_backbone(dict(type="ResNetABI_v2_large", arch_settings=[1, 1, 1, 1, 1], strides=[2, 1, 2, 1, 2])),  # noqa: E731
+                  P.NRTREncoder(n_layers=1), P.NRTRDecoder(n_layers=1, num_classes=93, max_seq_len=8, start_idx=91, padding_idx=92))
+    monkeypatch.delenv("TPSPP_COMPUTE_DTYPE", raising=False)
+    assert [m.compute_dtype for m in mk()] == [None] * 4
+    monkeypatch.setenv("TPSPP_COMPUTE_DTYPE", "bf16x3")
+    assert [m.compute_dtype for m in mk()] == ["bf16x3"] * 4
+    monkeypatch.setenv("TPSPP_COMPUTE_DTYPE", "bf16")
+    assert [m.compute_dtype for m in mk()] == [None, torch.bfloat16, torch.bfloat16, torch.bfloat16]
+    monkeypatch.setenv("TPSPP_COMPUTE_DTYPE", "fp16")
+    with pytest.raises(ValueError, match="TPSPP_COMPUTE_DTYPE"):
+        P.NRTREncoder(n_layers=1)

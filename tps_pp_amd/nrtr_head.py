@@ -22,6 +22,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .precision import default_compute_dtype
 from . import ops
 from .registry import (CONVERTORS, DECODERS, DETECTORS, ENCODERS, build_backbone, build_convertor,
                        build_decoder, build_encoder, build_preprocessor)
@@ -185,7 +186,7 @@ class NRTREncoder(nn.Module):
             raise ValueError("d_model must equal n_head * d_k (linear_q maps dim_k -> dim_k)")
         self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
         self.dropout_p = float(dropout)    # (only the training graph applies it)
-        self.compute_dtype = None          # torch.bfloat16: the wide projections on the bf16 matrix cores
+        self.compute_dtype = default_compute_dtype()   # torch.bfloat16: the wide projections on the bf16 matrix cores
         self.layer_stack = nn.ModuleList([
             TFEncoderLayer(d_model, d_inner, n_head, d_k, d_v, dropout=dropout, **kwargs) for _ in range(n_layers)])
         self.layer_norm = nn.LayerNorm(d_model)
@@ -266,7 +267,7 @@ class NRTRDecoder(nn.Module):
         self.padding_idx, self.start_idx, self.max_seq_len = padding_idx, start_idx, max_seq_len
         self.d_model, self.d_inner, self.n_head = d_model, d_inner, n_head
         self.dropout_p = float(dropout)    # (only the training graph applies it)
-        self.compute_dtype = None          # torch.bfloat16: encoder K/V projected on the bf16 matrix cores, kept as bf16
+        self.compute_dtype = default_compute_dtype()   # torch.bfloat16: encoder K/V projected on the bf16 matrix cores, kept as bf16
         self.trg_word_emb = nn.Embedding(num_classes, d_embedding, padding_idx=padding_idx)
         self.position_enc = PositionalEncoding(d_embedding, n_position=n_position)
         self.layer_stack = nn.ModuleList([

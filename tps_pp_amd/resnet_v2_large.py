@@ -16,6 +16,7 @@ transformation stage on the HIP kernels, forward and backward.
 import torch
 import torch.nn as nn
 
+from .precision import default_compute_dtype
 from . import ops
 from .registry import BACKBONES
 
@@ -130,7 +131,7 @@ class ResNetABI_v2_large(nn.Module):
         self.init_cfg = init_cfg
         self.strides = list(strides)       # read by EncodeDecodeRecognizer to pick the TPS_PP wiring that fits
         # None: follow the input dtype; torch.bfloat16: bf16 convolutions; "bf16x3": fp32 tensors, three-term split
-        self.compute_dtype = None
+        self.compute_dtype = default_compute_dtype()
         self.out_indices = out_indices
         self.last_stage_pool = last_stage_pool
         self.block = BasicBlock

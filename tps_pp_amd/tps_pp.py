@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 import os
 
+from .precision import default_compute_dtype
 from . import constants, ops
 from .registry import BACKBONES, PREPROCESSOR
 
@@ -322,7 +323,8 @@ class TPS_PP(nn.Module):
         self.type = variant
         # None: follow the input dtype (fp32 -> exact fp32 kernels); torch.bfloat16: bf16 convolutions;
         # "bf16x3": fp32 tensors, three-term bf16 split in the convolutions
-        self.compute_dtype = None
+        _d = default_compute_dtype()
+        self.compute_dtype = _d if _d == "bf16x3" else None      # (bf16: TPS_PP follows its input's dtype)
         self.visual_point = visual_point
         self.num_fiducial = point_size[0] * point_size[1]
         self.img_size = img_size

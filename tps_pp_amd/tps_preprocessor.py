@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import constants, ops
+from .precision import default_compute_dtype
 from .registry import PREPROCESSOR
 
 
@@ -96,6 +97,8 @@ class LocalizationNetwork(nn.Module):
         cw = self._hip_weights()
         x = batch_img.float().contiguous()
         mode = getattr(self, "compute_dtype", None)
+        if mode is None and not hasattr(self, "compute_dtype"):
+            mode = default_compute_dtype()
         if mode == torch.bfloat16 or mode == "bf16x3":
             # bf16 configuration: the four convolutions on the bf16 matrix cores (fp32 maps in and out: operands are
             # rounded as they are staged, accumulation / bias / ReLU fp32); pooling and the two FCs stay fp32.
