@@ -113,6 +113,35 @@ def line_regions(bench):
     return max(tried), rf.get("multi_stream", {}).get("regions_us"), rf.get("one_stream", {}).get("regions_us")
 
 
+def protocol_rows(sub, logname):
+    """Per-protocol aggregates (streams, dispatches, total, average, min, max, sorted periods) of the warp kernel in one traced
+    bench run -- the same split as protocol_tables(), without the per-dispatch file."""
+    pth = os.path.join(SRC, sub, "bench_kernel_trace.csv")
+    log = os.path.join(SRC, logname)
+    if not (os.path.exists(pth) and os.path.exists(log)):
+        return []
+    lines = [l for l in open(log) if l.startswith("{")]
+    if not lines:
+        return []
+    bench = json.loads(lines[-1])
+    steps, warm, R = bench["steps"], bench["warmup"], int(bench["config"].get("repeats", 1))
+    S, _, _ = line_regions(bench)
+    rows = timeline(pth, KERNEL, steps)
+    lo, agg = warm, []
+    for streams in ([S, 1] if S > 1 else [S]):
+        durs, periods = [], []
+        for reg in range(R):
+            sel = rows[lo:lo + steps]
+            if len(sel) < steps:
+                break
+            lo += steps
+            durs += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
+            periods.append((max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)) / len(sel))
+        if durs:
+            agg.append((streams, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs), sorted(periods)))
+    return agg
+
+
 def protocol_tables():
     """The driver's command in the kernel trace, reduced so that the timeline can be recomputed from profiles/ alone:
     rNN_bench_dispatches.csv  -- every dispatch of the warp kernel (protocol, region, queue, start, end; ns from the first)
@@ -245,10 +274,19 @@ def main():
         rd = csv.reader(fin)
         wr = csv.writer(fout, quoting=csv.QUOTE_NONNUMERIC)
         wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "PeriodNs_per_region", "Source"])
+        ALG = 39403520                                       # algorithmic bytes per launch
         for streams, n, tot, avg, mn, mx, periods in agg:
-            wr.writerow([f"{KERNEL} | timed regions on {streams} stream(s)", n, tot, round(avg, 1), "", mn, mx,
-                         " ".join(f"{x:.0f}" for x in periods),
-                         "python3 bench.py --gpus 1 --steps 20 --warmup 5 (trace_driver; dispatches in " + f"{TAG}_bench_dispatches.csv)"])
+            wr.writerow([f"{KERNEL} | timed regions on {streams} stream(s) | {ALG} B / average / 8 TB/s = {ALG / avg / 8000.0:.3f}",
+                         n, tot, round(avg, 1), "", mn, mx, " ".join(f"{x:.0f}" for x in periods),
+                         "python3 bench.py --gpus 1 --steps 20 --warmup 5 (trace_driver; dispatches in " + f"{TAG}_bench_dispatches.csv); "
+                         "20-launch regions: the profiler's per-dispatch work stretches duration and period"])
+        # the long regions (400 launches): the kernel's own duration with every launch behind the previous one is the
+        # one-stream row of these -- the figure bench.py's roofline.one_stream_frac (un-profiled) is to be compared with
+        for sub, logname, cmd in (("trace", "bench_trace.log", "python3 bench.py --steps 400 --warmup 50"),
+                                  ("trace1", "bench_trace1.log", "python3 bench.py --steps 400 --warmup 50 --streams 1")):
+            for streams, n, tot, avg, mn, mx, periods in protocol_rows(sub, logname):
+                wr.writerow([f"{KERNEL} | timed regions on {streams} stream(s) | {ALG} B / average / 8 TB/s = {ALG / avg / 8000.0:.3f}",
+                             n, tot, round(avg, 1), "", mn, mx, " ".join(f"{x:.0f}" for x in periods), cmd + " (400-launch regions)"])
         for i, row in enumerate(rd):
             if i == 0:
                 continue
