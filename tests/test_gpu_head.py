@@ -418,6 +418,53 @@ def test_decoder_persistent_step_matches_the_launch_pipeline(cuda, n, seq):
             os.environ["TPSPP_HEAD_NO_PERSIST"] = old
 
 
+def test_decoder_persistent_kernel_other_depths_and_widths(cuda):
+    """The persistent decoder kernel outside the reference's default shape: an ODD number of layers (the activations' x / y
+    buffers end a step swapped: the step loop inside the launch and the host's per-step launches must both follow) and
+    d_inner = 512 (four 16-wide k-steps per wavefront in the w2 projection instead of two), 96 and 40 encoder tokens (wider images:
+    the cross-attention then walks a wavefront's two heads one after the other), every head configuration, greedy and
+    teacher-forced, against the launch pipeline: exact-fp32 head bit-identical, reduced heads within 5e-5 / 5e-4 with identical
+    tokens; one launch per step and write-through stores bit-equal to the default."""
+    import os
+    from tps_pp_amd.nrtr_head import NRTRDecoder
+    torch.manual_seed(11)
+    n, seq = 45, 7
+    for n_layers, d_inner, T in ((3, 512, 64), (1, 256, 64), (2, 512, 64), (2, 256, 96), (1, 256, 40)):
+        dec = NRTRDecoder(n_layers=n_layers, d_inner=d_inner, num_classes=93, max_seq_len=seq, start_idx=91, padding_idx=92).eval().to(cuda)
+        with torch.no_grad():
+            dec.classifier.weight.mul_(6.0)
+        enc = torch.randn(n, T, 512, device=cuda)         # (T > 64 encoder tokens: the cross-attention's one-head-at-a-time form)
+        metas = [dict(valid_ratio=(1.0, 0.6)[i % 2]) for i in range(n)]
+        forced = torch.randint(0, 90, (n, seq), device=cuda)
+        forced[:, 0] = 91
+        try:
+            for cd in (None, "bf16x3", torch.bfloat16):
+                dec.compute_dtype = cd
+                with torch.no_grad():
+                    os.environ["TPSPP_HEAD_NO_PERSIST"] = "1"
+                    want = dec(None, enc, None, metas, train_mode=False)
+                    want_tok = dec.last_tokens.clone()
+                    want_tf = dec(None, enc, dict(padded_targets=forced), metas, train_mode=True)
+                    del os.environ["TPSPP_HEAD_NO_PERSIST"]
+                    got = dec(None, enc, None, metas, train_mode=False)
+                    got_tok = dec.last_tokens.clone()
+                    got_tf = dec(None, enc, dict(padded_targets=forced), metas, train_mode=True)
+                    tag = (n_layers, d_inner, T, cd)
+                    assert torch.isfinite(got).all() and torch.equal(got_tok, want_tok), tag
+                    if cd is None:
+                        assert torch.equal(got, want) and torch.equal(got_tf, want_tf), tag
+                    assert float((got - want).abs().max()) <= (5e-5 if cd != torch.bfloat16 else 5e-4), (tag, float((got - want).abs().max()))
+                    assert float((got_tf - want_tf).abs().max()) <= (1e-3 if cd == torch.bfloat16 else 1e-4) * float(want_tf.abs().max()), tag
+                    for var in ("TPSPP_HEAD_STEP_LAUNCHES", "TPSPP_HEAD_WRITE_THROUGH"):
+                        os.environ[var] = "1"
+                        one = dec(None, enc, None, metas, train_mode=False)
+                        del os.environ[var]
+                        assert torch.equal(one, got), (tag, var)
+        finally:
+            for var in ("TPSPP_HEAD_NO_PERSIST", "TPSPP_HEAD_STEP_LAUNCHES", "TPSPP_HEAD_WRITE_THROUGH"):
+                os.environ.pop(var, None)
+
+
 TOKGEMM_CASES = [
     # name, K, Co, M, act, residual, out dtype, x3
     ("qkv_wide", 512, 1536, 32768, None, False, torch.float32, False),          # 256-output workgroups
