@@ -436,6 +436,9 @@ def test_classic_backward_single_launch_against_the_two_kernel_route(cuda, C, hw
         os.environ.pop("TPSPP_BWD_TWO_KERNELS", None)
         if old is not None:
             os.environ["TPSPP_BWD_TWO_KERNELS"] = old
+    # dL/d input not wanted (the kernel then skips the accumulators): the same dL/dC', bit for bit
+    g_no = ops.warp_backward(go, img, grid, ctrl, gg.inv_delta_C, gg.P_hat, hw, P_hat_t=P_hat_t, need_in0=False)
+    assert g_no[0] is None and torch.equal(g_no[2][1:], got[2][1:])
     # float64 on the same fp32 grid, images without the NaN
     with torch.enable_grad():
         gd = grid[1:].cpu().double().reshape(n - 1, hw[0], hw[1], 2).requires_grad_(True)
