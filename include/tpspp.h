@@ -30,8 +30,9 @@
 extern "C" {
 #endif
 
-#define TPSPP_ABI_VERSION 3   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
-                               3: tpspp_down_fused_bf16_fwd / _x3_fwd / _f32_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_fwd and tpspp_front_bf16_fwd takes feat0 = feat1 = NULL */
+#define TPSPP_ABI_VERSION 4   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
+                               3: tpspp_down_fused_bf16_fwd / _x3_fwd / _f32_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_fwd and tpspp_front_bf16_fwd takes feat0 = feat1 = NULL;
+                               4 (round 6): tpspp_nrtr_decoder_fwd takes status_out, tpspp_resize_normalize_fwd takes interpolation */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -101,7 +102,8 @@ int tpspp_table_mirror_symmetry(const float* p_hat_host, int p_hat_ld, int Ho, i
  * read by the span-staging kernel (tpspp_warp_span.h).  tpspp_prepared_table_floats:
  * buffer size in floats, 0 when the geometry has no prepared form (needs Ho % 16 == 0, Wo % 4 == 0).  One-off
  * preparation, like the transposition.  Pass the buffer
- * as p_hat_t together with TPSPP_TABLE_PACKED (and TPSPP_TABLE_MIRROR4 once the symmetry has been verified).
+ * as p_hat_t together with TPSPP_TABLE_PACKED | TPSPP_TABLE_SPAN (and TPSPP_TABLE_MIRROR4 once the symmetry has been verified).
+ * The buffer's size grew in round 5 (the third section): size it with THIS function, never with a remembered formula.
  * replaces nothing in the reference (its table is a module buffer, tps_preprocessor.py:187-188); see tpspp_warp_fwd.
  */
 size_t tpspp_prepared_table_floats(int Ho, int Wo, int F);
@@ -111,11 +113,19 @@ int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo,
 #define TPSPP_TABLE_MIRROR4 1      /* table_flags bit: symmetry verified by the caller */
 #define TPSPP_TABLE_PACKED 8       /* table_flags bit: p_hat_t is a tpspp_prepare_mirror_table buffer (the packed copy
                                       follows the transposed table).  Never changes results. */
+#define TPSPP_TABLE_SPAN 32        /* table_flags bit, with TPSPP_TABLE_PACKED: the buffer was sized by THIS library's
+                                      tpspp_prepared_table_floats and filled by its tpspp_prepare_mirror_table, i.e. it carries the
+                                      third section (round 5) that the span-staging kernel of the large geometries reads.  A
+                                      caller still holding a two-section buffer of an earlier build omits the bit and gets the
+                                      kernels that do not read behind the second section.  Never changes results. */
 #define TPSPP_SCORE_TRANSPOSED 2   /* table_flags bit: `score` is laid out (N, F, n) instead of the
                                       reference's (N, n, F): lanes that own consecutive pixels then read
                                       it coalesced.  Same values, same results. */
 #define TPSPP_BWD_FIXED_POINT 16   /* table_flags bit of tpspp_warp_bwd only: accumulate dL/d input in 64-bit fixed point (bitwise
                                     * reproducible from run to run) instead of the default fp64 LDS atomics; per call, any stream */
+#define TPSPP_BWD_TWO_KERNELS 64   /* table_flags bit of tpspp_warp_bwd only: never the one-launch form of the classic rectifier's call
+                                    * (A/B runs, tests); per call.  The environment variable of the same name, read once when
+                                    * the first backward runs, does the same for a whole process. */
 #define TPSPP_IO_BF16 4            /* table_flags bit: in0 / in1 / out0 / out1 hold bfloat16 (the pointers are
                                       reinterpreted; everything else stays fp32).  The bf16 configuration
                                       (BASELINE.json configs[2]): T, grid and interpolation in fp32 exactly as
@@ -129,7 +139,7 @@ int tpspp_prepare_mirror_table(const float* p_hat, int p_hat_ld, int Ho, int Wo,
  *   ctrl (N,F,2); score (N,Ho*Wo,F) or NULL; inv_delta_c (F+3,F+3); p_hat / p_hat_ld / p_xy as in
  *   tpspp_build_grid; p_hat_t_or_null = tpspp_transpose_p_hat(p_hat) (same values, enables the
  *   coalesced / LDS-staged fast kernels; NULL selects the generic kernel -- identical results);
- *   table_flags: OR of TPSPP_TABLE_MIRROR4, TPSPP_TABLE_PACKED (only meaningful with p_hat_t),
+ *   table_flags: OR of TPSPP_TABLE_MIRROR4, TPSPP_TABLE_PACKED, TPSPP_TABLE_SPAN (only meaningful with p_hat_t),
  *   TPSPP_SCORE_TRANSPOSED (none of them changes results) and TPSPP_IO_BF16 (bf16 images in and out);
  *   grid_or_null (N,Ho*Wo,2); idx_or_null (N,Ho*Wo,2) int32 = NW corner in in0.
  * replaces: GridGenerator.build_P_prime + F.grid_sample   tps_preprocessor.py:71-83
@@ -162,7 +172,10 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
  * The classic rectifier's call (one input of <= 3 channels, no score, transposed table given, 1024 < Ho*Wo <= 4096, the
  * fp64 accumulator) is ONE launch; every other call a sampling + a parameter kernel.  Same sampling arithmetic either way;
  * dL/d control points of the one-launch form sums 8-term fp32 chains in fp64 (the two-kernel form: ~12-term chains), the
- * two agree within 5e-5 of the largest entry.  (Environment TPSPP_BWD_TWO_KERNELS=1: always two kernels -- A/B runs, tests.)
+ * two agree within 5e-5 of the largest entry.  Which form runs depends on these arguments only: in1 == NULL, score == NULL,
+ * p_xy == NULL (p_xy means the TPS_PP table layout, whose p_hat lacks the [1, x, y] columns the one-launch form reads from the
+ * transposed classic table), p_hat_t given and 16-byte aligned, C0 <= 3, F <= 21, Ho*Wo in (1024, 4096] and a multiple of 4,
+ * the fp64 accumulator, and the TPSPP_BWD_TWO_KERNELS flag bit / environment variable unset.
  * replaces: autograd through backbones/tps_pp/tps_pp.py:467-496,597-615;
  *           preprocessor/tps_preprocessor.py:71-83,270-282
  */
@@ -469,6 +482,10 @@ int tpspp_warp_set_trace(long long* device_buf);
  * (phase 0 = entry; 8 phases per layer, then the classifier); the buffer must hold steps x workgroups x 64 int64.  NULL
  * (default) disables it. */
 int tpspp_head_set_trace(long long* device_buf);
+/* Lab / test hook: occupies the device for a while -- `workgroups` workgroups of one wavefront, each holding `lds_bytes` of LDS
+ * (>= 64 KB keeps a workgroup of the persistent decoder, ~103 KB, off that CU), spin for `milliseconds` of wall-clock time
+ * (<= 2000) on `stream`.  tests/test_gpu_head.py uses it to decode on a partly occupied device. */
+int tpspp_lab_occupy(int workgroups, int lds_bytes, int milliseconds, tpspp_stream_t stream);
 
 /* ===== Recogniser head after TPS++: NRTR encoder / decoder ==========
  *
@@ -520,17 +537,25 @@ int tpspp_linear_ln_fwd(const float* x, int K, int M, float eps, const float* w_
 /*
  * ResizeOCR + ToTensorOCR + NormalizeOCR on the GPU: N uint8 HWC crops of different
  * sizes, packed in one device buffer, -> out (N, C, H, W) fp32.  Image n (src_h[n] x src_w[n] x C at
- * src_packed + src_offsets[n]) is resized to H x resize_w[n] with OpenCV's 8-bit INTER_LINEAR arithmetic
- * (11-bit fixed-point weights; INTER_AREA for an exact 2x2 shrink), columns >= resize_w[n] hold pad_value, and every
+ * src_packed + src_offsets[n]) is resized to H x resize_w[n], columns >= resize_w[n] hold pad_value, and every
  * byte v of channel c becomes lut[c*256 + v] (the caller tabulates (v/255 - mean[c]) / std[c] in fp32).
  * The widths come from the host logic of ResizeOCR.__call__ (tps_pp_amd/ocr_transforms.py).
- * PARITY UNPINNED against OpenCV (absent at build time); bit-exact against oracle/resize_oracle.py.
+ *   interpolation   ResizeOCR's `backend` (ocr_transforms.py:34-36,46,65 -> mmcv.imresize(..., backend=)):
+ *     TPSPP_RESIZE_CV2 (0)     backend None / 'cv2': OpenCV's 8-bit INTER_LINEAR arithmetic (11-bit fixed-point weights;
+ *                              INTER_AREA for an exact 2x2 shrink).  PARITY UNPINNED against OpenCV (absent at build time);
+ *                              bit-exact against oracle/resize_oracle.py.
+ *     TPSPP_RESIZE_PILLOW (1)  backend 'pillow': Image.resize(size, Image.BILINEAR) on uint8 -- Pillow's Resample.c (double
+ *                              coefficients of the support-scaled triangle filter, 22-bit fixed point, horizontal pass into
+ *                              uint8, then the vertical pass).  PINNED: bit-exact against the installed Pillow's outputs
+ *                              (tests/golden/resize_pillow.npz, written by tests/golden/make_resize_golden.py).
  * replaces: mmocr/datasets/pipelines/ocr_transforms.py:67-156 (mmcv.imresize + mmcv.impad, TF.to_tensor, TF.normalize)
  */
+#define TPSPP_RESIZE_CV2    0
+#define TPSPP_RESIZE_PILLOW 1
 int tpspp_resize_normalize_fwd(const unsigned char* src_packed, const long long* src_offsets,
                                const int* src_h, const int* src_w, const int* resize_w,
                                const float* lut, int pad_value, int N, int C, int H, int W,
-                               float* out, tpspp_stream_t stream);
+                               float* out, int interpolation, tpspp_stream_t stream);
 
 /*
  * flags bit of tpspp_nrtr_encoder_fwd / tpspp_nrtr_decoder_fwd (the bf16 configuration, BASELINE.json configs[4]):
@@ -602,6 +627,30 @@ int tpspp_nrtr_encoder_fwd(const float* feat, int N, int C, int T, int d_inner, 
  *                (keys holding padding_idx are masked out of the self-attention).
  * One position per step against cached keys/values: same results as the reference's full re-run of the
  * padded sequence at every step, up to fp32 summation order.  Nothing synchronises with the host.
+ *
+ * How the steps run, and what that asks of the caller.  With d_model 512, 8 heads, num_out <= 128, <= 8 layers and the
+ * arranged per-step weights present, the max_seq_len steps of up to 512 images run as ONE persistent launch: 16 workgroups
+ * (one per CU, 512 threads, ~103 KB of LDS) per 32 images synchronise among themselves through device counters
+ * (tpspp_head_persist.h).  That form has two requirements, both ENFORCED by this entry point rather than left to the caller:
+ *   (1) co-residency: a group of 8 such clusters (128 workgroups) must be resident together.  The call queries the device's
+ *       CU count and the kernel's occupancy; a device (or CU-masked / CPX partition) that cannot hold 128 workgroups gets the
+ *       launch-per-phase pipeline instead (same scores: bit-identical for the exact-fp32 head, within 2e-5 with identical
+ *       tokens for the reduced-precision heads), one that holds 128..255 gets 256 images per launch.  Under stream capture
+ *       the launch pipeline is used as well.
+ *   (2) one persistent decode in flight per device and process: every such call makes `stream` wait (hipStreamWaitEvent, no
+ *       host synchronisation) for the previous persistent decode issued by this process on the same device, whatever stream
+ *       that one ran on.  Decodes issued from several streams / threads are therefore safe and simply run one after the
+ *       other; kernels of other streams may overlap a decode (its clusters wait for their CUs).  Decodes issued by ANOTHER
+ *       PROCESS on the same device are not seen by this guard: one process per GPU, as everywhere in this library.
+ * Failure is loud, never silent: if a cluster's barrier is not completed within TPSPP_HEAD_TIMEOUT_MS (environment,
+ * wall-clock milliseconds, default 4000; only possible when (2) is violated from outside the process, or the device is held
+ * by another kernel for that long), the scores of that cluster's images are NaN for EVERY step from the failing one to
+ * max_seq_len - 1, and *status_out = 1; no step of `out` is left uninitialised and the call itself has long returned
+ * TPSPP_OK (it is asynchronous).
+ *   status_out   device int32 (or NULL): written on `stream` behind the decode -- 0 = every step completed, 1 = a barrier
+ *                timed out (scores NaN as described).  Read it with the copy that fetches the scores / tokens; the Python
+ *                wrapper (tps_pp_amd.nrtr_head) does and raises TpsppError.  TPSPP_HEAD_NO_PERSIST=1 (environment) forces
+ *                the launch pipeline, which has no such failure mode (status 0).
  * replaces: textrecog/decoders/nrtr_decoder.py:95-113,131-177, common/layers/transformer_layers.py:133-163
  */
 int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner, int n_layers,
@@ -611,7 +660,17 @@ int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner
                            int max_seq_len,
                            int start_idx, int padding_idx, const int* valid_len,
                            const int* forced_tokens, void* workspace, size_t workspace_bytes,
-                           float* out, int* tokens_out, int flags, tpspp_stream_t stream);
+                           float* out, int* tokens_out, int* status_out, int flags, tpspp_stream_t stream);
+
+/*
+ * AttnConvertor.tensor2idx on the device: scores (N, L, C) fp32 (the decoder's per-step soft-max scores, or any tensor of
+ * that shape) -> per position the maximum (val_out (N, L)) and its first index, torch.max's tie and NaN rules; idx_out (N, L)
+ * int32 holds that index where the reference's scan KEEPS the character -- position before the image's first end_idx and
+ * index != padding_idx -- and -1 elsewhere.  The host then needs one copy of 2 x N x L words per batch.
+ * replaces: textrecog/convertors/attn.py:124-140 (torch.max per image, two device->host copies per image, the Python scan)
+ */
+int tpspp_attn_tensor2idx_fwd(const float* scores, int N, int L, int C, int end_idx, int padding_idx,
+                              int* idx_out, float* val_out, tpspp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -69,6 +69,81 @@ def imresize_bilinear_u8(img, size):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+# ---- backend='pillow': PIL.Image.resize(size, Image.BILINEAR) on uint8 -- PINNED against the installed Pillow ---------------
+# (mmcv.imresize(img, size, backend='pillow') = np.array(Image.fromarray(img).resize(size, Image.BILINEAR)),
+# mmcv/image/geometric.py; the reference forwards ResizeOCR's `backend` there: ocr_transforms.py:46,65,99-101.)
+# Restates Pillow's src/libImaging/Resample.c (12.x; unchanged since 7.0): precompute_coeffs in double -- support = 1.0 x
+# max(scale, 1), window [int(center - support + 0.5), int(center + support + 0.5)) clipped to the image, triangle weights
+# at (x + xmin - center + 0.5) / max(scale, 1) summed in ascending order and divided by their sum --, normalize_coeffs_8bpc
+# (int(0.5 + k * 2^22)), then the horizontal pass into a uint8 image, then the vertical pass, each
+# clip8((2^21 + sum(pixel * k)) >> 22).  tests/golden/make_resize_golden.py writes Pillow's own outputs for seeded crops to
+# tests/golden/resize_pillow.npz and asserts this function reproduces every one bit for bit.
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_coeffs(in_size, out_size):
+    """-> list of (xmin, int32 coefficient array) per output index (precompute_coeffs + normalize_coeffs_8bpc)."""
+    scale = float(in_size) / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ss = 1.0 / filterscale
+    out = []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)                     # (C cast: truncation toward zero)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ws, ww = [], 0.0
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            if t < 0.0:
+                t = -t
+            w = 1.0 - t if t < 1.0 else 0.0
+            ws.append(w)
+            ww += w
+        ks = []
+        for w in ws:
+            if ww != 0.0:
+                w = w / ww
+            ks.append(int(-0.5 + w * (1 << PIL_PRECISION_BITS)) if w < 0 else int(0.5 + w * (1 << PIL_PRECISION_BITS)))
+        out.append((xmin, np.asarray(ks, dtype=np.int64)))
+    return out
+
+
+def _pil_clip8(v):
+    return np.clip(v >> PIL_PRECISION_BITS, 0, 255)
+
+
+def imresize_pillow_bilinear_u8(img, size):
+    """img (H, W, C) or (H, W) uint8 -> (h, w[, C]) uint8, size = (w, h): Pillow's Image.resize(size, Image.BILINEAR)."""
+    img = np.ascontiguousarray(img)
+    assert img.dtype == np.uint8 and img.ndim in (2, 3)
+    squeeze = img.ndim == 2
+    if squeeze:
+        img = img[:, :, None]
+    H, W, C = img.shape
+    w, h = int(size[0]), int(size[1])
+    cur = img.astype(np.int64)
+    if w != W:                                                  # horizontal pass first (ImagingResample: need_horizontal)
+        nxt = np.empty((H, w, C), dtype=np.int64)
+        for xx, (xmin, k) in enumerate(_pil_coeffs(W, w)):
+            acc = (1 << (PIL_PRECISION_BITS - 1)) + (cur[:, xmin:xmin + len(k), :] * k[None, :, None]).sum(1)
+            nxt[:, xx, :] = _pil_clip8(acc)
+        cur = nxt
+    if h != H:
+        nxt = np.empty((h, cur.shape[1], C), dtype=np.int64)
+        for yy, (ymin, k) in enumerate(_pil_coeffs(H, h)):
+            acc = (1 << (PIL_PRECISION_BITS - 1)) + (cur[ymin:ymin + len(k), :, :] * k[:, None, None]).sum(0)
+            nxt[yy] = _pil_clip8(acc)
+        cur = nxt
+    out = cur.astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
+
+
 def resize_plan(img_shape, height, min_width=None, max_width=None, keep_aspect_ratio=True,
                 width_downsample_ratio=1.0 / 16):
     """Host logic of ResizeOCR.__call__ (ocr_transforms.py:83-121) for one image:
@@ -95,10 +170,12 @@ def resize_plan(img_shape, height, min_width=None, max_width=None, keep_aspect_r
                 resize_shape=(height, int(resize_w), c), pad_shape=(height, int(out_w), c))
 
 
-def resize_ocr(img, height, min_width=None, max_width=None, keep_aspect_ratio=True, img_pad_value=0):
-    """ResizeOCR on one uint8 HWC image -> (padded image, plan)."""
+def resize_ocr(img, height, min_width=None, max_width=None, keep_aspect_ratio=True, img_pad_value=0, backend=None):
+    """ResizeOCR on one uint8 HWC image -> (padded image, plan).  backend None / 'cv2': the (unpinned) OpenCV restatement;
+    'pillow': the (pinned) Pillow restatement."""
     p = resize_plan(img.shape, height, min_width, max_width, keep_aspect_ratio)
-    r = imresize_bilinear_u8(img, (p["resize_w"], height))
+    resize = imresize_pillow_bilinear_u8 if backend == "pillow" else imresize_bilinear_u8
+    r = resize(img, (p["resize_w"], height))
     if p["out_w"] > p["resize_w"]:
         pad = np.full((height, p["out_w"] - p["resize_w"], img.shape[2]), img_pad_value, dtype=np.uint8)
         r = np.concatenate([r, pad], axis=1)                    # mmcv.impad: right / bottom padding
@@ -115,12 +192,12 @@ def to_tensor_normalize(img_u8, mean, std):
     return t.sub_(m).div_(s).numpy()
 
 
-def preprocess_batch(imgs, height, min_width, max_width, keep_aspect_ratio, img_pad_value, mean, std):
+def preprocess_batch(imgs, height, min_width, max_width, keep_aspect_ratio, img_pad_value, mean, std, backend=None):
     """The test pipeline of configs/_base_/recog_pipelines/crnn_pp_pipeline.py:85-95 on a list of images ->
     (N, C, height, max_width) fp32, list of plans."""
     outs, plans = [], []
     for im in imgs:
-        r, p = resize_ocr(im, height, min_width, max_width, keep_aspect_ratio, img_pad_value)
+        r, p = resize_ocr(im, height, min_width, max_width, keep_aspect_ratio, img_pad_value, backend)
         outs.append(to_tensor_normalize(r, mean, std))
         plans.append(p)
     return np.stack(outs), plans

@@ -397,7 +397,6 @@ def test_classic_backward_single_launch_against_the_two_kernel_route(cuda, C, hw
     route (which keeps fp32 partial sums of ~12 terms per lane: measured 1.8e-5 apart) and within 3e-5 of float64 on the
     same grid (measured 1.5e-5: the fp32 coordinate gradients of the sampler, amplified by |inv_delta_C| ~ 220).  From gentle to strong deformations (folds, coordinates clamped
     at the borders), a NaN in the incoming gradient (stays in its four taps; that image's dL/dC' is NaN in both routes)."""
-    import os
     import torch.nn.functional as Fn
     from tps_pp_amd import constants
     g = torch.Generator(device=cuda).manual_seed(17 + C + hw[1])
@@ -412,30 +411,22 @@ def test_classic_backward_single_launch_against_the_two_kernel_route(cuda, C, hw
     go[0, 0, 3, 7] = float("nan")
     _, _, grid, _ = ops.warp(img, ctrl, gg.inv_delta_C, gg.P_hat, hw, want_grid=True, P_hat_t=P_hat_t, table_flags=flags)
 
-    def run():
-        return ops.warp_backward(go, img, grid, ctrl, gg.inv_delta_C, gg.P_hat, hw, P_hat_t=P_hat_t)
+    def run(two_kernels=False):
+        return ops.warp_backward(go, img, grid, ctrl, gg.inv_delta_C, gg.P_hat, hw, P_hat_t=P_hat_t, two_kernels=two_kernels)
 
-    old = os.environ.pop("TPSPP_BWD_TWO_KERNELS", None)
-    try:
-        os.environ["TPSPP_BWD_TWO_KERNELS"] = "1"
-        want = run()
-        del os.environ["TPSPP_BWD_TWO_KERNELS"]
-        for rep in range(3):
-            got = run()
-            gi, wi = got[0], want[0]
-            assert torch.equal(torch.isnan(gi), torch.isnan(wi)) and int(torch.isnan(gi).sum()) in range(1, 5)
-            ok = ~torch.isnan(wi)
-            ia, ib = gi[ok].view(torch.int32).long(), wi[ok].view(torch.int32).long()
-            ia = torch.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
-            ib = torch.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
-            assert int((ia - ib).abs().max()) <= 1, ("dL/d input", C, hw, rep, int((ia - ib).abs().max()))
-            # image 0 carries the NaN: its dL/dC' is NaN in both routes; the others are finite
-            assert torch.isnan(got[2][0]).all() == torch.isnan(want[2][0]).all()
-            close(got[2][1:], want[2][1:].cpu().numpy(), 5e-5, "dL/d control points (single launch against two kernels)")
-    finally:
-        os.environ.pop("TPSPP_BWD_TWO_KERNELS", None)
-        if old is not None:
-            os.environ["TPSPP_BWD_TWO_KERNELS"] = old
+    want = run(two_kernels=True)                 # (the per-call TPSPP_BWD_TWO_KERNELS bit; the environment variable is read once)
+    for rep in range(3):
+        got = run()
+        gi, wi = got[0], want[0]
+        assert torch.equal(torch.isnan(gi), torch.isnan(wi)) and int(torch.isnan(gi).sum()) in range(1, 5)
+        ok = ~torch.isnan(wi)
+        ia, ib = gi[ok].view(torch.int32).long(), wi[ok].view(torch.int32).long()
+        ia = torch.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+        ib = torch.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+        assert int((ia - ib).abs().max()) <= 1, ("dL/d input", C, hw, rep, int((ia - ib).abs().max()))
+        # image 0 carries the NaN: its dL/dC' is NaN in both routes; the others are finite
+        assert torch.isnan(got[2][0]).all() == torch.isnan(want[2][0]).all()
+        close(got[2][1:], want[2][1:].cpu().numpy(), 5e-5, "dL/d control points (single launch against two kernels)")
     # dL/d input not wanted (the kernel then skips the accumulators): the same dL/dC', bit for bit
     g_no = ops.warp_backward(go, img, grid, ctrl, gg.inv_delta_C, gg.P_hat, hw, P_hat_t=P_hat_t, need_in0=False)
     assert g_no[0] is None and torch.equal(g_no[2][1:], got[2][1:])

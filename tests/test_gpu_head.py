@@ -575,3 +575,184 @@ def test_recognizer_training_steps_through_the_hip_warp(cuda):
     with torch.no_grad():
         res = m(img, [dict(mm) for mm in metas], return_loss=False)
     assert len(res) == n and all(isinstance(r["text"], str) for r in res)
+
+
+# ---- round 6: the persistent decode is safe to overlap, and its failure is loud -----------------------------------------------
+def _decoders(cuda, count, seq=40):
+    """`count` NRTRDecoder modules with the same weights (each has its own workspace, as independent requests have)."""
+    from tps_pp_amd.nrtr_head import NRTRDecoder
+    torch.manual_seed(21)
+    first = NRTRDecoder(num_classes=93, max_seq_len=seq, start_idx=91, padding_idx=92).eval().to(cuda)
+    with torch.no_grad():
+        first.classifier.weight.mul_(6.0)
+    decs = [first]
+    for _ in range(count - 1):
+        d = NRTRDecoder(num_classes=93, max_seq_len=seq, start_idx=91, padding_idx=92).eval().to(cuda)
+        d.load_state_dict(first.state_dict())
+        decs.append(d)
+    return decs
+
+
+@pytest.mark.parametrize("cd", [None, torch.bfloat16], ids=["fp32", "bf16"])
+def test_persistent_decodes_on_several_streams_equal_the_serial_ones(cuda, cd):
+    """Round-5 review: two (three) persistent decodes in flight on different streams could each get part of their clusters
+    resident and starve.  tpspp_nrtr_decoder_fwd now orders every persistent decode of a device behind the previous one
+    (an event, no host synchronisation): decodes issued back to back on three streams -- from one thread and from three
+    threads -- give exactly the serial results and status 0; nothing is NaN."""
+    import threading
+    n = 512
+    decs = _decoders(cuda, 3)
+    for d in decs:
+        d.compute_dtype = cd
+    encs = [torch.randn(n, 64, 512, device=cuda) for _ in decs]
+    with torch.no_grad():
+        serial = [d(None, e, None, None, train_mode=False).clone() for d, e in zip(decs, encs)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=cuda) for _ in decs]
+        for rep in range(2):
+            outs = [None] * len(decs)
+
+            def work(i):
+                with torch.no_grad(), torch.cuda.stream(streams[i]):
+                    outs[i] = decs[i](None, encs[i], None, None, train_mode=False)
+
+            if rep == 0:
+                for i in range(len(decs)):
+                    work(i)
+            else:
+                ts = [threading.Thread(target=work, args=(i,)) for i in range(len(decs))]
+                for t in ts:
+                    t.start()
+                for t in ts:
+                    t.join()
+            torch.cuda.synchronize()
+            for i, d in enumerate(decs):
+                d.check_status()
+                assert torch.isfinite(outs[i]).all(), (rep, i)
+                assert torch.equal(outs[i], serial[i]), (rep, i, float((outs[i] - serial[i]).abs().max()))
+
+
+def test_persistent_decode_on_a_partly_occupied_device(cuda):
+    """A decode while another stream holds 96 CUs for 60 ms (tpspp_lab_occupy: one workgroup per CU with 100 KB of LDS, so no
+    decoder workgroup fits beside it): the decode's clusters wait for their CUs -- the barrier timeout is wall-clock time,
+    4 s by default -- and the result equals the unobstructed one; status 0, nothing NaN."""
+    from tps_pp_amd import _lib
+    n = 512
+    (dec,) = _decoders(cuda, 1)
+    enc = torch.randn(n, 64, 512, device=cuda)
+    with torch.no_grad():
+        want = dec(None, enc, None, None, train_mode=False).clone()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=cuda)
+        for wgs in (96, 200):
+            _lib.check(_lib.lib().tpspp_lab_occupy(wgs, 100 * 1024, 60, side.cuda_stream), "tpspp_lab_occupy")
+            got = dec(None, enc, None, None, train_mode=False)
+            torch.cuda.synchronize()
+            dec.check_status()
+            assert torch.isfinite(got).all() and torch.equal(got, want), wgs
+
+
+def test_persistent_decode_timeout_is_loud(cuda):
+    """The failure path on demand (TPSPP_HEAD_TEST_STALL: one workgroup of the first cluster sits out two timeouts at step 2,
+    TPSPP_HEAD_TIMEOUT_MS=20): the status word is 1, `AttnConvertor.tensor2idx` / `NRTRDecoder.check_status` raise
+    TpsppError instead of decoding NaN into strings, the stalled cluster's scores are NaN from step 2 to the LAST step (no
+    step is left uninitialised), every other cluster's are untouched -- and the next decode is clean."""
+    import os
+    from tps_pp_amd import _lib
+    n, seq = 100, 9
+    (dec,) = _decoders(cuda, 1, seq)
+    conv = AttnConvertor(dict_type="DICT90", with_unknown=True, max_seq_len=seq)
+    enc = torch.randn(n, 64, 512, device=cuda)
+    with torch.no_grad():
+        want = dec(None, enc, None, None, train_mode=False).clone()
+        want_idx = conv.tensor2idx(want)
+        os.environ["TPSPP_HEAD_TEST_STALL"] = "2"
+        os.environ["TPSPP_HEAD_TIMEOUT_MS"] = "20"
+        try:
+            out = dec(None, enc, None, None, train_mode=False)
+        finally:
+            del os.environ["TPSPP_HEAD_TEST_STALL"], os.environ["TPSPP_HEAD_TIMEOUT_MS"]
+        with pytest.raises(_lib.TpsppError, match="timed out"):
+            conv.tensor2idx(out)
+        with pytest.raises(_lib.TpsppError, match="timed out"):
+            dec.check_status()
+        assert int(dec.last_status.cpu()[0]) == 1
+        o = out.cpu()
+        assert torch.equal(o[:32, :2], want[:32, :2].cpu())                  # steps before the stall completed
+        assert torch.isnan(o[:32, 2:]).all()                                 # the stalled cluster: NaN from step 2 to the end
+        assert torch.equal(o[32:], want[32:].cpu())                          # the other clusters never noticed
+        again = dec(None, enc, None, None, train_mode=False)
+        assert conv.tensor2idx(again) == want_idx and torch.equal(again, want)
+
+
+def test_persistent_decode_respects_the_devices_capacity(cuda):
+    """Co-residency guard: a device that cannot hold a group of 8 clusters (TPSPP_HEAD_PERSIST_GROUPS=0 stands in for a small
+    or CU-masked part) gets the launch pipeline -- for the exact-fp32 head the same bits as TPSPP_HEAD_NO_PERSIST=1 --, one that
+    holds a single group decodes 256 images per launch: same scores as the default in both cases."""
+    import os
+    n, seq = 557, 5
+    (dec,) = _decoders(cuda, 1, seq)
+    enc = torch.randn(n, 64, 512, device=cuda)
+    metas = [dict(valid_ratio=(1.0, 0.5)[i % 2]) for i in range(n)]
+    with torch.no_grad():
+        want = dec(None, enc, None, metas, train_mode=False).clone()
+        try:
+            os.environ["TPSPP_HEAD_NO_PERSIST"] = "1"
+            pipeline = dec(None, enc, None, metas, train_mode=False).clone()
+            del os.environ["TPSPP_HEAD_NO_PERSIST"]
+            for groups in ("0", "1"):
+                os.environ["TPSPP_HEAD_PERSIST_GROUPS"] = groups
+                got = dec(None, enc, None, metas, train_mode=False)
+                dec.check_status()
+                assert torch.equal(got, pipeline if groups == "0" else want), groups
+        finally:
+            os.environ.pop("TPSPP_HEAD_NO_PERSIST", None)
+            os.environ.pop("TPSPP_HEAD_PERSIST_GROUPS", None)
+    assert torch.equal(pipeline, want)                                        # (exact-fp32 head: bit-identical routes)
+
+
+@pytest.mark.parametrize("n,L,C", [(5, 40, 92), (67, 70, 92), (3, 1, 7), (33, 64, 130)])
+def test_attn_tensor2idx_kernel_against_the_reference_scan(cuda, n, L, C):
+    """`tpspp_attn_tensor2idx_fwd` (arg-max with torch.max's first-index tie rule, NaN beating numbers, skip <PAD>, stop at
+    the first <EOS>) against the reference's own composition on the CPU (convertors/attn.py:124-140 = the CPU branch of
+    `AttnConvertor.tensor2idx`): identical index lists and bit-identical scores; ties, rows of -inf, NaN, more than 64
+    positions."""
+    g = torch.Generator().manual_seed(n * 1000 + L)
+    conv = AttnConvertor(dict_type="DICT90", with_unknown=True, max_seq_len=L)
+    conv.end_idx, conv.padding_idx = min(conv.end_idx, C - 2), min(conv.padding_idx, C - 1)
+    x = torch.rand((n, L, C), generator=g)
+    x = (x * 8).round() / 8                                                    # many exact ties
+    x[:, :, conv.end_idx] += (torch.rand((n, L), generator=g) < 0.08).float()      # an <EOS> here and there
+    x[:, :, conv.padding_idx] += (torch.rand((n, L), generator=g) < 0.1).float()   # <PAD> before it
+    if n > 2 and L > 1:
+        x[1, 0] = float("-inf")
+        x[2, L - 1, 3] = float("nan")
+        x[2, L - 1, 5] = float("nan")
+    want_i, want_s = conv.tensor2idx(x)
+    got_i, got_s = conv.tensor2idx(x.to(cuda))
+    assert got_i == want_i
+    assert len(got_s) == len(want_s)
+    for a, b in zip(got_s, want_s):
+        assert np.array_equal(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), equal_nan=True)
+
+
+def test_eval_mode_with_autograd_enabled_says_so_once(cuda, caplog):
+    """Frozen-BatchNorm fine-tuning (model.eval(), grad enabled, trainable parameters) runs the HIP inference kernels, whose
+    outputs carry no graph: every module that takes that path says so once instead of silently returning detached tensors
+    (round-5 ADVICE; TPS_PP already did)."""
+    import logging
+    from tps_pp_amd import ResNetABI_v2_large
+    enc, dec = small_modules(cuda)
+    feat = torch.zeros(2, cases.HD_SMALL["d_model"], 2, 4, device=cuda)
+    with caplog.at_level(logging.WARNING, logger="tps_pp_amd"):
+        for _ in range(2):
+            out_enc = enc(feat, None)
+            out = dec(feat, out_enc, None, None, train_mode=False)
+    msgs = [r.getMessage() for r in caplog.records if "records no graph" in r.getMessage()]
+    assert sum("NRTREncoder" in m for m in msgs) == 1 and sum("NRTRDecoder" in m for m in msgs) == 1
+    assert not out.requires_grad
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="tps_pp_amd"), torch.no_grad():
+        enc2, _ = small_modules(cuda)
+        enc2(feat, None)
+    assert not [r for r in caplog.records if "records no graph" in r.getMessage()]      # no_grad inference: silent

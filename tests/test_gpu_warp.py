@@ -46,7 +46,7 @@ def test_classic_warp_matches_reference_golden(cuda):
     assert torch.equal(P_hat_t, P_hat.t().contiguous())
     assert ops.table_mirror_symmetry(K["classic_P_hat"], cases.CL_HW, cases.CL_F) == 1
     P_prep, packed = ops.prepare_mirror_table(P_hat, cases.CL_HW)
-    assert packed == ops.TABLE_PACKED and torch.equal(P_prep, P_hat_t)
+    assert packed == ops.TABLE_PACKED | ops.TABLE_SPAN and torch.equal(P_prep, P_hat_t)
     try:
         # 1 = gather, 3 = LDS-staged kernel, 2 = LDS-staged kernel on the mirror-symmetric table,
         # 5 = image-pair kernel, 6 = in-place kernel (both: prepared table), 0 = whatever the library picks for a prepared table
@@ -101,7 +101,7 @@ def test_packed_table_contract(cuda):
     from oracle import tps_oracle as O
     ph128 = O.classic_constants(20, (32, 128))["P_hat"]
     p128, f128 = ops.prepare_mirror_table(dev(ph128, cuda), (32, 128))
-    assert f128 == ops.TABLE_PACKED
+    assert f128 == ops.TABLE_PACKED | ops.TABLE_SPAN
     tail = p128._base[23 * 4096:].cpu().numpy().reshape(8, 2, 6, 64, 4)
     ref = np.zeros((8, 2, 6, 64, 4), np.float32)
     for t_ in range(512):
@@ -306,7 +306,7 @@ def test_inplace_kernel_vs_oracle(cuda, oracle, N, C, H, W, perturb):
     P_hat = dev(Kc["P_hat"], cuda)
     assert ops.table_mirror_symmetry(Kc["P_hat"], (H, W), F) == 1
     prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
-    assert packed == ops.TABLE_PACKED
+    assert packed == ops.TABLE_PACKED | ops.TABLE_SPAN
     try:
         ops.set_warp_tuning(0, 0, 6, 0)
         for want in (True, False):
@@ -469,7 +469,7 @@ def test_runtime_geometry_kernel_forced(cuda, oracle, N, C, H, W):
     ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
     P_hat = dev(Kc["P_hat"], cuda)
     prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
-    assert packed == ops.TABLE_PACKED
+    assert packed == ops.TABLE_PACKED | ops.TABLE_SPAN
     ops.set_warp_tuning(kernel_choice=7)
     try:
         for want in (True, False):
@@ -499,7 +499,7 @@ def test_runtime_geometry_kernel_geometry_sweep(cuda, oracle):
         Kc = oracle.classic_constants(F, (H, W))
         P_hat = dev(Kc["P_hat"], cuda)
         prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
-        assert packed == ops.TABLE_PACKED, (H, W)
+        assert packed == ops.TABLE_PACKED | ops.TABLE_SPAN, (H, W)
         ctrl = oracle.classic_initial_ctrl(F)[None] + 0.3 * synth.dyadic((N, F, 2), "sw.ctrl", i)
         img = synth.dyadic((N, C, H, W), "sw.img", i)
         ref = oracle.warp(img, ctrl, Kc["inv_delta_C"], Kc["P_hat"], (H, W), want_grid=True, want_idx=True)
@@ -545,7 +545,7 @@ def test_span_staging_kernel_forced(cuda, oracle, N, C, H, W):
     flat[13::997] = -0.0
     P_hat = dev(Kc["P_hat"], cuda)
     prep, packed = ops.prepare_mirror_table(P_hat, (H, W))
-    assert packed == ops.TABLE_PACKED
+    assert packed == ops.TABLE_PACKED | ops.TABLE_SPAN
     inv = dev(Kc["inv_delta_C"], cuda)
     try:
         for noise, knob in ((0.03, 0), (0.45, 0), (0.1, 64), (0.1, 2 | (40 << 8)), (0.03, 0 | (150 << 8)), (0.03, 128), (0.45, 128),
@@ -587,6 +587,16 @@ def test_span_staging_kernel_is_the_default_for_large_geometries(cuda, oracle):
         args = (dev(img, cuda), dev(ctrl, cuda), dev(Kc["inv_delta_C"], cuda), P_hat, (H, W))
         kw = dict(P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | packed)
         assert_biteq(ops.warp(*args, **kw)[0], ref["out0"], f"default {H}x{W}")
+        # a caller that does not vouch for the three-section layout (no TABLE_SPAN: a buffer sized by an earlier build) never
+        # reaches the kernel that reads the third section -- same bits from the other kernels, kernel_choice 8 refused
+        kw2 = dict(P_hat_t=prep, table_flags=ops.TABLE_MIRROR4 | ops.TABLE_PACKED)
+        assert_biteq(ops.warp(*args, **kw2)[0], ref["out0"], f"two-section promise {H}x{W}")
+        try:
+            ops.set_warp_tuning(kernel_choice=8)
+            with pytest.raises(Exception, match="do not qualify"):
+                ops.warp(*args, **kw2)
+        finally:
+            ops.set_warp_tuning()
         try:
             ops.set_warp_tuning(kernel_choice=7)
             assert_biteq(ops.warp(*args, **kw)[0], ref["out0"], f"kernel_choice 7 {H}x{W}")

@@ -6,7 +6,12 @@ GPU part: the kernel bit for bit against the oracle on ragged batches.  The inte
 "parity unpinned" against a real cv2 (OpenCV is not installed here: see oracle/resize_oracle.py); what stands in for
 it are (i) expected arrays for tiny cases derived step by step from OpenCV's published 8-bit INTER_LINEAR arithmetic
 (HAND_CASES below, tables in the comments) and (ii) properties any correct resize has.  Until a fixture produced by
-cv2 itself exists the row stays "partial"."""
+cv2 itself exists THAT backend stays unpinned.
+
+Round 6: `backend='pillow'` (ocr_transforms.py:34-36,46,65 -> mmcv.imresize -> Image.resize(size, Image.BILINEAR)) IS pinned:
+tests/golden/resize_pillow.npz holds the installed Pillow's own outputs on seeded crops (tests/golden/make_resize_golden.py
+regenerates the inputs from tps_pp_amd/synth.py); the oracle's restatement of Pillow's Resample.c and the HIP kernel both
+reproduce them bit for bit."""
 import math
 
 import numpy as np
@@ -207,3 +212,89 @@ def test_gpu_preprocessor_gray_and_upscaled_images(cuda):
         pre([np.zeros((4, 4, 1), dtype=np.float32)])
     with pytest.raises(ValueError):
         pre([])
+
+
+# ---- backend='pillow': pinned against the installed Pillow's own outputs (tests/golden/resize_pillow.npz) -------------------
+def pillow_fixture():
+    import os
+    import sys
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import make_resize_golden as MG
+    G = np.load(os.path.join(here, "resize_pillow.npz"))
+    cases = []
+    for i, ((H, W, C, w, h), kind) in enumerate(zip(G["cases"].tolist(), G["kinds"].tolist())):
+        assert (H, W, C, w, h, kind) == tuple(MG.CASES[i]), "fixture and generator disagree: regenerate the fixture"
+        cases.append((MG.make_input(i, H, W, C, kind), (w, h), G[f"out{i}"]))
+    return cases
+
+
+def test_pillow_oracle_reproduces_the_pillow_fixture():
+    cases = pillow_fixture()
+    assert len(cases) >= 12
+    for i, (img, size, want) in enumerate(cases):
+        got = RO.imresize_pillow_bilinear_u8(img, size)
+        assert got.shape == want.shape and np.array_equal(got, want), (i, img.shape, size)
+    # and, where Pillow is importable (the build container), against the library itself on fresh shapes
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    g = np.random.default_rng(9)
+    for t in range(40):
+        H, W, w = int(g.integers(1, 80)), int(g.integers(1, 250)), int(g.integers(4, 161))
+        img = g.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        assert np.array_equal(RO.imresize_pillow_bilinear_u8(img, (w, 32)), np.array(Image.fromarray(img).resize((w, 32), Image.BILINEAR)))
+
+
+def test_backend_is_honoured_or_refused():
+    assert ResizeOCR(32, max_width=128).interpolation() == 0
+    assert ResizeOCR(32, max_width=128, backend="cv2").interpolation() == 0
+    assert ResizeOCR(32, max_width=128, backend="pillow").interpolation() == 1
+    with pytest.raises(ValueError, match="not supported for resize"):
+        ResizeOCR(32, max_width=128, backend="turbojpeg").interpolation()      # (mmcv.imresize raises ValueError as well)
+    # the two backends are different arithmetic: on a 3.1x horizontal shrink Pillow averages 7 source columns, OpenCV takes 2
+    img = (synth.dyadic((31, 400, 3), "backend.diff", 1) * 127.5 + 127.5).astype(np.uint8)
+    a, _ = RO.resize_ocr(img, 32, 32, 128, False, backend="pillow")
+    b, _ = RO.resize_ocr(img, 32, 32, 128, False)
+    assert a.shape == b.shape and not np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_pillow_backend_equals_the_pillow_fixture_bit_for_bit(cuda):
+    """`ResizeOCR(backend='pillow')` on the GPU against the installed Pillow's outputs: every fixture case alone (so that its
+    own width is the batch's width) through `OCRBatchPreprocessor`, identity normalisation -> value / 255 exactly."""
+    for i, (img, (w, h), want) in enumerate(pillow_fixture()):
+        C = img.shape[2]
+        pre = OCRBatchPreprocessor(ResizeOCR(h, min_width=w, max_width=w, keep_aspect_ratio=False, backend="pillow"),
+                                   NormalizeOCR([0.0] * C, [1.0] * C), cuda)
+        out, _ = pre([img])
+        ref = RO.to_tensor_normalize(want, [0.0] * C, [1.0] * C)
+        got = out.cpu().numpy()[0]
+        assert got.shape == ref.shape, (i, got.shape, ref.shape)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (i, img.shape, (w, h), float(np.abs(got - ref).max() * 255))
+    with pytest.raises(ValueError, match="not supported for resize"):
+        OCRBatchPreprocessor(ResizeOCR(32, max_width=128, keep_aspect_ratio=False, backend="nope"), NormalizeOCR([0.0], [1.0]), cuda)(
+            [np.zeros((4, 4, 1), np.uint8)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep,mn,mx,pad", [(False, 32, 128, 0), (True, 32, 128, 0), (True, 32, 160, 7), (False, None, 100, 255)])
+def test_gpu_pillow_backend_ragged_batches_equal_the_pinned_oracle(cuda, keep, mn, mx, pad):
+    imgs = ragged_images(23, 5) + [np.random.default_rng(2).integers(0, 256, (150, 1000, 3), dtype=np.uint8)]
+    pre = OCRBatchPreprocessor(ResizeOCR(32, min_width=mn, max_width=mx, keep_aspect_ratio=keep, img_pad_value=pad, backend="pillow"),
+                               NormalizeOCR(MEAN, STD), cuda)
+    out, metas = pre(imgs)
+    ref, plans = RO.preprocess_batch(imgs, 32, mn, mx, keep, pad, MEAN, STD, backend="pillow")
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    cv, _ = RO.preprocess_batch(imgs, 32, mn, mx, keep, pad, MEAN, STD)
+    assert not np.array_equal(ref, cv)                                        # (the other backend is different arithmetic)
+    for m, p in zip(metas, plans):
+        assert m["valid_ratio"] == p["valid_ratio"] and tuple(m["resize_shape"]) == tuple(p["resize_shape"])
+    # grayscale crops handed over as (H, W) arrays, as mmcv.imread(color_type='grayscale') does
+    gray = [im[:, :, 0].copy() for im in imgs[:7]]
+    pre1 = OCRBatchPreprocessor(ResizeOCR(32, min_width=mn, max_width=mx, keep_aspect_ratio=keep, img_pad_value=pad, backend="pillow"),
+                                NormalizeOCR([0.5], [0.5]), cuda)
+    ref1, _ = RO.preprocess_batch([g[:, :, None] for g in gray], 32, mn, mx, keep, pad, [0.5], [0.5], backend="pillow")
+    assert np.array_equal(pre1(gray)[0].cpu().numpy().view(np.uint32), ref1.view(np.uint32))

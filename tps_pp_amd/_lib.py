@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtpspp_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _f = ctypes.c_void_p       # device pointers travel as integers
 _i = ctypes.c_int
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "tpspp_warp_set_tuning": ([_i, _i, _i, _i], _i),
     "tpspp_warp_set_trace": ([_f], _i),
     "tpspp_head_set_trace": ([_f], _i),
+    "tpspp_lab_occupy": ([_i, _i, _i, _f], _i),
     "tpspp_warp_bwd_workspace_floats": ([_i, _i, _i], ctypes.c_size_t),
     "tpspp_warp_bwd_set_accumulator": ([_i], _i),
     "tpspp_warp_bwd": ([_f, _f, _i, _i, _i, _f, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _i,
@@ -55,12 +56,13 @@ _SIGNATURES = {
     "tpspp_layernorm_cm_fwd": ([_f, _f, _f, _i, _i, ctypes.c_float, _f, _f], _i),
     "tpspp_attn_enc_fwd": ([_f, _i, _i, _i, _f, _f, _f], _i),
     "tpspp_linear_ln_fwd": ([_f, _i, _i, ctypes.c_float, _f, _f, _i, _f, _i, _f, _i, _f, _f], _i),
-    "tpspp_resize_normalize_fwd": ([_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _f], _i),
+    "tpspp_resize_normalize_fwd": ([_f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f, _i, _f], _i),
     "tpspp_nrtr_encoder_workspace": ([_i, _i, _i, _i], ctypes.c_size_t),
     "tpspp_nrtr_decoder_workspace": ([_i] * 7, ctypes.c_size_t),
     "tpspp_nrtr_encoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, ctypes.c_size_t, _f, _f, _i, _f], _i),
     "tpspp_nrtr_decoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _f,
-                                _f, ctypes.c_size_t, _f, _f, _i, _f], _i),
+                                _f, ctypes.c_size_t, _f, _f, _f, _i, _f], _i),
+    "tpspp_attn_tensor2idx_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f], _i),
 }
 
 _lib = None

@@ -26,6 +26,8 @@
 #include <cmath>
 
 #include "tpspp_common.h"
+
+#include <mutex>
 #include "tpspp_tokgemm.h"
 
 #include <cstdlib>
@@ -1479,12 +1481,79 @@ size_t dec_ws_bytes(int N, int C, int T, int Di, int n_layers, int L, int Cc)
     return s;
 }
 
+
+// ---- the persistent decode's two requirements (include/tpspp.h, tpspp_nrtr_decoder_fwd) -----------------------------------
+// (1) Co-residency.  The 16 workgroups of a cluster spin on each other's counter, and blocks are dispatched in order: a launch
+//     makes progress iff a whole GROUP of 8 clusters (128 consecutive blocks) can be resident.  persist_groups() = how many such
+//     groups the device holds at once (CU count x the kernel's occupancy at 512 threads + sizeof(PShared) of LDS, / 128), capped
+//     at 2 (512 images per launch); 0 -- a smaller part, a CU-masked or CPX partition, a failed attribute call -- sends the
+//     decode down the launch-per-phase pipeline.
+// (2) One persistent decode in flight per device.  Two of them on two streams are harmless by themselves (in-order dispatch:
+//     one of them always owns a whole group), three can starve each other until the timeout; instead of reasoning about the
+//     dispatcher, every persistent decode waits (hipStreamWaitEvent, no host synchronisation) for the event recorded behind
+//     the previous one on this device, whatever its stream, and records its own.  Decodes of one process therefore never
+//     overlap each other on a device; kernels of other streams may overlap them freely (they finish on their own, the barrier
+//     timeout is wall-clock time).  Other PROCESSES on the same device are not seen by this guard: one process per GPU.
+struct PersistDevice {
+    hipEvent_t done = nullptr;
+    bool recorded = false;
+    int groups[6] = {-1, -1, -1, -1, -1, -1};               // per kernel instantiation; -1 = not queried yet
+};
+std::mutex g_persist_mu;
+PersistDevice g_persist_dev[tpspp::kMaxDevices];
+
+template <typename Kern>
+int persist_groups(PersistDevice& D, int which, Kern kern, int dev)
+{
+    if (D.groups[which] < 0) {
+        int groups = 0, cus = 0, per_cu = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared)) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, sizeof(PShared)) == hipSuccess) {
+            groups = (int)(((long)cus * per_cu) / 128);
+            if (groups > 2) groups = 2;
+        }
+        (void)hipGetLastError();
+        D.groups[which] = groups;
+    }
+    int groups = D.groups[which];
+    if (const char* f = getenv("TPSPP_HEAD_PERSIST_GROUPS")) {   // lab / test switch (read per call): pretend the device holds fewer groups
+        const int v = atoi(f);
+        if (v >= 0 && v < groups) groups = v;
+    }
+    return groups;
+}
+
+// lab / test kernel (tpspp_lab_occupy): `blocks` workgroups that hold `lds` bytes of LDS each and spin on the wall clock
+__global__ void __launch_bounds__(64) lab_occupy_kernel(long long ticks, int* sink)
+{
+    extern __shared__ int occ_smem[];
+    const long long t0 = (long long)wall_clock64();
+    int n = 0;
+    while ((long long)wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(64); ++n; }
+    if (n < 0) { occ_smem[threadIdx.x] = n; sink[0] = occ_smem[0]; }       // (never: keeps the LDS allocation alive)
+}
+
 }  // namespace
 
 TPSPP_EXPORT int tpspp_head_set_trace(long long* device_buf)
 {
     g_head_trace = device_buf;
     return TPSPP_OK;
+}
+
+TPSPP_EXPORT int tpspp_lab_occupy(int workgroups, int lds_bytes, int milliseconds, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(workgroups > 0 && workgroups <= 4096 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && milliseconds > 0 && milliseconds <= 2000,
+                  "tpspp_lab_occupy: workgroups in [1, 4096], lds_bytes in [0, 160 KB], milliseconds in [1, 2000]");
+    static bool attr_done[tpspp::kMaxDevices] = {};
+    if (tpspp::first_use_on_device(attr_done)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(lab_occupy_kernel, dim3((unsigned)workgroups), dim3(64), (size_t)lds_bytes, tpspp::as_stream(stream),
+                       (long long)milliseconds * 100000, (int*)nullptr);
+    return tpspp::check_launch("tpspp_lab_occupy");
 }
 
 TPSPP_EXPORT size_t tpspp_nrtr_encoder_workspace(int N, int C, int T, int d_inner)
@@ -1645,7 +1714,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                                         int max_seq_len,
                                         int start_idx, int padding_idx, const int* valid_len,
                                         const int* forced_tokens, void* workspace, size_t workspace_bytes,
-                                        float* out, int* tokens_out, int flags, tpspp_stream_t stream)
+                                        float* out, int* tokens_out, int* status_out, int flags, tpspp_stream_t stream)
 {
     TPSPP_REQUIRE(n_layers > 0 && layer_ptrs_len == n_layers * D_COUNT + 1,
                   "tpspp_nrtr_decoder_fwd: layer_ptrs_len must be n_layers * %d + 1 (24 pointers per layer, then the "
@@ -1735,7 +1804,27 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     const unsigned pair_blocks = (unsigned)((N * H + 3) / 4);
     int rc = 0;
     // ---- the step as ONE persistent launch (tpspp_head_persist.h): every head configuration, d_model 512, 8 heads ----
-    const bool persist = fast && C == 512 && H == 8 && num_out <= 128 && n_layers <= kPMaxLayers && !g_head_qcross && !head_no_persist();
+    bool persist = fast && C == 512 && H == 8 && num_out <= 128 && n_layers <= kPMaxLayers && !g_head_qcross && !head_no_persist();
+    auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2, false> : dec_step_persist_kernel<unsigned short, 4, false>)
+              : gemm_f32 ? (d_inner == 256 ? dec_step_persist_kernel<float, 2, true> : dec_step_persist_kernel<float, 4, true>)
+                    : (d_inner == 256 ? dec_step_persist_kernel<float, 2, false> : dec_step_persist_kernel<float, 4, false>);
+    int dev = 0, groups = 0;
+    if (persist) {
+        // requirement (1): a whole group of clusters resident, else the launch pipeline below; not under stream capture (the
+        // in-flight guard's events would become graph nodes)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= tpspp::kMaxDevices ||
+            hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            persist = false;
+        } else {
+            std::lock_guard<std::mutex> lk(g_persist_mu);
+            groups = persist_groups(g_persist_dev[dev], (b16 ? 2 : gemm_f32 ? 4 : 0) + (d_inner == 256 ? 0 : 1), kern, dev);
+            persist = groups > 0;
+        }
+    }
+    if (status_out && !persist && hipMemsetAsync(status_out, 0, sizeof(int), st) != hipSuccess)
+        return tpspp::check_launch("tpspp_nrtr_decoder_fwd(status)");
     if (persist) {
         PStep PS;
         for (int l = 0; l < n_layers; ++l) {
@@ -1755,18 +1844,20 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         PS.pairs = 2;
         PS.trace = g_head_trace;
         PS.no_plain = getenv("TPSPP_HEAD_WRITE_THROUGH") ? 1 : 0;
+        // barrier timeout: wall-clock milliseconds (default 4000) -> units of 1024 ticks of the 100 MHz clock
+        { const char* tv = getenv("TPSPP_HEAD_TIMEOUT_MS"); const long ms = tv ? atol(tv) : 4000; PS.timeout_k = (int)((ms < 1 ? 1 : ms > 60000 ? 60000 : ms) * 100000 / 1024); }
+        { const char* tv = getenv("TPSPP_HEAD_TEST_STALL"); PS.test_stall_step = tv ? atoi(tv) : -1; }
         // odd clusters start 15 us late (TPSPP_HEAD_STAGGER_US overrides; 0 = together): bf16x3 20.0 -> 19.4 ms, bf16 15.4 -> 15.0
         { const char* sv = getenv("TPSPP_HEAD_STAGGER_US"); PS.stagger = (sv ? atoi(sv) : (N > 32 ? 15 : 0)) * 100; }
+        // requirement (2): behind the previous persistent decode of this device, whatever stream it ran on
+        std::lock_guard<std::mutex> lk(g_persist_mu);
+        PersistDevice& PD = g_persist_dev[dev];
+        if (!PD.done && hipEventCreateWithFlags(&PD.done, hipEventDisableTiming) != hipSuccess)
+            return tpspp::check_launch("tpspp_nrtr_decoder_fwd(event)");
+        if (PD.recorded && hipStreamWaitEvent(st, PD.done, 0) != hipSuccess)
+            return tpspp::check_launch("tpspp_nrtr_decoder_fwd(wait for the previous persistent decode)");
         if (hipMemsetAsync(pcounters, 0, ((size_t)(N + 31) / 32 * 32 + 64) * sizeof(int), st) != hipSuccess)
             return tpspp::check_launch("tpspp_nrtr_decoder_fwd(memset)");
-        auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2, false> : dec_step_persist_kernel<unsigned short, 4, false>)
-                  : gemm_f32 ? (d_inner == 256 ? dec_step_persist_kernel<float, 2, true> : dec_step_persist_kernel<float, 4, true>)
-                        : (d_inner == 256 ? dec_step_persist_kernel<float, 2, false> : dec_step_persist_kernel<float, 4, false>);
-        static bool attr_done[6][tpspp::kMaxDevices] = {};
-        if (tpspp::first_use_on_device(attr_done[(b16 ? 2 : gemm_f32 ? 4 : 0) + (d_inner == 256 ? 0 : 1)])) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(PShared));
-            (void)hipGetLastError();
-        }
         hipLaunchKernelGGL(dec_embed_kernel, dim3((unsigned)((C * N + 255) / 256)), dim3(256), 0, st, emb, pos_table, tokens, Lt, 0, C,
                            N, x, 1);
         const int per_step = 8 * n_layers + 2;                 // cluster barriers of one step
@@ -1776,11 +1867,12 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
         // bf16x3 19.67 -> 19.07, bf16 14.29 -> 13.83 at batch 512.)  TPSPP_HEAD_STEP_LAUNCHES=1: one launch per step -- same
         // scores (tests/test_gpu_head.py), for A/B runs.
         const int per_launch = getenv("TPSPP_HEAD_STEP_LAUNCHES") ? 1 : L;
+        const int img_per_launch = 256 * groups;               // every cluster of a launch resident: `groups` x 8 clusters x 32 images
         for (int s = 0; s < L; s += per_launch) {
             // (+ one placement-check barrier per launch)
             PS.x = x; PS.y = y; PS.step = s; PS.nsteps = per_launch; PS.bar_base = s * per_step + s / per_launch;
-            for (int n0 = 0; n0 < N; n0 += 512) {              // <= 256 workgroups per launch: every cluster resident
-                const int nimg = N - n0 < 512 ? N - n0 : 512;
+            for (int n0 = 0; n0 < N; n0 += img_per_launch) {
+                const int nimg = N - n0 < img_per_launch ? N - n0 : img_per_launch;
                 PS.n0 = n0; PS.counters = pcounters + (n0 >> 5) * 32;
                 PS.nclusters = (nimg + 31) / 32;
                 // cluster c = 8 j + x is the 16 blocks 8 (16 j + ct) + x: one XCD per cluster (see the kernel)
@@ -1791,8 +1883,12 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
                 if (s + 1 < L) { float* t = x; x = y; y = t; }     // the next step's embedding went to y
             }
         }
+        const hipError_t rec = hipEventRecord(PD.done, st);
+        PD.recorded = PD.recorded || rec == hipSuccess;
         if (tokens_out)
             (void)hipMemcpyAsync(tokens_out, tokens, (size_t)N * Lt * sizeof(int), hipMemcpyDeviceToDevice, st);
+        if (status_out)
+            (void)hipMemcpyAsync(status_out, PS.err, sizeof(int), hipMemcpyDeviceToDevice, st);
         return tpspp::check_launch("tpspp_nrtr_decoder_fwd(persistent step)");
     }
     for (int s = 0; s < L && fast; ++s) {
@@ -1898,4 +1994,66 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     if (tokens_out)
         (void)hipMemcpyAsync(tokens_out, tokens, (size_t)N * Lt * sizeof(int), hipMemcpyDeviceToDevice, st);
     return tpspp::check_launch("tpspp_nrtr_decoder_fwd");
+}
+
+// ===== AttnConvertor.tensor2idx on the device (round 6) =================================================================
+// scores (N, L, C): per position the maximum and its FIRST index (torch.max's tie rule; a NaN beats every number, as in ATen's
+// reduction), then the reference's scan per image -- skip <PAD>, stop at the first <EOS> (convertors/attn.py:124-137) -- so that
+// the host needs ONE copy of (N, L) indices + (N, L) scores instead of the score tensor's arg-max in fp64 and a Python scan.
+// One wavefront per image: lanes over classes while reducing a position, lane = position while scanning.
+namespace {
+__global__ void __launch_bounds__(256)
+attn_tensor2idx_kernel(const float* __restrict__ scores, int N, int L, int C, int end_idx, int pad_idx,
+                       int* __restrict__ idx_out, float* __restrict__ val_out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= N) return;
+    bool ended = false;                                     // (wave-uniform)
+    for (int l0 = 0; l0 < L; l0 += kWave) {
+        const int nl = L - l0 < kWave ? L - l0 : kWave;
+        float my_v = 0.0f;
+        int my_i = -1;
+        for (int j = 0; j < nl; ++j) {
+            const float* row = scores + ((size_t)b * L + l0 + j) * C;
+            float mx = -INFINITY;
+            int am = 0x7fffffff;
+            bool nan = false;
+            for (int c = lane; c < C; c += kWave) {
+                const float v = row[c];
+                if (!nan && (v != v)) { nan = true; mx = v; am = c; }
+                else if (!nan && (v > mx || am == 0x7fffffff)) { mx = v; am = c; }   // (first element always taken: a row of -inf has index 0)
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(mx, off, kWave);
+                const int oi = __shfl_xor(am, off, kWave);
+                const bool on = __shfl_xor((int)nan, off, kWave) != 0;
+                const bool take = oi != 0x7fffffff &&
+                                  (am == 0x7fffffff || (on && !nan) || (on == nan && (on ? oi < am : (ov > mx || (ov == mx && oi < am)))));
+                if (take) { mx = ov; am = oi; nan = on; }
+            }
+            if (lane == j) { my_v = mx; my_i = am; }
+        }
+        const bool valid = lane < nl;
+        const unsigned long long ends = __ballot(valid && my_i == end_idx);
+        const int first_end = ended ? 0 : (ends ? __ffsll((long long)ends) - 1 : kWave);
+        if (valid) {
+            const bool keep = lane < first_end && my_i != pad_idx;
+            idx_out[(size_t)b * L + l0 + lane] = keep ? my_i : -1;
+            val_out[(size_t)b * L + l0 + lane] = my_v;
+        }
+        ended = ended || ends != 0;
+    }
+}
+}  // namespace
+
+TPSPP_EXPORT int tpspp_attn_tensor2idx_fwd(const float* scores, int N, int L, int C, int end_idx, int padding_idx,
+                                           int* idx_out, float* val_out, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(scores && idx_out && val_out && N > 0 && L > 0 && C > 0, "tpspp_attn_tensor2idx_fwd: bad argument");
+    TPSPP_REQUIRE((size_t)N * L * C < ((size_t)1 << 40) && N <= (1 << 30), "tpspp_attn_tensor2idx_fwd: batch too large");
+    hipLaunchKernelGGL(attn_tensor2idx_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, tpspp::as_stream(stream), scores, N, L, C,
+                       end_idx, padding_idx, idx_out, val_out);
+    return tpspp::check_launch("tpspp_attn_tensor2idx_fwd");
 }

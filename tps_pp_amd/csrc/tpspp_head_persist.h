@@ -3,8 +3,10 @@
 //
 // Replaces, per decoding step: mmocr/models/textrecog/decoders/nrtr_decoder.py:153-177 (one position through
 // `_attention` + classifier + soft-max / arg-max) = 6 x common/layers/transformer_layers.py:133-163 -- the same
-// arithmetic, in the same order, as the launch-per-phase pipeline of tpspp_nrtr_decoder_fwd (its 50 launches per step):
-// scores are BIT-IDENTICAL to that pipeline (tests/test_gpu_head.py).
+// arithmetic, in the same order, as the launch-per-phase pipeline of tpspp_nrtr_decoder_fwd (its 50 launches per step): the
+// exact-fp32 head's scores are BIT-IDENTICAL to that pipeline; the reduced-precision heads (bf16 / bf16x3) split a projection's
+// K over eight wavefronts instead of four, so their scores agree within 2e-5 with identical decided tokens
+// (tests/test_gpu_head.py::test_decoder_persistent_step_matches_the_launch_pipeline).
 //
 // Why one launch: a step is a chain of 50 dependent phases of 4-9 us each, and every launch pays 2.8 us before its first
 // instruction plus 1.35 us of gap (scripts/ubench/gemm_chain_bench.hip: 6.35 us per dependent projection launch).  The
@@ -79,6 +81,9 @@ struct PStep {
     int stagger;                              // odd clusters start this many 10-ns ticks late (see the kernel); 0 = together
     long long* trace;                         // optional (tpspp_head_set_trace): 64 wall-clock stamps (100 MHz) per workgroup and step
     int no_plain;                             // lab / test switch (TPSPP_HEAD_WRITE_THROUGH=1): write-through stores whatever the placement
+    int timeout_k;                            // cluster-barrier timeout, units of 1024 ticks of the 100 MHz wall clock (10.24 us)
+    int test_stall_step;                      // test hook (TPSPP_HEAD_TEST_STALL=step): workgroup 3 of the launch's first cluster sits out
+                                              // two timeouts at the start of that step -- its partners time out: the failure path, on demand; -1 off
 };
 
 constexpr int kPXPitch = 516;                 // floats per staged X row (512 + 4: fragment reads hit all banks)
@@ -88,21 +93,28 @@ constexpr int kPXPitch = 516;                 // floats per staged X row (512 + 
 // for exactly the prefetches -- weights, residual, cached keys -- that are meant to fly across this barrier)
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// sFlag[0]: the barrier's verdict for the workgroup; sFlag[1]: the timeout in units of 1024 ticks of the 100 MHz wall clock
+// (PShared::flag / ::timeout_k, set once per launch from PStep::timeout_k).  The timeout is WALL-CLOCK time, not a poll count:
+// a cluster whose partners are not resident yet (the device is partly occupied by another stream's kernel) waits for them as
+// long as the host allows (tpspp.h: TPSPP_HEAD_TIMEOUT_MS, default 4 s), whatever a poll costs.
 __device__ __forceinline__ bool cluster_barrier(int* cnt, int target, int* sFlag, int* err)
 {
     wg_barrier_lds();                                        // every wavefront has drained its stores (drain_stores())
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
-        for (int spin = 0; spin < (1 << 21); ++spin) {
+        const long long t0 = (long long)wall_clock64();
+        const long long lim = (long long)sFlag[1] << 10;
+        for (unsigned spin = 1;; ++spin) {
             if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(2);
+            if ((spin & 63u) == 0 && (long long)wall_clock64() - t0 > lim) break;
         }
-        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *sFlag = ok;
+        if (!ok) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        sFlag[0] = ok;
     }
     wg_barrier_lds();
-    return *sFlag != 0;
+    return sFlag[0] != 0;
 }
 
 // ---- a projection phase: out (M, Co) = act(LN?(X) W + bias) [+ res] for the cluster's 32 tokens, tiles ct0 .. ct0 + NT - 1.
@@ -156,7 +168,7 @@ struct PShared {
     float sX[32 * kPXPitch];
     float sRed[8][16][kWave];
     float sS1[16][32], sS2[16][32];
-    int flag;
+    int flag, timeout_k;                      // cluster_barrier's sFlag[0], sFlag[1] (adjacent, in this order)
 };
 
 // One projection phase, called by all 8 wavefronts.  Returns false after a barrier timeout.
@@ -499,6 +511,21 @@ dec_step_persist_kernel(const PStep P)
         const long long t0 = (long long)wall_clock64();
         while ((long long)wall_clock64() - t0 < P.stagger) __builtin_amdgcn_s_sleep(8);
     }
+    // A barrier timeout is made LOUD (include/tpspp.h, tpspp_nrtr_decoder_fwd): *err = 1 (the host hands it to the caller as
+    // *status_out and the Python wrapper raises), and the scores of the workgroup's two images become NaN for EVERY step from the
+    // failing one on -- no later step of `out` is left uninitialised -- before the workgroup leaves.
+    auto fail_from = [&](int step0) {
+        if (wv < 2) {
+            const int b = tbg * 32 + 2 * ct + wv;
+            if (b < N)
+                for (int s = step0; s < P.Lsteps; ++s)
+                    for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + s) * P.num_out + c] = __builtin_nanf("");
+        }
+    };
+    if (tid == 0) S.timeout_k = P.timeout_k;
+    // (one launch per step, TPSPP_HEAD_STEP_LAUNCHES: a decode that has failed in an earlier launch does not wait out a timeout
+    // in each of the remaining ones)
+    if (P.step > 0 && __hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { fail_from(P.step); return; }
     // ---- placement check (one extra cluster barrier per launch): every workgroup ORs the id of the XCD it runs on into the
     // cluster's mask; one bit set = the whole cluster shares an L2 and its exchanged data goes out as ORDINARY stores (the
     // line stays in that L2: st16_x), else as write-through stores as in the first version of this kernel.  Measured at
@@ -507,16 +534,12 @@ dec_step_persist_kernel(const PStep P)
     {
         if (tid == 0) {
             const unsigned id = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID[3:0]
+            // (word 1 of the cluster's counters is zeroed once per decode, not per launch: with one launch per step a
+            // misplacement seen once keeps the cluster on write-through stores for the rest of the decode -- conservative)
             __hip_atomic_fetch_or(cnt + 1, 1 << id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) {
-            if (wv < 2) {                                      // (as fail() below)
-                const int b = tbg * 32 + 2 * ct + wv;
-                if (b < N) for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + P.step) * P.num_out + c] = __builtin_nanf("");
-            }
-            return;
-        }
+        if (!cluster_barrier(cnt, 16 * (++bar), &S.flag, P.err)) { fail_from(P.step); return; }
         if (tid == 0) S.flag = __hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wg_barrier_lds();
         const int mask = S.flag;                               // (the next barrier's flag write sits behind its own workgroup barrier)
@@ -529,13 +552,11 @@ dec_step_persist_kernel(const PStep P)
         ++stamp_i;
     };
     stamp();
-    auto fail = [&]() {
-        // barrier timeout: make it loud -- this step's scores of the workgroup's images become NaN
-        if (wv < 2) {
-            const int b = tbg * 32 + 2 * ct + wv;
-            if (b < N) for (int c = lane; c < P.num_out; c += kWave) P.out[((size_t)b * P.Lsteps + step) * P.num_out + c] = __builtin_nanf("");
-        }
-    };
+    auto fail = [&]() { fail_from(step); };
+    if (step == P.test_stall_step && tb == 0 && ct == 3) {     // test hook: see PStep::test_stall_step
+        const long long t0 = (long long)wall_clock64(), lim = (long long)P.timeout_k << 11;
+        while ((long long)wall_clock64() - t0 < lim) __builtin_amdgcn_s_sleep(32);
+    }
 
     for (int l = 0; l < P.n_layers; ++l) {
         const PLayer& W = P.L[l];
@@ -612,8 +633,10 @@ dec_step_persist_kernel(const PStep P)
                 if (more) {
                     const float* er = P.emb + (size_t)tok * C;
                     const float* pr = P.pos + (size_t)(step + 1) * C;
-                    // (system-scope stores as well: a plain store leaves the line in this XCD's L2, and the NEXT launch's
-                    // system-scope loads of the row -- after another XCD has rewritten it -- were served from that stale line)
+                    // (st16_x: an ordinary store when `plain` -- safe because the row's only reader is this cluster's next step,
+                    // i.e. the SAME XCD inside the SAME launch (its L2 holds the line); without the placement guarantee, or with
+                    // one launch per step on a cluster that was ever seen spread over XCDs, write-through: a plain store would
+                    // leave the line in this XCD's L2 and a reader on another XCD could be served a stale copy)
                     for (int c = 4 * lane; c < C; c += 4 * kWave) {
                         const float4 e4 = *reinterpret_cast<const float4*>(er + c), p4 = *reinterpret_cast<const float4*>(pr + c);
                         st16_x(y + (size_t)b * C + c, hf32x4{e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w}, plain);

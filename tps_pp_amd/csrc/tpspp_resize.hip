@@ -11,6 +11,15 @@
 // against oracle/resize_oracle.py (the same restatement) and not against OpenCV itself.  "/255, -mean, /std" is a
 // 256-entry table per channel computed by the caller with torch's own fp32 arithmetic, hence exact.
 //
+// Round 6 -- interpolation 1 = backend='pillow' (ocr_transforms.py:46,65,99-101 forward `backend` to mmcv.imresize, whose
+// pillow branch is Image.fromarray(img).resize(size, Image.BILINEAR)): resize_norm_pillow_kernel restates Pillow's
+// src/libImaging/Resample.c -- precompute_coeffs in double (support = max(scale, 1), window [int(center - support + 0.5),
+// int(center + support + 0.5)) clipped to the image, triangle weights normalised by their ascending sum),
+// normalize_coeffs_8bpc (int(0.5 + k 2^22)), horizontal pass into uint8, then the vertical pass, each
+// clip8((2^21 + sum(pixel * k)) >> 22).  IEEE double +, -, *, / with -ffp-contract=off are the same operations on the device as
+// in Pillow's C on the host, so the coefficients are computed where they are used.  PINNED: tests/golden/resize_pillow.npz
+// holds the installed Pillow's own outputs (tests/golden/make_resize_golden.py) and the -m gpu test compares bit for bit.
+//
 // Bound: HBM, trivially (one thread per output pixel: 4 taps x C bytes in, C floats out; 49 KB per 32x128 image).
 #include "tpspp_common.h"
 
@@ -85,13 +94,112 @@ resize_norm_kernel(const ResizeParams P)
     }
 }
 
+// ---- Pillow's BILINEAR (Resample.c) --------------------------------------------------------------------------------------
+struct PilAxis { int lo, n; double center, ss, ww; };
+
+__device__ __forceinline__ double pil_triangle(double x)
+{
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// precompute_coeffs for ONE output index d of an axis resampled in_size -> out_size (box = the whole image)
+__device__ __forceinline__ PilAxis pil_axis(int d, int in_size, int out_size)
+{
+    PilAxis A;
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;                 // bilinear: support 1.0
+    A.ss = 1.0 / filterscale;
+    A.center = ((double)d + 0.5) * scale;
+    int lo = (int)(A.center - support + 0.5);
+    if (lo < 0) lo = 0;
+    int hi = (int)(A.center + support + 0.5);
+    if (hi > in_size) hi = in_size;
+    A.lo = lo;
+    A.n = hi - lo;
+    double ww = 0.0;
+    for (int x = 0; x < A.n; ++x) ww += pil_triangle(((double)(x + lo) - A.center + 0.5) * A.ss);
+    A.ww = ww;
+    return A;
+}
+
+// k[x] / ww, then normalize_coeffs_8bpc
+__device__ __forceinline__ int pil_coef(const PilAxis& A, int x)
+{
+    double w = pil_triangle(((double)(x + A.lo) - A.center + 0.5) * A.ss);
+    if (A.ww != 0.0) w = w / A.ww;
+    return w < 0.0 ? (int)(-0.5 + w * 4194304.0) : (int)(0.5 + w * 4194304.0);
+}
+
+__device__ __forceinline__ int pil_clip8(int v)
+{
+    v >>= 22;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+template <int C>
+__global__ void __launch_bounds__(256)
+resize_norm_pillow_kernel(const ResizeParams P)
+{
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.H * P.W) return;
+    const int y = p / P.W, x = p - y * P.W;
+    const int SH = P.sh[n], SW = P.sw[n], DW = P.dw[n];
+    const unsigned char* img = P.src + P.off[n];
+    float* o = P.out + ((size_t)n * C * P.H + y) * P.W + x;
+    const size_t plane = (size_t)P.H * P.W;
+    if (x >= DW) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c * plane] = P.lut[c * 256 + P.pad_value];
+        return;
+    }
+    // (an axis that is not resized has the coefficients {2^22} / {2^22, 0}: the pass Pillow skips is an exact identity here)
+    const PilAxis AX = pil_axis(x, SW, DW), AY = pil_axis(y, SH, P.H);
+    constexpr int KC = 8;                                      // horizontal coefficients kept in registers (scale <= 3.5)
+    int kx[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) kx[j] = j < AX.n ? pil_coef(AX, j) : 0;
+    int vacc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) vacc[c] = 1 << 21;
+    for (int i = 0; i < AY.n; ++i) {
+        const int ky = pil_coef(AY, i);
+        const unsigned char* row = img + ((size_t)(AY.lo + i) * SW + AX.lo) * C;
+        int acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 1 << 21;
+        if (AX.n <= KC) {
+#pragma unroll
+            for (int j = 0; j < KC; ++j)
+                if (j < AX.n) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += (int)row[j * C + c] * kx[j];
+                }
+        } else {
+            for (int j = 0; j < AX.n; ++j) {
+                const int k = pil_coef(AX, j);
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] += (int)row[j * C + c] * k;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) vacc[c] += pil_clip8(acc[c]) * ky;          // the horizontal pass's uint8 image, times ky
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c * plane] = P.lut[c * 256 + pil_clip8(vacc[c])];
+}
+
 }  // namespace
 
 TPSPP_EXPORT int tpspp_resize_normalize_fwd(const unsigned char* src_packed, const long long* src_offsets,
                                             const int* src_h, const int* src_w, const int* resize_w,
                                             const float* lut, int pad_value, int N, int C, int H, int W,
-                                            float* out, tpspp_stream_t stream)
+                                            float* out, int interpolation, tpspp_stream_t stream)
 {
+    TPSPP_REQUIRE(interpolation == TPSPP_RESIZE_CV2 || interpolation == TPSPP_RESIZE_PILLOW,
+                  "tpspp_resize_normalize_fwd: interpolation must be TPSPP_RESIZE_CV2 (0) or TPSPP_RESIZE_PILLOW (1)");
     TPSPP_REQUIRE(src_packed && src_offsets && src_h && src_w && resize_w && lut && out,
                   "tpspp_resize_normalize_fwd: null pointer");
     TPSPP_REQUIRE(N >= 0 && C >= 1 && C <= 4 && H > 0 && W > 0 && pad_value >= 0 && pad_value <= 255,
@@ -102,6 +210,16 @@ TPSPP_EXPORT int tpspp_resize_normalize_fwd(const unsigned char* src_packed, con
     P.src = src_packed; P.off = src_offsets; P.sh = src_h; P.sw = src_w; P.dw = resize_w; P.lut = lut; P.out = out;
     P.N = N; P.C = C; P.H = H; P.W = W; P.pad_value = pad_value;
     const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)N);
-    hipLaunchKernelGGL(resize_norm_kernel, grid, dim3(256), 0, tpspp::as_stream(stream), P);
+    hipStream_t st = tpspp::as_stream(stream);
+    if (interpolation == TPSPP_RESIZE_PILLOW) {
+        switch (C) {
+        case 1: hipLaunchKernelGGL(resize_norm_pillow_kernel<1>, grid, dim3(256), 0, st, P); break;
+        case 2: hipLaunchKernelGGL(resize_norm_pillow_kernel<2>, grid, dim3(256), 0, st, P); break;
+        case 3: hipLaunchKernelGGL(resize_norm_pillow_kernel<3>, grid, dim3(256), 0, st, P); break;
+        default: hipLaunchKernelGGL(resize_norm_pillow_kernel<4>, grid, dim3(256), 0, st, P); break;
+        }
+    } else {
+        hipLaunchKernelGGL(resize_norm_kernel, grid, dim3(256), 0, st, P);
+    }
     return tpspp::check_launch("tpspp_resize_normalize_fwd");
 }

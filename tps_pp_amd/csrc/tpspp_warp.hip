@@ -1134,7 +1134,8 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
             return tpspp::check_launch("tpspp_warp_fwd(in-place, run-time geometry)");
         if (g_tune_kernel == 9)
             return tpspp::fail(TPSPP_EINVAL, "tpspp_warp_fwd: shape / table do not qualify for the run-time-geometry in-place kernel");
-        if (packed_ok && (want_geo || g_tune_kernel == 8) && tpspp::span_table_waves(Ho, Wo) > 0) {
+        // (the third section exists only in buffers of the current layout: TPSPP_TABLE_SPAN, include/tpspp.h)
+        if (packed_ok && (table_flags & TPSPP_TABLE_SPAN) && (want_geo || g_tune_kernel == 8) && tpspp::span_table_waves(Ho, Wo) > 0) {
             const int QPg = tpspp::geo_qp(Ho, Wo);
             const int KGs = (F + 3 + 3) / 4;
             const int NWg = (tpspp::geo_nthr(Ho, Wo, QPg) + kWave - 1) / kWave;

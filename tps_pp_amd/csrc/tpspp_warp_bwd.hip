@@ -864,7 +864,12 @@ TPSPP_EXPORT int tpspp_warp_bwd(const float* g_out0, const float* in0, int C0, i
     const size_t kLds2 = 16 * 1024;
     // the classic geometry: sampling + parameter gradients in one launch (warp_bwd_classic_kernel)
     const bool fixed_point = g_bwd_fixed_point || (table_flags & TPSPP_BWD_FIXED_POINT);
-    if (!in1 && !score && !p_xy && !fixed_point && !getenv("TPSPP_BWD_TWO_KERNELS") && C0 <= 3 && F + 3 <= 24 &&
+    // (p_xy != NULL means the TPS_PP table layout -- p_hat is (n, F) without the [1, x, y] columns this kernel reads from the
+    // transposed classic table --, so it excludes the one-launch form whether or not a score is given; the classic rectifier
+    // never passes it: tps_pp_amd/tps_preprocessor.py.  The environment switch is read once; per call: TPSPP_BWD_TWO_KERNELS.)
+    static const bool two_kernels_env = getenv("TPSPP_BWD_TWO_KERNELS") != nullptr;
+    const bool two_kernels = two_kernels_env || (table_flags & TPSPP_BWD_TWO_KERNELS);
+    if (!in1 && !score && !p_xy && !fixed_point && !two_kernels && C0 <= 3 && F + 3 <= 24 &&
         p_hat_t_or_null && reinterpret_cast<uintptr_t>(p_hat_t_or_null) % 16 == 0 && P.n % 4 == 0 &&
         P.n > 1024 && P.n <= 4096 && (size_t)C0 * plane0 * 2 <= 78 * 1024 && (size_t)C0 * plane0 * 2 >= (size_t)P.n * 8 &&
         (size_t)C0 * plane0 * 2 >= (size_t)C0 * plane0 + ((size_t)W0 + 1) * 4 &&

@@ -98,5 +98,11 @@ def recognize_sharded(decode_local, n_total: int, convertor, group=None):
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank}: decode_local returned {local.shape[0]} rows for a shard of {hi - lo}")
     scores = all_gather_rows(local, n_total, group)
+    # this rank's decoder status word (NRTRDecoder attaches it to its output) rides along to the one device->host copy
+    # `tensor2idx` makes: a barrier timeout of the persistent decode raises here, on the rank it happened on, instead of
+    # NaN scores being decoded into strings (a raising rank fails the job)
+    status = getattr(local, "_tpspp_status", None)
+    if status is not None and scores is not local:
+        scores._tpspp_status = status
     indexes, char_scores = convertor.tensor2idx(scores)
     return [dict(text=t, score=s) for t, s in zip(convertor.idx2str(indexes), char_scores)]

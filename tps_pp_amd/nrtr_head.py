@@ -239,6 +239,7 @@ class NRTREncoder(nn.Module):
             ops.require_gpu(feat, "NRTREncoder")
             return self._forward_graph(feat.float(), img_metas)
         ops.require_gpu(feat, "NRTREncoder")
+        ops.warn_detached_once(self, "NRTREncoder")
         table, g, b = self._weights()
         n, c, h, w = feat.shape
         if c != self.d_model:
@@ -319,6 +320,7 @@ class NRTRDecoder(nn.Module):
 
     def _run(self, out_enc, img_metas, forced):
         ops.require_gpu(out_enc, "NRTRDecoder", torch.is_grad_enabled() and out_enc.requires_grad)
+        ops.warn_detached_once(self, "NRTRDecoder")
         n, t, c = out_enc.shape
         if c != self.d_model:
             raise ValueError(f"NRTRDecoder: encoder width {c} != d_model {self.d_model}")
@@ -328,11 +330,19 @@ class NRTRDecoder(nn.Module):
         table, emb, pos, cls = self._weights()
         vl = _valid_len(img_metas, n, t, out_enc.device)
         seq_len = self.max_seq_len if forced is None else forced.shape[1]
-        out, tokens = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, emb, pos, cls,
-                                       seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self,
-                                       flags=_head_flags(self.compute_dtype))
-        self.last_tokens = tokens
+        out, tokens, status = ops.nrtr_decoder(enc_cm, n, t, table, len(self.layer_stack), self.d_inner, emb, pos, cls,
+                                               seq_len, self.start_idx, self.padding_idx, vl, forced, holder=self,
+                                               flags=_head_flags(self.compute_dtype))
+        # The decode is asynchronous; its status word (0, or 1 after a barrier timeout of the persistent step kernel:
+        # include/tpspp.h) travels with the scores: `AttnConvertor.tensor2idx` / `dist.recognize_sharded` fetch it in the copy
+        # they make anyway and raise `TpsppError`; `check_status()` is the explicit (synchronising) form.
+        self.last_tokens, self.last_status = tokens, status
+        out._tpspp_status = status
         return out
+
+    def check_status(self):
+        """Raises `TpsppError` if the last decode reported a barrier timeout (synchronises with that decode)."""
+        ops.check_decoder_status(getattr(self, "last_status", None))
 
     def _forward_train_graph(self, out_enc, targets, img_metas):
         """`NRTRDecoder.forward_train` (nrtr_decoder.py:95-151: embedding + position table, pad & causal self-attention
@@ -473,17 +483,25 @@ class AttnConvertor(BaseConvertor):
         return {"targets": tensors, "padded_targets": torch.stack(padded_targets, 0).long()}
 
     def tensor2idx(self, outputs, img_metas=None):
-        # one device->host copy for the batch instead of the reference's two per image, and the per-character scan
-        # (skip <PAD>, stop at the first <EOS>: attn.py:124-137) as array operations per batch
-        max_value, max_idx = torch.max(outputs.detach(), -1)       # (the reference detaches as well: attn.py:129-130)
-        both = torch.stack([max_idx.to(torch.float64), max_value.to(torch.float64)]).cpu().numpy()
-        idx, val = both[0].astype(np.int64), both[1]
-        n, L = idx.shape
-        is_end = idx == self.end_idx
-        first_end = np.where(is_end.any(1), is_end.argmax(1), L)
-        keep = (np.arange(L)[None, :] < first_end[:, None]) & (idx != self.padding_idx)
+        """`attn.py:112-143`.  A GPU tensor: arg-max, maximum and the scan (skip <PAD>, stop at the first <EOS>) run in one HIP
+        kernel and ONE device->host copy brings (N, L) indices + scores (the reference: two copies per image) -- together
+        with the decoder's status word when `outputs` comes from `NRTRDecoder` (a barrier timeout raises `TpsppError`
+        instead of decoding NaN scores into strings).  A CPU tensor (host-side tests, outputs gathered on the host): the
+        reference's own `torch.max` per batch."""
+        outputs = outputs.detach()                                  # (the reference detaches as well: attn.py:129-130)
+        if outputs.is_cuda:
+            idx, val = ops.attn_tensor2idx(outputs.float(), self.end_idx, self.padding_idx,
+                                           status=getattr(outputs, "_tpspp_status", None))
+            keep = idx >= 0
+        else:
+            max_value, max_idx = torch.max(outputs, -1)
+            idx, val = max_idx.numpy().astype(np.int64), max_value.numpy()
+            n, L = idx.shape
+            is_end = idx == self.end_idx
+            first_end = np.where(is_end.any(1), is_end.argmax(1), L)
+            keep = (np.arange(L)[None, :] < first_end[:, None]) & (idx != self.padding_idx)
         counts = keep.sum(1)
-        flat_i, flat_v = idx[keep].tolist(), val[keep].tolist()
+        flat_i, flat_v = idx[keep].tolist(), val[keep].astype(np.float64).tolist()
         indexes, scores, o = [], [], 0
         for c in counts.tolist():
             indexes.append(flat_i[o:o + c])

@@ -46,6 +46,7 @@ class NRTRModalityTransform(nn.Module):
         ops.require_gpu(x, "NRTRModalityTransform")
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
             return self._forward_torch(x.float())           # training graph (round 5): autograd, BatchNorm batch statistics
+        ops.warn_detached_once(self, "NRTRModalityTransform")
         c1, c2, lin = self._weights()
         x = ops.conv2d([x.float().contiguous()], c1, 2, True)
         x = ops.conv2d([x], c2, 2, True)

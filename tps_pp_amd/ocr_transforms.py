@@ -8,8 +8,11 @@ over the whole batch (`tpspp_resize_normalize_fwd`) instead of a per-sample Open
 loader.  `OCRBatchPreprocessor` strings them together the way `configs/_base_/recog_pipelines/crnn_pp_pipeline.py:85-95`
 does and returns the tensor plus the `img_metas` the recogniser reads (`resize_shape`, `valid_ratio`, ...).
 
-The interpolation follows OpenCV's 8-bit INTER_LINEAR arithmetic; it could not be pinned against OpenCV itself
-(not installed at build time): see oracle/resize_oracle.py and DESIGN.md section 7.  No CPU fallback.
+`backend` is honoured as the reference forwards it to `mmcv.imresize` (ocr_transforms.py:34-36,46,65,99-101):
+`'pillow'` -> Pillow's `Image.resize(size, Image.BILINEAR)` arithmetic, PINNED bit for bit against the installed Pillow
+(tests/golden/resize_pillow.npz); `None` / `'cv2'` -> OpenCV's 8-bit INTER_LINEAR arithmetic, which could not be pinned
+against OpenCV itself (not installed at build time): see oracle/resize_oracle.py and DESIGN.md section 4f; anything else
+raises `ValueError` when the transform is applied, as `mmcv.imresize` does.  No CPU fallback.
 """
 import math
 
@@ -47,6 +50,15 @@ class ResizeOCR:
         self.img_pad_value = img_pad_value
         self.width_downsample_ratio = width_downsample_ratio
         self.backend = backend
+
+    def interpolation(self):
+        """`backend` -> the kernel's interpolation code (`mmcv.imresize`: None = the global backend, cv2 by default;
+        an unknown name raises ValueError there as well, at call time)."""
+        if self.backend in (None, "cv2"):
+            return ops.RESIZE_CV2
+        if self.backend == "pillow":
+            return ops.RESIZE_PILLOW
+        raise ValueError(f"backend: {self.backend} is not supported for resize. Supported backends are 'cv2', 'pillow'")
 
     def _dst(self, rank=0):
         if isinstance(self.height, int):
@@ -109,11 +121,14 @@ class OCRBatchPreprocessor:
         arrs = []
         for im in imgs:
             a = im.cpu().numpy() if isinstance(im, torch.Tensor) else np.asarray(im)
+            if a.ndim == 2:                   # a grayscale crop as mmcv.imread(color_type='grayscale') hands it over
+                a = a[:, :, None]
             if a.dtype != np.uint8 or a.ndim != 3:
-                raise TypeError("OCRBatchPreprocessor: images must be uint8 (H, W, C) arrays")
+                raise TypeError("OCRBatchPreprocessor: images must be uint8 (H, W, C) or (H, W) arrays")
             arrs.append(np.ascontiguousarray(a))
         if not arrs:
             raise ValueError("OCRBatchPreprocessor: empty batch")
+        interpolation = self.resize.interpolation()          # (raises for an unknown backend)
         C = arrs[0].shape[2]
         plans = [self.resize.plan(a.shape, rank) for a in arrs]
         H, W = plans[0]["height"], plans[0]["out_w"]
@@ -132,7 +147,7 @@ class OCRBatchPreprocessor:
         meta_d = torch.from_numpy(meta).to(self.device)
         offs_d = torch.from_numpy(offs).to(self.device)
         out = ops.resize_normalize(packed, offs_d, meta_d[0], meta_d[1], meta_d[2], self._lut,
-                                   self.resize.img_pad_value, len(arrs), C, H, W)
+                                   self.resize.img_pad_value, len(arrs), C, H, W, interpolation)
         metas = [dict(ori_shape=a.shape, img_shape=p["resize_shape"], resize_shape=p["resize_shape"],
                       pad_shape=p["pad_shape"], valid_ratio=p["valid_ratio"],
                       img_norm_cfg=dict(mean=self.normalize.mean, std=self.normalize.std))

@@ -40,6 +40,20 @@ def require_gpu(t, who, training=False):
                                   "torch.no_grad() (SURVEY.md section 8f, row F2)")
 
 
+def warn_detached_once(module, who):
+    """Eval mode with autograd enabled and trainable parameters (the usual frozen-BatchNorm fine-tuning set-up): the HIP
+    inference path records no graph, so a loss computed from its output has no grad_fn.  Said once per module instead of
+    failing silently; `.train()` (or an input that requires grad) selects the PyTorch training graph."""
+    if not torch.is_grad_enabled() or getattr(module, "_warned_detached", False):
+        return
+    if any(p.requires_grad for p in module.parameters()):
+        import logging
+        logging.getLogger("tps_pp_amd").warning(
+            "%s in eval mode with autograd enabled: the HIP inference path records no graph, so no gradient will reach "
+            "this module's parameters (call .train() -- forward_train needs it --, or wrap inference in torch.no_grad())", who)
+    module._warned_detached = True
+
+
 def solve_T(inv_delta_C, ctrl):
     """torch.bmm(inv_delta_C.repeat(N,1,1), cat(ctrl, zeros(N,3,2)))  -> (N, F+3, 2)
     (tps_preprocessor.py:273-280, tps_pp.py:484-494)."""
@@ -108,14 +122,17 @@ TABLE_MIRROR4 = 1
 SCORE_TRANSPOSED = 2
 IO_BF16 = 4              # TPSPP_IO_BF16: in0 / in1 / out0 / out1 are bfloat16
 BWD_FIXED_POINT = 16     # TPSPP_BWD_FIXED_POINT: tpspp_warp_bwd accumulates dL/d input in 64-bit fixed point (this call only)
+BWD_TWO_KERNELS = 64     # TPSPP_BWD_TWO_KERNELS: tpspp_warp_bwd never takes the classic one-launch form (this call only)
 TABLE_PACKED = 8         # TPSPP_TABLE_PACKED: P_hat_t is the head of a prepare_mirror_table() buffer
+TABLE_SPAN = 32          # TPSPP_TABLE_SPAN: ... of the current three-section layout (the span-staging kernel reads the third)
 
 
 def prepare_mirror_table(P_hat, out_hw):
     """One-off preparation of a classic-layout table for the image-pair kernel (`tpspp_prepare_mirror_table`):
     returns `(P_hat_t, flags)` where `P_hat_t` is the usual (F+3, n) transposed table -- a view of the head of a
     larger buffer whose tail is the packed copy -- and `flags` is `TABLE_PACKED`; for a geometry without a
-    prepared form: `(transpose_p_hat(P_hat), 0)`.  OR `TABLE_MIRROR4` in once the symmetry has been verified."""
+    prepared form: `(transpose_p_hat(P_hat), 0)`.  OR `TABLE_MIRROR4` in once the symmetry has been verified.
+    `flags` is `TABLE_PACKED | TABLE_SPAN`: the buffer has the current three-section layout."""
     P_hat = _chk("P_hat", P_hat, 2)
     n, cols = P_hat.shape
     Ho, Wo = int(out_hw[0]), int(out_hw[1])
@@ -128,7 +145,7 @@ def prepare_mirror_table(P_hat, out_hw):
     with torch.cuda.device(P_hat.device):
         rc = _lib.lib().tpspp_prepare_mirror_table(_ptr(P_hat), cols, Ho, Wo, cols - 3, _ptr(buf), _stream(P_hat))
     _lib.check(rc, "tpspp_prepare_mirror_table")
-    return buf[:cols * n].view(cols, n), TABLE_PACKED
+    return buf[:cols * n].view(cols, n), TABLE_PACKED | TABLE_SPAN
 
 
 def _chk_table(who, P_hat, P_hat_t, n, out_hw, table_flags):
@@ -1153,7 +1170,11 @@ def nrtr_encoder(feat, table, n_layers, d_inner, ln_g, ln_b, valid_len=None, hol
 
 def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_folded, max_seq_len,
                  start_idx, padding_idx, valid_len=None, forced_tokens=None, holder=None, flags=0):
-    """`tpspp_nrtr_decoder_fwd` -> (out (N, L, num_out), tokens (N, L+1) int32)."""
+    """`tpspp_nrtr_decoder_fwd` -> (out (N, L, num_out), tokens (N, L+1) int32, status (1,) int32).
+    `status` is the device word the decode leaves behind itself: 0 = every step completed, 1 = a cluster barrier of the
+    persistent step kernel timed out (the affected images' scores are NaN from that step on; include/tpspp.h).  Nothing
+    here synchronises; whoever copies the scores / tokens to the host reads it in the same copy (`check_decoder_status`,
+    `attn_tensor2idx`)."""
     enc_cm = _chk("enc_cm", enc_cm, 2)
     C = enc_cm.shape[0]
     if enc_cm.shape[1] != N * T:
@@ -1164,7 +1185,10 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_fol
     nbytes = L.tpspp_nrtr_decoder_workspace(N, C, T, d_inner, n_layers, max_seq_len, num_out)
     ws = _workspace(holder if holder is not None else table, nbytes, enc_cm.device)
     out = torch.empty((N, max_seq_len, num_out), device=enc_cm.device, dtype=torch.float32)
-    tokens = torch.empty((N, max_seq_len + 1), device=enc_cm.device, dtype=torch.int32)
+    # tokens and the status word in one buffer: one device->host copy fetches both
+    tok_status = torch.empty((N * (max_seq_len + 1) + 1,), device=enc_cm.device, dtype=torch.int32)
+    tokens = tok_status[:-1].view(N, max_seq_len + 1)
+    status = tok_status[-1:]
     if forced_tokens is not None:
         if forced_tokens.dtype != torch.int32 or tuple(forced_tokens.shape) != (N, max_seq_len) or \
                 not forced_tokens.is_contiguous() or forced_tokens.device != enc_cm.device:
@@ -1173,14 +1197,54 @@ def nrtr_decoder(enc_cm, N, T, table, n_layers, d_inner, emb, pos_table, cls_fol
         rc = L.tpspp_nrtr_decoder_fwd(_ptr(enc_cm), N, C, T, d_inner, n_layers, table.ptr, len(table),
                                       _ptr(emb), _ptr(pos_table), pos_table.shape[0], _ptr(w_cls), _ptr(cls_colsum),
                                       _ptr(b_cls), num_out, max_seq_len, int(start_idx), int(padding_idx), _ptr(valid_len),
-                                      _ptr(forced_tokens), ws.data_ptr(), ws.numel(), _ptr(out), _ptr(tokens),
-                                      int(flags), _stream(enc_cm))
+                                      _ptr(forced_tokens), ws.data_ptr(), ws.numel(), _ptr(out), tokens.data_ptr(),
+                                      status.data_ptr(), int(flags), _stream(enc_cm))
     _lib.check(rc, "tpspp_nrtr_decoder_fwd")
-    return out, tokens
+    return out, tokens, status
 
 
-def resize_normalize(packed, offsets, src_h, src_w, resize_w, lut, pad_value, N, C, H, W):
-    """`tpspp_resize_normalize_fwd`: packed uint8 HWC images -> (N, C, H, W) fp32 (ocr_transforms.py:67-156)."""
+DECODER_TIMEOUT_MESSAGE = (
+    "tpspp_nrtr_decoder_fwd: a cluster barrier of the persistent decoder kernel timed out (status 1): the scores of the "
+    "affected images are NaN.  The kernel needs its workgroups co-resident; this happens only when another PROCESS runs a "
+    "persistent decode on the same GPU or the device stayed occupied for longer than TPSPP_HEAD_TIMEOUT_MS "
+    "(include/tpspp.h).  TPSPP_HEAD_NO_PERSIST=1 selects the launch-per-phase pipeline.")
+
+
+def check_decoder_status(status):
+    """Synchronising check of a decode's status word (one 4-byte device->host copy): raises `TpsppError` on a timeout."""
+    if status is not None and int(status.cpu()[0]) != 0:
+        raise _lib.TpsppError(DECODER_TIMEOUT_MESSAGE)
+
+
+def attn_tensor2idx(scores, end_idx, padding_idx, status=None):
+    """`tpspp_attn_tensor2idx_fwd` + ONE device->host copy: (idx (N, L) int32 numpy with -1 where the reference's scan drops
+    the position, val (N, L) float32 numpy).  `status`: a decode's status word, fetched in the same copy; non-zero raises."""
+    scores = _chk("scores", scores, 3)
+    N, L, C = scores.shape
+    # [idx (N*L) | val (N*L) as raw bits | status]: one int32 buffer, one copy
+    buf = torch.empty((2 * N * L + 1,), device=scores.device, dtype=torch.int32)
+    with torch.cuda.device(scores.device):
+        rc = _lib.lib().tpspp_attn_tensor2idx_fwd(_ptr(scores), N, L, C, int(end_idx), int(padding_idx), buf.data_ptr(),
+                                                  buf.data_ptr() + 4 * N * L, _stream(scores))
+    _lib.check(rc, "tpspp_attn_tensor2idx_fwd")
+    if status is not None and status.device == scores.device:
+        buf[-1:].copy_(status)
+    else:
+        buf[-1:].zero_()
+    host = buf.cpu().numpy()
+    if host[-1] != 0:
+        raise _lib.TpsppError(DECODER_TIMEOUT_MESSAGE)
+    return host[:N * L].reshape(N, L), host[N * L:2 * N * L].view("float32").reshape(N, L)
+
+
+RESIZE_CV2, RESIZE_PILLOW = 0, 1
+
+
+def resize_normalize(packed, offsets, src_h, src_w, resize_w, lut, pad_value, N, C, H, W, interpolation=RESIZE_CV2):
+    """`tpspp_resize_normalize_fwd`: packed uint8 HWC images -> (N, C, H, W) fp32 (ocr_transforms.py:67-156).
+    `interpolation`: RESIZE_CV2 (OpenCV's INTER_LINEAR arithmetic, unpinned) or RESIZE_PILLOW (Pillow's BILINEAR, pinned)."""
+    if interpolation not in (RESIZE_CV2, RESIZE_PILLOW):
+        raise ValueError("resize_normalize: interpolation must be RESIZE_CV2 or RESIZE_PILLOW")
     for name, t, dt in (("packed", packed, torch.uint8), ("offsets", offsets, torch.int64), ("src_h", src_h, torch.int32),
                         ("src_w", src_w, torch.int32), ("resize_w", resize_w, torch.int32), ("lut", lut, torch.float32)):
         if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -1194,19 +1258,22 @@ def resize_normalize(packed, offsets, src_h, src_w, resize_w, lut, pad_value, N,
     with torch.cuda.device(packed.device):
         rc = _lib.lib().tpspp_resize_normalize_fwd(_ptr(packed), _ptr(offsets), _ptr(src_h), _ptr(src_w), _ptr(resize_w),
                                                    _ptr(lut), int(pad_value), int(N), int(C), int(H), int(W), _ptr(out),
-                                                   _stream(packed))
+                                                   int(interpolation), _stream(packed))
     _lib.check(rc, "tpspp_resize_normalize_fwd")
     return out
 
 
 # ---- backward of the fused warp ------------------------------------------------
 def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None, score=None, in1=None,
-                  g_out1=None, P_hat_t=None, need_in0=True, need_in1=True, need_score=True, fixed_point=False):
+                  g_out1=None, P_hat_t=None, need_in0=True, need_in1=True, need_score=True, fixed_point=False,
+                  two_kernels=False):
     """`tpspp_warp_bwd`: (g_in0 | None, g_in1 | None, g_ctrl, g_score | None) for the call
     `warp(in0, ctrl, inv_delta_C, P_hat, out_hw, P_xy, score, in1)`; `grid` is that call's grid output.
     `fixed_point=True` (TPSPP_BWD_FIXED_POINT, this call only): dL/d input accumulated in 64-bit fixed point -- bitwise
     reproducible from run to run; the default fp64 LDS atomics keep every term's bits but their sum depends on arrival
-    order, so two runs may differ by one fp32 ulp at rounding ties (include/tpspp.h)."""
+    order, so two runs may differ by one fp32 ulp at rounding ties (include/tpspp.h).  `two_kernels=True`
+    (TPSPP_BWD_TWO_KERNELS, this call only): the sampling + parameter kernels even where the classic rectifier's one-launch
+    form would run."""
     g_out0, in0 = _chk("g_out0", g_out0, 4), _chk("in0", in0, 4)
     grid, ctrl = _chk("grid", grid, 3), _chk("ctrl", ctrl, 3)
     inv_delta_C, P_hat = _chk("inv_delta_C", inv_delta_C, 2), _chk("P_hat", P_hat, 2)
@@ -1216,7 +1283,7 @@ def warp_backward(g_out0, in0, grid, ctrl, inv_delta_C, P_hat, out_hw, P_xy=None
     n = Ho * Wo
     if tuple(g_out0.shape) != (N, C0, Ho, Wo) or tuple(grid.shape) != (N, n, 2):
         raise ValueError("warp_backward: g_out0 / grid shape")
-    flags = BWD_FIXED_POINT if fixed_point else 0
+    flags = (BWD_FIXED_POINT if fixed_point else 0) | (BWD_TWO_KERNELS if two_kernels else 0)
     g_score = None
     if score is not None:
         if tuple(score.shape) != (N, n, F):

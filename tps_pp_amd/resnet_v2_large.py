@@ -43,6 +43,7 @@ class BasicBlock(nn.Module):
         ops.require_gpu(x, "BasicBlock")
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
             return self._forward_torch(x)                 # training graph (round 5): autograd, BatchNorm batch statistics
+        ops.warn_detached_once(self, "BasicBlock")
         return self._forward_hip(x)
 
     def _forward_torch(self, x):
@@ -184,6 +185,7 @@ class ResNetABI_v2_large(nn.Module):
             # PyTorch compositions of their own layers; `tpsnet` (in .train() mode as well) regresses with PyTorch layers and
             # runs the transformation stage on the HIP kernels in both directions (tps_pp.TPS_PP._forward_autograd)
             return self._forward_torch(x.float(), tpsnet, **kwargs)
+        ops.warn_detached_once(self, "ResNetABI_v2_large")
         if x.dtype == torch.bfloat16 or self.compute_dtype == torch.bfloat16:
             # bf16 configuration (BASELINE.json configs[4]): every convolution on the bf16 matrix cores, bf16
             # activations in HBM (also through `tpsnet`, which follows its input dtype); the feature map handed
