@@ -294,6 +294,15 @@ def test_attn_convertor_matches_the_reference():
     for t, k in enumerate([10, 11, 91, 12, 13]):
         out[0, t, k] = 1.0
     assert c.idx2str(c.tensor2idx(out)[0]) == ["ab"]
+    # tensor2str (what simple_test calls) = idx2str(tensor2idx()) in one pass, multi-character tokens (<UKN>) included
+    st, sc = c.tensor2str(torch.from_numpy(G["out_dec"]))
+    assert st == [str(s) for s in G["text"]] and sc == scores
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand((33, 40, 92), generator=g)
+    x[:, :, c.end_idx] += (torch.rand((33, 40), generator=g) < 0.05).float()
+    x[:, :, c.unknown_idx] += (torch.rand((33, 40), generator=g) < 0.03).float()
+    i2, s2 = c.tensor2idx(x)
+    assert c.tensor2str(x) == (c.idx2str(i2), s2) and any("<UKN>" in t for t in c.idx2str(i2))
 
 
 def test_head_rejects_unsupported_configurations():

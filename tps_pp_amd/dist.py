@@ -104,5 +104,9 @@ def recognize_sharded(decode_local, n_total: int, convertor, group=None):
     status = getattr(local, "_tpspp_status", None)
     if status is not None and scores is not local:
         scores._tpspp_status = status
-    indexes, char_scores = convertor.tensor2idx(scores)
-    return [dict(text=t, score=s) for t, s in zip(convertor.idx2str(indexes), char_scores)]
+    if hasattr(convertor, "tensor2str"):
+        texts, char_scores = convertor.tensor2str(scores)
+    else:
+        indexes, char_scores = convertor.tensor2idx(scores)
+        texts = convertor.idx2str(indexes)
+    return [dict(text=t, score=s) for t, s in zip(texts, char_scores)]

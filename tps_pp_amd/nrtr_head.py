@@ -488,18 +488,7 @@ class AttnConvertor(BaseConvertor):
         with the decoder's status word when `outputs` comes from `NRTRDecoder` (a barrier timeout raises `TpsppError`
         instead of decoding NaN scores into strings).  A CPU tensor (host-side tests, outputs gathered on the host): the
         reference's own `torch.max` per batch."""
-        outputs = outputs.detach()                                  # (the reference detaches as well: attn.py:129-130)
-        if outputs.is_cuda:
-            idx, val = ops.attn_tensor2idx(outputs.float(), self.end_idx, self.padding_idx,
-                                           status=getattr(outputs, "_tpspp_status", None))
-            keep = idx >= 0
-        else:
-            max_value, max_idx = torch.max(outputs, -1)
-            idx, val = max_idx.numpy().astype(np.int64), max_value.numpy()
-            n, L = idx.shape
-            is_end = idx == self.end_idx
-            first_end = np.where(is_end.any(1), is_end.argmax(1), L)
-            keep = (np.arange(L)[None, :] < first_end[:, None]) & (idx != self.padding_idx)
+        idx, val, keep = self._scan(outputs)
         counts = keep.sum(1)
         flat_i, flat_v = idx[keep].tolist(), val[keep].astype(np.float64).tolist()
         indexes, scores, o = [], [], 0
@@ -508,6 +497,49 @@ class AttnConvertor(BaseConvertor):
             scores.append(flat_v[o:o + c])
             o += c
         return indexes, scores
+
+    def _scan(self, outputs):
+        """-> (idx (N, L) int, val (N, L) float32, keep (N, L) bool) on the host: per-position arg-max / maximum and the
+        positions the reference's scan keeps (attn.py:124-137)."""
+        status = getattr(outputs, "_tpspp_status", None)            # (an attribute: read it before detach() makes a new tensor)
+        outputs = outputs.detach()                                  # (the reference detaches as well: attn.py:129-130)
+        if outputs.is_cuda:
+            idx, val = ops.attn_tensor2idx(outputs.float(), self.end_idx, self.padding_idx, status=status)
+            return idx, val, idx >= 0
+        max_value, max_idx = torch.max(outputs, -1)
+        idx, val = max_idx.numpy().astype(np.int64), max_value.numpy()
+        n, L = idx.shape
+        is_end = idx == self.end_idx
+        first_end = np.where(is_end.any(1), is_end.argmax(1), L)
+        return idx, val, (np.arange(L)[None, :] < first_end[:, None]) & (idx != self.padding_idx)
+
+    def tensor2str(self, outputs, img_metas=None):
+        """`idx2str(tensor2idx(outputs)[0])` and the scores in one pass -> (strings, scores): what `simple_test` needs
+        (encode_decode_recognizer.py:219-232).  The strings are decoded from ONE code-point array for the whole batch instead
+        of a Python join per character; rows holding a multi-character token (<UKN>, ...) take the per-character join."""
+        idx, val, keep = self._scan(outputs)
+        table = getattr(self, "_code_table", None)
+        if table is None or table[1] is not self.idx2char or len(table[0]) != len(self.idx2char):
+            codes = np.array([ord(ch) if len(ch) == 1 else 0 for ch in self.idx2char], dtype=np.uint32)
+            table = self._code_table = (codes, self.idx2char)
+        counts = keep.sum(1).tolist()
+        flat_i = idx[keep]
+        flat_c = table[0][flat_i]
+        text = flat_c.astype("<u4").tobytes().decode("utf-32-le")
+        flat_v = val[keep].astype(np.float64).tolist()
+        slow = bool((flat_c == 0).any())
+        strings, scores, o = [], [], 0
+        for c in counts:
+            strings.append(text[o:o + c])
+            scores.append(flat_v[o:o + c])
+            o += c
+        if slow:                                                    # a multi-character dictionary entry somewhere in the batch
+            o = 0
+            for r, c in enumerate(counts):
+                if c and (flat_c[o:o + c] == 0).any():
+                    strings[r] = "".join(self.idx2char[i] for i in flat_i[o:o + c].tolist())
+                o += c
+        return strings, scores
 
 
 @DETECTORS.register_module()
@@ -606,8 +638,11 @@ class EncodeDecodeRecognizer(nn.Module):
             out_dec = self.decoder(feat, out_enc, None, img_metas, train_mode=False)
         else:
             out_dec = out_enc
-        label_indexes, label_scores = self.label_convertor.tensor2idx(out_dec, img_metas)
-        label_strings = self.label_convertor.idx2str(label_indexes)
+        if hasattr(self.label_convertor, "tensor2str"):     # tensor2idx + idx2str in one pass (same strings, same scores)
+            label_strings, label_scores = self.label_convertor.tensor2str(out_dec, img_metas)
+        else:
+            label_indexes, label_scores = self.label_convertor.tensor2idx(out_dec, img_metas)
+            label_strings = self.label_convertor.idx2str(label_indexes)
         return [dict(text=s, score=sc) for s, sc in zip(label_strings, label_scores)]
 
     def merge_aug_results(self, aug_results):
