@@ -28,6 +28,7 @@ __global__ void __launch_bounds__(256) k(const uint4* __restrict__ K, const uint
     for (int i = 0; i < NP; ++i) s += vr[i].x ^ vr[i].y ^ vr[i].z ^ vr[i].w;
     if (s == 0xdeadbeefu) out[pair] = 1.0f;
 }
+static int g_nb = 512;  // images per launch (round 6: an image GROUP whose six layers of K / V fit the 256 MB Infinity Cache)
 static int g_layers = 6;   // distinct K / V tensors cycled through (1: the same 134 MB every launch -- they stay in the 256 MB Infinity Cache)
 template <int B, bool HM> void run(const char* name, uint4* Kb, uint4* Vb, float* out, size_t layer_units)
 {
@@ -36,17 +37,19 @@ template <int B, bool HM> void run(const char* name, uint4* Kb, uint4* Vb, float
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
         for (int i = 0; i < n; ++i)      // six layers' worth of different tensors in turn, as in the decoder
-            hipLaunchKernelGGL((k<B, HM>), dim3(1024), dim3(256), 0, 0, Kb + (i % g_layers) * layer_units, Vb + (i % g_layers) * layer_units, out, 512);
+            hipLaunchKernelGGL((k<B, HM>), dim3((g_nb * 8 + 3) / 4), dim3(256), 0, 0, Kb + (i % g_layers) * layer_units, Vb + (i % g_layers) * layer_units, out, g_nb);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double bytes = 2.0 * 512 * 64 * 512 * B;
+        const double bytes = 2.0 * g_nb * 64 * 512 * B;
         printf("%-22s %6.2f us per launch = %.2f TB/s\n", name, ms * 1e3 / n, bytes / (ms * 1e-3 / n) / 1e12);
     }
 }
 int main(int argc, char** argv)
 {
     if (argc > 1) g_layers = atoi(argv[1]);
-    printf("cycling through %d layer(s) of K / V\n", g_layers);
+    if (argc > 2) g_nb = atoi(argv[2]);
+    printf("cycling through %d layer(s) of K / V, %d images per launch: working set %.0f MB (fp32) / %.0f MB (bf16)\n", g_layers, g_nb,
+           g_layers * 2.0 * g_nb * 64 * 512 * 4 / 1e6, g_layers * 2.0 * g_nb * 64 * 512 * 2 / 1e6);
     const size_t layer_units = (size_t)512 * 64 * 512 * 4 / 16;
     uint4 *Kb, *Vb; float* out;
     hipMalloc(&Kb, 6 * layer_units * 16); hipMalloc(&Vb, 6 * layer_units * 16); hipMalloc(&out, 4096 * 4);
