@@ -447,7 +447,8 @@ int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* src_dims, int 
 int tpspp_conv_bf16_chunk_channels(int kernel_size);
 
 /* Tuning / testing (results do not depend on it).  Bit 0: tpspp_conv2d_fwd uses its generic kernel even when
- * weight_tiled is given.  Bit 1: tpspp_conv2d_bf16_fwd does not use the persistent kernel for blocked 3x3 layers. */
+ * weight_tiled is given.  Bit 1: tpspp_conv2d_bf16_fwd does not use the persistent kernel for blocked 3x3 layers.
+ * Bit 2: ... nor the wide-tile kernel (tpspp_conv3_wide.hip) for the blocked 3x3 layers with >= 128 output channels. */
 int tpspp_conv_set_tuning(int flags);
 
 /*

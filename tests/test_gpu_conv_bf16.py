@@ -190,6 +190,48 @@ def test_conv_bf16_persistent_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name,
         assert torch.equal(got, want)
 
 
+WIDE_CASES = [
+    # name, C (= Cin = Cout), H, W, res_mode, relu, N      (8x32: one image per workgroup; 4x16: four images per workgroup)
+    ("layer3 128->128 @8x32 + residual", 128, 8, 32, 2, True, 37),
+    ("layer4 256->256 @8x32 + residual", 256, 8, 32, 2, True, 9),
+    ("layer5 512->512 @4x16 + residual, ragged group", 512, 4, 16, 2, True, 6),
+    ("256->256 @8x32, no residual, no ReLU", 256, 8, 32, 0, False, 3),
+    ("128->128 @4x16, residual after the ReLU, one image", 128, 4, 16, 1, True, 1),
+    ("full machine 256->256 @8x32", 256, 8, 32, 2, True, 515),
+]
+
+
+@pytest.mark.parametrize("name,C,H,W,res_mode,relu,N", WIDE_CASES, ids=[c[0] for c in WIDE_CASES])
+def test_conv3_wide_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, C, H, W, res_mode, relu, N):
+    """tpspp_conv3_wide.hip (round 6: 128 x 64 wavefront tiles, the weight streamed from L2 into registers five taps ahead, the
+    patch by LDS-DMA into a ring of three buffers) against the tiled kernel on the same blocked tensors
+    (tpspp_conv_set_tuning bit 2 switches it off): the backbone's stage 3 - 5 shapes, with and without the blocked residual,
+    a ragged last image group, more workgroups than the machine holds at once; twice (no state survives a launch); and
+    against the CPU reference on bf16-rounded operands."""
+    from tps_pp_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(len(name) + C)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = torch.randn((C, C, 3, 3), generator=g) / np.sqrt(C * 9.0)
+    b = torch.randn((C,), generator=g) * 0.1
+    r = torch.randn((N, C, H, W), generator=g) if res_mode else None
+    xs = [(ops.Blocked.from_nchw(x.to(cuda)), 1, 1)]
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    res = ops.Blocked.from_nchw(r.to(cuda)) if res_mode else None
+    kw = dict(relu=relu, residual=res, res_mode=res_mode, out_blocked=True)
+    try:
+        _lib.lib().tpspp_conv_set_tuning(4)
+        want = ops.conv2d_bf16(xs, cw, (1, 1), **kw).t.view(torch.int16).clone()
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
+    for _ in range(2):
+        got = ops.conv2d_bf16(xs, cw, (1, 1), **kw)
+        assert torch.equal(got.t.view(torch.int16), want), name
+    if N <= 40:
+        ref = ref_conv([(rb(x), 1, 1)], w, b, 3, (1, 1), relu, rb(r) if res_mode else None, res_mode)
+        out = got.nchw().float().cpu()
+        assert float((out - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("fg_dtype", ["bf16", "f32"])
 def test_front_bf16_fused_against_cpu_reference(cuda, fg_dtype):
     """tpspp_front_bf16_fwd (down0 / down1 / down2 / cat + Upsample + down_feat in one register-chained kernel)

@@ -24,6 +24,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-ff
 
 # per-file extra flags: tpspp_warp_geo.hip without the SLP vectoriser (it packs the grid chains into v_pk_fma_f32: slower)
 EXTRA = {"tpspp_warp_geo.hip": ["-fno-slp-vectorize"]}
+if os.environ.get("TPSPP_BUILD_WIDE_LAB"):      # timing experiments of tpspp_conv3_wide.hip (scripts/debug/bench_wide.py)
+    EXTRA["tpspp_conv3_wide.hip"] = ["-DTPSPP_WIDE_LAB"]
 
 
 def sources():

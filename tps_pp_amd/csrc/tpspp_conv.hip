@@ -809,12 +809,13 @@ int g_conv_force_generic = 0;
 
 }  // namespace
 
-namespace tpspp { int g_conv_bf16_no_persist = 0; }      // read by tpspp_conv_bf16.hip
+namespace tpspp { int g_conv_bf16_no_persist = 0; int g_conv_bf16_no_wide = 0; }      // read by tpspp_conv_bf16.hip
 
 TPSPP_EXPORT int tpspp_conv_set_tuning(int flags)
 {
     g_conv_force_generic = (flags & 1) ? 1 : 0;
     tpspp::g_conv_bf16_no_persist = (flags & 2) ? 1 : 0;
+    tpspp::g_conv_bf16_no_wide = (flags & 4) ? 1 : 0;
     return TPSPP_OK;
 }
 

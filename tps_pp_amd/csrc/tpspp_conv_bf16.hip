@@ -92,6 +92,10 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     TPSPP_REQUIRE((long)N * ((Cout + BN - 1) / BN) <= 65535, "tpspp_conv2d_bf16_fwd: grid too large");
     hipStream_t st = tpspp::as_stream(stream);
     bool ok = false;
+    // the wide blocked 3x3 layers of the backbone (>= 128 output channels on 8x32 / 4x16 maps): 128 x 64 wavefront tiles, weights
+    // streamed into registers (tpspp_conv3_wide.hip); bit-identical results
+    if (!split3 && KH == 3 && sh == 1 && sw == 1 && !tpspp::g_conv_bf16_no_wide && tpspp::conv3_wide_launch(P, st))
+        return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
     // the big blocked 3x3 layers: persistent, LDS-DMA-fed kernel (tpspp_conv_bf16_persist.hip); bit-identical results
     if (!split3 && KH == 3 && !tpspp::g_conv_bf16_no_persist && tpspp::conv_bf16_persist_launch(P, sh, sw, st))
         return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
