@@ -198,6 +198,8 @@ WIDE_CASES = [
     ("256->256 @8x32, no residual, no ReLU", 256, 8, 32, 0, False, 3),
     ("128->128 @4x16, residual after the ReLU, one image", 128, 4, 16, 1, True, 1),
     ("full machine 256->256 @8x32", 256, 8, 32, 2, True, 515),
+    ("last block 512->512 @4x16 + residual, fp32 NCHW out", 512, 4, 16, 2, True, 7),
+    ("256->256 @8x32, fp32 NCHW out, no residual", 256, 8, 32, 0, True, 2),
 ]
 
 
@@ -217,18 +219,21 @@ def test_conv3_wide_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, C, H, W, 
     xs = [(ops.Blocked.from_nchw(x.to(cuda)), 1, 1)]
     cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
     res = ops.Blocked.from_nchw(r.to(cuda)) if res_mode else None
-    kw = dict(relu=relu, residual=res, res_mode=res_mode, out_blocked=True)
+    f32_out = "fp32 NCHW" in name
+    kw = dict(relu=relu, residual=res, res_mode=res_mode)
+    kw.update({"out_dtype": torch.float32} if f32_out else {"out_blocked": True})
+    raw = (lambda o: o.view(torch.int32)) if f32_out else (lambda o: o.t.view(torch.int16))
     try:
         _lib.lib().tpspp_conv_set_tuning(4)
-        want = ops.conv2d_bf16(xs, cw, (1, 1), **kw).t.view(torch.int16).clone()
+        want = raw(ops.conv2d_bf16(xs, cw, (1, 1), **kw)).clone()
     finally:
         _lib.lib().tpspp_conv_set_tuning(0)
     for _ in range(2):
         got = ops.conv2d_bf16(xs, cw, (1, 1), **kw)
-        assert torch.equal(got.t.view(torch.int16), want), name
+        assert torch.equal(raw(got), want), name
     if N <= 40:
         ref = ref_conv([(rb(x), 1, 1)], w, b, 3, (1, 1), relu, rb(r) if res_mode else None, res_mode)
-        out = got.nchw().float().cpu()
+        out = (got if f32_out else got.nchw()).float().cpu()
         assert float((out - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6
 
 
@@ -541,6 +546,10 @@ C1X1_CASES = [
     ("layer3 128->128 @8x32, no relu", 128, 128, 8, 32, False, 300),
     ("layer2 64->64 @16x64, ragged trips", 64, 64, 16, 64, True, 129),
     ("layer3 first 64->128 @16x64, one image", 64, 128, 16, 64, True, 1),
+    # round 6: layers whose whole weight does not fit the LDS run as output-channel slices (2 / 4 launches); 4x16 maps (a tile
+    # spans several images)
+    ("layer5 first 256->512 @8x32, two slices", 256, 512, 8, 32, True, 261),
+    ("128->256 @4x16: a tile spans several images", 128, 256, 4, 16, False, 36),
 ]
 
 

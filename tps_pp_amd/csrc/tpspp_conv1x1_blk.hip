@@ -17,6 +17,7 @@
 //   * results leave as 16-byte units of the blocked output (v_permlane32_swap pairs the two half-wavefronts' halves).
 // Bound: HBM.
 #include "tpspp_conv_bf16_impl.h"
+#include <cstdlib>
 
 namespace {
 
@@ -28,8 +29,12 @@ constexpr int kMaxLds = 160 * 1024;
 // next tile's units are requested BEFORE this tile's products and land under them.
 template <int NT, int NKS, int NW>
 __global__ void __launch_bounds__(NW * 64, 1)
-conv1x1_blk_kernel(const BParams P, int ntiles)
+conv1x1_blk_kernel(const BParams P, int ntiles, int cg_total, int cg0)
 {
+    // (round 6: a launch may own a SLICE of the output channels -- groups cg0 .. cg0 + 4 NT - 1 of cg_total -- so that layers whose
+    // whole weight does not fit the LDS (256 -> 512, 512 -> 512) run as 2 / 4 launches of this kernel, each streaming the
+    // activations once; P.wt / P.bias then point at the slice; and a tile is 32 NW pixels of the flat (image, pixel) index, so
+    // maps smaller than a tile (4x16) are taken as well)
     extern __shared__ u32x4 sAll[];
     constexpr int WUNITS = NT * 32 * NKS * 2;               // Cout * Cin / 8 units of 16 bytes
     u32x4* const sW = sAll;
@@ -44,14 +49,14 @@ conv1x1_blk_kernel(const BParams P, int ntiles)
     const int HW = P.Ho * P.Wo;
     constexpr int TPX = NW * 32;                             // pixels per tile
     constexpr bool EARLY = NW == 4;
-    const int tpi = HW / TPX;                                // tiles per image
     const u32x4* const src = reinterpret_cast<const u32x4*>(P.src[0].p);
     constexpr int nch = NKS / 2;                             // 32-channel chunks of the arranged weight
     const bool relu1 = P.relu == 1;
 
     u32x4 b[NKS], bn[EARLY ? NKS : 1];
     auto fetch = [&](int tile, u32x4* dst) {
-        const int n = tile / tpi, px = (tile - n * tpi) * TPX + 32 * wv + l31;
+        const int gp = tile * TPX + 32 * wv + l31;           // (HW is a multiple of 32: a fragment's pixels share an image)
+        const int n = gp / HW, px = gp - n * HW;
         const u32x4* s = src + ((size_t)n * (2 * NKS) + half) * HW + px;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) dst[ks] = s[(size_t)(2 * ks) * HW];
@@ -59,7 +64,8 @@ conv1x1_blk_kernel(const BParams P, int ntiles)
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile, b);
     for (; tile < ntiles; tile += gridDim.x) {
-        const int n = tile / tpi, px = (tile - n * tpi) * TPX + 32 * wv + l31;
+        const int gp = tile * TPX + 32 * wv + l31;
+        const int n = gp / HW, px = gp - n * HW;
         const int next = tile + (int)gridDim.x;
         if (EARLY && next < ntiles) fetch(next, bn);
         f32x16 acc[NT];
@@ -91,7 +97,7 @@ conv1x1_blk_kernel(const BParams P, int ntiles)
         } else if (next < ntiles) {
             fetch(next, b);                                  // in flight under the epilogue and the other wavefronts' products
         }
-        unsigned short* const ob = reinterpret_cast<unsigned short*>(P.out) + ((size_t)n * (4 * NT) * HW + px) * 8;
+        unsigned short* const ob = reinterpret_cast<unsigned short*>(P.out) + (((size_t)n * cg_total + cg0) * HW + px) * 8;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             tpspp_u32x2 pk[4];
@@ -118,14 +124,17 @@ conv1x1_blk_kernel(const BParams P, int ntiles)
     }
 }
 
-template <int NT, int NKS>
-bool launch(const BParams& P, hipStream_t st)
+// SL: launches per layer, each owning NT x 32 of the SL x NT x 32 output channels
+template <int NT, int NKS, int SL = 1>
+bool launch(const BParams& P0, hipStream_t st)
 {
     constexpr int NW = (NT * 16 + NKS * 4 > 160) ? 4 : 8;      // accumulators + operands per lane
     const size_t lds = (size_t)NT * 32 * NKS * 2 * 16 + (size_t)NT * 32 * 4;
     if (lds > (size_t)kMaxLds) return false;
-    const int HW = P.Ho * P.Wo;
-    const long nt = (long)P.N * (HW / (NW * 32));
+    const int HW = P0.Ho * P0.Wo;
+    const long total = (long)P0.N * HW;
+    if (HW % 32 || total % (NW * 32)) return false;
+    const long nt = total / (NW * 32);
     if (nt <= 0 || nt > 0x3fffffffL) return false;
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -141,7 +150,14 @@ bool launch(const BParams& P, hipStream_t st)
             return false;
         }
     }
-    hipLaunchKernelGGL((conv1x1_blk_kernel<NT, NKS, NW>), dim3((unsigned)(nt < ncu ? nt : ncu)), dim3(NW * 64), lds, st, P, (int)nt);
+    for (int sl = 0; sl < SL; ++sl) {
+        BParams P = P0;
+        // arranged weight: [64-output tile][32-channel chunk][4 k groups][64 outputs][8]: a slice of NT x 32 outputs is NT / 2 tiles
+        P.wt = P0.wt + (size_t)sl * (NT / 2) * (NKS / 2) * 4 * 64;
+        if (P0.bias) P.bias = P0.bias + sl * NT * 32;
+        hipLaunchKernelGGL((conv1x1_blk_kernel<NT, NKS, NW>), dim3((unsigned)(nt < ncu ? nt : ncu)), dim3(NW * 64), lds, st, P, (int)nt,
+                           SL * NT * 4, sl * NT * 4);
+    }
     return true;
 }
 
@@ -150,16 +166,22 @@ bool launch(const BParams& P, hipStream_t st)
 namespace tpspp {
 
 // true when the kernel took the layer: 1x1, stride 1, one blocked bf16 source at its own resolution, blocked bf16 output,
-// bias / ReLU only, Cin and Cout in {64, 128, 256}, whole 256-pixel tiles
+// bias / ReLU only, Cin and Cout in {64, 128, 256} (+ 256 -> 512, 512 -> 512 as output-channel slices), whole 32 NW-pixel tiles
+// of the flat (image, pixel) index
 bool conv1x1_blk_launch(const BParams& P, hipStream_t st)
 {
     if (P.nsrc != 1 || P.src[0].f32 != 2 || P.out_f32 != 2 || P.res || P.res_mode || P.post_scale || P.relu > 1) return false;
     if (P.src[0].lh || P.src[0].lw || P.src[0].H != P.Ho || P.src[0].W != P.Wo || P.src[0].C != P.Cin) return false;
-    if ((P.Ho * P.Wo) % 256) return false;
     if ((reinterpret_cast<size_t>(P.src[0].p) | reinterpret_cast<size_t>(P.out) | reinterpret_cast<size_t>(P.wt)) & 15) return false;
 #define TPSPP_C1(CI, CO) if (P.Cin == CI && P.Cout == CO) return launch<CO / 32, CI / 16>(P, st);
     TPSPP_C1(64, 64) TPSPP_C1(64, 128) TPSPP_C1(128, 128) TPSPP_C1(128, 256) TPSPP_C1(256, 256)
 #undef TPSPP_C1
+    // the first layer of the last stage: the weight of an output-channel slice in LDS, one launch per slice (132 -> 82 us at batch
+    // 512).  Not 512 -> 512 on the 4x16 maps: four slices of 131 KB for ONE 128-pixel tile per workgroup measured 74 us against the
+    // tiled kernel's 55 (TPSPP_C1X1_512=1 selects it for the bit-identity test).
+    if (P.Cin == 256 && P.Cout == 512) return launch<8, 16, 2>(P, st);
+    static const bool c512 = getenv("TPSPP_C1X1_512") != nullptr;
+    if (c512 && P.Cin == 512 && P.Cout == 512) return launch<4, 32, 4>(P, st);
     return false;
 }
 

@@ -70,7 +70,7 @@ struct WCfg {
     static_assert(NI * TH * TW == 256 && PSN >= kWave && TW % 16 == 0 && (32 % TW == 0 || TW % 32 == 0), "tile = 256 pixels");
 };
 
-// EPI: 0 bias (+ ReLU); 1 + blocked bf16 residual (res_mode 1 / 2).  Output: blocked bf16.
+// EPI bit 0: + blocked bf16 residual (res_mode 1 / 2); bit 1: fp32 NCHW output (the backbone's last block) instead of blocked bf16.
 // LAB (timing experiments only, TPSPP_WIDE_LAB in the environment; results are WRONG for LAB != 0): bit 0 no barrier per chunk,
 // bit 1 no weight loads inside the loop, bit 2 no DMA inside the loop, bit 3 no epilogue stores / residual loads, bit 4 the
 // weight loads re-read the same 8 KB (L1 hits); TPSPP_WIDE_LAB=108: the product kernel with the weight loads 8 taps ahead
@@ -234,7 +234,8 @@ conv3_wide_kernel(const BParams P)
     // every residual unit of the wavefront's 128 x 64 tile is requested BEFORE the first result is formed (32 loads of 8 bytes
     // per lane in flight together: one memory latency per workgroup instead of one per (fragment, channel half) -- the
     // epilogue was 12 % of the 256 -> 256 layer with the loads next to their use)
-    tpspp_u32x2 rres[EPI == 1 ? 4 : 1][2][4];
+    constexpr bool RES = (EPI & 1) != 0, F32OUT = (EPI & 2) != 0;
+    tpspp_u32x2 rres[RES ? 4 : 1][2][4];
     int pixo[4], nimg[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -242,7 +243,7 @@ conv3_wide_kernel(const BParams P)
         const int im = tp / HW;
         pixo[f] = tp - im * HW;
         nimg[f] = n0 + im;
-        if constexpr (EPI == 1) {
+        if constexpr (RES) {
             const bool valid = nimg[f] < P.N;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
@@ -264,7 +265,7 @@ conv3_wide_kernel(const BParams P)
             for (int g = 0; g < 4; ++g) {
                 float v[4];
                 float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (EPI == 1) {
+                if constexpr (RES) {
                     const tpspp_u32x2 rb = rres[f][h2][g];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rv[e] = bf16_bits_to_f32((unsigned short)((rb[e >> 1] >> (16 * (e & 1))) & 0xffffu));
@@ -272,9 +273,17 @@ conv3_wide_kernel(const BParams P)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = acc[f][h2][4 * g + e] + bq[h2][g][e];
-                    if constexpr (EPI == 1) { if (P.res_mode == 2) v[e] = v[e] + rv[e]; }
+                    if constexpr (RES) { if (P.res_mode == 2) v[e] = v[e] + rv[e]; }
                     if (relu1) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-                    if constexpr (EPI == 1) { if (P.res_mode == 1) v[e] = v[e] + rv[e]; }
+                    if constexpr (RES) { if (P.res_mode == 1) v[e] = v[e] + rv[e]; }
+                }
+                if constexpr (F32OUT) {
+                    // fp32 NCHW: a half-wavefront's 32 pixels of one channel are 128 contiguous bytes
+                    float* ob = reinterpret_cast<float*>(P.out) + ((size_t)(valid ? n : 0) * P.Cout + ctile * BN + 32 * h2 + 8 * g + 4 * half) * HW + pix_o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (valid) ob[(size_t)e * HW] = v[e];
+                    continue;
                 }
                 bpk[g][0] = pack2_bf16(v[0], v[1]); bpk[g][1] = pack2_bf16(v[2], v[3]);
                 if (g & 1) {
@@ -312,6 +321,11 @@ bool launch_w(const BParams& P, hipStream_t st)
         }
     }
 #endif
+    if (P.out_f32 == 1) {
+        if (P.res_mode) hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 3, 5>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 2, 5>), grid, dim3(256), 0, st, P);
+        return true;
+    }
     if (P.res_mode) hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 1, 5>), grid, dim3(256), 0, st, P);
     else hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 0, 5>), grid, dim3(256), 0, st, P);
     return true;
@@ -322,10 +336,10 @@ bool launch_w(const BParams& P, hipStream_t st)
 namespace tpspp {
 
 // true when the wide-tile kernel took the layer: 3x3 stride 1, plain bf16, ONE blocked source at full resolution, Cin a multiple
-// of 32, Cout a multiple of 128, blocked bf16 output (+ blocked bf16 residual), bias / ReLU only, 8x32 or 4x16 maps
+// of 32, Cout a multiple of 128, blocked bf16 or fp32 NCHW output (+ blocked bf16 residual), bias / ReLU only, 8x32 or 4x16 maps
 bool conv3_wide_launch(const BParams& P, hipStream_t st)
 {
-    if (P.nsrc != 1 || P.src[0].f32 != 2 || P.src[0].lh || P.src[0].lw || P.out_f32 != 2 || P.post_scale || P.relu > 1) return false;
+    if (P.nsrc != 1 || P.src[0].f32 != 2 || P.src[0].lh || P.src[0].lw || (P.out_f32 != 2 && P.out_f32 != 1) || P.post_scale || P.relu > 1) return false;
     if ((P.Cin % 32) || (P.Cout % 128) || P.Cin < 64 || P.src[0].C != P.Cin) return false;
     if (P.res_mode && P.res_f32 != 2) return false;
     if (P.Ho != P.Hi || P.Wo != P.Wi) return false;
