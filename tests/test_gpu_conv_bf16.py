@@ -237,6 +237,32 @@ def test_conv3_wide_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, C, H, W, 
         assert float((out - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("C,H,N,relu", [(3, 32, 37, True), (3, 32, 771, True), (1, 8, 5, False), (3, 4, 1, True)])
+def test_stem_kernel_is_the_tiled_kernel_bit_for_bit(cuda, C, H, N, relu):
+    """tpspp_conv_stem.hip (round 6: the backbone's 3 -> 32 stem on the fp32 image, persistent workgroups, swapped matrix operands so
+    that results leave as 16-byte pieces of the NCHW rows) against the tiled kernel (tpspp_conv_set_tuning bit 2 switches it off):
+    the same bits; several trips per workgroup (771 images = 6168 tiles), a one-channel image, a single tile; and against the CPU
+    reference on bf16-rounded operands."""
+    from tps_pp_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(C * 100 + H + N)
+    x = torch.randn((N, C, H, 128), generator=g)
+    w = torch.randn((32, C, 3, 3), generator=g) / np.sqrt(C * 9.0)
+    b = torch.randn((32,), generator=g) * 0.1
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    xd = x.to(cuda)
+    try:
+        _lib.lib().tpspp_conv_set_tuning(4)
+        want = ops.conv2d_bf16([xd], cw, 1, relu=relu).view(torch.int16).clone()
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
+    for _ in range(2):
+        got = ops.conv2d_bf16([xd], cw, 1, relu=relu)
+        assert got.dtype == torch.bfloat16 and torch.equal(got.view(torch.int16), want)
+    if N <= 40:
+        ref = ref_conv([(x, 1, 1)], w, b, 3, (1, 1), relu, None, 0)
+        assert float((got.float().cpu() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6
+
+
 @pytest.mark.parametrize("fg_dtype", ["bf16", "f32"])
 def test_front_bf16_fused_against_cpu_reference(cuda, fg_dtype):
     """tpspp_front_bf16_fwd (down0 / down1 / down2 / cat + Upsample + down_feat in one register-chained kernel)

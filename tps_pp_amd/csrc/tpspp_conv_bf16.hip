@@ -96,6 +96,9 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     // streamed into registers (tpspp_conv3_wide.hip); bit-identical results
     if (!split3 && KH == 3 && sh == 1 && sw == 1 && !tpspp::g_conv_bf16_no_wide && tpspp::conv3_wide_launch(P, st))
         return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
+    // the backbone's stem (3 fp32 channels -> 32 bf16 NCHW): tpspp_conv_stem.hip; bit-identical results
+    if (!split3 && KH == 3 && sh == 1 && sw == 1 && !tpspp::g_conv_bf16_no_wide && tpspp::conv_stem_launch(P, st))
+        return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
     // the big blocked 3x3 layers: persistent, LDS-DMA-fed kernel (tpspp_conv_bf16_persist.hip); bit-identical results
     if (!split3 && KH == 3 && !tpspp::g_conv_bf16_no_persist && tpspp::conv_bf16_persist_launch(P, sh, sw, st))
         return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
