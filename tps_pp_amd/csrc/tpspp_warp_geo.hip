@@ -123,10 +123,10 @@ bool plan_span(int C, int H, int W, int F, SpanPlan* p)
     return false;
 }
 
-template <int C, bool AUX, bool SPEC>
+template <int C, bool AUX, bool SPEC, typename G = tpspp_span::SpanRT>
 void launch_span_one(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStream_t st)
 {
-    auto kern = tpspp_span::tps_warp_span_kernel<20, C, AUX, SPEC>;
+    auto kern = tpspp_span::tps_warp_span_kernel<20, C, AUX, SPEC, G>;
     static bool attr_done[kMaxDevices] = {};
     if (first_use_on_device(attr_done)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -136,9 +136,30 @@ void launch_span_one(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStr
     hipLaunchKernelGGL(kern, dim3(blocks), dim3((unsigned)(pl.NWv * kWave)), pl.lds, st, P);
 }
 
+int g_span_no_fixed = 0;     // lab knob (TPSPP_SPAN_RUNTIME=1): the run-time-geometry form for the instantiated geometries as well
+
+// the instantiated geometries (C = 3, no auxiliary outputs): taken when the plan is exactly the one they were compiled for
+template <typename G, bool SPEC>
+bool span_fixed_matches(const tpspp_span::SpanParams& P, const SpanPlan& pl)
+{
+    return P.H == G::H && P.W == G::W && pl.BW == G::BW && pl.CG == G::CG && pl.RG == G::RG && pl.bands == G::BANDS &&
+           pl.nthr == G::NTHR && (pl.spec != 0) == SPEC && (!SPEC || pl.margin == G::MARGIN);
+}
+
 template <int C>
 void launch_span_aux(const tpspp_span::SpanParams& P, const SpanPlan& pl, hipStream_t st)
 {
+    if constexpr (C == 3) {
+        static const bool rt = getenv("TPSPP_SPAN_RUNTIME") != nullptr;
+        if (!rt && !g_span_no_fixed && !P.grid && !P.idx && !P.force_gather) {
+            using G64x200 = tpspp_span::SpanFix<64, 200, 8, 13, 8, 8, 2>;
+            using G48x160 = tpspp_span::SpanFix<48, 160, 16, 5, 12, 4, 2>;
+            using G64x256 = tpspp_span::SpanFix<64, 256, 32, 4, 32, 8, 0>;
+            if (span_fixed_matches<G64x200, true>(P, pl)) { launch_span_one<3, false, true, G64x200>(P, pl, st); return; }
+            if (span_fixed_matches<G48x160, true>(P, pl)) { launch_span_one<3, false, true, G48x160>(P, pl, st); return; }
+            if (span_fixed_matches<G64x256, false>(P, pl)) { launch_span_one<3, false, false, G64x256>(P, pl, st); return; }
+        }
+    }
     if (pl.spec) {
         if (P.grid || P.idx) launch_span_one<C, true, true>(P, pl, st);
         else launch_span_one<C, false, true>(P, pl, st);

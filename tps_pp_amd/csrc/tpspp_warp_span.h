@@ -99,17 +99,31 @@ __device__ __forceinline__ void span_dma16(const void* g, unsigned lds_byte)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(lds_byte), "v"(g) : "memory", "m0");
 }
 
-template <int F, int C, bool AUX, bool SPEC = false>
+// Geometry policy (round 6): SpanRT takes every size from the launch arguments; SpanFix<...> makes them compile-time constants for
+// the geometries that are instantiated (tpspp_warp_geo.hip: 64x200, 48x160, 64x256 -- row pitch, plane size, block shape, band
+// decomposition and window margin fold into immediates and shifts: the kernel is bound by vector-ALU issue).
+struct SpanRT { static constexpr bool fixed = false; static constexpr int H = 0, W = 0, BW = 0, CG = 0, RG = 0, BANDS = 0, NTHR = 0, MARGIN = 0; };
+template <int H_, int W_, int BW_, int CG_, int RG_, int BANDS_, int MARGIN_>
+struct SpanFix {
+    static constexpr bool fixed = true;
+    static constexpr int H = H_, W = W_, BW = BW_, CG = CG_, RG = RG_, BANDS = BANDS_, MARGIN = MARGIN_;
+    static constexpr int NTHR = CG_ * (RG_ / BANDS_) * 32;
+};
+
+template <int F, int C, bool AUX, bool SPEC = false, typename G = SpanRT>
 __global__ void __launch_bounds__(1024, (AUX || C > 3) ? 4 : 7)        // <= 72 registers: two 13-wavefront workgroups per CU
 tps_warp_span_kernel(const SpanParams P)
 {
     constexpr int K = F + 3;
-    const int H = P.H, W = P.W, HW = H * W;
-    const int BW = P.BW, BH = 32 / BW, CG = P.CG;
+    const int H = G::fixed ? G::H : P.H, W = G::fixed ? G::W : P.W, HW = H * W;
+    const int BW = G::fixed ? G::BW : P.BW, BH = 32 / BW, CG = G::fixed ? G::CG : P.CG;
+    const int gRG = G::fixed ? G::RG : P.RG, gBands = G::fixed ? G::BANDS : P.bands, gNthr = G::fixed ? G::NTHR : P.nthr;
+    const int gMargin = G::fixed ? G::MARGIN : P.margin;
+    const int gLgBw = G::fixed ? (G::BW == 32 ? 5 : G::BW == 16 ? 4 : G::BW == 8 ? 3 : 2) : P.lg_bw;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float2* sT = reinterpret_cast<float2*>(smem);           // [K]
     int* sWord = reinterpret_cast<int*>(smem + ((2 * K + 3) & ~3));   // [0] T published, [2 + r] min y, [4 + r] max y of region r
-    float* sStage = smem + P.stage_off;
+    float* sStage = smem + span_stage_off(K);
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -117,7 +131,7 @@ tps_warp_span_kernel(const SpanParams P)
     const int NW = (int)(blockDim.x / kWave);
     // block -> (image, band): the bands of an image sit 8 blocks apart, i.e. on one XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int b = (slot / P.bands) * 8 + xcd, band = slot % P.bands;
+    const int b = (slot / gBands) * 8 + xcd, band = slot % gBands;
     if (b >= P.N) return;
 
     const unsigned row_bytes = (unsigned)HW * 4u;            // one plane
@@ -125,11 +139,11 @@ tps_warp_span_kernel(const SpanParams P)
     int w0[2] = {0, 0}, wlast[2] = {0, 0};                   // SPEC: first / last staged row of each region's window
     int wbytes0 = 0;                                         // SPEC: bytes of region 0's window = LDS offset of region 1's
     if constexpr (SPEC) {
-        const int rows_ = (P.RG / P.bands) * BH, ra_ = band * rows_;
-        w0[0] = ra_ - P.margin > 0 ? ra_ - P.margin : 0;
-        wlast[0] = (ra_ + rows_ + P.margin < H ? ra_ + rows_ + P.margin : H) - 1;
-        w0[1] = H - ra_ - rows_ - P.margin > 0 ? H - ra_ - rows_ - P.margin : 0;
-        wlast[1] = (H - ra_ + P.margin < H ? H - ra_ + P.margin : H) - 1;
+        const int rows_ = (gRG / gBands) * BH, ra_ = band * rows_;
+        w0[0] = ra_ - gMargin > 0 ? ra_ - gMargin : 0;
+        wlast[0] = (ra_ + rows_ + gMargin < H ? ra_ + rows_ + gMargin : H) - 1;
+        w0[1] = H - ra_ - rows_ - gMargin > 0 ? H - ra_ - rows_ - gMargin : 0;
+        wlast[1] = (H - ra_ + gMargin < H ? H - ra_ + gMargin : H) - 1;
         wbytes0 = C * (wlast[0] - w0[0] + 1) * W * 4;
         // A region's window in LDS: the C channels' rows back to back, EXACTLY wn W 4 bytes each (no rounding to whole 1-KB
         // pieces: with it 64x200 needs 43 KB per workgroup, three per CU; without, 39.4 KB, four).  A 1-KB piece may then
@@ -182,7 +196,7 @@ tps_warp_span_kernel(const SpanParams P)
 
     // thread -> its quadrant pixel: half-wavefront hw = block of BW columns x BH rows; row group rg (global over bands).
     // hw / CG on the scalar unit for the wavefront's first half, the second half is the next block (no vector division)
-    const int nhw = P.nthr >> 5;                             // live half-wavefronts (the last wavefront may be half empty)
+    const int nhw = gNthr >> 5;                             // live half-wavefronts (the last wavefront may be half empty)
     const int l5 = lane & 31;
     const int hw0 = 2 * wv < nhw ? 2 * wv : nhw - 1;
     const int rg0 = hw0 / CG, cg0 = hw0 - rg0 * CG;          // (uniform)
@@ -191,10 +205,10 @@ tps_warp_span_kernel(const SpanParams P)
     const bool live = lane < 32 ? 2 * wv < nhw : 2 * wv + 1 < nhw;
     const int rg_l = second ? (wrap ? rg0 + 1 : rg0) : rg0;
     const int cg = second ? (wrap ? 0 : cg0 + 1) : cg0;
-    const int rgpb = P.RG / P.bands;                         // row groups per band
+    const int rgpb = gRG / gBands;                         // row groups per band
     const int rg = band * rgpb + rg_l;
     const int c = cg * BW + (l5 & (BW - 1));                 // BW is a power of two; c < W (CG BW <= W)
-    const int r = rg * BH + (l5 >> P.lg_bw);
+    const int r = rg * BH + (l5 >> gLgBw);
     // (column groups may reach past the centre: such a lane's pixels are other lanes' mirror pixels, computed twice
     // with the same bits -- the table is mirror-symmetric -- and written twice with the same value)
     const int rows = rgpb * BH;                              // output rows of this band per region
