@@ -43,13 +43,22 @@ for mode in bf16only x3only; do
   timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc_$mode -o module -- \
       python3 scripts/bench_module.py 512 $mode > $OUT/mfma_module_$mode.log 2>&1
 done
+# 4b. (round 6) the bf16 backbone + TPS++ (the wide-tile 3x3 kernel, the stem kernel) and the wide layers alone, hot
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc_backbone -o module -- \
+    python3 scripts/debug/bench_backbone.py bf16 > $OUT/mfma_backbone.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_pmc_wide -o module -- \
+    python3 scripts/debug/bench_wide.py both > $OUT/mfma_wide.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_backbone_bf16 -o backbone_bf16 -- \
+    python3 scripts/debug/bench_backbone.py bf16 > $OUT/backbone_bf16.log 2>&1
+timeout 300 python3 scripts/debug/backbone_layers.py > $OUT/backbone_layers.log 2>&1
+timeout 300 python3 scripts/debug/bench_wide.py both > $OUT/bench_wide.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_module_x3 -o module_x3 -- \
     python3 scripts/bench_module.py 512 x3only > $OUT/module_x3.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_cal -o cal -- \
     ./scripts/ubench/mfma_bench > $OUT/mfma_cal.log 2>&1
 # 5. summaries are made HERE (the raw kernel traces of the recogniser / the driver's command are tens of MB each and
 #    gpurun copies back at most 64 MiB): gpurun_out/prof_summary/* is what gets committed under profiles/
-TAG=${TAG:-r05}
+TAG=${TAG:-r06}
 TPSPP_PROFILE_DST=gpurun_out/prof_summary python3 scripts/summarize_profiles.py $TAG > $OUT/summarize.log 2>&1
 find $OUT -name "*_kernel_trace.csv" -size +3M -delete
 find $OUT -name "*counter_collection.csv" -size +3M -delete

@@ -76,7 +76,12 @@ GRBM_GUI_ACTIVE summed over the 8 XCDs); utilisation below = the same ratio of a
         f.write("\n(counter collection serialises dispatches and slows kernels slightly; un-profiled rates are in DESIGN.md section 4b)\n")
         # the bf16 and "bf16x3" configurations of the same module: the pipe-busy ratio does not depend on the operand type
         for mode, title in (("bf16only", "bf16 configuration (`bench_module.py 512 bf16only`)"),
-                            ("x3only", '"bf16x3" configuration (`bench_module.py 512 x3only`): fp32 tensors, three bf16 MFMAs per product')):
+                            ("x3only", '"bf16x3" configuration (`bench_module.py 512 x3only`): fp32 tensors, three bf16 MFMAs per product'),
+                            ("backbone", "bf16 backbone + TPS++ (`scripts/debug/bench_backbone.py bf16`, batch 512: `conv3_wide_kernel` = the "
+                                         "128- to 512-channel 3x3 layers, `conv_stem_bf16_kernel` = the stem; round 6)"),
+                            ("wide", "the backbone's wide 3x3 layers alone, 35 launches back to back each (`scripts/debug/bench_wide.py both`): "
+                                     "`conv3_wide_kernel` against the tiled kernel it replaces (`conv_tiled_bf16_kernel<3, 1, 1, 4, 32, ...>` = "
+                                     "8x32 maps, `<3, 1, 1, 4, 16, 2, ...>` = 4x16 maps)")):
             pth = os.path.join(SRC, f"mfma_pmc_{mode}", "module_counter_collection.csv")
             if not os.path.exists(pth):
                 continue
@@ -345,7 +350,7 @@ Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / 
 """)
     # kernel stats of the wider rows (whole TPS++ module, whole recogniser, warp backward)
     for w, name in (("module", "module"), ("head", "recognizer"), ("backward", "warp_backward"),
-                    ("module_bf16", "module_bf16"), ("module_x3", "module_bf16x3")):
+                    ("module_bf16", "module_bf16"), ("module_x3", "module_bf16x3"), ("backbone_bf16", "backbone_bf16")):
         src = os.path.join(SRC, f"trace_{w}", f"{w}_kernel_stats.csv")
         if os.path.exists(src):
             rows = sorted(csv.DictReader(open(src)), key=lambda r: -float(r["TotalDurationNs"]))
@@ -361,6 +366,12 @@ Algorithmic bytes per launch (DESIGN.md section 5): {ALGO_BYTES:,} -> traffic / 
     if os.path.exists(cl):
         with open(os.path.join(DST, f"{TAG}_conv_fp32_bf16_vs_miopen.txt"), "w") as f:
             f.write("".join(l for l in open(cl) if "amdgpu.ids" not in l))
+    # round 6: every convolution call of the bf16 backbone with its shape / layouts / time, and the wide layers against the tiled kernel
+    for logname, dst in (("backbone_layers.log", "backbone_bf16_layers.txt"), ("bench_wide.log", "conv3_wide_vs_tiled.txt")):
+        pth = os.path.join(SRC, logname)
+        if os.path.exists(pth):
+            with open(os.path.join(DST, f"{TAG}_{dst}"), "w") as f:
+                f.write("".join(l for l in open(pth) if "amdgpu.ids" not in l))
     mfma_summary()
     print(json.dumps(js, indent=1))
 
