@@ -2,14 +2,20 @@
 
 TEST INFRASTRUCTURE, NOT PRODUCT: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py`` may import this.
 
-PARITY UNPINNED for the interpolation.  The reference resizes with ``mmcv.imresize`` (backend cv2, 'bilinear')
-= OpenCV ``cv::resize(..., INTER_LINEAR)`` on uint8 (mmocr/datasets/pipelines/ocr_transforms.py:101-121).  Neither
-cv2 nor mmcv is installed here (third-party: opencv-python, unpinned by the reference; mmcv-full 1.3.8-1.5.0), so
-``imresize_bilinear_u8`` restates OpenCV's published 8-bit algorithm (modules/imgproc/src/resize.cpp: 11-bit
-fixed-point coefficients, INTER_RESIZE_COEF_BITS = 11; the INTER_AREA substitution for an exact 2x2 shrink) and could
-not be checked against OpenCV itself.  What IS pinned, against the reference's own tests
-(tests/test_dataset/test_ocr_transforms.py:13-57): the host logic of ResizeOCR.__call__ (widths, padding,
-valid_ratio, shapes), ToTensorOCR and NormalizeOCR.
+The reference resizes with ``mmcv.imresize(img, size, backend=self.backend)`` (mmocr/datasets/pipelines/ocr_transforms.py:
+34-36,46,65,99-121); mmcv is a third-party dependency absent from /root/reference (mmcv-full 1.3.8-1.5.0), so both of its
+backends are restated here from the libraries it calls:
+
+* backend 'pillow' -- ``Image.fromarray(img).resize(size, Image.BILINEAR)``: ``imresize_pillow_bilinear_u8`` restates Pillow's
+  src/libImaging/Resample.c and is PINNED: tests/golden/make_resize_golden.py runs the installed Pillow (12.2) on seeded crops,
+  commits its outputs (tests/golden/resize_pillow.npz) and asserts this function reproduces them and 300 random shapes bit for bit.
+* backend None / 'cv2' -- OpenCV ``cv::resize(..., INTER_LINEAR)`` on uint8: PARITY UNPINNED.  cv2 is not installed here
+  (third-party: opencv-python, unpinned by the reference), so ``imresize_bilinear_u8`` restates OpenCV's published 8-bit
+  algorithm (modules/imgproc/src/resize.cpp: 11-bit fixed-point coefficients, INTER_RESIZE_COEF_BITS = 11; the INTER_AREA
+  substitution for an exact 2x2 shrink) and could not be checked against OpenCV itself.
+
+Pinned against the reference's own tests (tests/test_dataset/test_ocr_transforms.py:13-57) in both cases: the host logic of
+ResizeOCR.__call__ (widths, padding, valid_ratio, shapes), ToTensorOCR and NormalizeOCR.
 """
 import math
 
