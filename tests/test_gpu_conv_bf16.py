@@ -263,6 +263,38 @@ def test_stem_kernel_is_the_tiled_kernel_bit_for_bit(cuda, C, H, N, relu):
         assert float((got.float().cpu() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-6
 
 
+@pytest.mark.parametrize("name,H,W,stride,res_mode,f32_out,N", [
+    ("layer1 32->32 @16x64 + residual", 16, 64, (1, 1), 2, False, 301),
+    ("layer1 first 32->32 s2 @32x128 -> 16x64 + residual", 32, 128, (2, 2), 2, False, 67),
+    ("32->32 @16x64, fp32 NCHW out", 16, 64, (1, 1), 0, True, 5),
+    ("32->32 @8x32 (8x32 tiles)", 8, 32, (1, 1), 1, False, 515),
+])
+def test_conv_bf16_persistent_kernel_with_32_output_channels(cuda, name, H, W, stride, res_mode, f32_out, N):
+    """Round 6: the persistent 3x3 kernel also takes Cout = 32 (the backbone's first stage: the arranged weight's 64-channel tile
+    is zero-padded, the tensors have four channel groups): bit for bit the tiled kernel, blocked and fp32-NCHW output, blocked
+    residual, stride 2."""
+    from tps_pp_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(len(name))
+    xs = [(ops.Blocked.from_nchw(torch.randn((N, 32, H, W), generator=g).to(cuda)), 1, 1)]
+    w = torch.randn((32, 32, 3, 3), generator=g) / np.sqrt(32 * 9.0)
+    b = torch.randn((32,), generator=g) * 0.1
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    Ho, Wo = H // stride[0], W // stride[1]
+    res = ops.Blocked.from_nchw(torch.randn((N, 32, Ho, Wo), generator=g).to(cuda)) if res_mode else None
+    kw = dict(relu=True, residual=res, res_mode=res_mode)
+    kw.update({"out_dtype": torch.float32} if f32_out else {"out_blocked": True})
+    raw = lambda o: o.view(torch.int32) if f32_out else o.t.view(torch.int16)
+    try:
+        _lib.lib().tpspp_conv_set_tuning(2)
+        want = raw(ops.conv2d_bf16(xs, cw, stride, **kw)).clone()
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
+    for _ in range(2):
+        got = ops.conv2d_bf16(xs, cw, stride, **kw)
+        assert tuple((got if f32_out else got.t).shape[:2]) == ((N, 32) if f32_out else (N, 4))
+        assert torch.equal(raw(got), want)
+
+
 @pytest.mark.parametrize("fg_dtype", ["bf16", "f32"])
 def test_front_bf16_fused_against_cpu_reference(cuda, fg_dtype):
     """tpspp_front_bf16_fwd (down0 / down1 / down2 / cat + Upsample + down_feat in one register-chained kernel)

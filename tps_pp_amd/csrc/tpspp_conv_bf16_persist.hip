@@ -154,7 +154,7 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
     TRACE_INIT();
     STAMP();
     if (tid < 2 * NB + 1) flags[tid] = 0;
-    if (tid >= kWave && tid < 2 * kWave) sBias[tid - kWave] = P.bias ? P.bias[tid - kWave] : 0.0f;
+    if (tid >= kWave && tid < 2 * kWave) sBias[tid - kWave] = (P.bias && tid - kWave < P.Cout) ? P.bias[tid - kWave] : 0.0f;
     __syncthreads();                                        // the only barrier of the kernel: counters are zero
     STAMP();
 
@@ -338,6 +338,9 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
         }
 
         // ---- epilogue: bias, residual, ReLU; blocked bf16 (16-byte units) or fp32 NCHW ----
+        // (round 6: Cout = 32 -- the backbone's first stage -- runs here as well: the arranged weight's cout tile is zero-padded to
+        // 64, the upper half of the products is discarded, the tensors have CGo = Cout / 8 channel groups)
+        const int CGo = P.Cout >> 3;
         STAMP();
         float bq[2][4][4];                                   // re-read per tile from LDS: 32 registers the multiply keeps free
 #pragma unroll
@@ -359,7 +362,8 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
                     const int cu = 32 * h2 + 8 * g;              // + 4 * half + e
                     float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                     if constexpr (EPI == 1) {
-                        const size_t bunit = (((size_t)n * 8 + (cu >> 3)) * HoWo + pix_o) * 8 + 4 * half;
+                        const int cgr = (cu >> 3) < CGo ? (cu >> 3) : 0;      // (a channel group the tensor does not have: any valid unit)
+                        const size_t bunit = (((size_t)n * CGo + cgr) * HoWo + pix_o) * 8 + 4 * half;
                         const tpspp_u32x2 rb = *reinterpret_cast<const tpspp_u32x2*>(
                             reinterpret_cast<const unsigned short*>(P.res) + bunit);
 #pragma unroll
@@ -400,13 +404,15 @@ conv3_blk_persist_kernel(const BParams P, int ntx, int nty, int ntiles)
                             const tpspp_u32x2 d1 = __builtin_amdgcn_permlane32_swap(bpk[g - 1][1], bpk[g][1], false, false);
                             u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
                             const int kg = 4 * h2 + (g - 1) + half;
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(P.out) +
-                                                      (((size_t)n * 8 + kg) * HoWo + pix_o) * 8) = unit;
+                            if (kg < CGo)
+                                *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(P.out) +
+                                                          (((size_t)n * CGo + kg) * HoWo + pix_o) * 8) = unit;
                         }
                     } else {
-                        float* ob = reinterpret_cast<float*>(P.out) + ((size_t)n * 64 + cu + 4 * half) * HoWo + pix_o;
+                        float* ob = reinterpret_cast<float*>(P.out) + ((size_t)n * P.Cout + cu + 4 * half) * HoWo + pix_o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ob[(size_t)e * HoWo] = v[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (cu + 4 * half + e < P.Cout) ob[(size_t)e * HoWo] = v[e];
                     }
                 }
             }
@@ -485,11 +491,11 @@ extern "C" __attribute__((visibility("default"))) int tpspp_debug_conv_trace(lon
 
 namespace tpspp {
 
-// true when the persistent kernel took the layer: 3x3, plain bf16, every source blocked, 64 output channels, blocked
+// true when the persistent kernel took the layer: 3x3, plain bf16, every source blocked, 64 (or 32) output channels, blocked
 // output (+ blocked residual) or fp32-NCHW output, bias / ReLU only, whole tiles
 bool conv_bf16_persist_launch(const BParams& P, int sh, int sw, hipStream_t st)
 {
-    if (P.Cout != 64 || (P.Cin % kPKC) || P.post_scale || P.relu > 1) return false;
+    if ((P.Cout != 64 && P.Cout != 32) || (P.Cin % kPKC) || P.post_scale || P.relu > 1) return false;
     if (P.out_f32 != 2 && P.out_f32 != 1) return false;
     for (int i = 0; i < P.nsrc; ++i)
         if (P.src[i].f32 != 2 || (P.src[i].C % kPKC)) return false;
