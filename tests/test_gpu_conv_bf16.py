@@ -668,3 +668,31 @@ def test_down_fused_x3_is_front_then_stride2_conv_bit_for_bit(cuda, N, H):
     n0, n1, g2, gg = ops.front_bf16(o0, o1, x, fw, blocked=True, store01=False)
     assert n0 is None and n1 is None
     assert torch.equal(g2.t.view(torch.int32), f2.t.view(torch.int32)) and torch.equal(gg.view(torch.int32), fg.view(torch.int32))
+
+
+def test_backbone_hands_tpspp_blocked_maps_with_the_same_bits(cuda):
+    """Round 6: in the bf16 configuration our backbone keeps its stem output and its first stage's result in the blocked layout
+    when `tpsnet` is this package's TPS_PP in the 'ResNet45' wiring (only its down convolutions read them): the stem kernel's
+    blocked epilogue, the blocked 1x1 kernel at 32 input channels, the persistent 3x3 kernel at 32 output channels.  Same bits
+    as the NCHW hand-over a foreign backbone would make -- feature map, rectified map, control-point score."""
+    import tps_pp_amd as P
+    torch.manual_seed(3)
+    bb = P.build_backbone(dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=[2, 1, 2, 1, 2])).eval().to(cuda)
+    tps = P.TPS_PP(variant="ResNet45").eval().to(cuda)
+    bb.compute_dtype = torch.bfloat16
+    img = torch.rand(5, 3, 32, 128, device=cuda) * 2 - 1
+    seen = []
+    orig_fwd = tps.forward
+
+    def spy(x, outs, **kw):
+        seen.append([type(o).__name__ for o in outs])
+        return orig_fwd(x, outs, **kw)
+    tps.forward = spy
+    with torch.no_grad():
+        got = bb(img, tpsnet=tps, test=True)
+        tps.accepts_blocked_outs = lambda: False
+        want = bb(img, tpsnet=tps, test=True)
+    assert seen == [["Blocked", "Blocked"], ["Tensor", "Tensor"]], seen
+    assert torch.equal(got["output"].view(torch.int32), want["output"].view(torch.int32))
+    assert torch.equal(got["img_ref"].view(torch.int16), want["img_ref"].view(torch.int16))
+    assert torch.isfinite(got["output"]).all()

@@ -36,7 +36,7 @@ conv1x1_blk_kernel(const BParams P, int ntiles, int cg_total, int cg0)
     // activations once; P.wt / P.bias then point at the slice; and a tile is 32 NW pixels of the flat (image, pixel) index, so
     // maps smaller than a tile (4x16) are taken as well)
     extern __shared__ u32x4 sAll[];
-    constexpr int WUNITS = NT * 32 * NKS * 2;               // Cout * Cin / 8 units of 16 bytes
+    constexpr int WUNITS = ((NT + 1) / 2) * 64 * NKS * 2;   // (Cout rounded up to whole 64-channel tiles) * Cin / 8 units of 16 bytes
     u32x4* const sW = sAll;
     float* const sBias = reinterpret_cast<float*>(sAll + WUNITS);
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -129,7 +129,7 @@ template <int NT, int NKS, int SL = 1>
 bool launch(const BParams& P0, hipStream_t st)
 {
     constexpr int NW = (NT * 16 + NKS * 4 > 160) ? 4 : 8;      // accumulators + operands per lane
-    const size_t lds = (size_t)NT * 32 * NKS * 2 * 16 + (size_t)NT * 32 * 4;
+    const size_t lds = (size_t)((NT + 1) / 2) * 64 * NKS * 2 * 16 + (size_t)NT * 32 * 4;
     if (lds > (size_t)kMaxLds) return false;
     const int HW = P0.Ho * P0.Wo;
     const long total = (long)P0.N * HW;
@@ -175,6 +175,7 @@ bool conv1x1_blk_launch(const BParams& P, hipStream_t st)
     if ((reinterpret_cast<size_t>(P.src[0].p) | reinterpret_cast<size_t>(P.out) | reinterpret_cast<size_t>(P.wt)) & 15) return false;
 #define TPSPP_C1(CI, CO) if (P.Cin == CI && P.Cout == CO) return launch<CO / 32, CI / 16>(P, st);
     TPSPP_C1(64, 64) TPSPP_C1(64, 128) TPSPP_C1(128, 128) TPSPP_C1(128, 256) TPSPP_C1(256, 256)
+    TPSPP_C1(32, 32) TPSPP_C1(32, 64)             // (round 6: the backbone's first stage, when its maps are blocked)
 #undef TPSPP_C1
     // the first layer of the last stage: the weight of an output-channel slice in LDS, one launch per slice (132 -> 82 us at batch
     // 512).  Not 512 -> 512 on the 4x16 maps: four slices of 131 KB for ONE 128-pixel tile per workgroup measured 74 us against the

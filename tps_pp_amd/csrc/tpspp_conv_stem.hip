@@ -36,6 +36,11 @@ struct StemP {
     int N, C, H, ntiles, relu;
 };
 
+// BLK: blocked bf16 output (N, 4, H, W, 8) instead of NCHW -- when only convolutions read the map (the backbone hands TPS++ its
+// first two maps blocked when TPS++ says it takes them: tps_pp_amd/resnet_v2_large.py).  The products then run in the usual
+// orientation (D[cout][pixel]: a lane = a pixel, its registers = channels), results leave as 16-byte units through
+// v_permlane32_swap, no LDS tile.
+template <bool BLK>
 __global__ void __launch_bounds__(256, 2)
 conv_stem_bf16_kernel(const StemP P)
 {
@@ -53,6 +58,11 @@ conv_stem_bf16_kernel(const StemP P)
 #pragma unroll
     for (int t = 0; t < 9; ++t) wf[t] = __builtin_bit_cast(bf16x8, P.wt[(t * 2 + half) * BN + l31]);
     const float bias = P.bias ? P.bias[l31] : 0.0f;
+    float bq[4][4];                                          // BLK: this lane's 16 channels 8 g + 4 half + e
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[g][e] = (BLK && P.bias) ? P.bias[8 * g + 4 * half + e] : 0.0f;
     if (tid == 0) sP[kSPS] = u32x4{0u, 0u, 0u, 0u};
 
     // this thread's patch positions (fixed over the tiles)
@@ -109,8 +119,36 @@ conv_stem_bf16_kernel(const StemP P)
             for (int f = 0; f < 4; ++f) {
                 const int pos = half ? kSPS : (wv + ky) * kSPW + 32 * f + l31 + kx;
                 const bf16x8 a = __builtin_bit_cast(bf16x8, sP[pos]);
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[tap], acc[f], 0, 0, 0);
+                if constexpr (BLK) acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap], a, acc[f], 0, 0, 0);
+                else acc[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf[tap], acc[f], 0, 0, 0);
             }
+        }
+        if constexpr (BLK) {
+            // D[cout][pixel]: register 4 g + e of lane (pixel l31, half) = channel 8 g + 4 half + e; the two half-wavefronts hold
+            // the halves of a 16-byte unit
+            unsigned short* const ob = P.out + (((size_t)n * 4 * H + (y0 + wv)) * kSW) * 8;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                tpspp_u32x2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[f][4 * g + e] + bq[g][e];
+                        if (P.relu) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                    }
+                    pk[g][0] = pack2_bf16(v[0], v[1]); pk[g][1] = pack2_bf16(v[2], v[3]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const tpspp_u32x2 d0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    const tpspp_u32x2 d1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    u32x4 unit; unit[0] = d0[0]; unit[1] = d1[0]; unit[2] = d0[1]; unit[3] = d1[1];
+                    *reinterpret_cast<u32x4*>(ob + ((size_t)(g + half) * plane + 32 * f + l31) * 8) = unit;
+                }
+            }
+            continue;
         }
         // D[pixel][cout]: register 4 g + e of lane (cout l31, half) = pixel 32 f + 8 g + 4 half + e: four consecutive pixels
         unsigned* const ot = sO[wv];
@@ -144,10 +182,11 @@ conv_stem_bf16_kernel(const StemP P)
 namespace tpspp {
 
 // true when the stem kernel took the layer: 3x3 stride 1, ONE fp32 NCHW source of <= 3 channels at its own resolution, 32 output
-// channels, bf16 NCHW output, bias / ReLU only, 128 columns, rows a multiple of 4
+// channels, bf16 NCHW or blocked bf16 output, bias / ReLU only, 128 columns, rows a multiple of 4
 bool conv_stem_launch(const BParams& P, hipStream_t st)
 {
-    if (P.nsrc != 1 || P.src[0].f32 != 1 || P.src[0].lh || P.src[0].lw || P.out_f32 != 0 || P.res_mode || P.post_scale || P.relu > 1) return false;
+    if (P.nsrc != 1 || P.src[0].f32 != 1 || P.src[0].lh || P.src[0].lw || (P.out_f32 != 0 && P.out_f32 != 2) || P.res_mode || P.post_scale ||
+        P.relu > 1) return false;
     if (P.Cin > 3 || P.Cout != 32 || P.Wo != kSW || P.Wi != kSW || P.Ho != P.Hi || (P.Ho % kSTH) || P.nchunks != 1) return false;
     if ((reinterpret_cast<size_t>(P.out) | reinterpret_cast<size_t>(P.wt)) & 15) return false;
     const long nt = (long)P.N * (P.Ho / kSTH);
@@ -161,7 +200,8 @@ bool conv_stem_launch(const BParams& P, hipStream_t st)
     S.in = reinterpret_cast<const float*>(P.src[0].p); S.wt = P.wt; S.bias = P.bias; S.out = reinterpret_cast<unsigned short*>(P.out);
     S.N = P.N; S.C = P.Cin; S.H = P.Ho; S.ntiles = (int)nt; S.relu = P.relu;
     const long slots = (long)ncu * 3;
-    hipLaunchKernelGGL(conv_stem_bf16_kernel, dim3((unsigned)(nt < slots ? nt : slots)), dim3(256), 0, st, S);
+    if (P.out_f32 == 2) hipLaunchKernelGGL(conv_stem_bf16_kernel<true>, dim3((unsigned)(nt < slots ? nt : slots)), dim3(256), 0, st, S);
+    else hipLaunchKernelGGL(conv_stem_bf16_kernel<false>, dim3((unsigned)(nt < slots ? nt : slots)), dim3(256), 0, st, S);
     return true;
 }
 

@@ -508,6 +508,7 @@ class Blocked:
         self.t = t
         self.shape = (t.shape[0], t.shape[1] * 8, t.shape[2], t.shape[3])
         self.dtype, self.device = t.dtype, t.device
+        self.requires_grad, self.is_cuda = False, t.is_cuda      # (a product of the HIP inference kernels: no autograd graph)
 
     @staticmethod
     def from_nchw(x):

@@ -191,8 +191,14 @@ class ResNetABI_v2_large(nn.Module):
             # activations in HBM (also through `tpsnet`, which follows its input dtype); the feature map handed
             # to the encoder leaves the last block in fp32
             last = getattr(self, self.res_layers[-1])[-1]
-            return self._run(x, tpsnet, self._stem_bf16, lambda blk, t, inner: blk._forward_hip_bf16(
-                t, torch.float32 if blk is last else torch.bfloat16, out_blocked=inner), **kwargs)
+            # round 6: the stem's and the first stage's results are read by convolutions only when `tpsnet` is this package's
+            # TPS_PP in the 'ResNet45' wiring (its three down convolutions) -- they then stay in the blocked layout as well
+            # (the stem kernel writes it directly, the first stage's last block keeps it); same bits either way
+            blocked_outs = tpsnet is not None and getattr(tpsnet, "accepts_blocked_outs", lambda: False)() and \
+                len(self.res_layers) > 2
+            stem = (lambda t: self._stem_bf16(t, out_blocked=True)) if blocked_outs else self._stem_bf16
+            return self._run(x, tpsnet, stem, lambda blk, t, inner: blk._forward_hip_bf16(
+                t, torch.float32 if blk is last else torch.bfloat16, out_blocked=inner), blocked_stage0=blocked_outs, **kwargs)
         if self.compute_dtype == "bf16x3":
             # fp32 tensors everywhere, every convolution product the three-term bf16 split (~5e-6 per layer); a
             # `tpsnet` that should do the same needs its own compute_dtype = "bf16x3"
@@ -200,7 +206,7 @@ class ResNetABI_v2_large(nn.Module):
                              lambda blk, t, inner: blk._forward_hip_bf16(t, torch.float32, True, out_blocked=inner), **kwargs)
         return self._run(x, tpsnet, self._stem, lambda blk, t, inner: blk(t), **kwargs)
 
-    def _stem_bf16(self, x, x3=False):
+    def _stem_bf16(self, x, x3=False, out_blocked=False):
         mods = [self.conv1, self.bn1]
         key = tuple((t.data_ptr(), t._version) for m in mods for t in list(m.parameters()) + list(m.buffers()))
         name = "_cw16x3_cache" if x3 else "_cw16_cache"
@@ -211,9 +217,11 @@ class ResNetABI_v2_large(nn.Module):
                                            bn=(bn.weight, bn.bias, bn.running_mean, bn.running_var))
             cache = (key, cw)
             setattr(self, name, cache)
+        if out_blocked and not x3:
+            return ops.conv2d_bf16([x], cache[1], 1, True, out_blocked=True)
         return ops.conv2d_bf16([x], cache[1], 1, True, out_dtype=torch.float32 if x3 else torch.bfloat16)
 
-    def _run(self, x, tpsnet, stem, apply_block, **kwargs):
+    def _run(self, x, tpsnet, stem, apply_block, blocked_stage0=False, **kwargs):
         x = stem(x)
         outs = []
         outputs = None
@@ -227,7 +235,7 @@ class ResNetABI_v2_large(nn.Module):
             # the results of stages 0 / 1 are handed to `tpsnet` (with `outs`) and the last stage's to the caller: those stay
             # NCHW; the others only feed the next stage's first block, whose convolutions take the blocked layout as well
             # (its two 1x1 layers then run on tpspp_conv1x1_blk.hip)
-            hidden = 2 <= i < len(self.res_layers) - 1
+            hidden = 2 <= i < len(self.res_layers) - 1 or (i == 0 and blocked_stage0)
             for j, blk in enumerate(blocks):
                 # `inner`: nobody but this backbone's next block reads the result
                 x = apply_block(blk, x, j + 1 < len(blocks) or hidden)

@@ -585,6 +585,14 @@ class TPS_PP(nn.Module):
             "configs/textrecog/nrtr/nrtr_tps++.py produce the latter; the reference itself fails here) -- build with "
             "variant='ResNet45' / call set_variant(), or leave variant unset before loading the checkpoint")
 
+    def accepts_blocked_outs(self):
+        """Does this module take `outs[0]` / `outs[1]` as `ops.Blocked` bf16 maps?  Only the 'ResNet45' wiring on the HIP inference
+        path, where nothing but the three down convolutions reads them (`_regress_hip_bf16`): our own backbone then keeps its
+        first two maps in the layout its convolutions exchange (resnet_v2_large.py: `_run`; round 6).  A foreign backbone hands
+        over NCHW tensors as the reference does; both give the same bits."""
+        return (self.type == "ResNet45" and not self.training and self.compute_dtype != "bf16x3"
+                and getattr(self, "_stage_tap", None) is None)
+
     def _bf16(self, batch_img):
         """bf16 compute when the caller hands over bf16 activations or sets `compute_dtype`.  The module's
         own parameters and TPS constants stay fp32 (`module.bfloat16()` would round `hat_C`, whose entries
