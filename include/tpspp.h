@@ -664,6 +664,14 @@ int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T, int d_inner
                            float* out, int* tokens_out, int* status_out, int flags, tpspp_stream_t stream);
 
 /*
+ * Layout change between bf16 convolutions and the sampler: in_blocked (N, C/8, HW, 8) bf16 (tpspp_conv2d_bf16_fwd's layout
+ * code 2) -> out_nchw (N, C, HW) bf16.  C % 8 == 0, HW % 64 == 0, 16-byte aligned tensors.  Same values.
+ * (The bf16 backbone's second stage ends on the persistent blocked kernel; the warp reads channel planes.)
+ * replaces nothing in the reference (its maps are NCHW throughout).
+ */
+int tpspp_blocked_to_nchw_bf16(const void* in_blocked, int N, int C, int HW, void* out_nchw, tpspp_stream_t stream);
+
+/*
  * AttnConvertor.tensor2idx on the device: scores (N, L, C) fp32 (the decoder's per-step soft-max scores, or any tensor of
  * that shape) -> per position the maximum (val_out (N, L)) and its first index, torch.max's tie and NaN rules; idx_out (N, L)
  * int32 holds that index where the reference's scan KEEPS the character -- position before the image's first end_idx and

@@ -696,3 +696,14 @@ def test_backbone_hands_tpspp_blocked_maps_with_the_same_bits(cuda):
     assert torch.equal(got["output"].view(torch.int32), want["output"].view(torch.int32))
     assert torch.equal(got["img_ref"].view(torch.int16), want["img_ref"].view(torch.int16))
     assert torch.isfinite(got["output"]).all()
+
+
+def test_blocked_to_nchw_kernel(cuda):
+    """`tpspp_blocked_to_nchw_bf16` (`ops.Blocked.nchw_hip`) = the PyTorch permutation, bit for bit; ragged sizes."""
+    for n, c, h, w in ((3, 64, 16, 64), (1, 8, 8, 8), (5, 32, 4, 16), (2, 256, 8, 32)):
+        g = torch.Generator(device="cpu").manual_seed(n + c)
+        x = torch.randn((n, c, h, w), generator=g).to(cuda).bfloat16()
+        b = ops.Blocked.from_nchw(x)
+        got = b.nchw_hip()
+        assert got.dtype == torch.bfloat16 and torch.equal(got.view(torch.int16), x.view(torch.int16))
+        assert got._tpspp_blocked is b

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "tpspp_nrtr_encoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, ctypes.c_size_t, _f, _f, _i, _f], _i),
     "tpspp_nrtr_decoder_fwd": ([_f, _i, _i, _i, _i, _i, _f, _i, _f, _f, _i, _f, _f, _f, _i, _i, _i, _i, _f, _f,
                                 _f, ctypes.c_size_t, _f, _f, _f, _i, _f], _i),
+    "tpspp_blocked_to_nchw_bf16": ([_f, _i, _i, _i, _f, _f], _i),
     "tpspp_attn_tensor2idx_fwd": ([_f, _i, _i, _i, _i, _i, _f, _f, _f], _i),
 }
 

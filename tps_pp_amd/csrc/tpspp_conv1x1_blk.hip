@@ -187,3 +187,50 @@ bool conv1x1_blk_launch(const BParams& P, hipStream_t st)
 }
 
 }  // namespace tpspp
+
+// ---- blocked bf16 (N, C/8, HW, 8) -> NCHW bf16 (N, C, HW) (round 6) -----------------------------------------------------------
+// For the one map of the bf16 backbone that both convolutions and the sampler read (the second stage's result: TPS++'s down2
+// takes the blocked form, the warp needs channel planes): the 3x3 layer that produces it runs on the persistent kernel (blocked
+// output, 52 us against 115 us for the tiled kernel's NCHW epilogue) and this copy makes the planes (67 MB in, 67 MB out).
+// A wavefront moves 64 pixels of one channel group: 64 units of 16 bytes in (1 KB contiguous), through its own 1-KB LDS tile, out
+// as eight 16-byte pieces per channel plane (128 contiguous bytes per plane).
+namespace {
+__global__ void __launch_bounds__(256)
+blocked_to_nchw_bf16_kernel(const u32x4* __restrict__ in, unsigned short* __restrict__ out, int CG, int HW, long nseg)
+{
+    __shared__ unsigned short tile[4][64 * 8 + 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long seg = (long)blockIdx.x * 4 + wv;                // (image, channel group, 64-pixel segment)
+    if (seg >= nseg) return;
+    const int spp = HW / 64;                                   // segments per plane
+    const long plane_id = seg / spp;                           // n * CG + cg
+    const int p0 = (int)(seg - plane_id * spp) * 64;
+    const u32x4 u = in[plane_id * HW + p0 + lane];
+    unsigned short* t = tile[wv];
+    *reinterpret_cast<u32x4*>(t + lane * 8) = u;               // [pixel][8 channels]
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the tile is private to the wavefront)
+    const int c = lane >> 3, chunk = lane & 7;                 // this lane: channel c of the group, pixels 8 chunk .. 8 chunk + 7
+    unsigned v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = (unsigned)t[(8 * chunk + 2 * i) * 8 + c] | ((unsigned)t[(8 * chunk + 2 * i + 1) * 8 + c] << 16);
+    const long n = plane_id / CG;
+    const int cg = (int)(plane_id - n * CG);
+    unsigned short* o = out + ((n * CG + cg) * 8 + c) * (long)HW + p0 + 8 * chunk;
+    *reinterpret_cast<u32x4*>(o) = u32x4{v[0], v[1], v[2], v[3]};
+}
+}  // namespace
+
+TPSPP_EXPORT int tpspp_blocked_to_nchw_bf16(const void* in_blocked, int N, int C, int HW, void* out_nchw, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(in_blocked && out_nchw && N >= 0 && C > 0 && HW > 0, "tpspp_blocked_to_nchw_bf16: bad argument");
+    TPSPP_REQUIRE(C % 8 == 0 && HW % 64 == 0, "tpspp_blocked_to_nchw_bf16: channels a multiple of 8, pixels per plane a multiple of 64");
+    TPSPP_REQUIRE(((reinterpret_cast<size_t>(in_blocked) | reinterpret_cast<size_t>(out_nchw)) & 15) == 0,
+                  "tpspp_blocked_to_nchw_bf16: 16-byte aligned tensors");
+    if (N == 0) return TPSPP_OK;
+    const long nseg = (long)N * (C / 8) * (HW / 64);
+    TPSPP_REQUIRE((nseg + 3) / 4 <= 0x7fffffffL, "tpspp_blocked_to_nchw_bf16: too large");
+    hipLaunchKernelGGL(blocked_to_nchw_bf16_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, tpspp::as_stream(stream),
+                       reinterpret_cast<const u32x4*>(in_blocked), reinterpret_cast<unsigned short*>(out_nchw), C / 8, HW, nseg);
+    return tpspp::check_launch("tpspp_blocked_to_nchw_bf16");
+}

@@ -519,6 +519,20 @@ class Blocked:
         n, c, h, w = self.shape
         return self.t.permute(0, 1, 4, 2, 3).reshape(n, c, h, w).contiguous()
 
+    def nchw_hip(self):
+        """`tpspp_blocked_to_nchw_bf16`: the same tensor as `nchw()` by a HIP kernel (the product path; `nchw()` is a
+        PyTorch composition for tests and edges); the result remembers its blocked twin (`_tpspp_blocked`) so that a
+        convolution further on can take the cheaper source."""
+        n, c, h, w = self.shape
+        if not self.t.is_cuda or (h * w) % 64:
+            raise _lib.TpsppError("Blocked.nchw_hip: needs a GPU tensor with H * W a multiple of 64 (no CPU fallback)")
+        out = torch.empty((n, c, h, w), device=self.t.device, dtype=torch.bfloat16)
+        with torch.cuda.device(self.t.device):
+            rc = _lib.lib().tpspp_blocked_to_nchw_bf16(self.t.data_ptr(), n, c, h * w, out.data_ptr(), _stream(self.t))
+        _lib.check(rc, "tpspp_blocked_to_nchw_bf16")
+        out._tpspp_blocked = self
+        return out
+
     def data_ptr(self):
         return self.t.data_ptr()
 

@@ -235,10 +235,15 @@ class ResNetABI_v2_large(nn.Module):
             # the results of stages 0 / 1 are handed to `tpsnet` (with `outs`) and the last stage's to the caller: those stay
             # NCHW; the others only feed the next stage's first block, whose convolutions take the blocked layout as well
             # (its two 1x1 layers then run on tpspp_conv1x1_blk.hip)
-            hidden = 2 <= i < len(self.res_layers) - 1 or (i == 0 and blocked_stage0)
+            # (blocked_stage0, round 6: TPS++ takes blocked maps -- stage 0's result stays blocked; stage 1's last 3x3 runs on the
+            # persistent blocked kernel as well and its result is brought to NCHW planes for the sampler by one copy kernel,
+            # remembering its blocked twin for TPS++'s down2)
+            hidden = 2 <= i < len(self.res_layers) - 1 or (i <= 1 and blocked_stage0)
             for j, blk in enumerate(blocks):
                 # `inner`: nobody but this backbone's next block reads the result
                 x = apply_block(blk, x, j + 1 < len(blocks) or hidden)
+            if i == 1 and blocked_stage0 and isinstance(x, ops.Blocked):
+                x = x.nchw_hip()
         return {"output": x, "img_ref": outputs.get("output", None) if outputs is not None else None}
 
     def _forward_torch(self, x, tpsnet=None, **kwargs):

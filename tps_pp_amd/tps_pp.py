@@ -530,7 +530,9 @@ class TPS_PP(nn.Module):
             if feat0 is not None:
                 cat_srcs = [c16([feat0], cw["down0_1"], 2, **blk), c16([feat1], cw["down1_1"], 2, **blk), feat2]
         else:
-            cat_srcs = [c16([o0], cw["down0"], 2, **blk), c16([o1], cw["down1"], 1, **blk), c16([x], cw["down2"], 1, **blk)]
+            # (x may carry its blocked twin -- our backbone's second stage ends on the blocked kernel: ops.Blocked.nchw_hip)
+            xb = x if x3 else getattr(x, "_tpspp_blocked", x)
+            cat_srcs = [c16([o0], cw["down0"], 2, **blk), c16([o1], cw["down1"], 1, **blk), c16([xb], cw["down2"], 1, **blk)]
             feat_grid = x
         p = self.MSFA.conv.stride
         tap = self._tap
