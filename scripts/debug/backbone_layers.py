@@ -8,12 +8,15 @@ dev = torch.device("cuda:0"); N = 512
 torch.manual_seed(0)
 bb = P.build_backbone(dict(type="ResNetABI_v2_large", arch_settings=[3, 4, 6, 6, 3], strides=[2, 1, 2, 1, 2])).eval().to(dev)
 tps = P.TPS_PP(variant="ResNet45").eval().to(dev)
-bb.compute_dtype = torch.bfloat16
+mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+bb.compute_dtype = torch.bfloat16 if mode == "bf16" else "bf16x3"
+if mode != "bf16":
+    tps.compute_dtype = "bf16x3"
 img = torch.rand(N, 3, 32, 128, device=dev) * 2 - 1
 orig = ops.conv2d_bf16
 rows = []
 def lay(t):
-    return "blk" if isinstance(t, ops.Blocked) else ("f32" if t.dtype == torch.float32 else "b16")
+    return ("blk32" if isinstance(t, ops.Blocked32) else "blk") if isinstance(t, ops.Blocked) else ("f32" if t.dtype == torch.float32 else "b16")
 def wrapped(srcs, cw, stride=(1, 1), relu=True, residual=None, res_mode=0, out_dtype=torch.bfloat16, out_blocked=False):
     f = lambda: orig(srcs, cw, stride, relu, residual, res_mode, out_dtype, out_blocked)
     out = f(); torch.cuda.synchronize()
