@@ -88,8 +88,16 @@ conv3_wide_kernel(const BParams P)
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int ph = wv & 1, ch = wv >> 1;                       // pixel half, channel half of the 256 x 128 workgroup tile
-    const int ctile = 2 * (int)blockIdx.x + ch;                // 64-channel tile of the arranged weight
-    const int n0 = (int)blockIdx.y * NI;
+    // block -> (image group, 128-channel tile), XCD-aware: blocks are dealt to the 8 XCDs round-robin, and the CT workgroups
+    // that share an image group's patch should share an L2 -- block L = 8 (CT q + t) + x is tile t of image group 8 q + x, so the
+    // CT readers of a patch are the blocks x, x + 8, ... of one XCD (PMC, 512 -> 512 @4x16: 179 MB fetched per launch with the
+    // tiles of a group on four XCDs, against 72 MB algorithmic)
+    const int CT = P.Cout >> 7;
+    const int L = (int)blockIdx.x, xq = L >> 3;
+    const int grp = (xq / CT) * 8 + (L & 7), t128 = xq % CT;
+    const int ctile = 2 * t128 + ch;                           // 64-channel tile of the arranged weight
+    const int n0 = grp * NI;
+    if (n0 >= P.N) return;                                     // (the last group of eight may be incomplete; uniform per block)
     const int nchunks = P.nchunks;                             // even (checked by the launcher)
     const int HW = TH * TW;
     const int CG = P.Cin >> 3;                                 // channel groups of the source
@@ -302,8 +310,10 @@ conv3_wide_kernel(const BParams P)
 template <int TH, int TW, int NI>
 bool launch_w(const BParams& P, hipStream_t st)
 {
-    const dim3 grid((unsigned)(P.Cout / 128), (unsigned)((P.N + NI - 1) / NI));
-    if (grid.y > 65535u) return false;
+    const long groups = (P.N + NI - 1) / NI;
+    const long blocks = ((groups + 7) / 8) * 8 * (P.Cout / 128);     // (see the kernel: block -> (image group, channel tile))
+    if (blocks > 0x7fffffffL) return false;
+    const dim3 grid((unsigned)blocks);
 #ifdef TPSPP_WIDE_LAB
     if (const char* lv = getenv("TPSPP_WIDE_LAB")) {
         switch (atoi(lv)) {
