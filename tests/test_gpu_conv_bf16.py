@@ -707,3 +707,32 @@ def test_blocked_to_nchw_kernel(cuda):
         got = b.nchw_hip()
         assert got.dtype == torch.bfloat16 and torch.equal(got.view(torch.int16), x.view(torch.int16))
         assert got._tpspp_blocked is b
+
+
+@pytest.mark.parametrize("name,cin,cout,H,W,relu,f32_out,N", [
+    ("layer5 first 256->512 @8x32", 256, 512, 8, 32, True, False, 37),
+    ("layer4 256->256 @8x32, full machine", 256, 256, 8, 32, True, False, 515),
+    ("layer5 512->512 @4x16, ragged group of eight", 512, 512, 4, 16, True, False, 530),
+    ("512->512 @4x16, fp32 NCHW out, no relu, two images", 512, 512, 4, 16, False, True, 2),
+])
+def test_conv1x1_wide_kernel_is_the_tiled_kernel_bit_for_bit(cuda, name, cin, cout, H, W, relu, f32_out, N):
+    """The wide-tile kernel's 1x1 form (tpspp_conv3_wide.hip, KS = 1: 32-channel chunks, two k-steps per chunk, the weight three
+    k-steps ahead) for the 1x1 layers with >= 256 input channels, against the tiled kernel (tpspp_conv_set_tuning(6): neither the
+    wide kernels nor the blocked 1x1 kernel): the same bits."""
+    from tps_pp_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + N)
+    x = torch.randn((N, cin, H, W), generator=g)
+    w = torch.randn((cout, cin, 1, 1), generator=g) / np.sqrt(cin)
+    b = torch.randn((cout,), generator=g) * 0.2
+    xb = ops.Blocked.from_nchw(x.to(cuda))
+    cw = ops.prep_conv_weight_bf16(w.to(cuda), conv_bias=b.to(cuda))
+    kw = {"out_dtype": torch.float32} if f32_out else {"out_blocked": True}
+    raw = (lambda o: o.view(torch.int32)) if f32_out else (lambda o: o.t.view(torch.int16))
+    try:
+        _lib.lib().tpspp_conv_set_tuning(6)
+        want = raw(ops.conv2d_bf16([xb], cw, 1, relu=relu, **kw)).clone()
+    finally:
+        _lib.lib().tpspp_conv_set_tuning(0)
+    for _ in range(2):
+        got = ops.conv2d_bf16([xb], cw, 1, relu=relu, **kw)
+        assert torch.equal(raw(got), want)

@@ -41,8 +41,14 @@
 
 namespace {
 
-constexpr int kGKG = 2;                          // channel groups of 8 per 16-channel chunk
-constexpr int kGSlab = 9 * kGKG * BN;            // 16-byte units of a (cout tile, chunk) slab: 1152
+// KS = 3: a chunk is 16 channels (2 groups of 8) x 9 taps, one 16-deep k-step per tap; KS = 1 (round 6, late: the 1x1 layers of
+// the last stage): a chunk is 32 channels (4 groups) = 2 k-steps, no halo.  Either way step u of chunk c is k-step c U + u of the
+// whole sum and its A fragments sit 128 (c U + u) units into the cout tile's arranged weight.
+template <int KS> struct WK {
+    static constexpr int U = KS == 3 ? 9 : 2;        // inner steps (matrix k-steps) per chunk
+    static constexpr int KG = KS == 3 ? 2 : 4;       // channel groups of 8 per chunk
+    static constexpr int PD = KS == 3 ? 5 : 3;       // k-steps the weight loads run ahead; ring of PD + 1 slots divides 2 U
+};
 // (PD = taps the weight loads run ahead of their use; ring of PD + 1 register slots, PD + 1 dividing the 18 taps of an
 // unrolled chunk pair: 5 -> 6 slots, 8 -> 9 slots)
 constexpr int kGNB = 3;                          // patch buffers
@@ -56,9 +62,10 @@ __device__ __forceinline__ void wdma16(const void* g, unsigned lds_byte)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory", "m0");
 }
 
-template <int TH, int TW, int NI>
+template <int TH, int TW, int NI, int KS = 3>
 struct WCfg {
-    static constexpr int PH = TH + 2, PW = TW + 2, PS = PH * PW, PSN = NI * PS;
+    static constexpr int kGKG = WK<KS>::KG;
+    static constexpr int PH = TH + KS - 1, PW = TW + KS - 1, PS = PH * PW, PSN = NI * PS;
     static constexpr int NPI = (PSN + kWave - 1) / kWave;      // DMA instructions per channel group
     static constexpr int NDMA = kGKG * NPI;                     // per chunk
     static constexpr int MAXJ = (NDMA + 3) / 4;                 // per wavefront and chunk
@@ -74,14 +81,16 @@ struct WCfg {
 // LAB (timing experiments only, TPSPP_WIDE_LAB in the environment; results are WRONG for LAB != 0): bit 0 no barrier per chunk,
 // bit 1 no weight loads inside the loop, bit 2 no DMA inside the loop, bit 3 no epilogue stores / residual loads, bit 4 the
 // weight loads re-read the same 8 KB (L1 hits); TPSPP_WIDE_LAB=108: the product kernel with the weight loads 8 taps ahead
-template <int TH, int TW, int NI, int EPI, int kGPD, int LAB = 0>
+template <int TH, int TW, int NI, int EPI, int kGPD, int LAB = 0, int KS = 3>
 __global__ void __launch_bounds__(256, 2)
 conv3_wide_kernel(const BParams P)
 {
-    using Cfg = WCfg<TH, TW, NI>;
+    using Cfg = WCfg<TH, TW, NI, KS>;
     constexpr int PW = Cfg::PW, PS = Cfg::PS, PSN = Cfg::PSN, NPI = Cfg::NPI, MAXJ = Cfg::MAXJ, BUFU = Cfg::BUFU, HS = Cfg::HS;
+    constexpr int kGKG = Cfg::kGKG, U = WK<KS>::U;
     constexpr int kGRing = kGPD + 1;
-    static_assert(18 % kGRing == 0, "the ring must turn a whole number of times per unrolled chunk pair");
+    constexpr int DPS = (MAXJ + U - 1) / U;                     // DMA instructions a wavefront issues per inner step
+    static_assert((2 * U) % kGRing == 0, "the ring must turn a whole number of times per unrolled chunk pair");
     __shared__ u32x4 sB[kGNB * BUFU];
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -116,7 +125,7 @@ conv3_wide_kernel(const BParams P)
         const int e = start + lane;
         const int im = e / PS, r = e - im * PS;
         const int py = r / PW, px = r - py * PW;
-        const int iy = py - 1, ix = px - 1, n = n0 + im;
+        const int iy = py - (KS - 1) / 2, ix = px - (KS - 1) / 2, n = n0 + im;
         dok[i] = j < Cfg::NDMA && n < P.N && iy >= 0 && iy < TH && ix >= 0 && ix < TW;
         dsrc[i] = reinterpret_cast<const char*>(reinterpret_cast<const u32x4*>(P.src[0].p) +
                                                 ((size_t)(dok[i] ? n : 0) * CG + g) * HW + (dok[i] ? iy * TW + ix : 0));
@@ -145,8 +154,8 @@ conv3_wide_kernel(const BParams P)
     }
     // the weight stream of this wavefront: slab (ctile, chunk) follows (ctile, chunk - 1): tap T of the whole sum is at
     // wA[128 T + 32 h2] (units)
-    const u32x4* const wA = P.wt + (size_t)ctile * nchunks * kGSlab + half * BN + l31;
-    const int taps_total = nchunks * 9;
+    const u32x4* const wA = P.wt + (size_t)ctile * nchunks * (U * 2 * BN) + half * BN + l31;
+    const int taps_total = nchunks * U;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -179,15 +188,19 @@ conv3_wide_kernel(const BParams P)
             const u32x4* const pb = sB + (c % kGNB) * BUFU;
             auto fetch_b = [&](int tap, int slot) {
                 const int ky = tap / 3, kx = tap - ky * 3;
+                const int boff = KS == 3 ? ky * PW + kx : tap * 2 * HS;      // (1x1: k-step `tap` reads channel groups 2 tap, 2 tap + 1)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) fb[slot][f] = __builtin_bit_cast(bf16x8, pb[fpos[f] + ky * PW + kx]);
+                for (int f = 0; f < 4; ++f) fb[slot][f] = __builtin_bit_cast(bf16x8, pb[fpos[f] + boff]);
             };
             fetch_b(0, 0);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int tl = cc * 9 + tap;                      // tap of the unrolled pair: ring slot tl % kGRing (compile time)
-                const int T = c * 9 + tap;
-                if (tap < MAXJ && more) dma_one(c + 2, tap);
+            for (int tap = 0; tap < U; ++tap) {
+                const int tl = cc * U + tap;                      // step of the unrolled pair: ring slot tl % kGRing (compile time)
+                const int T = c * U + tap;
+                if (more) {
+#pragma unroll
+                    for (int i = tap * DPS; i < (tap + 1) * DPS && i < MAXJ; ++i) dma_one(c + 2, i);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(LAB & 2)) {   // the weight fragments of tap T + kGPD -> the slot tap T - 1 has just freed
                     const int Tn = T + kGPD;
@@ -196,7 +209,7 @@ conv3_wide_kernel(const BParams P)
                     fa[(tl + kGPD) % kGRing][0] = wA[(size_t)Tc * 128];
                     fa[(tl + kGPD) % kGRing][1] = wA[(size_t)Tc * 128 + 32];
                 }
-                if (tap + 1 < 9) fetch_b(tap + 1, (tap + 1) & 1);
+                if (tap + 1 < U) fetch_b(tap + 1, (tap + 1) & 1);
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[tl % kGRing][0]);
                 const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[tl % kGRing][1]);
 #pragma unroll
@@ -307,14 +320,16 @@ conv3_wide_kernel(const BParams P)
     }
 }
 
-template <int TH, int TW, int NI>
+template <int TH, int TW, int NI, int KS = 3>
 bool launch_w(const BParams& P, hipStream_t st)
 {
     const long groups = (P.N + NI - 1) / NI;
     const long blocks = ((groups + 7) / 8) * 8 * (P.Cout / 128);     // (see the kernel: block -> (image group, channel tile))
     if (blocks > 0x7fffffffL) return false;
     const dim3 grid((unsigned)blocks);
+    constexpr int PD = WK<KS>::PD;
 #ifdef TPSPP_WIDE_LAB
+    if constexpr (KS == 3) {
     if (const char* lv = getenv("TPSPP_WIDE_LAB")) {
         switch (atoi(lv)) {
         case 1: hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 1, 5, 1>), grid, dim3(256), 0, st, P); return true;
@@ -330,14 +345,15 @@ bool launch_w(const BParams& P, hipStream_t st)
         default: break;
         }
     }
+    }
 #endif
     if (P.out_f32 == 1) {
-        if (P.res_mode) hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 3, 5>), grid, dim3(256), 0, st, P);
-        else hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 2, 5>), grid, dim3(256), 0, st, P);
+        if (P.res_mode) hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 3, PD, 0, KS>), grid, dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 2, PD, 0, KS>), grid, dim3(256), 0, st, P);
         return true;
     }
-    if (P.res_mode) hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 1, 5>), grid, dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 0, 5>), grid, dim3(256), 0, st, P);
+    if (P.res_mode) hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 1, PD, 0, KS>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((conv3_wide_kernel<TH, TW, NI, 0, PD, 0, KS>), grid, dim3(256), 0, st, P);
     return true;
 }
 
@@ -355,6 +371,23 @@ bool conv3_wide_launch(const BParams& P, hipStream_t st)
     if (P.Ho != P.Hi || P.Wo != P.Wi) return false;
     if (P.Ho == 8 && P.Wo == 32) return launch_w<8, 32, 1>(P, st);
     if (P.Ho == 4 && P.Wo == 16) return launch_w<4, 16, 4>(P, st);
+    return false;
+}
+
+// the same kernel for 1x1 layers (KS = 1: 32-channel chunks, no halo), where it measures faster than the blocked 1x1 kernel
+// (tpspp_conv1x1_blk.hip: whole weight in LDS) or that kernel's weight does not fit: Cin >= 256 -- 256 -> 256 44 -> 33 us,
+// 256 -> 512 133 (tiled) / 82 (sliced) -> 53 us on 8x32 maps, 512 -> 512 on 4x16 maps 55 (tiled) -> 25 us at batch 512; the
+// 128-channel layers measure the same on both and stay where they were.  Stride 1, one blocked source, Cin a multiple of 64,
+// Cout a multiple of 128, blocked bf16 or fp32 NCHW output
+bool conv1x1_wide_launch(const BParams& P, hipStream_t st)
+{
+    if (P.nsrc != 1 || P.src[0].f32 != 2 || P.src[0].lh || P.src[0].lw || (P.out_f32 != 2 && P.out_f32 != 1) || P.post_scale || P.relu > 1) return false;
+    static const bool all = getenv("TPSPP_C1X1_WIDE_ALL") != nullptr;        // (lab: every qualifying 1x1 layer, not only Cin >= 256)
+    if ((P.Cin % 64) || (P.Cout % 128) || P.src[0].C != P.Cin || (P.Cin < 256 && !all)) return false;
+    if (P.res_mode && P.res_f32 != 2) return false;
+    if (P.Ho != P.Hi || P.Wo != P.Wi) return false;
+    if (P.Ho == 8 && P.Wo == 32) return launch_w<8, 32, 1, 1>(P, st);
+    if (P.Ho == 4 && P.Wo == 16) return launch_w<4, 16, 4, 1>(P, st);
     return false;
 }
 

@@ -102,6 +102,9 @@ TPSPP_EXPORT int tpspp_conv2d_bf16_fwd(const void* const* src_ptrs, const int* s
     // the big blocked 3x3 layers: persistent, LDS-DMA-fed kernel (tpspp_conv_bf16_persist.hip); bit-identical results
     if (!split3 && KH == 3 && !tpspp::g_conv_bf16_no_persist && tpspp::conv_bf16_persist_launch(P, sh, sw, st))
         return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
+    // 1x1 layers with >= 256 input channels between blocked maps: the wide-tile kernel's 1x1 form (tpspp_conv3_wide.hip)
+    if (!split3 && KH == 1 && sh == 1 && sw == 1 && !tpspp::g_conv_bf16_no_wide && tpspp::conv1x1_wide_launch(P, st))
+        return tpspp::check_launch("tpspp_conv2d_bf16_fwd");
     // 1x1 layers between blocked maps (the backbone's BasicBlocks): every activation read once, the weight in LDS
     // (tpspp_conv1x1_blk.hip); bit-identical results
     if (!split3 && KH == 1 && sh == 1 && sw == 1 && !tpspp::g_conv_bf16_no_persist && tpspp::conv1x1_blk_launch(P, st))

@@ -642,6 +642,7 @@ bool conv1x1_blk_launch(const BParams& P, hipStream_t st);
 // defined in tpspp_conv3_wide.hip: 3x3 stride-1 layers with >= 128 output channels between blocked maps (128 x 64 wavefront
 // tiles, weights streamed from L2 into registers); false when it does not apply
 bool conv3_wide_launch(const BParams& P, hipStream_t st);
+bool conv1x1_wide_launch(const BParams& P, hipStream_t st);   // the same kernel for the 1x1 layers with >= 256 input channels
 // defined in tpspp_conv_stem.hip: the backbone's stem (3x3, <= 3 fp32 input channels -> 32 bf16 NCHW); false when it does not apply
 bool conv_stem_launch(const BParams& P, hipStream_t st);
 extern int g_conv_bf16_no_persist;           // tpspp_conv_set_tuning bit 1
