@@ -643,22 +643,24 @@ def main():
         torch.cuda.synchronize(dev)
         return max(b.elapsed_time(e) for e in e1 for b in e0), time.perf_counter() - t0
 
-    def best_of(nstreams, first):
-        """`repeats` timed regions of exactly `steps` steps each (barrier + synchronize before each); the fastest counts.
-        A 20-step region is 0.2 ms: one region alone is at the mercy of the queues' wake-up after the synchronize."""
-        res = []
-        for r in range(R):
-            barrier()
-            res.append(timed(a.steps, nstreams, first + r * a.steps))
-        return res
-
     for i in range(a.warmup):
         step(i)
+    # `repeats` timed regions of exactly `steps` steps per protocol (barrier + synchronize before each).  A 20-step region is
+    # 0.2 ms: one region alone is at the mercy of the queues' wake-up after the synchronize.
     R = a.repeats if a.repeats > 0 else (5 if a.steps <= 200 else 1)
-    reg_m = best_of(S, a.warmup)
-    # the same steps with every launch behind the previous one (one stream): what a kernel trace shows as the
-    # kernel's own duration
-    reg_1 = best_of(1, a.warmup) if S > 1 else reg_m
+    # Round 6: the two protocols' regions are INTERLEAVED (S-stream region r, then one-stream region r, r = 0 .. R - 1) instead of
+    # all S-stream regions first: on some boxes of the pool the first regions after the warm-up steps are measurably slower than
+    # the later ones (r06: 9.88, 9.48, 9.24, 9.03, 9.08 us over five consecutive one-stream regions), and the protocol that ran
+    # first carried all of that.  Same regions, same estimator (median per protocol), neither protocol favoured.
+    reg_m, reg_1 = [], []
+    for r in range(R):
+        barrier()
+        reg_m.append(timed(a.steps, S, a.warmup + 2 * r * a.steps))
+        if S > 1:
+            barrier()
+            reg_1.append(timed(a.steps, 1, a.warmup + (2 * r + 1) * a.steps))
+    if S == 1:
+        reg_1 = reg_m
     # a region's time is the MAX over ranks (every rank times the same R regions behind the same barriers); the
     # estimator is then the fastest region, with the median and every region's time reported beside it
     tt = torch.tensor([[list(x) for x in reg_m], [list(x) for x in reg_1]], device=dev, dtype=torch.float64)   # (2, R, 2)
@@ -770,6 +772,7 @@ def main():
                                         "trace shows as the kernel's duration + launch gap); roofline.multi_stream_* = overlapped "
                                         "launches (period between launches); `wall_ms_per_step` = host clock incl. the synchronize",
                        "ms_per_step_min_over_ranks": ev_ms_min / a.steps,
+                       "region_order": "interleaved" if S > 1 else "one protocol",
                        "preconditioning": f"{a.precondition_ms:.0f} ms of plain device copies over the bench buffers "
                                           "before the warm-up steps (clock ramp; not steps)"},
             "max_abs_err_vs_oracle": max_err,

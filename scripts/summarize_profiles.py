@@ -118,6 +118,16 @@ def line_regions(bench):
     return max(tried), rf.get("multi_stream", {}).get("regions_us"), rf.get("one_stream", {}).get("regions_us")
 
 
+def region_sequence(bench, S, R):
+    """(streams, region index) of every timed region in DISPATCH order: round 6 interleaves the protocols (config.region_order),
+    earlier lines ran all S-stream regions first."""
+    if S <= 1:
+        return [(S, r) for r in range(R)]
+    if bench.get("config", {}).get("region_order") == "interleaved":
+        return [(st, r) for r in range(R) for st in (S, 1)]
+    return [(S, r) for r in range(R)] + [(1, r) for r in range(R)]
+
+
 def protocol_rows(sub, logname):
     """Per-protocol aggregates (streams, dispatches, total, average, min, max, sorted periods) of the warp kernel in one traced
     bench run -- the same split as protocol_tables(), without the per-dispatch file."""
@@ -132,19 +142,16 @@ def protocol_rows(sub, logname):
     steps, warm, R = bench["steps"], bench["warmup"], int(bench["config"].get("repeats", 1))
     S, _, _ = line_regions(bench)
     rows = timeline(pth, KERNEL, steps)
-    lo, agg = warm, []
-    for streams in ([S, 1] if S > 1 else [S]):
-        durs, periods = [], []
-        for reg in range(R):
-            sel = rows[lo:lo + steps]
-            if len(sel) < steps:
-                break
-            lo += steps
-            durs += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
-            periods.append((max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)) / len(sel))
-        if durs:
-            agg.append((streams, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs), sorted(periods)))
-    return agg
+    lo, per = warm, collections.OrderedDict()
+    for streams, reg in region_sequence(bench, S, R):
+        sel = rows[lo:lo + steps]
+        if len(sel) < steps:
+            break
+        lo += steps
+        durs, periods = per.setdefault(streams, ([], []))
+        durs += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
+        periods.append((max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)) / len(sel))
+    return [(streams, len(d), sum(d), sum(d) / len(d), min(d), max(d), sorted(p)) for streams, (d, p) in per.items() if d]
 
 
 def protocol_tables():
@@ -167,19 +174,18 @@ def protocol_tables():
     lo, out, agg = warm, [], []
     for i, r in enumerate(rows[:warm]):
         out.append(("warmup", S, -1, i, r))
-    for streams in ([S, 1] if S > 1 else [S]):
-        durs, periods = [], []
-        for reg in range(R):
-            sel = rows[lo:lo + steps]
-            if len(sel) < steps:
-                break
-            for i, r in enumerate(sel):
-                out.append(("timed", streams, reg, lo + i, r))
-            lo += steps
-            durs += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
-            periods.append((max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)) / len(sel))
-        if durs:
-            agg.append((streams, len(durs), sum(durs), sum(durs) / len(durs), min(durs), max(durs), sorted(periods)))
+    per = collections.OrderedDict()
+    for streams, reg in region_sequence(bench, S, R):
+        sel = rows[lo:lo + steps]
+        if len(sel) < steps:
+            break
+        for i, r in enumerate(sel):
+            out.append(("timed", streams, reg, lo + i, r))
+        lo += steps
+        durs, periods = per.setdefault(streams, ([], []))
+        durs += [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
+        periods.append((max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)) / len(sel))
+    agg = [(streams, len(d), sum(d), sum(d) / len(d), min(d), max(d), sorted(p)) for streams, (d, p) in per.items() if d]
     for i, r in enumerate(rows[lo:]):
         out.append(("after", 1, -1, lo + i, r))
     with open(os.path.join(DST, f"{TAG}_bench_dispatches.csv"), "w", newline="") as f:
@@ -213,23 +219,21 @@ def timeline_summary():
         R = int(bench["config"].get("repeats", 1))
         S, reg_m, reg_1 = line_regions(bench)
         rows = timeline(pth, KERNEL, steps)
-        protos = [(S, reg_m)]
-        if S > 1:
-            protos.append((1, reg_1))
+        regs_of = {S: reg_m, 1: reg_1 if S > 1 else reg_m}
         lo = warm
         out = []
-        for streams, regs_us in protos:
-            for r in range(R):
-                sel = rows[lo:lo + steps]
-                lo += steps
-                if len(sel) < steps:
-                    break
-                dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
-                span = max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)
-                queues = sorted({x.get("Queue_Id", "?") for x in sel})
-                overlap = sum(1 for p, q in zip(sel, sel[1:]) if int(q["Start_Timestamp"]) < int(p["End_Timestamp"]))
-                out.append((streams, r, len(sel), sum(dur) / len(dur) / 1e3, span / len(sel) / 1e3, len(queues), overlap,
-                            regs_us[r] if regs_us and r < len(regs_us) else None))
+        for streams, r in region_sequence(bench, S, R):
+            regs_us = regs_of[streams]
+            sel = rows[lo:lo + steps]
+            lo += steps
+            if len(sel) < steps:
+                break
+            dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel]
+            span = max(int(x["End_Timestamp"]) for x in sel) - min(int(x["Start_Timestamp"]) for x in sel)
+            queues = sorted({x.get("Queue_Id", "?") for x in sel})
+            overlap = sum(1 for p, q in zip(sel, sel[1:]) if int(q["Start_Timestamp"]) < int(p["End_Timestamp"]))
+            out.append((streams, r, len(sel), sum(dur) / len(dur) / 1e3, span / len(sel) / 1e3, len(queues), overlap,
+                        regs_us[r] if regs_us and r < len(regs_us) else None))
         blocks.append((tag, bench, out))
     if not blocks:
         return
@@ -244,8 +248,8 @@ one stream the two coincide up to the launch gap.  The bench's HIP events bracke
 the few microseconds between the start event and the first kernel's start are in the line's figure and not in the trace's
 period -- at K = 20 launches per region that is ~0.5 us per launch (5-6 %), at K = 400 the two agree within 1 %.
 Computed by scripts/summarize_profiles.py from the
-`*_kernel_trace.csv` of each run (the dispatches of `{KERNEL}` in dispatch order: warm-up, the S-stream regions, the
-one-stream regions).  Profiled runs are slower than un-profiled ones (rocprofv3 adds per-dispatch work), so the trace's
+`*_kernel_trace.csv` of each run (the dispatches of `{KERNEL}` in dispatch order: warm-up, then the timed regions -- round 6:
+S-stream region r and one-stream region r alternate (`config.region_order`), earlier rounds ran the S-stream regions first).  Profiled runs are slower than un-profiled ones (rocprofv3 adds per-dispatch work), so the trace's
 period is compared with the bench line of THE SAME run.
 
 """)
