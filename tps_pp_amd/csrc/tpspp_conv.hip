@@ -339,6 +339,19 @@ conv_tiled_f32_kernel(const ConvParams P)
     const bool relu1 = P.relu == 1;
     auto epilogue = [&](auto simple_c) {
         constexpr bool SIMPLE = decltype(simple_c)::value;
+        // every residual value of the lane's 32 outputs is requested BEFORE the first result is stored (round 6): `out` may
+        // alias `res` for all the compiler knows, so a load behind a store waits for it -- 32 memory latencies per workgroup,
+        // 65 us of the 410 us of a 64 -> 64 layer on 16x64 maps (the lesson of tpspp_tokgemm.hip / tpspp_conv3_wide.hip)
+        float rres[SIMPLE ? 1 : 32];
+        if constexpr (!SIMPLE) {
+    #pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int h2 = i >> 4, g = (i >> 2) & 3, e = i & 3;
+                const int cu = 32 * h2 + 8 * g;
+                const bool ok = valid && (full_c || co_base + cu + 4 * half + e < P.Cout);
+                rres[i] = (P.res_mode && ok) ? (P.res + ((size_t)n0 * P.Cout + co_base + cu + e) * HoWo)[lo] : 0.0f;
+            }
+        }
     #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
     #pragma unroll
@@ -364,7 +377,7 @@ conv_tiled_f32_kernel(const ConvParams P)
                         if (relu1) v = v > 0.0f ? v : 0.0f;
                     } else {
                         const int co = co4 + e;
-                        const float rv = (P.res_mode && ok) ? (P.res + ((size_t)n0 * P.Cout + co_base + cu + e) * HoWo)[lo] : 0.0f;
+                        const float rv = rres[16 * h2 + 4 * g + e];
                         if (P.res_mode == 2) v = v + rv;
                         if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
                         else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -473,8 +486,17 @@ conv1x1_wide_f32_kernel(const ConvParams P)
             }
         }
     } else if (pix < HoWo) {
+        // the residual of all 64 outputs of the lane before the first store (see conv_tiled_f32_kernel's epilogue): the encoder's
+        // and decoder's projections with a residual in the exact-fp32 head take this path
+        // (one 32-channel accumulator at a time: all 64 values in flight together push the kernel past 256 registers)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            float rres[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
+                rres[r] = (P.res_mode && co < P.Cout) ? P.res[((size_t)n * P.Cout + co) * HoWo + pix] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co_base + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -482,10 +504,10 @@ conv1x1_wide_f32_kernel(const ConvParams P)
                     float v = acc[j][r];
                     if (P.bias) v = v + P.bias[co];
                     const size_t o = ((size_t)n * P.Cout + co) * HoWo + pix;
-                    if (P.res_mode == 2) v = v + P.res[o];
+                    if (P.res_mode == 2) v = v + rres[r];
                     if (P.relu == 1) v = v > 0.0f ? v : 0.0f;
                     else if (P.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                    if (P.res_mode == 1) v = v + P.res[o];
+                    if (P.res_mode == 1) v = v + rres[r];
                     if (P.post_scale) v = v * P.post_scale[co] + P.post_shift[co];
                     P.out[o] = v;
                 }
