@@ -59,6 +59,11 @@ CASES = [
     ("skinny 1x1 512->92 ragged", [(512, 1, 77, 1, 1)], 92, 1, (1, 1), True, 0, 1),
     ("skinny 1x1 K=100 odd sizes", [(100, 3, 5, 1, 1)], 37, 1, (1, 1), True, 2, 3),
     ("skinny 1x1 K=6", [(6, 1, 40, 1, 1)], 8, 1, (1, 1), False, 0, 2),
+    # strided 1x1 (the backbone's downsample branches; round 6: the tiled kernel staging only the pixels it uses)
+    ("downsample 1x1 s2 256->512 @8x32 -> 4x16 (two-image tile, odd batch)", [(256, 8, 32, 1, 1)], 512, 1, (2, 2), False, 0, 5),
+    ("downsample 1x1 s2 64->128 @16x64 -> 8x32", [(64, 16, 64, 1, 1)], 128, 1, (2, 2), False, 0, 3),
+    ("downsample 1x1 s2 32->32 @32x128 -> 16x64", [(32, 32, 128, 1, 1)], 32, 1, (2, 2), True, 0, 2),
+    ("downsample 1x1 s2 K=40 odd map 7x21 -> 4x11, Cout=36", [(40, 7, 21, 1, 1)], 36, 1, (2, 2), True, 2, 3),
 ]
 
 

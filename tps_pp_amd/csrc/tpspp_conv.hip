@@ -166,8 +166,9 @@ template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1>
 struct TileCfg {
     static constexpr int KW = KH;
     static constexpr int TAPS = KH * KW;
-    static constexpr int PH = (TH - 1) * SH + KH;      // patch rows
-    static constexpr int PW = (TW - 1) * SW + KW;      // patch cols
+    // (a strided 1x1 layer stages ONLY the pixels it uses -- patch = tile, source pixel (SH y, SW x): round 6)
+    static constexpr int PH = KH == 1 ? TH : (TH - 1) * SH + KH;      // patch rows
+    static constexpr int PW = KH == 1 ? TW : (TW - 1) * SW + KW;      // patch cols
     static constexpr int PS = PH * PW;                 // floats per channel of the patch
     static constexpr int KCK = KC * TAPS;
     static constexpr int PATCH1 = KC * PS;             // one image's patch
@@ -205,7 +206,7 @@ conv_tiled_f32_kernel(const ConvParams P)
     const int timg = tp / (TH * TW), tpi = tp - timg * (TH * TW);
     const int ty = tpi / TW, tx = tpi - ty * TW;
     const int n = n0 + timg;                                    // the image this lane's pixel belongs to
-    const int lane_base = timg * PATCH1 + half * PS + ty * SH * PW + tx * SW;
+    const int lane_base = timg * PATCH1 + half * PS + (KH == 1 ? ty * PW + tx : ty * SH * PW + tx * SW);
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -230,7 +231,7 @@ conv_tiled_f32_kernel(const ConvParams P)
         const int im = NI > 1 ? e / PATCH1 : 0, e1 = e - im * PATCH1;
         const int ci = e1 / PS, r = e1 - ci * PS;
         const int py = r / PW, px = r - py * PW;
-        const int iy = iy_base + py, ix = ix_base + px;
+        const int iy = KH == 1 ? (oy0 + py) * SH : iy_base + py, ix = KH == 1 ? (ox0 + px) * SW : ix_base + px;
         const bool ok = e < PATCH && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
         t_iy[i] = ok ? iy : -1; t_ix[i] = ix; t_ci[i] = ci; t_im[i] = im;
     }
@@ -795,6 +796,14 @@ bool launch_tiled_any(const ConvParams& P, int KH, hipStream_t st)
     // leaving half of its rows empty
     const bool small_map = P.Ho <= 4 && P.Wo <= 16 && P.N >= 2;
     if (KH == 1) {
+        // strided 1x1 (the backbone's downsample branches; round 6): the tiled kernel, staging only the pixels the layer uses
+        // (TileCfg), instead of the im2col kernel -- 256 -> 512 on 8x32 -> 4x16 maps ran at 27 TFLOP/s there
+        if (P.sh == 2 && P.sw == 2) {
+            if (small_map) TPSPP_TILE2(1, 2, 2, 4, 16, 32)
+            if (P.Wo >= 64) TPSPP_TILE(1, 2, 2, 2, 64, 32)
+            if (P.Wo >= 32) TPSPP_TILE(1, 2, 2, 4, 32, 32)
+            TPSPP_TILE(1, 2, 2, 8, 16, 32)
+        }
         if (P.sh != 1 || P.sw != 1) return false;
         if (small_map) TPSPP_TILE2(1, 1, 1, 4, 16, 32)
         if (P.Wo >= 128) TPSPP_TILE(1, 1, 1, 1, 128, 32)
