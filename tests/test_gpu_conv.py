@@ -59,6 +59,11 @@ CASES = [
     ("skinny 1x1 512->92 ragged", [(512, 1, 77, 1, 1)], 92, 1, (1, 1), True, 0, 1),
     ("skinny 1x1 K=100 odd sizes", [(100, 3, 5, 1, 1)], 37, 1, (1, 1), True, 2, 3),
     ("skinny 1x1 K=6", [(6, 1, 40, 1, 1)], 8, 1, (1, 1), False, 0, 2),
+    # at most 32 output channels: the one-accumulator form of the tiled kernel (round 6)
+    ("stem 3x3 3->32 @32x128", [(3, 32, 128, 1, 1)], 32, 3, (1, 1), True, 0, 2),
+    ("BasicBlock 3x3 32->32 + residual @16x64", [(32, 16, 64, 1, 1)], 32, 3, (1, 1), True, 2, 3),
+    ("3x3 s2 32->32 + residual, Cout=24 ragged", [(32, 16, 64, 1, 1)], 24, 3, (2, 2), True, 2, 3),
+    ("1x1 32->32 @32x128", [(32, 32, 128, 1, 1)], 32, 1, (1, 1), True, 0, 2),
     # strided 1x1 (the backbone's downsample branches; round 6: the tiled kernel staging only the pixels it uses)
     ("downsample 1x1 s2 256->512 @8x32 -> 4x16 (two-image tile, odd batch)", [(256, 8, 32, 1, 1)], 512, 1, (2, 2), False, 0, 5),
     ("downsample 1x1 s2 64->128 @16x64 -> 8x32", [(64, 16, 64, 1, 1)], 128, 1, (2, 2), False, 0, 3),

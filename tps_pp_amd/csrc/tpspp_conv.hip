@@ -177,7 +177,9 @@ struct TileCfg {
     static constexpr int NW4 = (KCK * BN / 4 + kThreads - 1) / kThreads;  // weight float4 per thread
 };
 
-template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1>
+// NB (round 6): accumulators per wavefront -- 2 = the 64-channel tile; 1 for layers with at most 32 output channels (the
+// backbone's first stage, its stem): the second accumulator multiplied zeros there, half of the layer's matrix time.
+template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1, int NB = 2>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_tiled_f32_kernel(const ConvParams P)
 {
@@ -317,9 +319,11 @@ conv_tiled_f32_kernel(const ConvParams P)
             for (int c2 = 0; c2 < KC / 2; ++c2) {
                 const float b = sP[lane_base + 2 * c2 * PS + ky * PW + kx];
                 const float a0 = sW[(tap * KC + 2 * c2 + half) * BN + l31];
-                const float a1 = sW[(tap * KC + 2 * c2 + half) * BN + 32 + l31];
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                if constexpr (NB == 2) {
+                    const float a1 = sW[(tap * KC + 2 * c2 + half) * BN + 32 + l31];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -346,7 +350,7 @@ conv_tiled_f32_kernel(const ConvParams P)
         float rres[SIMPLE ? 1 : 32];
         if constexpr (!SIMPLE) {
     #pragma unroll
-            for (int i = 0; i < 32; ++i) {
+            for (int i = 0; i < 16 * NB; ++i) {
                 const int h2 = i >> 4, g = (i >> 2) & 3, e = i & 3;
                 const int cu = 32 * h2 + 8 * g;
                 const bool ok = valid && (full_c || co_base + cu + 4 * half + e < P.Cout);
@@ -354,7 +358,7 @@ conv_tiled_f32_kernel(const ConvParams P)
             }
         }
     #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
+        for (int h2 = 0; h2 < NB; ++h2) {
     #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cu = 32 * h2 + 8 * g;                       // + 4*half (in `lo`) + e
@@ -782,7 +786,8 @@ void launch_tiled(const ConvParams& P, hipStream_t st)
     const int ctiles = (P.Cout + BN - 1) / BN;
     const dim3 grid((unsigned)((P.Wo + TW - 1) / TW), (unsigned)((P.Ho + TH - 1) / TH),
                     (unsigned)(((P.N + NI - 1) / NI) * ctiles));
-    hipLaunchKernelGGL((conv_tiled_f32_kernel<KH, SH, SW, TH, TW, KC, NI>), grid, dim3(kThreads), 0, st, P);
+    if (P.Cout <= 32) hipLaunchKernelGGL((conv_tiled_f32_kernel<KH, SH, SW, TH, TW, KC, NI, 1>), grid, dim3(kThreads), 0, st, P);
+    else hipLaunchKernelGGL((conv_tiled_f32_kernel<KH, SH, SW, TH, TW, KC, NI>), grid, dim3(kThreads), 0, st, P);
 }
 
 // picks a tile for the output width; returns false when no tiled instantiation fits
