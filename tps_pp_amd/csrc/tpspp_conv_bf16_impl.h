@@ -108,7 +108,9 @@ struct BCfg {
 // pixels]), and is brought into the channel-innermost patch image by ds_read_b64_tr_b16: a 16-lane group points at
 // 4 channel rows x 16 pixels and each lane receives 4 consecutive channels of its pixel.  Per chunk and thread: 4-6
 // loads of 16 bytes + ~4 x (2 transposing reads + 1 16-byte write) instead of 32 loads + 32 packs.
-template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false, int NF = 2, bool WIDE = false>
+// NB (round 6): 32-channel accumulators per fragment -- 2 = the 64-channel tile; 1 for layers with at most 32 output channels
+// (instantiated for the three-term split only: the bf16x3 backbone's first stage; its second accumulator multiplied zeros).
+template <int KH, int SH, int SW, int TH, int TW, int NI, int KC, bool X3 = false, int NF = 2, bool WIDE = false, int NB = 2>
 __global__ void __launch_bounds__(kThreads, 2)
 conv_tiled_bf16_kernel(const BParams P)
 {
@@ -385,23 +387,23 @@ conv_tiled_bf16_kernel(const BParams P)
 #pragma unroll
             for (int ks = 0; ks < KC / 16; ++ks) {
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + l31]);
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + 32 + l31]);
-                bf16x8 a0l, a1l;
+                bf16x8 a1 = a0, a0l = a0, a1l = a0;
+                if constexpr (NB == 2) a1 = __builtin_bit_cast(bf16x8, sW[(tap * KG + 2 * ks + half) * BN + 32 + l31]);
                 if constexpr (X3) {
                     a0l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + l31]);
-                    a1l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + 32 + l31]);
+                    if constexpr (NB == 2) a1l = __builtin_bit_cast(bf16x8, sW[WSLAB + (tap * KG + 2 * ks + half) * BN + 32 + l31]);
                 }
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, sP[fpos[f] + (2 * ks) * PSN + ky * PW + kx]);
                     acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bh, acc[f][0], 0, 0, 0);
-                    acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[f][1], 0, 0, 0);
+                    if constexpr (NB == 2) acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bh, acc[f][1], 0, 0, 0);
                     if constexpr (X3) {
                         const bf16x8 bl = __builtin_bit_cast(bf16x8, sP[KG * PSN + fpos[f] + (2 * ks) * PSN + ky * PW + kx]);
                         acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bl, acc[f][0], 0, 0, 0);
-                        acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bl, acc[f][1], 0, 0, 0);
+                        if constexpr (NB == 2) acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bl, acc[f][1], 0, 0, 0);
                         acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, bh, acc[f][0], 0, 0, 0);
-                        acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh, acc[f][1], 0, 0, 0);
+                        if constexpr (NB == 2) acc[f][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, bh, acc[f][1], 0, 0, 0);
                     }
                 }
             }
@@ -417,7 +419,7 @@ conv_tiled_bf16_kernel(const BParams P)
     const bool full_c = co_base + BN <= P.Cout;                  // uniform
     float bq[2][4][4];
 #pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
+    for (int h2 = 0; h2 < NB; ++h2)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = co_base + 32 * h2 + 8 * g + 4 * half;
@@ -454,7 +456,7 @@ conv_tiled_bf16_kernel(const BParams P)
             const bool valid = oy < P.Ho && ox < P.Wo && n < P.N;
             const unsigned lo = valid ? (unsigned)((fimg[f] * P.Cout + 4 * half) * HoWo + oy * P.Wo + ox) : 0u;
     #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
+            for (int h2 = 0; h2 < NB; ++h2) {
                 tpspp_u32x2 bpk[4];
     #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -581,6 +583,12 @@ void launch_b(const BParams& P, hipStream_t st)
     if constexpr (KH == 3 && SH == 1 && SW == 1 && !X3 && (TW % 16) == 0) {
         if (wide_staging_applies(P)) {
             hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3, NF, true>), grid, dim3(kThreads), 0, st, P);
+            return;
+        }
+    }
+    if constexpr (X3) {
+        if (P.Cout <= 32) {                                   // one accumulator per fragment (see the kernel, NB)
+            hipLaunchKernelGGL((conv_tiled_bf16_kernel<KH, SH, SW, TH, TW, NI, KC, X3, NF, false, 1>), grid, dim3(kThreads), 0, st, P);
             return;
         }
     }
