@@ -59,6 +59,10 @@ CASES = [
     ("ragged 1x1 40->132 @12x44", [(40, 12, 44, 1, 1, "f32")], 132, 1, (1, 1), False, 2, "f32", 3),
     ("1x1 256->512 @4x16", [(256, 4, 16, 1, 1, "bf16")], 512, 1, (1, 1), True, 0, None, 7),
     ("3x3 @16x16 odd channels 24->64", [(24, 16, 16, 1, 1, "bf16")], 64, 3, (1, 1), False, 0, None, 2),
+    # at most 32 output channels (round 6: the one-accumulator form of the tiled kernel in the three-term split)
+    ("BasicBlock 3x3 32->32 + residual @16x64", [(32, 16, 64, 1, 1, "f32")], 32, 3, (1, 1), True, 2, "f32", 3),
+    ("3x3 s2 32->32 + residual @32x128 -> 16x64", [(32, 32, 128, 1, 1, "f32")], 32, 3, (2, 2), True, 2, "f32", 2),
+    ("1x1 32->24 ragged @16x64", [(32, 16, 64, 1, 1, "f32")], 24, 1, (1, 1), True, 0, None, 3),
 ]
 
 
