@@ -179,8 +179,11 @@ struct TileCfg {
 
 // NB (round 6): accumulators per wavefront -- 2 = the 64-channel tile; 1 for layers with at most 32 output channels (the
 // backbone's first stage, its stem): the second accumulator multiplied zeros there, half of the layer's matrix time.
+// (round 6: the stride-2 3x3 tiles are compiled for THREE workgroups per CU -- with two as the bound the compiler spent 169 - 175
+// registers on them, i.e. two waves per SIMD; 168 is three.  512 -> 512 stride 2: 1622 -> 1417 us.  The stride-1 tiles use
+// 116 - 124 registers (four workgroups per CU) whatever the bound says, and measured 1.3 % slower when compiled for three.)
 template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1, int NB = 2>
-__global__ void __launch_bounds__(kThreads, 2)
+__global__ void __launch_bounds__(kThreads, (KH == 3 && SH == 2 && SW == 2) ? 3 : 2)
 conv_tiled_f32_kernel(const ConvParams P)
 {
     using Cfg = TileCfg<KH, SH, SW, TH, TW, KC, NI>;
@@ -224,19 +227,40 @@ conv_tiled_f32_kernel(const ConvParams P)
     // the tile / beyond the batch), column, channel inside the chunk and image are worked out once.  (Decoding them, two
     // integer divisions by the upsampling factors and a predicated load per element and chunk made the staging 8.7 vector
     // instructions per MFMA -- 5 k per wavefront in a 64 -> 64 layer, `SQ_INSTS_VALU` -- and held the matrix pipe at 60 %.)
-    int t_iy[NP], t_ix[NP], t_ci[NP], t_im[NP];
+    // LEAN (round 6, the stride-2 3x3 tiles: 2.5x the patch elements per thread): only the element's offset and one validity bit
+    // are kept -- row, column, channel and image are worked out again when a new source is entered (and per chunk on the
+    // upsampling paths, which no stride-2 layer of the model takes) -- so that these tiles fit the 168 registers of three
+    // workgroups per CU (see __launch_bounds__ above) without spilling.
+    constexpr bool LEAN = KH == 3 && SH == 2 && SW == 2;
+    static_assert(NP <= 32, "one validity bit per staged element");
+    int t_iy[LEAN ? 1 : NP], t_ix[LEAN ? 1 : NP], t_ci[LEAN ? 1 : NP], t_im[LEAN ? 1 : NP];
     unsigned t_off[NP];
+    unsigned vmask = 0u;
     int t_src = -1;                                                   // the source t_off was computed for
+    auto decode = [&](int i, int& iy, int& ix, int& ci, int& im) -> bool {
+        const int e = tid + i * kThreads;
+        im = NI > 1 ? e / PATCH1 : 0;
+        const int e1 = e - im * PATCH1;
+        ci = e1 / PS;
+        const int r = e1 - ci * PS;
+        const int py = r / PW, px = r - py * PW;
+        iy = KH == 1 ? (oy0 + py) * SH : iy_base + py;
+        ix = KH == 1 ? (ox0 + px) * SW : ix_base + px;
+        return e < PATCH && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
+    };
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int e = tid + i * kThreads;
-        const int im = NI > 1 ? e / PATCH1 : 0, e1 = e - im * PATCH1;
-        const int ci = e1 / PS, r = e1 - ci * PS;
-        const int py = r / PW, px = r - py * PW;
-        const int iy = KH == 1 ? (oy0 + py) * SH : iy_base + py, ix = KH == 1 ? (ox0 + px) * SW : ix_base + px;
-        const bool ok = e < PATCH && iy >= 0 && iy < P.Hi && ix >= 0 && ix < P.Wi && (n0 + im) < P.N;
-        t_iy[i] = ok ? iy : -1; t_ix[i] = ix; t_ci[i] = ci; t_im[i] = im;
+        int iy, ix, ci, im;
+        const bool ok = decode(i, iy, ix, ci, im);
+        if constexpr (LEAN) { if (ok) vmask |= 1u << i; }
+        else { t_iy[i] = ok ? iy : -1; t_ix[i] = ix; t_ci[i] = ci; t_im[i] = im; }
     }
+    // element i: valid?  row / column / channel / image (LEAN: worked out again)
+    auto el_ok = [&](int i) -> bool { if constexpr (LEAN) return (vmask >> i) & 1u; else return t_iy[i] >= 0; };
+    auto el = [&](int i, int& iy, int& ix, int& ci, int& im) {
+        if constexpr (LEAN) { (void)decode(i, iy, ix, ci, im); }
+        else { iy = t_iy[i]; ix = t_ix[i]; ci = t_ci[i]; im = t_im[i]; }
+    };
 
     auto prefetch = [&](int chunk) {
         const int c0 = chunk * KC;
@@ -255,30 +279,35 @@ conv_tiled_f32_kernel(const ConvParams P)
             if (t_src != s) {
                 t_src = s;
 #pragma unroll
-                for (int i = 0; i < NP; ++i)
-                    t_off[i] = t_iy[i] >= 0 ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + t_iy[i] * cur.W + t_ix[i]) : 0u;
+                for (int i = 0; i < NP; ++i) {
+                    int iy, ix, ci, im;
+                    el(i, iy, ix, ci, im);
+                    t_off[i] = el_ok(i) ? (unsigned)(im * img_stride + ci * plane + iy * cur.W + ix) : 0u;
+                }
             }
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const float v = sp[t_off[i]];
-                rp[i] = t_iy[i] >= 0 ? v : 0.0f;
+                rp[i] = el_ok(i) ? v : 0.0f;
             }
         } else if (pow2) {                                            // nearest upsampling by 1 / 2 / 4: shifts
             const int lh = 31 - __builtin_clz(cur.uh), lw = 31 - __builtin_clz(cur.uw);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const bool ok = t_iy[i] >= 0 && t_ci[i] < cleft;
-                const unsigned off = ok ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + (t_iy[i] >> lh) * cur.W +
-                                                     (t_ix[i] >> lw)) : 0u;
+                int iy, ix, ci, im;
+                el(i, iy, ix, ci, im);
+                const bool ok = el_ok(i) && ci < cleft;
+                const unsigned off = ok ? (unsigned)(im * img_stride + ci * plane + (iy >> lh) * cur.W + (ix >> lw)) : 0u;
                 const float v = sp[off];
                 rp[i] = ok ? v : 0.0f;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const bool ok = t_iy[i] >= 0 && t_ci[i] < cleft;
-                const unsigned off = ok ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + (t_iy[i] / cur.uh) * cur.W +
-                                                     t_ix[i] / cur.uw) : 0u;
+                int iy, ix, ci, im;
+                el(i, iy, ix, ci, im);
+                const bool ok = el_ok(i) && ci < cleft;
+                const unsigned off = ok ? (unsigned)(im * img_stride + ci * plane + (iy / cur.uh) * cur.W + ix / cur.uw) : 0u;
                 const float v = sp[off];
                 rp[i] = ok ? v : 0.0f;
             }
