@@ -181,9 +181,10 @@ struct TileCfg {
 // backbone's first stage, its stem): the second accumulator multiplied zeros there, half of the layer's matrix time.
 // (round 6: the stride-2 3x3 tiles are compiled for THREE workgroups per CU -- with two as the bound the compiler spent 169 - 175
 // registers on them, i.e. two waves per SIMD; 168 is three.  512 -> 512 stride 2: 1622 -> 1417 us.  The stride-1 tiles use
-// 116 - 124 registers (four workgroups per CU) whatever the bound says, and measured 1.3 % slower when compiled for three.)
+// 116 - 124 registers (four workgroups per CU) whatever the bound says, and measured 1.3 % slower when compiled for three.
+// The 1x1 tiles are compiled for four: they sat at 128 registers until an unrelated edit made them 133.)
 template <int KH, int SH, int SW, int TH, int TW, int KC, int NI = 1, int NB = 2>
-__global__ void __launch_bounds__(kThreads, (KH == 3 && SH == 2 && SW == 2) ? 3 : 2)
+__global__ void __launch_bounds__(kThreads, KH == 1 ? 4 : (KH == 3 && SH == 2 && SW == 2) ? 3 : 2)
 conv_tiled_f32_kernel(const ConvParams P)
 {
     using Cfg = TileCfg<KH, SH, SW, TH, TW, KC, NI>;
@@ -276,6 +277,21 @@ conv_tiled_f32_kernel(const ConvParams P)
             // the common case -- a source at full resolution, a whole chunk: the element's offset from the chunk's first
             // channel does not depend on the chunk (t_off, worked out when the source was entered), so an element is one
             // load and one select
+            if constexpr (KH == 1) {
+                // (the 1x1 tiles keep the plain form: through the el() / el_ok() helpers below they compiled to 133 registers
+                // instead of 128 -- three wavefronts per SIMD instead of four, 94 against 81 us on the 64 -> 64 layers)
+                if (t_src != s) {
+                    t_src = s;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        t_off[i] = t_iy[i] >= 0 ? (unsigned)(t_im[i] * img_stride + t_ci[i] * plane + t_iy[i] * cur.W + t_ix[i]) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const float v = sp[t_off[i]];
+                    rp[i] = t_iy[i] >= 0 ? v : 0.0f;
+                }
+            } else {
             if (t_src != s) {
                 t_src = s;
 #pragma unroll
@@ -289,6 +305,7 @@ conv_tiled_f32_kernel(const ConvParams P)
             for (int i = 0; i < NP; ++i) {
                 const float v = sp[t_off[i]];
                 rp[i] = el_ok(i) ? v : 0.0f;
+            }
             }
         } else if (pow2) {                                            // nearest upsampling by 1 / 2 / 4: shifts
             const int lh = 31 - __builtin_clz(cur.uh), lw = 31 - __builtin_clz(cur.uw);

@@ -94,8 +94,10 @@ transpose2d_kernel(const float* __restrict__ in, int rows, int cols, float* __re
 // Workgroup = 16 columns x 16 interleaved channel slices; a thread keeps its C/16 values in registers
 // (one pass over x, all loads in flight together: a decoder step has only a few hundred columns, so
 // the kernel is latency-bound unless every load is issued up front).  C <= 16 * VPT.
+// (round 6: compiled for three workgroups per CU -- VPT = 32 took 176 registers, two wavefronts per SIMD, in a kernel that only
+// waits for memory)
 template <int VPT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, VPT <= 32 ? 3 : 1)
 layernorm_cm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                     int C, int M, float eps, float* __restrict__ y)
 {
@@ -243,8 +245,10 @@ attn_enc_kernel(const float* __restrict__ qkv, int C, int M, int T, const int* _
 // get probability 0.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+// (round 6: compiled for three workgroups per CU -- NJ = 2, the 64-token case, took 172 registers = two wavefronts per SIMD,
+// 168 is three; the kernel waits for memory)
 template <int NJ>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, NJ <= 2 ? 3 : 1)
 attn_enc_mfma_kernel(const float* __restrict__ qkv, int C, int M, int T, const int* __restrict__ valid_len,
                      float* __restrict__ out)
 {
