@@ -316,6 +316,22 @@ def classic_warp_extra(dev, hw, nstreams, kernel_choice=0):
             if bool(flags & ops.TABLE_PACKED) else "LDS-staged kernel", "rotating_buffer_sets": int(nbuf)}
 
 
+def device_clocks():
+    """Best effort: rocm-smi's clock / power readings of the first card, sampled right behind the timed regions (the boxes of
+    the pool differ by ~8 % in the overlapped launch period at an identical plain-copy rate; the line carries what the device
+    reported).  None when rocm-smi is missing or says nothing parseable."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        out = subprocess.run([exe, "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(out[out.index("{"):])
+        card = d[sorted(d)[0]]
+        return {k.strip(" :").replace(" ", "_"): v.strip("()") for k, v in card.items() if isinstance(v, str)}
+    except Exception:                                          # noqa: BLE001  (informational only)
+        return None
+
+
 def recognizer_measurement(dev, timeit):
     """BASELINE.json configs[3]/[4] shape at one GPU: the whole NRTR + TPS++ recogniser (backbone, TPS++,
     6+6-layer transformer, greedy 40-step decoding, label conversion) on 3x32x128 images, batch 512,
@@ -674,6 +690,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tt_min, op=dist.ReduceOp.MIN)
     tt, tt_min = tt.cpu(), tt_min.cpu()
+    clocks = device_clocks() if rank == 0 else None          # (right behind the last region: what the device ran at)
     regions_m = [float(x) for x in tt[0, :, 0]]              # ms per region, `steps` launches each
     regions_1 = [float(x) for x in tt[1, :, 0]]
 
@@ -778,6 +795,7 @@ def main():
                                         "launches (period between launches); `wall_ms_per_step` = host clock incl. the synchronize",
                        "ms_per_step_min_over_ranks": ev_ms_min / a.steps,
                        "region_order": "interleaved" if S > 1 else "one protocol",
+                       "device_clocks_after_regions": clocks,
                        "preconditioning": f"{a.precondition_ms:.0f} ms of plain device copies over the bench buffers "
                                           "before the warm-up steps (clock ramp; not steps)"},
             "max_abs_err_vs_oracle": max_err,
