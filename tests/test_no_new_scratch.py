@@ -15,8 +15,8 @@ SCAN = os.path.join(ROOT, "scripts", "debug", "scratch_scan.py")
 # kernels known to have a private segment, none of them launched per batch on a measured path (profiles/r06_warp_lab.txt):
 ALLOWED = (
     r"tps_warp_geo_kernel<20, \d, \d, 2, true>",                # run-time geometry WITH grid / index outputs (tests, training forward)
-    r"dec_step_persist_kernel<float, \d, (true|false)>",        # exact-fp32 / bf16x3 persistent decoder: spills in the > 64-token path
-    r"dec_step_persist_kernel<unsigned short, \d, false>",      # 20-byte stack object, no spills
+    r"dec_step_persist_kernel<float, \d, (true|false), true>",  # exact-fp32 / bf16x3 persistent decoder, the instantiation for > 64 tokens
+    r"dec_step_persist_kernel<unsigned short, \d, false, true>",  # the same for the bf16 head: a 20-byte stack object, no spills
     r"warp_bwd_sample_lds2_kernel<4, 1024, (true|false)>",      # backward for more than 1024 output pixels
     r"warp_bwd_params_kernel<64, 1, false, 1, false>",          # 20-byte stack object, no spills
     r"tps_warp_stream_kernel<32, false, true, 2, (true|false)>",  # plane-streaming warp without a score: 2 registers

@@ -1501,7 +1501,7 @@ size_t dec_ws_bytes(int N, int C, int T, int Di, int n_layers, int L, int Cc)
 struct PersistDevice {
     hipEvent_t done = nullptr;
     bool recorded = false;
-    int groups[6] = {-1, -1, -1, -1, -1, -1};               // per kernel instantiation; -1 = not queried yet
+    int groups[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};      // per kernel instantiation; -1 = not queried yet
 };
 std::mutex g_persist_mu;
 PersistDevice g_persist_dev[tpspp::kMaxDevices];
@@ -1809,9 +1809,13 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
     int rc = 0;
     // ---- the step as ONE persistent launch (tpspp_head_persist.h): every head configuration, d_model 512, 8 heads ----
     bool persist = fast && C == 512 && H == 8 && num_out <= 128 && n_layers <= kPMaxLayers && !g_head_qcross && !head_no_persist();
-    auto kern = b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2, false> : dec_step_persist_kernel<unsigned short, 4, false>)
-              : gemm_f32 ? (d_inner == 256 ? dec_step_persist_kernel<float, 2, true> : dec_step_persist_kernel<float, 4, true>)
-                    : (d_inner == 256 ? dec_step_persist_kernel<float, 2, false> : dec_step_persist_kernel<float, 4, false>);
+    const bool tbig = T > kWave;                              // more than 64 encoder tokens: the kernel's other instantiation
+    auto kern = tbig ? (b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2, false, true> : dec_step_persist_kernel<unsigned short, 4, false, true>)
+                            : gemm_f32 ? (d_inner == 256 ? dec_step_persist_kernel<float, 2, true, true> : dec_step_persist_kernel<float, 4, true, true>)
+                                       : (d_inner == 256 ? dec_step_persist_kernel<float, 2, false, true> : dec_step_persist_kernel<float, 4, false, true>))
+                     : (b16 ? (d_inner == 256 ? dec_step_persist_kernel<unsigned short, 2, false> : dec_step_persist_kernel<unsigned short, 4, false>)
+                            : gemm_f32 ? (d_inner == 256 ? dec_step_persist_kernel<float, 2, true> : dec_step_persist_kernel<float, 4, true>)
+                                       : (d_inner == 256 ? dec_step_persist_kernel<float, 2, false> : dec_step_persist_kernel<float, 4, false>));
     int dev = 0, groups = 0;
     if (persist) {
         // requirement (1): a whole group of clusters resident, else the launch pipeline below; not under stream capture (the
@@ -1823,7 +1827,7 @@ TPSPP_EXPORT int tpspp_nrtr_decoder_fwd(const float* enc_cm, int N, int C, int T
             persist = false;
         } else {
             std::lock_guard<std::mutex> lk(g_persist_mu);
-            groups = persist_groups(g_persist_dev[dev], (b16 ? 2 : gemm_f32 ? 4 : 0) + (d_inner == 256 ? 0 : 1), kern, dev);
+            groups = persist_groups(g_persist_dev[dev], (tbig ? 6 : 0) + (b16 ? 2 : gemm_f32 ? 4 : 0) + (d_inner == 256 ? 0 : 1), kern, dev);
             persist = groups > 0;
         }
     }

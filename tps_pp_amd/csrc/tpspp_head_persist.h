@@ -435,7 +435,9 @@ __device__ __forceinline__ bool pself_phase(const PStep& P, const PLayer& W, int
     return ok;
 }
 
-template <typename KV>
+// TBIG (round 6): the instantiation for more than 64 encoder tokens (one wavefront per head, four 64-token groups).  Compiled into
+// the same kernel as the 64-token path it cost that path's kernel 60 spilled registers and ~1 % of a decode: two instantiations.
+template <typename KV, bool TBIG>
 __device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, int ab, int ah0, int lane, PShared& S, int* cnt, int target, bool plain)
 {
     asm volatile("" : "+v"(lane));                         // (opaque per phase: see pgemm_phase)
@@ -447,7 +449,7 @@ __device__ __forceinline__ bool pcross_phase(const PStep& P, const PLayer& W, in
     nvalid = nvalid < P.T ? nvalid : P.T;
     const float* qrow = P.qkv + (size_t)ab * 3 * P.C;     // (q: pitch 3 C, see the step kernel)
     bool ok = true;
-    if (P.T <= kWave) {
+    if constexpr (!TBIG) {
         ok = cross_attend2<KV, true>(qrow, reinterpret_cast<const KV*>(W.Kx), reinterpret_cast<const KV*>(W.Vx), P.C, P.T, nvalid, ab, ah0,
                                      lane, P.a, bar, plain);
     } else {
@@ -480,7 +482,7 @@ __device__ __forceinline__ float ld4_sys(const float* p)
 }
 
 // KSW2 = d_inner / 128 (2 or 4).  grid = clusters x 16 workgroups of 512 threads; dynamic LDS = sizeof(PShared).
-template <typename KV, int KSW2, bool F32>
+template <typename KV, int KSW2, bool F32, bool TBIG = false>
 __global__ void __launch_bounds__(512)
 dec_step_persist_kernel(const PStep P)
 {
@@ -587,7 +589,7 @@ dec_step_persist_kernel(const PStep P)
         }
         stamp();
         // 5. cross-attention against the encoder keys / values -> a
-        if (!pcross_phase<KV>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar), plain)) { fail(); return; }
+        if (!pcross_phase<KV, TBIG>(P, W, ab, ah0, lane, S, cnt, 16 * (++bar), plain)) { fail(); return; }
         stamp();
         // 6. x = y + fc(a)                                                         transformer_layers.py:158-159
         {
