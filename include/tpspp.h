@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-#define TPSPP_ABI_VERSION 4   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
+#define TPSPP_ABI_VERSION 5   /* 2 (round 4): tpspp_warp_bwd and tpspp_nrtr_decoder_fwd carry the sizes of their workspace / pointer table;
                                3: tpspp_down_fused_bf16_fwd / _x3_fwd / _f32_fwd, tpspp_token_gemm_bf16_fwd, tpspp_front_fwd and tpspp_front_bf16_fwd takes feat0 = feat1 = NULL;
-                               4 (round 6): tpspp_nrtr_decoder_fwd takes status_out, tpspp_resize_normalize_fwd takes interpolation */
+                               4 (round 6): tpspp_nrtr_decoder_fwd takes status_out, tpspp_resize_normalize_fwd takes interpolation;
+                               5 (round 6): tpspp_warp_plan_create / _run / _run_on / _destroy */
 
 #define TPSPP_OK        0
 #define TPSPP_EINVAL  (-22)  /* bad argument (null pointer, non-positive size, unsupported shape) */
@@ -152,6 +153,28 @@ int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
                    const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
                    float* out0, float* out1, float* grid_or_null, int32_t* idx_or_null,
                    tpspp_stream_t stream);
+
+/*
+ * Prepared calls of tpspp_warp_fwd (round 6; ABI 5).  A caller that rectifies batch after batch into the same buffers -- a
+ * serving loop, bench.py -- hands the 25 arguments over ONCE: tpspp_warp_plan_run(plan) is tpspp_warp_fwd with the stored
+ * arguments (same checks, same dispatch, same kernel, same results), tpspp_warp_plan_run_on the same on another stream.  What it
+ * saves is the caller's foreign-function marshalling per launch (ctypes: 1.6 of ~4.3 us), which matters when the device needs
+ * ~8 us per batch and, at the start of a burst, waits for the host.  The plan holds POINTERS, not copies: the buffers must
+ * outlive it.  tpspp_warp_plan_create allocates a small host structure (the only entry point that allocates);
+ * tpspp_warp_plan_destroy(NULL) is a no-op.  Thread safety: a plan is immutable after creation.
+ * replaces: the same call sites as tpspp_warp_fwd (tps_preprocessor.py:71-83, tps_pp.py:597-615).
+ */
+typedef struct tpspp_warp_plan tpspp_warp_plan_t;
+int tpspp_warp_plan_create(const float* in0, int C0, int H0, int W0,
+                           const float* in1, int C1, int H1, int W1,
+                           const float* ctrl, const float* score,
+                           const float* inv_delta_c, const float* p_hat, int p_hat_ld, const float* p_xy,
+                           const float* p_hat_t_or_null, int table_flags, int N, int F, int Ho, int Wo,
+                           float* out0, float* out1, float* grid_or_null, int32_t* idx_or_null,
+                           tpspp_stream_t stream, tpspp_warp_plan_t** plan_out);
+int tpspp_warp_plan_run(const tpspp_warp_plan_t* plan);
+int tpspp_warp_plan_run_on(const tpspp_warp_plan_t* plan, tpspp_stream_t stream);
+void tpspp_warp_plan_destroy(tpspp_warp_plan_t* plan);
 
 /*
  * Backward of tpspp_warp_fwd: given dL/d out0 [, dL/d out1] returns

@@ -17,7 +17,7 @@ def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(tpspp_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|void|const char\*)\s+(tpspp_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out
@@ -98,3 +98,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.TpsppError, match="no CPU or PyTorch fallback"):
         _lib.lib()
+
+
+def test_prepared_warp_plan_entry_points(lib):
+    """tpspp_warp_plan_create / _run / _run_on / _destroy (ABI 5) without a GPU: an empty batch runs through the stored
+    arguments' checks and launches nothing; argument errors come back as codes."""
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, vp).value
+    args = (vp(p), ci(3), ci(32), ci(100), vp(0), ci(0), ci(0), ci(0), vp(p), vp(0), vp(p), vp(p), ci(23), vp(0), vp(0), ci(0),
+            ci(0), ci(20), ci(32), ci(100), vp(p), vp(0), vp(0), vp(0), vp(0))
+    h = vp()
+    assert lib.tpspp_warp_plan_create(*args, ctypes.byref(h)) == 0 and h.value
+    assert lib.tpspp_warp_plan_run(h) == 0                       # N = 0: the same early return as tpspp_warp_fwd
+    assert lib.tpspp_warp_plan_run_on(h, vp(0)) == 0
+    lib.tpspp_warp_plan_destroy(h)
+    lib.tpspp_warp_plan_destroy(vp(0))                           # no-op
+    assert lib.tpspp_warp_plan_run(vp(0)) == -22 and b"NULL plan" in lib.tpspp_last_error()
+    assert lib.tpspp_warp_plan_create(*args, None) == -22
+    bad = list(args); bad[0] = vp(0)                             # in0 = NULL
+    h2 = vp()
+    assert lib.tpspp_warp_plan_create(*bad, ctypes.byref(h2)) == -22 and not h2.value
+    # a plan whose stored arguments are wrong fails at run time with tpspp_warp_fwd's message
+    bad = list(args); bad[17] = ci(70)                           # F + 3 > 64
+    assert lib.tpspp_warp_plan_create(*bad, ctypes.byref(h2)) == 0
+    assert lib.tpspp_warp_plan_run(h2) == -22 and b"F" in lib.tpspp_last_error()
+    lib.tpspp_warp_plan_destroy(h2)

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtpspp_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _f = ctypes.c_void_p       # device pointers travel as integers
 _i = ctypes.c_int
@@ -25,6 +25,11 @@ _SIGNATURES = {
     "tpspp_prepare_mirror_table": ([_f, _i, _i, _i, _i, _f, _f], _i),
     "tpspp_warp_fwd": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i,
                         _f, _f, _f, _f, _f], _i),
+    "tpspp_warp_plan_create": ([_f, _i, _i, _i, _f, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i,
+                                _f, _f, _f, _f, _f, _f], _i),
+    "tpspp_warp_plan_run": ([_f], _i),
+    "tpspp_warp_plan_run_on": ([_f, _f], _i),
+    "tpspp_warp_plan_destroy": ([_f], None),
     "tpspp_conv2d_fwd": ([_f, _f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _f], _i),
     "tpspp_conv2d_bf16_fwd": ([_f, _f, _i, _f, _f, _f, _i, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _f], _i),
     "tpspp_conv_bf16_chunk_channels": ([_i], _i),

@@ -20,6 +20,7 @@
 //
 // Compiled with -ffp-contract=off: the ONLY fused operations are the explicit fmaf() below.
 #include "tpspp_common.h"
+#include <new>
 #include "tpspp_warp_dev.h"
 #include "tpspp_warp_stream.h"
 #include "tpspp_warp_pair.h"
@@ -1255,4 +1256,59 @@ TPSPP_EXPORT int tpspp_warp_fwd(const float* in0, int C0, int H0, int W0,
     else if (F == 32) launch_warp<32>(P, grid, block, lds, st);
     else              launch_warp<0>(P, grid, block, lds, st);
     return tpspp::check_launch("tpspp_warp_fwd");
+}
+
+// ---- prepared calls (round 6) -----------------------------------------------------------------------------------------------
+// A serving loop that rectifies batch after batch into the same buffers pays, per launch, for handing 25 arguments through its
+// language's foreign-function layer (ctypes: 1.6 us of a ~4.3 us launch call, against a device that needs ~8 us per 512-image
+// batch -- and at the start of a burst the device waits for the host, not the other way round).  A plan keeps the arguments on
+// this side: tpspp_warp_plan_run is tpspp_warp_fwd with the stored arguments (same checks, same dispatch, same kernel).
+struct tpspp_warp_plan {
+    const float* in0; int C0, H0, W0;
+    const float* in1; int C1, H1, W1;
+    const float* ctrl; const float* score; const float* inv_delta_c; const float* p_hat; int p_hat_ld;
+    const float* p_xy; const float* p_hat_t; int table_flags, N, F, Ho, Wo;
+    float* out0; float* out1; float* grid; int32_t* idx;
+    tpspp_stream_t stream;
+};
+
+TPSPP_EXPORT int tpspp_warp_plan_create(const float* in0, int C0, int H0, int W0,
+                                        const float* in1, int C1, int H1, int W1,
+                                        const float* ctrl, const float* score,
+                                        const float* inv_delta_c, const float* p_hat, int p_hat_ld,
+                                        const float* p_xy, const float* p_hat_t, int table_flags,
+                                        int N, int F, int Ho, int Wo,
+                                        float* out0, float* out1, float* grid_or_null, int32_t* idx_or_null,
+                                        tpspp_stream_t stream, tpspp_warp_plan_t** plan_out)
+{
+    TPSPP_REQUIRE(plan_out, "tpspp_warp_plan_create: plan_out is NULL");
+    *plan_out = nullptr;
+    TPSPP_REQUIRE(in0 && ctrl && inv_delta_c && p_hat && out0, "tpspp_warp_plan_create: null pointer");
+    tpspp_warp_plan* p = new (std::nothrow) tpspp_warp_plan{in0, C0, H0, W0, in1, C1, H1, W1, ctrl, score, inv_delta_c, p_hat, p_hat_ld,
+                                                             p_xy, p_hat_t, table_flags, N, F, Ho, Wo, out0, out1, grid_or_null,
+                                                             idx_or_null, stream};
+    TPSPP_REQUIRE(p, "tpspp_warp_plan_create: out of host memory");
+    *plan_out = p;
+    return TPSPP_OK;
+}
+
+TPSPP_EXPORT int tpspp_warp_plan_run(const tpspp_warp_plan_t* p)
+{
+    TPSPP_REQUIRE(p, "tpspp_warp_plan_run: NULL plan");
+    return tpspp_warp_fwd(p->in0, p->C0, p->H0, p->W0, p->in1, p->C1, p->H1, p->W1, p->ctrl, p->score, p->inv_delta_c, p->p_hat,
+                          p->p_hat_ld, p->p_xy, p->p_hat_t, p->table_flags, p->N, p->F, p->Ho, p->Wo, p->out0, p->out1, p->grid, p->idx,
+                          p->stream);
+}
+
+TPSPP_EXPORT int tpspp_warp_plan_run_on(const tpspp_warp_plan_t* p, tpspp_stream_t stream)
+{
+    TPSPP_REQUIRE(p, "tpspp_warp_plan_run_on: NULL plan");
+    return tpspp_warp_fwd(p->in0, p->C0, p->H0, p->W0, p->in1, p->C1, p->H1, p->W1, p->ctrl, p->score, p->inv_delta_c, p->p_hat,
+                          p->p_hat_ld, p->p_xy, p->p_hat_t, p->table_flags, p->N, p->F, p->Ho, p->Wo, p->out0, p->out1, p->grid, p->idx,
+                          stream);
+}
+
+TPSPP_EXPORT void tpspp_warp_plan_destroy(tpspp_warp_plan_t* p)
+{
+    delete p;
 }

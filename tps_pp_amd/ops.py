@@ -324,16 +324,29 @@ class WarpPlan:
         self._fn = _lib.lib().tpspp_warp_fwd
         self.out0, self.out1 = out0, out1
         self._dev = in0.device
+        # round 6: the arguments live on the library's side (tpspp_warp_plan_create); run() hands over one pointer instead of
+        # marshalling 25 arguments per launch (1.6 of ~4.3 us of host time per call)
+        L = _lib.lib()
+        handle = ctypes.c_void_p()
+        _lib.check(L.tpspp_warp_plan_create(*self._args, ctypes.byref(handle)), "tpspp_warp_plan_create")
+        self._handle, self._run, self._run_on, self._destroy = handle, L.tpspp_warp_plan_run, L.tpspp_warp_plan_run_on, L.tpspp_warp_plan_destroy
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None and getattr(self, "_destroy", None) is not None:
+            try:
+                self._destroy(h)
+            except Exception:                                  # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def run(self, stream=None):
         """One launch on the stream that was current when the plan was built; pass `stream` (a torch.cuda.Stream)
         to launch on another one (the caller orders the buffers' producers / consumers on it)."""
         if stream is not None:
             import ctypes
-            args = self._args[:-1] + (ctypes.c_void_p(stream.cuda_stream),)
-            rc = self._fn(*args)
+            rc = self._run_on(self._handle, ctypes.c_void_p(stream.cuda_stream))
         else:
-            rc = self._fn(*self._args)
+            rc = self._run(self._handle)
         if rc != 0:
             _lib.check(rc, "tpspp_warp_fwd")
         return self.out0, self.out1
