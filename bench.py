@@ -35,6 +35,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   this box's host cores on a bounded sample of the same workload (N = 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -654,6 +655,8 @@ def main():
         its last launch; the region's time is latest end - earliest start (the maximum over all (start, end) pairs)."""
         e0 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
+        gc_was = gc.isenabled()
+        gc.disable()                                           # (a collection inside a 160-us region is a host hiccup the device sees)
         t0 = time.perf_counter()
         # (round 6: a stream's start event is recorded right in front of ITS first launch instead of all start events first --
         # the device sat idle behind the earliest start event while the host recorded the others, ~2.5 us of every region)
@@ -669,6 +672,8 @@ def main():
         for k in range(nstreams):
             e1[k].record(streams[k])
         torch.cuda.synchronize(dev)
+        if gc_was:
+            gc.enable()
         return max(b.elapsed_time(e) for e in e1 for b in e0), time.perf_counter() - t0
 
     for i in range(a.warmup):
