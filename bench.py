@@ -318,19 +318,30 @@ def classic_warp_extra(dev, hw, nstreams, kernel_choice=0):
 
 
 def device_clocks():
-    """Best effort: rocm-smi's clock / power readings of the first card, sampled right behind the timed regions (the boxes of
-    the pool differ by ~8 % in the overlapped launch period at an identical plain-copy rate; the line carries what the device
-    reported).  None when rocm-smi is missing or says nothing parseable."""
-    import shutil
-    import subprocess
-    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    try:
-        out = subprocess.run([exe, "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
-        d = json.loads(out[out.index("{"):])
-        card = d[sorted(d)[0]]
-        return {k.strip(" :").replace(" ", "_"): v.strip("()") for k, v in card.items() if isinstance(v, str)}
-    except Exception:                                          # noqa: BLE001  (informational only)
-        return None
+    """Best effort: the device's current clock levels as the amdgpu driver's sysfs files report them, read right behind the
+    timed regions (no child process: rocm-smi is a `#!/usr/bin/env python3` script, and a process that has initialised the GPU
+    must not exec one on this pool).  The cards are not mapped to HIP devices here: the levels of every card that shows an
+    active shader clock are listed.  None when nothing is readable."""
+    import glob
+    out = {}
+    for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_*clk")):
+        try:
+            cur = [ln.strip() for ln in open(f).read().splitlines() if ln.strip().endswith("*")]
+        except OSError:
+            continue
+        if cur:
+            card = f.split("/")[4]
+            out.setdefault(card, {})[os.path.basename(f)[len("pp_dpm_"):]] = cur[0].rstrip(" *")
+
+    def mhz(v):
+        try:
+            return int(v.split(":")[1].strip().lower().replace("mhz", ""))
+        except (IndexError, ValueError):
+            return 0
+    # only the cards whose shader clock is up (this process's GPU -- and whatever other GPUs of the node are busy for other
+    # tenants at that moment: the host's cores are shared with them)
+    busy = {c: {k: v for k, v in d.items() if k in ("sclk", "mclk", "fclk", "socclk")} for c, d in out.items() if mhz(d.get("sclk", "")) >= 1000}
+    return {"cards_with_shader_clock_up": busy, "cards_in_sysfs": len(out)} if out else None
 
 
 def recognizer_measurement(dev, timeit):
