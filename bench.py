@@ -666,6 +666,13 @@ def main():
         its last launch; the region's time is latest end - earliest start (the maximum over all (start, end) pairs)."""
         e0 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
+        # torch creates the HIP event at its first record(): that would be a hipEventCreate between the start event and the
+        # first launch (and another one in front of the second stream's first launch).  Record every event once here and
+        # synchronize again -- still in front of the region; record() re-uses the handle
+        for k in range(nstreams):
+            e0[k].record(streams[k])
+            e1[k].record(streams[k])
+        torch.cuda.synchronize(dev)
         gc_was = gc.isenabled()
         gc.disable()                                           # (a collection inside a 160-us region is a host hiccup the device sees)
         t0 = time.perf_counter()
