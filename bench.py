@@ -284,9 +284,12 @@ def classic_warp_extra(dev, hw, nstreams, kernel_choice=0):
     def timed(nsteps, ns):
         for i in range(50):
             plans[i % nbuf][i % ns].run()
-        torch.cuda.synchronize(dev)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = [torch.cuda.Event(enable_timing=True) for _ in range(ns)]
+        e0.record(streams[0])                                  # (created at their first record: in front of the region)
+        for k in range(ns):
+            e1[k].record(streams[k])
+        torch.cuda.synchronize(dev)
         e0.record(streams[0])
         for st in streams[1:ns]:
             st.wait_event(e0)
