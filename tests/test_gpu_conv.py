@@ -64,6 +64,9 @@ CASES = [
     ("BasicBlock 3x3 32->32 + residual @16x64", [(32, 16, 64, 1, 1)], 32, 3, (1, 1), True, 2, 3),
     ("3x3 s2 32->32 + residual, Cout=24 ragged", [(32, 16, 64, 1, 1)], 24, 3, (2, 2), True, 2, 3),
     ("1x1 32->32 @32x128", [(32, 32, 128, 1, 1)], 32, 1, (1, 1), True, 0, 2),
+    # stride-2 3x3 tiles with upsampled / concatenated sources: the lean index bookkeeping's other paths (round 6)
+    ("3x3 s2 on an up2 source @8x32 -> 16x64 -> 8x32", [(64, 8, 32, 2, 2)], 64, 3, (2, 2), True, 0, 3),
+    ("3x3 s2 on cat(full, up(3,1)) @12x20", [(8, 12, 20, 1, 1), (8, 4, 20, 3, 1)], 40, 3, (2, 2), True, 2, 2),
     # strided 1x1 (the backbone's downsample branches; round 6: the tiled kernel staging only the pixels it uses)
     ("downsample 1x1 s2 256->512 @8x32 -> 4x16 (two-image tile, odd batch)", [(256, 8, 32, 1, 1)], 512, 1, (2, 2), False, 0, 5),
     ("downsample 1x1 s2 64->128 @16x64 -> 8x32", [(64, 16, 64, 1, 1)], 128, 1, (2, 2), False, 0, 3),
