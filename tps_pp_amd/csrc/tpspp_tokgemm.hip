@@ -32,6 +32,7 @@
 // 47 %: one wavefront's LDS reads are not yet overlapped with its own matrix instructions), stores at HBM speed but not
 // under another workgroup's loop.
 #include "tpspp_common.h"
+#include <cstdlib>
 #include "tpspp_tokgemm.h"
 
 namespace {
@@ -252,7 +253,10 @@ void launch_tok_gemm(const TokGemmArgs& a, hipStream_t st)
 {
     const int ntt = (a.M + BM - 1) / BM;
     // 256 outputs per workgroup where that still leaves two workgroups per CU, else 128
-    const bool wide = a.Co % 256 == 0 && (a.Co / 256) * ntt >= 512;
+    // (round 6: only the three-term split keeps the 256-output tile -- in plain bf16 the 128-output tile's 128 registers
+    // (four workgroups per CU against two at 208) beat the halved re-staging of X: encoder 2.42 -> 2.33 ms at batch 512;
+    // with the split it is the other way round, 3.15 against 3.21)
+    const bool wide = a.x3 && a.Co % 256 == 0 && (a.Co / 256) * ntt >= 512;
     const int nct = a.Co / (wide ? 256 : 128);
     const unsigned blocks = (unsigned)(((ntt + 7) / 8) * 8 * nct);
     if (a.x3) {
