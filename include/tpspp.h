@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer to densely packed row-major fp32 (int32 for indices); tensors
- *     are NCHW like the reference's.  No allocation, no ownership transfer, no host synchronisation:
+ *     are NCHW like the reference's.  No allocation (one exception: tpspp_warp_plan_create's small host
+ *     structure, freed by tpspp_warp_plan_destroy), no ownership transfer, no host synchronisation:
  *     work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and
  *     the call returns immediately.  Re-entrant per stream.
  *   - return value: 0 on success, a negative TPSPP_E* code otherwise; tpspp_last_error() returns a
