@@ -426,6 +426,15 @@ def test_full_size_batch512_properties(cuda, oracle):
     plan.run()
     plan.run()
     assert_biteq(out_p, ox, "WarpPlan vs ops.warp")
+    # ... and on another stream (tpspp_warp_plan_run_on), ordered by the caller; the plan outlives neither buffer (it holds
+    # pointers) and is destroyed with the Python object
+    other = torch.cuda.Stream(cuda)
+    out_p.zero_()
+    other.wait_stream(torch.cuda.current_stream(cuda))
+    plan.run(other)
+    torch.cuda.current_stream(cuda).wait_stream(other)
+    assert_biteq(out_p, ox, "WarpPlan.run(stream) vs ops.warp")
+    del plan
     with pytest.raises(ValueError):
         ops.WarpPlan(dev(x, cuda), dev(ctrl, cuda), inv, P_hat, (32, 100), out_p[:, :2])
 
